@@ -1,0 +1,232 @@
+// Flash-style GQA attention for gfx950, head_dim 128, packed tokens, shared-prefix KV reuse.
+//
+// One workgroup = one 32-query block of one sequence x one KV head; its G = num_heads/num_kv_heads
+// waves are the G query heads that share that KV head, so a K/V tile is staged into LDS once per
+// group.  Per 32-key tile each wave computes S^T = K.Q^T (keys on MFMA rows, queries on lanes:
+// "swapped" product, v_mfma_f32_32x32x16_bf16), so a lane owns ONE query: its running max / sum are
+// lane-local and only the two 32-lane halves are combined.  The S^T accumulator, exponentiated and
+// packed to bf16, is directly the B operand of O^T = V^T.P^T; the V^T A-operand comes from the
+// row-major V tile by the transposed LDS read ds_read_b64_tr_b16.
+//
+// LDS images (16-B chunk c of key row r):  K: chunk c ^ (r & 15)   (ds_read_b128 of 32 rows, conflict-free)
+//                                          V: chunk c ^ ((r & 3) << 2)  (4 rows of a tr-read block on 4 bank quarters)
+#include "attention.hpp"
+
+#define HD 128
+#define KT 32  // keys per tile
+#define QB 32  // queries per block
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <bool USE_TR, int MAXC>
+__global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t k_lds[KT * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t v_lds[KT * HD];
+    __shared__ uint32_t vis_lds[KT / 4];  // 32 visibility bytes
+
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int G = p.num_heads / p.num_kv_heads;
+    const int kh = blockIdx.y;
+    const int head = kh * G + wave;
+    const int blk = blockIdx.x;
+    const int s = p.blk_seq[blk], q0 = p.blk_q0[blk];
+    const int sstart = p.seq_start[s], slen = p.seq_len[s];
+    const int plen = p.pfx_len[s];
+    const int pstart = plen > 0 ? p.pfx_start[s] : 0;
+
+    const int qi = lane & 31, hf = lane >> 5;
+    const int qtok = sstart + min(q0 + qi, slen - 1);
+    const int koff = p.num_heads * HD + kh * HD;
+    const int voff = (p.num_heads + p.num_kv_heads) * HD + kh * HD;
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (q = lane&31, half hf) holds Q[q][16ks + 8hf .. +7]
+    bf16x8 qf[8];
+    {
+        const bf16_t* qrow = p.qkv + (int64_t)qtok * p.ldq + head * HD + 8 * hf;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+    }
+
+    const int n_ptiles = (plen + KT - 1) / KT;
+    const int own_keys = min(q0 + QB, slen);
+    const int n_tiles = n_ptiles + (own_keys + KT - 1) / KT;
+
+    f32x16 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    const float NEG = -1.0e30f;
+    float m_run = NEG, l_run = 0.f;
+    const float c_log2 = p.scale * 1.4426950408889634f;
+
+    // staging: 1024 16-B chunks per tile (512 K + 512 V) spread over the workgroup's threads
+    // (MAXC * nthreads >= 1024: launch_attention picks MAXC from the group size)
+    uint4 st[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) st[i] = make_uint4(0, 0, 0, 0);
+
+    auto tile_desc = [&](int t, int& base_tok, int& k0, int& seg_len, bool& causal) __attribute__((always_inline)) {
+        if (t < n_ptiles) { base_tok = pstart; k0 = t * KT; seg_len = plen; causal = false; }
+        else { base_tok = sstart; k0 = (t - n_ptiles) * KT; seg_len = slen; causal = true; }
+    };
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        int base_tok, k0, seg_len; bool causal;
+        tile_desc(t, base_tok, k0, seg_len, causal);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int idx = tid + i * nthreads;
+            if (idx < 1024) {
+                const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;
+                const int kk = min(k0 + row, seg_len - 1);
+                st[i] = *(const uint4*)(p.qkv + (int64_t)(base_tok + kk) * p.ldq + (isv ? voff : koff) + 8 * ch);
+            }
+        }
+    };
+    auto store_tile = [&](int t) __attribute__((always_inline)) {
+        int base_tok, k0, seg_len; bool causal;
+        tile_desc(t, base_tok, k0, seg_len, causal);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int idx = tid + i * nthreads;
+            if (idx < 1024) {
+                const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;
+                if (isv) *(uint4*)(v_lds + row * HD + 8 * (ch ^ ((row & 3) << 2))) = st[i];
+                else *(uint4*)(k_lds + row * HD + 8 * (ch ^ (row & 15))) = st[i];
+            }
+        }
+        if (tid < KT) {
+            const int kk = k0 + tid;
+            const uint8_t v = (kk < seg_len) ? p.key_visible[base_tok + kk] : (uint8_t)0;
+            ((uint8_t*)vis_lds)[tid] = v ? 1 : 0;
+        }
+    };
+
+    load_tile(0);
+    for (int t = 0; t < n_tiles; ++t) {
+        __syncthreads();  // everyone finished reading the previous tile
+        store_tile(t);
+        __syncthreads();
+        if (t + 1 < n_tiles) load_tile(t + 1);
+
+        int base_tok, k0, seg_len; bool causal;
+        tile_desc(t, base_tok, k0, seg_len, causal);
+
+        // ---- S^T = K . Q^T : A = K fragment (lane: key = lane&31, chunk 2ks+hf), B = qf[ks]
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        {
+            const int key = lane & 31;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(k_lds + key * HD + 8 * ((2 * ks + hf) ^ (key & 15)));
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax; this lane's keys: krow(r) = (r&3) + 8*(r>>2) + 4*hf
+        float pv[16];
+        float tmax = NEG;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t vb = vis_lds[2 * g + hf];  // bytes for keys 8g + 4hf + 0..3
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                const int kk = k0 + 8 * g + 4 * hf + j;
+                const bool ok = ((vb >> (8 * j)) & 0xFF) && (!causal || kk <= q0 + qi);
+                const float sv = ok ? sacc[r] * c_log2 : NEG;
+                pv[r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f(m_run - m_new);
+        float rsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = (pv[r] > 0.5f * NEG) ? exp2f(pv[r] - m_new) : 0.f;
+            pv[r] = e;
+            rsum += e;
+        }
+        rsum += __shfl_xor(rsum, 32);
+        l_run = l_run * alpha + rsum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // ---- P^T fragments: registers 8s..8s+7 are k-step s (k order: 16s + 8(j>>2) + 4hf + (j&3))
+        bf16x8 pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(pv[8 * s2 + 2 * j], pv[8 * s2 + 2 * j + 1]);
+            pf[s2] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+        }
+        // ---- O^T += V^T . P^T : A = V^T fragment (lane: d = 32db + (lane&31); keys 16s+4hf+{0..3} and +8)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 vf;
+                if constexpr (USE_TR) {
+                    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+                    const int dcol = 32 * db + 16 * g16 + 4 * (i16 & 3);  // first of this lane's 4 columns
+                    const int ch = dcol >> 3, within = dcol & 7;
+                    const int kr0 = 16 * s2 + 4 * hf + (i16 >> 2);
+                    const int kr1 = kr0 + 8;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(v_lds + kr0 * HD + 8 * (ch ^ ((kr0 & 3) << 2)) + within));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(v_lds + kr1 * HD + 8 * (ch ^ ((kr1 & 3) << 2)) + within));
+                    vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                } else {
+                    const int d = 32 * db + (lane & 31);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int kr = 16 * s2 + 8 * (j >> 2) + 4 * hf + (j & 3);
+                        vf[j] = (short)v_lds[kr * HD + 8 * ((d >> 3) ^ ((kr & 3) << 2)) + (d & 7)];
+                    }
+                }
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: o[db][r] is O[q = lane&31][d = 32db + (r&3) + 8(r>>2) + 4hf]
+    if (q0 + qi < slen) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* orow = p.out + (int64_t)(sstart + q0 + qi) * p.ldo + head * HD;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * db + 8 * g + 4 * hf;
+                *(uint2*)(orow + d) = make_uint2(pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                                                 pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+            }
+    }
+}
+
+int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
+    ARG_CHECK(p.qkv && p.out && p.key_visible && p.seq_start && p.seq_len && p.pfx_start && p.pfx_len && p.blk_seq && p.blk_q0);
+    ARG_CHECK(p.n_blocks > 0 && p.num_kv_heads > 0 && p.num_heads % p.num_kv_heads == 0);
+    ARG_CHECK(p.ldq % 8 == 0 && p.ldo % 4 == 0);
+    const int G = p.num_heads / p.num_kv_heads;
+    if (G > 8) { blim_set_error("attention: %d query heads per kv head > 8 unsupported", G); return BLIM_ERR_ARG; }
+    const dim3 grid(p.n_blocks, p.num_kv_heads), block(64 * G);
+#define ATTN_LAUNCH(TR, MC) hipLaunchKernelGGL((attn_kernel<TR, MC>), grid, block, 0, stream, p)
+    if (G >= 4) { if (use_tr_read) ATTN_LAUNCH(true, 4); else ATTN_LAUNCH(false, 4); }
+    else if (G >= 2) { if (use_tr_read) ATTN_LAUNCH(true, 8); else ATTN_LAUNCH(false, 8); }
+    else { if (use_tr_read) ATTN_LAUNCH(true, 16); else ATTN_LAUNCH(false, 16); }
+#undef ATTN_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { blim_set_error("attention launch failed: %s", hipGetErrorString(e)); return BLIM_ERR_HIP; }
+    return BLIM_OK;
+}

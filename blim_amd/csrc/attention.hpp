@@ -1,0 +1,27 @@
+// GQA attention over packed tokens with a shared prefix segment and a key-visibility mask (K6).
+// Semantics = the reference's eager/SDPA path (modeling_qwen2_flash.py:288-310, mask :1025-1040):
+//   query token i of sequence s attends to keys { all prefix tokens of s } U { own tokens 0..i },
+//   restricted to key_visible[token] != 0; query rows at invisible positions are still computed.
+//   A query with no visible key gets a zero output (the reference averages V uniformly there; such
+//   rows never reach a score -- DESIGN.md "fully masked rows").
+#pragma once
+#include "common.hpp"
+
+struct AttnParams {
+    const bf16_t* qkv;  // [T, ldq]: q heads | k heads | v heads, head_dim 128, RoPE already applied
+    int64_t ldq;
+    int num_heads, num_kv_heads;
+    const uint8_t* key_visible;  // [T]
+    const int32_t* seq_start;    // [S] first own token
+    const int32_t* seq_len;      // [S]
+    const int32_t* pfx_start;    // [S] first token of the shared prefix (ignored when pfx_len == 0)
+    const int32_t* pfx_len;      // [S]
+    const int32_t* blk_seq;      // [n_blocks] sequence of each 32-query block
+    const int32_t* blk_q0;       // [n_blocks] first query (offset inside the sequence) of the block
+    int n_blocks;
+    bf16_t* out;  // [T, num_heads*128]
+    int64_t ldo;
+    float scale;  // 1/sqrt(head_dim)
+};
+
+int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream);

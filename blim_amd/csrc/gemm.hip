@@ -1,0 +1,316 @@
+// bf16 MFMA GEMM for gfx950: 256x256x64 tiles, 8 waves (2 M x 4 N), each wave 128x64 of C as
+// 8x4 fragments of v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous ([rows][K]); tiles go
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave-instruction) into a
+// double buffer.  LDS image of a 1-KiB block (8 rows x 64 k):  [k-quarter q (32 B)][row 0..7][32 B],
+// i.e. bank-row q holds bytes [32q, 32q+32) of all 8 rows.  A 16-row fragment read (ds_read_b128, lane
+// = (row l&15, 16-B chunk l>>4)) then touches 16 distinct 16-B slots per hardware lane group:
+// conflict-free, with the permutation applied on the per-lane global SOURCE address (the LDS-DMA
+// destination is lane-linear).
+#include "gemm.hpp"
+
+#define BM 256
+#define BN 256
+#define BK 64
+#define NTHREADS 512
+#define TILE_BYTES (BM * BK * 2)           // 32 KiB per operand tile
+#define BUF_BYTES (2 * TILE_BYTES)         // A + B
+#define GROUP_M 8
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// 4x4 transpose inside each quad of lanes: in: lane c holds v[j] = X[row j][col c];
+// out: lane c holds v[j] = X[row c][col j].
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int lane) {
+    const bool odd = lane & 1;
+    float s0 = odd ? v0 : v1, s1 = odd ? v2 : v3;
+    float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    if (odd) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+    const bool hi = lane & 2;
+    s0 = hi ? v0 : v2; s1 = hi ? v1 : v3;
+    r0 = __shfl_xor(s0, 2); r1 = __shfl_xor(s1, 2);
+    if (hi) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // 128 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- tile mapping: XCD-contiguous chunks (blocks b, b+8, ... share an XCD), then grouped M order
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int nwg = ntm * ntn;
+    int pid;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int width = GROUP_M * ntn;
+    const int first_m = (pid / width) * GROUP_M;
+    const int gsz = min(ntm - first_m, GROUP_M);
+    const int tm = first_m + (pid % width) % gsz;
+    const int tn = (pid % width) / gsz;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // ---- per-lane LDS-DMA source pointers: wave w stages blocks w, w+8, w+16, w+24 of A and of B
+    const int sq = lane >> 4, sr = (lane >> 1) & 7, sc = 2 * sq + (lane & 1);  // LDS slot lane -> (row sr, chunk sc)
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = wave + 8 * i;
+        const int ra = min(row0 + 8 * b + sr, p.M - 1);
+        const int rb = min(col0 + 8 * b + sr, p.N - 1);
+        srcA[i] = p.A + (int64_t)ra * p.lda + 8 * sc;
+        srcB[i] = p.W + (int64_t)rb * p.K + 8 * sc;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = wave + 8 * i;
+            glds16(srcA[i] + (int64_t)kt * BK, base + b * 1024);
+            glds16(srcB[i] + (int64_t)kt * BK, base + TILE_BYTES + b * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (bytes) inside a tile
+    const int fr = lane & 15, fc = lane >> 4;
+    const int frag_off = (fr >> 3) * 1024 + (fr & 7) * 32 + (fc >> 1) * 256 + (fc & 1) * 16;
+    const int a_off = (16 * wm) * 1024 + frag_off;                 // + mi*2048 + ks*512
+    const int b_off = TILE_BYTES + (8 * wn) * 1024 + frag_off;     // + ni*2048 + ks*512
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* base = smem + cur * BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[8], b[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(base + b_off + ni * 2048 + ks * 512);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) a[mi] = *(const bf16x8*)(base + a_off + mi * 2048 + ks * 512);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // =========================================================================== epilogues
+    const int wrow0 = row0 + 128 * wm;  // wave's first row
+    const int wcol0 = col0 + 64 * wn;   // wave's first column (in W's row order)
+
+    if constexpr (EPI == EPI_LSE) {
+        // accumulators as the MFMA leaves them: lane holds col (lane&15) of frag ni, rows 4*(lane>>4)+j of frag mi.
+        float2* red = (float2*)smem;  // [4 wn][256 rows]
+        const int q4 = lane >> 4;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rl = 128 * wm + 16 * mi + 4 * q4 + j;  // row inside the tile
+                const int row = row0 + rl;
+                const int lab = (row < p.M) ? p.labels[row] : -1;
+                float v[4];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int col = wcol0 + 16 * ni + fr;
+                    v[ni] = (col < p.N) ? acc[mi][ni][j] : -INFINITY;
+                    if (col == lab) p.label_logit[row] = v[ni];
+                    mx = fmaxf(mx, v[ni]);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float sm = 0.f;
+                if (mx > -INFINITY) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) sm += __expf(v[ni] - mx);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                if (fr == 0) red[wn * 256 + rl] = make_float2(mx, sm);
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int row = row0 + tid;
+            if (row < p.M) {
+                float2 a0 = red[tid], a1 = red[256 + tid], a2 = red[512 + tid], a3 = red[768 + tid];
+                const float mx = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
+                float sm = 0.f;
+                if (mx > -INFINITY) {
+                    sm = a0.y * __expf(a0.x - mx) + a1.y * __expf(a1.x - mx) + a2.y * __expf(a2.x - mx) + a3.y * __expf(a3.x - mx);
+                }
+                p.lse_part[(int64_t)row * ntn + tn] = make_float2(mx, sm);
+            }
+        }
+        return;
+    } else {
+        const int tq = (lane & 15) >> 2;        // which 4-col group of the fragment this lane owns after the transpose
+        const int rsub = 4 * (lane >> 4) + (lane & 3);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int row = wrow0 + 16 * mi + rsub;
+            float t[4][4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
+                quad_transpose(v0, v1, v2, v3, lane);
+                t[ni][0] = v0; t[ni][1] = v1; t[ni][2] = v2; t[ni][3] = v3;
+            }
+            if (row >= p.M) continue;
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_RESID) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int col = wcol0 + 16 * ni + 4 * tq;
+                    if (col >= p.N) continue;
+                    float x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = t[ni][j];
+                    if constexpr (EPI != EPI_RESID) {
+                        if (p.bias) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) x[j] += (col + j < p.N) ? p.bias[col + j] : 0.f;
+                        }
+                    }
+                    if constexpr (EPI == EPI_BF16) {
+                        if (p.act == 1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) x[j] = gelu_erf(x[j]);
+                        }
+                        bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + col;
+                        if (col + 3 < p.N) {
+                            uint2 pk = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+                            *(uint2*)out = pk;
+                        } else {
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = f32_to_bf16(x[j]);
+                        }
+                    } else if constexpr (EPI == EPI_F32) {
+                        float* out = (float*)p.C + (int64_t)row * p.ldc + col;
+                        if (col + 3 < p.N && (p.ldc & 3) == 0) {
+                            *(float4*)out = make_float4(x[0] * p.scale, x[1] * p.scale, x[2] * p.scale, x[3] * p.scale);
+                        } else {
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = x[j] * p.scale;
+                        }
+                    } else {  // EPI_RESID
+                        float* out = (float*)p.C + (int64_t)row * p.ldc + col;
+                        if (col + 3 < p.N) {
+                            float4 o = *(float4*)out;
+                            o.x += x[0]; o.y += x[1]; o.z += x[2]; o.w += x[3];
+                            *(float4*)out = o;
+                        } else {
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j];
+                        }
+                    }
+                }
+            } else if constexpr (EPI == EPI_QKV) {
+                // fragments (2p, 2p+1) hold RoPE partners d and d+64 for q/k heads; v heads are in natural order.
+                const int head = wcol0 >> 7;
+                if (wcol0 < p.rope_cols) {
+                    const int pos = p.pos[row];
+                    const int gbase = ((wcol0 & 127) >> 5);  // 0 or 2
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int cst = wcol0 + 32 * pr + 4 * tq;       // stored col of the lo element
+                        const int d = 16 * (gbase + pr) + 4 * tq;      // natural d of the lo element (0..63)
+                        const float4 cs = *(const float4*)(p.rope_cos + (int64_t)pos * 64 + d);
+                        const float4 sn = *(const float4*)(p.rope_sin + (int64_t)pos * 64 + d);
+                        const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+                        float lo[4], hi[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float x1 = t[2 * pr][j] + (p.bias ? p.bias[cst + j] : 0.f);
+                            const float x2 = t[2 * pr + 1][j] + (p.bias ? p.bias[cst + 16 + j] : 0.f);
+                            lo[j] = x1 * c4[j] - x2 * s4[j];
+                            hi[j] = x2 * c4[j] + x1 * s4[j];
+                        }
+                        bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + head * 128 + d;
+                        *(uint2*)out = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]));
+                        *(uint2*)(out + 64) = make_uint2(pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const int col = wcol0 + 16 * ni + 4 * tq;
+                        if (col >= p.N) continue;
+                        float x[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[j] = t[ni][j] + (p.bias ? p.bias[col + j] : 0.f);
+                        bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + col;
+                        *(uint2*)out = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+                    }
+                }
+            } else if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int cst = wcol0 + 32 * pr;  // stored col of this 32-group
+                    if (cst >= p.N) continue;
+                    const int oc = (cst >> 5) * 16 + 4 * tq;  // output (intermediate) column
+                    float x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = silu_f(t[2 * pr][j]) * t[2 * pr + 1][j];
+                    bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + oc;
+                    *(uint2*)out = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_t(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        blim_set_error("gemm launch failed: %s", hipGetErrorString(e));
+        return BLIM_ERR_HIP;
+    }
+    return BLIM_OK;
+}
+
+int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
+    ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0);
+    ARG_CHECK(p.K % BK == 0);
+    ARG_CHECK(p.lda % 8 == 0);
+    ARG_CHECK(p.A && p.W);
+    switch (epi) {
+        case EPI_BF16: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_BF16>(p, stream);
+        case EPI_F32: ARG_CHECK(p.C); return launch_t<EPI_F32>(p, stream);
+        case EPI_RESID: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_RESID>(p, stream);
+        case EPI_QKV:
+            ARG_CHECK(p.C && p.pos && p.rope_cos && p.rope_sin && p.N % 128 == 0 && p.rope_cols % 128 == 0 && p.ldc % 4 == 0);
+            return launch_t<EPI_QKV>(p, stream);
+        case EPI_SWIGLU: ARG_CHECK(p.C && p.N % 32 == 0 && p.ldc % 4 == 0); return launch_t<EPI_SWIGLU>(p, stream);
+        case EPI_LSE: ARG_CHECK(p.labels && p.lse_part && p.label_logit); return launch_t<EPI_LSE>(p, stream);
+    }
+    blim_set_error("unknown epilogue %d", (int)epi);
+    return BLIM_ERR_ARG;
+}

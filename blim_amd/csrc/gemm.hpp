@@ -1,0 +1,47 @@
+// bf16 MFMA GEMM  C[M,N] = A[M,K] . W[N,K]^T  with fused epilogues (gfx950).
+// Covers K1 (projector), K4+K5 (QKV+bias+RoPE), K7 (o_proj+residual), K8 (SwiGLU, down+residual),
+// K10+K11 (lm_head + log-sum-exp + label gather), K13/K14 (visual head, video-vocabulary logits)
+// of SURVEY.md section 2.3.
+#pragma once
+#include "common.hpp"
+
+enum GemmEpi : int {
+    EPI_BF16 = 0,    // C bf16 [M,ldc] = act(acc + bias)
+    EPI_F32 = 1,     // C f32  [M,ldc] = (acc + bias) * scale
+    EPI_RESID = 2,   // C f32  [M,ldc] += acc                       (residual stream)
+    EPI_QKV = 3,     // C bf16 [M,ldc] = rope(acc + bias) for cols < rope_cols, acc + bias otherwise;
+                     //   W rows of every q/k head are stored pair-interleaved (see qkv_perm_row)
+    EPI_SWIGLU = 4,  // C bf16 [M, N/2] = silu(gate) * up;  W rows interleaved 16 gate / 16 up
+    EPI_LSE = 5,     // per (row, 256-col tile): (max, sum exp) partials + the label's logit
+};
+
+struct GemmParams {
+    const bf16_t* A;
+    int64_t lda;
+    const bf16_t* W;  // [N, K], row stride K
+    int M, N, K;
+    void* C;
+    int64_t ldc;
+    const float* bias;  // [N] (in W's row order) or nullptr
+    int act;            // EPI_BF16: 0 none, 1 exact-erf GELU
+    float scale;        // EPI_F32
+    // EPI_QKV
+    const int32_t* pos;      // [M] RoPE position of every row
+    const float* rope_cos;   // [max_pos, 64]
+    const float* rope_sin;
+    int rope_cols;           // (num_heads + num_kv_heads) * 128
+    // EPI_LSE
+    const int32_t* labels;   // [M] target column per row (or < 0)
+    float2* lse_part;        // [M, ceil(N/256)] (max, sumexp)
+    float* label_logit;      // [M]
+};
+
+// 256x256x64 tiles, 512 threads.  K % 64 == 0, lda % 8 == 0.  Rows/cols beyond M/N are clamped on
+// load and masked on store, so neither A nor W needs padding.
+int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream);
+
+// Row permutation used for q/k heads so that RoPE partners (d, d+64) land in the same lane:
+// stored row c' (0..127 within a head) holds natural row d = 16*(c'>>5) + (c'&15) + 64*((c'>>4)&1).
+static inline int qkv_perm_row(int cprime) { return 16 * (cprime >> 5) + (cprime & 15) + 64 * ((cprime >> 4) & 1); }
+// SwiGLU interleave: stored row r of the fused [2I, K] matrix: group g = r>>5, t = r&31:
+// t < 16 -> gate row 16g+t, else up row 16g+(t-16).

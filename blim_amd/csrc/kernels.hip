@@ -1,0 +1,300 @@
+// HBM-bound helper kernels (see kernels.hpp).  All loads/stores are 8-16 B per lane.
+#include "kernels.hpp"
+
+#define LAUNCH_CHECK(name)                                                           \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) {                                                      \
+            blim_set_error("%s launch failed: %s", name, hipGetErrorString(_e));     \
+            return BLIM_ERR_HIP;                                                     \
+        }                                                                            \
+    } while (0)
+
+static inline int grid_for(int64_t n, int per_block, int cap = 8192) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---------------------------------------------------------------------------- synthetic fill
+// Rule stated in blim_amd/synth.py (bit-exact with the numpy statement).
+__device__ __forceinline__ float bell_value(uint64_t seed, uint64_t tid, uint64_t idx, float scale, float mean) {
+    const uint64_t K0 = 0x9E3779B97F4A7C15ull, K1 = 0xBF58476D1CE4E5B9ull, K2 = 0x94D049BB133111EBull;
+    uint64_t z = seed * K0 + tid * K1 + idx + K0;
+    z = (z ^ (z >> 30)) * K1;
+    z = (z ^ (z >> 27)) * K2;
+    z = z ^ (z >> 31);
+    const int s = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)(z >> 48);
+    return __fadd_rn(__fmul_rn((float)(s - 131070), scale), mean);  // no fma contraction: matches numpy
+}
+
+__global__ void fill_bell_bf16_kernel(bf16_t* out, int64_t n, uint64_t seed, uint64_t tid, float scale, float mean) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            uint2 pk;
+            pk.x = pack_bf16x2(bell_value(seed, tid, i, scale, mean), bell_value(seed, tid, i + 1, scale, mean));
+            pk.y = pack_bf16x2(bell_value(seed, tid, i + 2, scale, mean), bell_value(seed, tid, i + 3, scale, mean));
+            *(uint2*)(out + i) = pk;
+        } else {
+            for (int64_t j = i; j < n; ++j) out[j] = f32_to_bf16(bell_value(seed, tid, j, scale, mean));
+        }
+    }
+}
+__global__ void fill_bell_f32_kernel(float* out, int64_t n, uint64_t seed, uint64_t tid, float scale, float mean, int round_bf16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = bell_value(seed, tid, i, scale, mean);
+        if (round_bf16) v = bf16_to_f32(f32_to_bf16(v));
+        out[i] = v;
+    }
+}
+int launch_fill_bell_bf16(bf16_t* out, int64_t n, uint64_t seed, uint64_t tensor_id, float scale, float mean, hipStream_t s) {
+    ARG_CHECK(out && n > 0 && ((uintptr_t)out & 7) == 0);
+    hipLaunchKernelGGL(fill_bell_bf16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, out, n, seed, tensor_id, scale, mean);
+    LAUNCH_CHECK("fill_bell_bf16");
+    return BLIM_OK;
+}
+int launch_fill_bell_f32(float* out, int64_t n, uint64_t seed, uint64_t tensor_id, float scale, float mean, int round_bf16, hipStream_t s) {
+    ARG_CHECK(out && n > 0);
+    hipLaunchKernelGGL(fill_bell_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, out, n, seed, tensor_id, scale, mean, round_bf16);
+    LAUNCH_CHECK("fill_bell_f32");
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- assemble (K2)
+__global__ void assemble_kernel(bf16_t* out, const int32_t* src, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats) {
+    const int chunks = H / 8;  // 16-B chunks per row
+    const int64_t total = n_tokens * chunks;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t t = i / chunks;
+        const int c = (int)(i - t * chunks);
+        const int32_t sidx = src[t];
+        const bf16_t* row = sidx >= 0 ? table + (int64_t)sidx * H : feats + (int64_t)(-(sidx + 1)) * H;
+        *(uint4*)(out + t * H + 8 * c) = *(const uint4*)(row + 8 * c);
+    }
+}
+int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats, hipStream_t s) {
+    ARG_CHECK(out && src_index && n_tokens > 0 && H % 8 == 0 && table);
+    hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(n_tokens * (H / 8), 256)), dim3(256), 0, s, out, src_index, n_tokens, H, table, feats);
+    LAUNCH_CHECK("assemble");
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- dtype converts
+__global__ void bf16_to_f32_kernel(float* out, const bf16_t* in, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const uint2 v = *(const uint2*)(in + i);
+            *(float4*)(out + i) = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u),
+                                              __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+        } else {
+            for (int64_t j = i; j < n; ++j) out[j] = bf16_to_f32(in[j]);
+        }
+    }
+}
+__global__ void f32_to_bf16_kernel(bf16_t* out, const float* in, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *(const float4*)(in + i);
+            *(uint2*)(out + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        } else {
+            for (int64_t j = i; j < n; ++j) out[j] = f32_to_bf16(in[j]);
+        }
+    }
+}
+int launch_bf16_to_f32(float* out, const bf16_t* in, int64_t n, hipStream_t s) {
+    ARG_CHECK(out && in && n > 0);
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, out, in, n);
+    LAUNCH_CHECK("bf16_to_f32");
+    return BLIM_OK;
+}
+int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s) {
+    ARG_CHECK(out && in && n > 0);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, out, in, n);
+    LAUNCH_CHECK("f32_to_bf16");
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- RMSNorm (K3/K9)
+// One wave per row; the row (H f32) is read once in float4 pieces and kept in registers when H <= 64*4*16.
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H,
+                                                      const float* w, float eps, bf16_t* out_bf16, float* out_f32) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int64_t src = rows ? rows[r] : r;
+    const float* xr = x + src * ldx;
+    const int nv = H / 4;  // float4 per row
+    float4 v[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = *(const float4*)(xr + 4 * c);
+            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 g = *(const float4*)(w + 4 * c);
+            const float o0 = g.x * (v[i].x * inv), o1 = g.y * (v[i].y * inv), o2 = g.z * (v[i].z * inv), o3 = g.w * (v[i].w * inv);
+            if (out_bf16) *(uint2*)(out_bf16 + r * H + 4 * c) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            if (out_f32) *(float4*)(out_f32 + r * H + 4 * c) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
+                   bf16_t* out_bf16, float* out_f32, hipStream_t s) {
+    ARG_CHECK(x && w && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0 && (out_bf16 || out_f32));
+    const int nv = H / 4;
+    const dim3 grid((unsigned)((n_rows + 3) / 4));
+    if (nv <= 64 * 4) {
+        hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_bf16, out_f32);
+    } else if (nv <= 64 * 16) {
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_bf16, out_f32);
+    } else {
+        blim_set_error("rmsnorm: hidden size %d > 4096 not supported", H);
+        return BLIM_ERR_ARG;
+    }
+    LAUNCH_CHECK("rmsnorm");
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- group mean (TVG clip tokens)
+__global__ void group_mean_kernel(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H) {
+    const int chunks = H / 4;
+    const int64_t total = n_out * chunks;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t o = i / chunks;
+        const int c = (int)(i - o * chunks);
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int j = 0; j < group; ++j) {
+            const uint2 v = *(const uint2*)(in + (o * group + j) * H + 4 * c);
+            a0 += __uint_as_float(v.x << 16); a1 += __uint_as_float(v.x & 0xFFFF0000u);
+            a2 += __uint_as_float(v.y << 16); a3 += __uint_as_float(v.y & 0xFFFF0000u);
+        }
+        const float inv = 1.0f / (float)group;
+        *(uint2*)(out + o * H + 4 * c) = make_uint2(pack_bf16x2(a0 * inv, a1 * inv), pack_bf16x2(a2 * inv, a3 * inv));
+    }
+}
+int launch_group_mean_bf16(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, hipStream_t s) {
+    ARG_CHECK(out && in && n_out > 0 && group > 0 && H % 4 == 0);
+    hipLaunchKernelGGL(group_mean_kernel, dim3(grid_for(n_out * (H / 4), 256)), dim3(256), 0, s, out, in, n_out, group, H);
+    LAUNCH_CHECK("group_mean");
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- LSE combine (K11)
+// One wave per row: combine the per-tile (max, sumexp) partials.
+__global__ __launch_bounds__(256) void lse_combine_kernel(const float2* part, int n_tiles, const float* label_logit, int64_t n_rows, float* logprob) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float2* pr = part + r * n_tiles;
+    float mx = -INFINITY;
+    for (int i = lane; i < n_tiles; i += 64) mx = fmaxf(mx, pr[i].x);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int i = lane; i < n_tiles; i += 64) {
+        const float2 v = pr[i];
+        if (v.x > -INFINITY) sm += v.y * expf(v.x - mx);
+    }
+    sm = wave_sum(sm);
+    if (lane == 0) logprob[r] = label_logit[r] - (mx + logf(sm));
+}
+int launch_lse_combine(const float2* part, int n_tiles, const float* label_logit, int64_t n_rows, float* logprob, hipStream_t s) {
+    ARG_CHECK(part && label_logit && logprob && n_rows > 0 && n_tiles > 0);
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, part, n_tiles, label_logit, n_rows, logprob);
+    LAUNCH_CHECK("lse_combine");
+    return BLIM_OK;
+}
+
+// score = sum / count_nonzero  (retrieval_utils.py:32, sign already folded: logprob = -loss)
+__global__ void segment_mean_kernel(const float* logprob, const int32_t* row_start, int n_pairs, float* score) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    float sm = 0.f;
+    int nz = 0;
+    for (int r = row_start[p]; r < row_start[p + 1]; ++r) {
+        const float v = logprob[r];
+        sm += v;
+        nz += (v != 0.f);
+    }
+    score[p] = sm / (float)nz;
+}
+int launch_segment_mean_nonzero(const float* logprob, const int32_t* row_start, int n_pairs, float* score, hipStream_t s) {
+    ARG_CHECK(logprob && row_start && score && n_pairs > 0);
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, s, logprob, row_start, n_pairs, score);
+    LAUNCH_CHECK("segment_mean");
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- CE on materialised logits
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* logits, int64_t ld, int V, const int32_t* labels, int64_t n_rows, float* logprob) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const int lab = labels[r];
+    if (lab < 0) {
+        if (threadIdx.x == 0) logprob[r] = 0.f;
+        return;
+    }
+    const float* row = logits + r * ld;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sm = 0.f;
+    for (int i = tid; i < V; i += 256) sm += expf(row[i] - mx);
+    sm = wave_sum(sm);
+    if (lane == 0) red[4 + w] = sm;
+    __syncthreads();
+    if (tid == 0) logprob[r] = row[lab] - (mx + logf(red[4] + red[5] + red[6] + red[7]));
+}
+int launch_ce_rows(const float* logits, int64_t ld, int V, const int32_t* labels, int64_t n_rows, float* logprob, hipStream_t s) {
+    ARG_CHECK(logits && labels && logprob && n_rows > 0 && V > 0);
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, s, logits, ld, V, labels, n_rows, logprob);
+    LAUNCH_CHECK("ce_rows");
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- TVG criterion (K15)
+// One workgroup per pair; each of its 4 waves takes clips round-robin.
+__global__ __launch_bounds__(256) void tvg_score_kernel(const float* logits, int64_t ld, int n_vocab, const int32_t* labels, int n_pairs, int clips, float* score) {
+    __shared__ float part[4];
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lab = labels[p];
+    float acc = 0.f;
+    for (int c = w; c < clips; c += 4) {
+        const float* row = logits + ((int64_t)p * clips + c) * ld;
+        float mx = -INFINITY;
+        for (int i = lane; i < n_vocab; i += 64) mx = fmaxf(mx, row[i]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int i = lane; i < n_vocab; i += 64) sm += expf(row[i] - mx);
+        sm = wave_sum(sm);
+        acc += row[lab] - (mx + logf(sm));
+    }
+    if (lane == 0) part[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) score[p] = (part[0] + part[1] + part[2] + part[3]) / (float)clips;
+}
+int launch_tvg_score(const float* logits, int64_t ld, int n_vocab, const int32_t* labels, int n_pairs, int clips, float* score, hipStream_t s) {
+    ARG_CHECK(logits && labels && score && n_pairs > 0 && clips > 0 && n_vocab > 0);
+    hipLaunchKernelGGL(tvg_score_kernel, dim3(n_pairs), dim3(256), 0, s, logits, ld, n_vocab, labels, n_pairs, clips, score);
+    LAUNCH_CHECK("tvg_score");
+    return BLIM_OK;
+}

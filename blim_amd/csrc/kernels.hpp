@@ -1,0 +1,34 @@
+// HBM-bound helper kernels of the scoring path (gfx950): synthetic fill, embedding gather (K2),
+// RMSNorm (K3/K9), log-sum-exp combine + masked mean (K11), cross-entropy on materialised logits,
+// TVG criterion (K15).
+#pragma once
+#include "common.hpp"
+
+int launch_fill_bell_bf16(bf16_t* out, int64_t n, uint64_t seed, uint64_t tensor_id, float scale, float mean, hipStream_t s);
+int launch_fill_bell_f32(float* out, int64_t n, uint64_t seed, uint64_t tensor_id, float scale, float mean, int round_bf16, hipStream_t s);
+
+// out[t, :] = src_index[t] >= 0 ? table[src_index[t], :] : feats[-(src_index[t]+1), :]      (bf16 rows of width H)
+int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats, hipStream_t s);
+
+// resid[t, :] = f32(embeds[t, :])
+int launch_bf16_to_f32(float* out, const bf16_t* in, int64_t n, hipStream_t s);
+int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s);
+
+// out[i, :] = bf16( w * x[rows ? rows[i] : i, :] * rsqrt(mean(x^2) + eps) ); optionally also f32 copy.
+int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
+                   bf16_t* out_bf16, float* out_f32, hipStream_t s);
+
+// mean over groups of `group` consecutive rows: out[i,:] = mean_j in[i*group + j, :]   (bf16 in/out, f32 accumulate)
+int launch_group_mean_bf16(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, hipStream_t s);
+
+// logprob[r] = label_logit[r] - logsumexp over the n_tiles (max, sumexp) partials of row r
+int launch_lse_combine(const float2* part, int n_tiles, const float* label_logit, int64_t n_rows, float* logprob, hipStream_t s);
+
+// score[p] = sum(logprob[rows of p]) / count_nonzero(...)  for rows [row_start[p], row_start[p+1])
+int launch_segment_mean_nonzero(const float* logprob, const int32_t* row_start, int n_pairs, float* score, hipStream_t s);
+
+// logprob[r] = log_softmax(logits[r, :V])[label[r]] (label < 0 -> 0), one workgroup per row
+int launch_ce_rows(const float* logits, int64_t ld, int V, const int32_t* labels, int64_t n_rows, float* logprob, hipStream_t s);
+
+// TVG criterion: logits [n_pairs*clips, n_vocab] f32 (row p*clips+c = pair p, clip c), label[p] -> score[p] = mean_c log_softmax[label]
+int launch_tvg_score(const float* logits, int64_t ld, int n_vocab, const int32_t* labels, int n_pairs, int clips, float* score, hipStream_t s);

@@ -1,0 +1,419 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU (numpy, fp32) restatement of the BLiM likelihood-scoring path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file, and
+only as the checker / the reported CPU baseline.  Nothing under blim_amd/ imports it; the product
+path fails loudly when the HIP library is missing.
+
+Parity status: PINNED.  tests/golden/*.npz were produced by oracle/gen_golden.py, which imports
+the reference's own modules from /root/reference in the build container
+and records their outputs; tests/test_oracle_golden.py checks every function below against
+those vectors.  The reference ships no tests or golden vectors of its own.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+All arithmetic is float32 ("the reference CPU/PyTorch path" of BASELINE.json's north_star).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+IGNORE_INDEX = -100          # videochat_flash/conversation.py:10
+IMAGE_TOKEN_INDEX = -200     # videochat_flash/conversation.py:11
+IMAGE_TOKEN_ID = 151645      # videochat_flash/conversation.py:13  (<|im_end|>)
+F32_MIN = np.float32(np.finfo(np.float32).min)
+
+
+@dataclass
+class OracleConfig:
+    vocab_size: int = 152064
+    hidden_size: int = 3584
+    intermediate_size: int = 18944
+    num_layers: int = 28
+    num_heads: int = 28
+    num_kv_heads: int = 4
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mm_hidden_size: int = 1024
+    num_clips: int = 4
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_heads
+
+
+def weight_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
+    """Canonical tensor names -> shapes ([out, in] like nn.Linear)."""
+    H, I, V, M = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.mm_hidden_size
+    hd = cfg.head_dim
+    s: Dict[str, Tuple[int, ...]] = {"embed_tokens": (V, H), "final_norm": (H,), "lm_head": (V, H),
+                                     "visual_head": (M, H)}
+    for p in ("mlp", "tvg_mlp"):
+        s[f"{p}.0.w"] = (H, M); s[f"{p}.0.b"] = (H,)
+        s[f"{p}.2.w"] = (H, H); s[f"{p}.2.b"] = (H,)
+    for i in range(cfg.num_layers):
+        L = f"layers.{i}."
+        s[L + "input_norm"] = (H,); s[L + "post_norm"] = (H,)
+        s[L + "q_proj.w"] = (cfg.num_heads * hd, H); s[L + "q_proj.b"] = (cfg.num_heads * hd,)
+        s[L + "k_proj.w"] = (cfg.num_kv_heads * hd, H); s[L + "k_proj.b"] = (cfg.num_kv_heads * hd,)
+        s[L + "v_proj.w"] = (cfg.num_kv_heads * hd, H); s[L + "v_proj.b"] = (cfg.num_kv_heads * hd,)
+        s[L + "o_proj.w"] = (H, H)
+        s[L + "gate_proj.w"] = (I, H); s[L + "up_proj.w"] = (I, H); s[L + "down_proj.w"] = (H, I)
+    return s
+
+
+def synthetic_weights(cfg: OracleConfig, seed: int) -> Dict[str, np.ndarray]:
+    """Seeded bf16-representable weights: matrices/biases bell(0, 0.02), norm weights bell(1, 0.1)."""
+    from . import synth_np
+    out = {}
+    for name, shape in weight_shapes(cfg).items():
+        if name.endswith("norm"):
+            out[name] = synth_np.tensor(seed, name, shape, std=0.1, mean=1.0)
+        else:
+            out[name] = synth_np.tensor(seed, name, shape, std=0.02)
+    return out
+
+
+# ----------------------------------------------------------------------------- primitive ops
+
+def rms_norm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
+    """modeling_qwen2_flash.py:93-98."""
+    x = x.astype(np.float32)
+    var = np.mean(x * x, axis=-1, keepdims=True, dtype=np.float32)
+    return w * (x * (np.float32(1.0) / np.sqrt(var + np.float32(eps))))
+
+
+def rope_tables(head_dim: int, theta: float, n_pos: int) -> Tuple[np.ndarray, np.ndarray]:
+    """modeling_qwen2_flash.py:112, 117-125: inv_freq = theta^(-2i/d); emb = cat(freqs, freqs)."""
+    inv = (np.float32(1.0) / (np.float32(theta) ** (np.arange(0, head_dim, 2, dtype=np.float32) / np.float32(head_dim)))).astype(np.float32)
+    fr = np.outer(np.arange(n_pos, dtype=np.float32), inv).astype(np.float32)
+    emb = np.concatenate([fr, fr], axis=-1)
+    return np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
+
+
+def apply_rope(x: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
+    """x: [B, heads, L, d]; half-split rotation, modeling_qwen2_flash.py:139-143, 168-171."""
+    d = x.shape[-1]
+    rot = np.concatenate([-x[..., d // 2:], x[..., : d // 2]], axis=-1)
+    return x * cos[None, None] + rot * sin[None, None]
+
+
+def silu(x: np.ndarray) -> np.ndarray:
+    return x / (np.float32(1.0) + np.exp(-x))
+
+
+def gelu(x: np.ndarray) -> np.ndarray:
+    """nn.GELU() default = exact erf form (mm_projector_builder.py:89)."""
+    from math import sqrt
+    try:
+        from scipy.special import erf
+    except Exception:  # pragma: no cover
+        erf = np.vectorize(math.erf)
+    return (np.float32(0.5) * x * (np.float32(1.0) + erf(x / np.float32(sqrt(2.0))))).astype(np.float32)
+
+
+def additive_mask(key_mask: np.ndarray, L: int) -> np.ndarray:
+    """[B, L] 0/1 key mask -> [B, 1, L, L] additive mask, 0 where (k <= q and key_mask[k]) else f32 min.
+
+    modeling_qwen2_flash.py:1033-1040 (transformers _prepare_4d_causal_attention_mask: causal mask
+    with the inverted key-padding mask filled in at finfo.min)."""
+    causal = np.tril(np.ones((L, L), dtype=bool))
+    vis = causal[None, :, :] & (key_mask.astype(bool)[:, None, :])
+    return np.where(vis, np.float32(0.0), F32_MIN)[:, None, :, :].astype(np.float32)
+
+
+def log_softmax(x: np.ndarray) -> np.ndarray:
+    m = np.max(x, axis=-1, keepdims=True)
+    z = x - m
+    return z - np.log(np.sum(np.exp(z), axis=-1, keepdims=True, dtype=np.float32))
+
+
+# ----------------------------------------------------------------------------- model
+
+class OracleModel:
+    """Restates VideoChatFlashQwenForCausalLM on the eval path (modeling_videochat_flash.py:572-629)."""
+
+    def __init__(self, cfg: OracleConfig, weights: Dict[str, np.ndarray]):
+        self.cfg = cfg
+        self.w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+        self.tvg_prefix_length = 0
+        self.video_vocab = None
+
+    # setters, modeling_videochat_flash.py:589-593
+    def set_tvg_prefix_length(self, n: int) -> None:
+        self.tvg_prefix_length = int(n)
+
+    def set_video_vocab(self, v) -> None:
+        self.video_vocab = v
+
+    # --- projector, mm_projector_builder.py:88-93, 156-159
+    def project_video(self, feat: np.ndarray, tvg: bool) -> np.ndarray:
+        p = "tvg_mlp" if tvg else "mlp"
+        h = feat.astype(np.float32) @ self.w[f"{p}.0.w"].T + self.w[f"{p}.0.b"]
+        h = gelu(h)
+        return (h @ self.w[f"{p}.2.w"].T + self.w[f"{p}.2.b"]).astype(np.float32)
+
+    def forward_visual(self, x: np.ndarray) -> np.ndarray:
+        """modeling_videochat_flash.py:598-599 (Linear H -> mm_hidden, no bias)."""
+        return (x.astype(np.float32) @ self.w["visual_head"].T).astype(np.float32)
+
+    # --- sequence assembly, modeling_videochat_flash.py:185-515 (hot branch)
+    def prepare_inputs_labels_for_multimodal(self, input_ids: np.ndarray, attention_mask: np.ndarray,
+                                             labels: np.ndarray, videos: Sequence[np.ndarray], tvg: bool = False):
+        """Returns (mask [B,L], cpn_mask [B,L], embeds [B,L,H], labels [B,L]).
+
+        input_ids/attention_mask/labels are the LEFT-padded [B, Lt] arrays of padding_ids();
+        videos is a list of B feature arrays [clips, T, mm_hidden]."""
+        B = input_ids.shape[0]
+        E = self.w["embed_tokens"]
+        rows_e, rows_l, rows_c = [], [], []
+        for b in range(B):
+            keep = attention_mask[b].astype(bool)                      # :333-334 strip the left pad
+            ids = input_ids[b][keep]
+            lab = labels[b][keep]
+            feat = self.project_video(videos[b], tvg)                  # :157-174
+            # :243  'pad' is a substring of 'spatial_nopad' -> mean over tokens for tvg, flatten otherwise
+            feat = feat.mean(axis=1) if tvg else feat.reshape(-1, feat.shape[-1])
+            where = np.nonzero(ids == IMAGE_TOKEN_INDEX)[0].tolist()
+            cuts = [-1] + where + [len(ids)]                           # :395
+            e_parts, l_parts, c_parts = [], [], []
+            img = 0
+            for i in range(len(cuts) - 1):
+                seg_ids = ids[cuts[i] + 1: cuts[i + 1]]
+                seg_lab = lab[cuts[i] + 1: cuts[i + 1]]
+                e_parts.append(E[seg_ids])                              # :402
+                l_parts.append(seg_lab)
+                if tvg and i == 0:                                      # :414-417
+                    m = np.zeros(len(seg_ids), dtype=np.int64)
+                    m[: self.tvg_prefix_length] = 1
+                else:                                                   # :419
+                    m = np.ones(len(seg_ids), dtype=np.int64)
+                c_parts.append(m)
+                if i < len(where):                                      # :421-433
+                    assert img == 0, "one <image> placeholder per row on the eval path"
+                    img += 1
+                    e_parts.append(feat)
+                    l_parts.append(np.full(feat.shape[0], IGNORE_INDEX, dtype=np.int64))
+                    c_parts.append(np.full(feat.shape[0], 1 if tvg else 0, dtype=np.int64))
+            rows_e.append(np.concatenate(e_parts, axis=0))
+            rows_l.append(np.concatenate(l_parts))
+            rows_c.append(np.concatenate(c_parts))
+        L = max(r.shape[0] for r in rows_e)                             # :460
+        H = self.cfg.hidden_size
+        embeds = np.zeros((B, L, H), dtype=np.float32)
+        out_lab = np.full((B, L), IGNORE_INDEX, dtype=np.int64)
+        mask = np.zeros((B, L), dtype=np.int64)
+        cpn = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):                                              # :472-485 right padding
+            n = rows_e[b].shape[0]
+            embeds[b, :n] = rows_e[b]
+            out_lab[b, :n] = rows_l[b]
+            mask[b, :n] = 1
+            cpn[b, :n] = rows_c[b]
+        return mask, cpn, embeds, out_lab
+
+    # --- decoder, modeling_qwen2_flash.py:952-1156 + 1392-1478
+    def decoder_layer(self, i: int, x: np.ndarray, add_mask: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
+        """modeling_qwen2_flash.py:742-800 with eager attention :247-326."""
+        c, w = self.cfg, self.w
+        P = f"layers.{i}."
+        B, L, H = x.shape
+        hd, nh, nkv = c.head_dim, c.num_heads, c.num_kv_heads
+        h = rms_norm(x, w[P + "input_norm"], c.rms_eps)
+        q = (h @ w[P + "q_proj.w"].T + w[P + "q_proj.b"]).reshape(B, L, nh, hd).transpose(0, 2, 1, 3)
+        k = (h @ w[P + "k_proj.w"].T + w[P + "k_proj.b"]).reshape(B, L, nkv, hd).transpose(0, 2, 1, 3)
+        v = (h @ w[P + "v_proj.w"].T + w[P + "v_proj.b"]).reshape(B, L, nkv, hd).transpose(0, 2, 1, 3)
+        q = apply_rope(q, cos, sin)
+        k = apply_rope(k, cos, sin)
+        rep = nh // nkv                                                 # repeat_kv :192-201
+        k = np.repeat(k, rep, axis=1)
+        v = np.repeat(v, rep, axis=1)
+        s = (q @ k.transpose(0, 1, 3, 2)) / np.float32(math.sqrt(hd)) + add_mask
+        s = s - np.max(s, axis=-1, keepdims=True)
+        p = np.exp(s)
+        p = p / np.sum(p, axis=-1, keepdims=True, dtype=np.float32)
+        a = (p @ v).transpose(0, 2, 1, 3).reshape(B, L, nh * hd)
+        x = x + a @ w[P + "o_proj.w"].T
+        h = rms_norm(x, w[P + "post_norm"], c.rms_eps)
+        g = silu(h @ w[P + "gate_proj.w"].T) * (h @ w[P + "up_proj.w"].T)
+        return (x + g @ w[P + "down_proj.w"].T).astype(np.float32)
+
+    def forward_hidden(self, embeds: np.ndarray, key_mask: np.ndarray, n_layers: Optional[int] = None) -> np.ndarray:
+        """Final-norm hidden states [B, L, H] (what .hidden_states carries, modeling_qwen2_flash.py:1139, 1472-1478)."""
+        c = self.cfg
+        x = embeds.astype(np.float32)
+        B, L, _ = x.shape
+        cos, sin = rope_tables(c.head_dim, c.rope_theta, L)             # positions arange(L), :998-1003
+        am = additive_mask(key_mask, L)
+        for i in range(c.num_layers if n_layers is None else n_layers):
+            x = self.decoder_layer(i, x, am, cos, sin)
+        return rms_norm(x, self.w["final_norm"], c.rms_eps).astype(np.float32)
+
+    def forward(self, embeds: np.ndarray, key_mask: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """(logits [B,L,V] f32, hidden [B,L,H]) -- modeling_qwen2_flash.py:1452-1453."""
+        h = self.forward_hidden(embeds, key_mask)
+        return (h @ self.w["lm_head"].T).astype(np.float32), h
+
+    def label_logprobs(self, hidden: np.ndarray, labels: np.ndarray) -> np.ndarray:
+        """Same numbers as vtg_criterion(forward(...).logits, labels) without the [B,L,V] tensor."""
+        B, L, _ = hidden.shape
+        out = np.zeros(B, dtype=np.float32)
+        W = self.w["lm_head"]
+        for b in range(B):
+            pos = np.nonzero(labels[b, 1:] != IGNORE_INDEX)[0]
+            if len(pos) == 0:
+                out[b] = np.float32("nan")
+                continue
+            lg = hidden[b, pos] @ W.T
+            lp = log_softmax(lg)[np.arange(len(pos)), labels[b, 1:][pos]]
+            nz = np.count_nonzero(lp)
+            out[b] = lp.sum(dtype=np.float32) / np.float32(nz)
+        return out
+
+
+# ----------------------------------------------------------------------------- criteria
+
+def vtg_criterion(logits: np.ndarray, labels: np.ndarray) -> np.ndarray:
+    """retrieval_utils.py:23-33: shift; CE(reduction none, ignore -100); -sum/count_nonzero per row."""
+    B = logits.shape[0]
+    sl = logits[:, :-1, :].astype(np.float32)
+    tl = labels[:, 1:]
+    lp = log_softmax(sl)
+    valid = tl != IGNORE_INDEX
+    idx = np.where(valid, tl, 0)
+    loss = -np.take_along_axis(lp, idx[..., None], axis=-1)[..., 0]
+    loss = np.where(valid, loss, np.float32(0.0)).astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return -(loss.sum(axis=1, dtype=np.float32) / np.count_nonzero(loss, axis=1).astype(np.float32))
+
+
+def tvg_criterion(logits: np.ndarray, labels: np.ndarray) -> np.ndarray:
+    """retrieval_utils.py:40-43: CE over the video vocabulary, mean over clips, negated."""
+    lp = log_softmax(logits.astype(np.float32))
+    loss = -np.take_along_axis(lp, labels[..., None], axis=-1)[..., 0]
+    return -loss.mean(axis=1, dtype=np.float32)
+
+
+# ----------------------------------------------------------------------------- scoring API
+
+def padding_ids(input_ids: List[np.ndarray], labels: List[np.ndarray], masks: List[np.ndarray], pad_token_id: int):
+    """retrieval_utils.py:155-167: LEFT-pad ids (pad id), labels (-100), masks (0)."""
+    n = len(input_ids)
+    L = max(len(x) for x in input_ids)
+    ids = np.full((n, L), pad_token_id, dtype=np.int64)
+    lab = np.full((n, L), IGNORE_INDEX, dtype=np.int64)
+    msk = np.zeros((n, L), dtype=np.int64)
+    for i in range(n):
+        c = len(input_ids[i])
+        ids[i, L - c:] = input_ids[i]
+        lab[i, L - c:] = labels[i]
+        msk[i, L - c:] = masks[i]
+    return ids, lab, msk
+
+
+def topk_indices(sims: np.ndarray, k: int) -> np.ndarray:
+    """sims.topk(k) indices, largest first (retrieval_utils.py:52, 117).  Inputs used for parity are tie-free."""
+    return np.argsort(-sims, kind="stable")[:k]
+
+
+def _tvg_scores(model: OracleModel, hidden: np.ndarray, labels: np.ndarray, video_vocab: np.ndarray,
+                vid_labels: np.ndarray, num_clips: int) -> np.ndarray:
+    """retrieval_utils.py:99, 104-107."""
+    B = hidden.shape[0]
+    p = np.array([np.nonzero(labels[b] == IMAGE_TOKEN_ID)[0][0] for b in range(B)])
+    idx = p[:, None] + (np.arange(num_clips) - (num_clips + 1))[None, :]
+    emb = np.stack([hidden[b, idx[b]] for b in range(B)])                # [B, clips, H]
+    emb = model.forward_visual(emb)                                     # [B, clips, M]
+    # bmm([clips,B,M],[clips,M,N]) -> [B, clips, N], / sqrt(M)
+    logits = np.einsum("bcm,ncm->bcn", emb, video_vocab.astype(np.float32)) / np.float32(math.sqrt(video_vocab.shape[-1]))
+    return tvg_criterion(logits.astype(np.float32), vid_labels)
+
+
+def compute_v2t_scores_x(S: np.ndarray, sims_rows: np.ndarray, start: int, input_ids, attention_masks, labels,
+                         video: List[np.ndarray], video_vocab: np.ndarray, tvg_video_labels: np.ndarray,
+                         model: OracleModel, topk: int, batch_size_eval: int, num_clips: int,
+                         forward_type: str, cpn: bool = False) -> np.ndarray:
+    """retrieval_utils.py:48-111: video query -> top-k text candidates, batches of bs."""
+    for i, sims in enumerate(sims_rows):
+        k = min(len(sims), topk)
+        idx = topk_indices(sims, k)
+        out = []
+        for j in range(0, k, batch_size_eval):
+            sel = idx[j: j + batch_size_eval]
+            n = len(sel)
+            vids = [video[start + i]] * n
+            mask, cpn_mask, emb, lab = model.prepare_inputs_labels_for_multimodal(
+                input_ids[sel], attention_masks[sel], labels[sel], vids, tvg=(forward_type == "tvg"))
+            hid = model.forward_hidden(emb, cpn_mask if cpn else mask)
+            if forward_type == "vtg":
+                out.append(model.label_logprobs(hid, lab))
+            else:
+                vl = np.full((n, num_clips), tvg_video_labels[start + i], dtype=np.int64)
+                out.append(_tvg_scores(model, hid, lab, video_vocab, vl, num_clips))
+        S[start + i, idx] = np.concatenate(out)
+    return S
+
+
+def compute_t2v_scores_x(S: np.ndarray, sims_rows: np.ndarray, start: int, input_ids, attention_masks, labels,
+                         video: List[np.ndarray], video_vocab: np.ndarray, tvg_video_labels: np.ndarray,
+                         model: OracleModel, topk: int, batch_size_eval: int, num_clips: int,
+                         forward_type: str, cpn: bool = False) -> np.ndarray:
+    """retrieval_utils.py:113-153: text query (row repeated) -> top-k video candidates."""
+    for i, sims in enumerate(sims_rows):
+        k = min(len(sims), topk)
+        idx = topk_indices(sims, k)
+        out = []
+        for j in range(0, k, batch_size_eval):
+            sel = idx[j: j + batch_size_eval]
+            n = len(sel)
+            vids = [video[v] for v in sel]
+            rep = lambda a: np.repeat(a[start + i][None, :], n, axis=0)
+            mask, cpn_mask, emb, lab = model.prepare_inputs_labels_for_multimodal(
+                rep(input_ids), rep(attention_masks), rep(labels), vids, tvg=(forward_type == "tvg"))
+            hid = model.forward_hidden(emb, cpn_mask if cpn else mask)
+            if forward_type == "vtg":
+                out.append(model.label_logprobs(hid, lab))
+            else:
+                vl = np.repeat(tvg_video_labels[sel][:, None], num_clips, axis=1)
+                out.append(_tvg_scores(model, hid, lab, video_vocab, vl, num_clips))
+        S[start + i, idx] = np.concatenate(out)
+    return S
+
+
+# ----------------------------------------------------------------------------- metrics
+
+def get_recall(t2v: np.ndarray, v2t: np.ndarray) -> Dict[str, float]:
+    """training_utils.py:173-221 with identity ground truth (ids {i: i}, :146-147)."""
+    def one(m):
+        if np.count_nonzero(m == 0) != 0:                               # zero sentinel :174-175
+            return 0.0, 0.0, 0.0
+        ranks = np.zeros(m.shape[0])
+        for i, row in enumerate(m):
+            order = np.argsort(row)[::-1]
+            ranks[i] = np.where(order == i)[0][0]
+        n = len(ranks)
+        return tuple(100.0 * np.count_nonzero(ranks < t) / n for t in (1, 5, 10))
+    v1, v5, v10 = one(v2t)
+    t1, t5, t10 = one(t2v)
+    vm, tm = (v1 + v5 + v10) / 3, (t1 + t5 + t10) / 3
+    r = {"t2v_r1": t1, "t2v_r5": t5, "t2v_r10": t10, "t2v_r_mean": tm,
+         "v2t_r1": v1, "v2t_r5": v5, "v2t_r10": v10, "v2t_r_mean": vm, "r_mean": (vm + tm) / 2}
+    return {k: round(v, 2) for k, v in r.items()}
+
+
+def combine_scores(t2v: Dict[str, np.ndarray], v2t: Dict[str, np.ndarray], alpha, c, cpn: bool, finetuned: bool):
+    """training_utils.py:150-167: CPN subtraction and the two linear ensembles."""
+    n = v2t["candidate_likelihood"].shape[0]
+    if cpn:
+        cpn_t2v = t2v["candidate_likelihood"] - alpha[0] * t2v["candidate_prior"] if finetuned else np.zeros((n, n))
+        cpn_v2t = v2t["candidate_likelihood"] - alpha[1] * v2t["candidate_prior"]
+    else:
+        cpn_t2v = t2v["candidate_likelihood"] if finetuned else np.zeros((n, n))
+        cpn_v2t = v2t["candidate_likelihood"]
+    blim_t2v = c[0] * t2v["query_likelihood"] + (1 - c[0]) * cpn_t2v
+    blim_v2t = c[1] * v2t["query_likelihood"] + (1 - c[1]) * cpn_v2t if finetuned else cpn_v2t
+    blim_t2v = c[2] * blim_t2v + (1 - c[2]) * t2v["internvideo2"]
+    blim_v2t = c[3] * blim_v2t + (1 - c[3]) * v2t["internvideo2"]
+    return cpn_t2v, cpn_v2t, blim_t2v, blim_v2t
