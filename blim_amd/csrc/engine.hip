@@ -1,0 +1,644 @@
+// C-ABI of the scoring engine (include/blim.h): weight store, workspaces and the launch sequence of
+// the decoder / scoring heads.  One engine per process per GPU; all kernels are launched on the
+// caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/blim.h"
+#include "attention.hpp"
+#include "common.hpp"
+#include "gemm.hpp"
+#include "kernels.hpp"
+
+// ---------------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+void blim_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* blim_last_error(void) { return g_err; }
+extern "C" int blim_abi_version(void) { return BLIM_ABI_VERSION; }
+
+#define TRY(expr)                 \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != BLIM_OK) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------------------- timing classes
+enum TimeClass { TC_GEMM_QKV = 0, TC_ATTN, TC_GEMM_O, TC_GEMM_GATEUP, TC_GEMM_DOWN, TC_NORM, TC_LMHEAD_LSE, TC_GEMM_OTHER, TC_MISC, TC_COUNT };
+static const char* kTimeClassNames[TC_COUNT] = {"gemm_qkv_rope", "attention", "gemm_o_resid", "gemm_gateup_swiglu", "gemm_down_resid",
+                                                "rmsnorm", "lm_head_lse", "gemm_other", "misc"};
+
+struct TimedSpan { hipEvent_t a, b; int cls; double flops; };
+
+// ---------------------------------------------------------------------------- engine
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct LayerW {
+    float* norm1 = nullptr; float* norm2 = nullptr;
+    bf16_t* wqkv = nullptr; float* bqkv = nullptr;
+    bf16_t* wo = nullptr; bf16_t* wgu = nullptr; bf16_t* wd = nullptr;
+};
+
+struct blim_engine {
+    blim_config c;
+    int hd = 128;
+    int qkv_n = 0;
+    std::vector<LayerW> L;
+    bf16_t* embed = nullptr; bf16_t* lm_head = nullptr; bf16_t* visual_head = nullptr;
+    float* final_norm = nullptr;
+    bf16_t* mlp_w0[2] = {nullptr, nullptr}; float* mlp_b0[2] = {nullptr, nullptr};
+    bf16_t* mlp_w2[2] = {nullptr, nullptr}; float* mlp_b2[2] = {nullptr, nullptr};
+    float* rope_cos = nullptr; float* rope_sin = nullptr;
+    std::map<std::string, bool> loaded;
+    std::vector<void*> owned;
+    // workspaces
+    DevBuf resid, xn, qkv, attn, act, hsel, lse_part, lab_logit, logprob, stage, proj_tmp, vh, tvg_logits, dense_idx;
+    // options / timing
+    int attn_tr = 1;
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+};
+
+static int dev_alloc(blim_engine* e, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes));
+    e->owned.push_back(*p);
+    return BLIM_OK;
+}
+static int ensure(DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return BLIM_OK;
+    if (b.p) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    const size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return BLIM_OK;
+}
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct SpanGuard {
+    blim_engine* e; hipStream_t s; int idx = -1;
+    SpanGuard(blim_engine* e_, hipStream_t s_, int cls, double flops) : e(e_), s(s_) {
+        if (!e->timing) return;
+        TimedSpan t; t.cls = cls; t.flops = flops;
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+        hipEventRecord(t.a, s);
+        e->spans.push_back(t);
+        idx = (int)e->spans.size() - 1;
+    }
+    ~SpanGuard() { if (idx >= 0) hipEventRecord(e->spans[idx].b, s); }
+};
+
+// ---------------------------------------------------------------------------- weight layout kernels
+// dst row r <- src row map(r); modes: 0 identity, 1 q/k RoPE pair interleave inside each 128-row head,
+// 2 gate rows of the fused gate|up matrix, 3 up rows.  SRC_F32: convert to bf16 (RNE).
+__device__ __forceinline__ int64_t src_row_of(int64_t r, int mode) {
+    if (mode == 1) { const int64_t h = r >> 7; const int c = (int)(r & 127); return (h << 7) + 16 * (c >> 5) + (c & 15) + 64 * ((c >> 4) & 1); }
+    return r;
+}
+template <bool SRC_F32>
+__global__ void place_rows_kernel(bf16_t* dst, const void* src, int64_t n_rows, int K, int mode) {
+    // grid-stride over (row, 4-element chunk)
+    const int chunks = K / 4;
+    const int64_t total = n_rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        int64_t drow, srow;
+        if (mode == 2) { srow = r; drow = (r >> 4) * 32 + (r & 15); }
+        else if (mode == 3) { srow = r; drow = (r >> 4) * 32 + 16 + (r & 15); }
+        else { drow = r; srow = src_row_of(r, mode); }
+        uint2 pk;
+        if (SRC_F32) {
+            const float4 v = *(const float4*)((const float*)src + srow * K + 4 * c);
+            pk = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        } else {
+            pk = *(const uint2*)((const bf16_t*)src + srow * K + 4 * c);
+        }
+        *(uint2*)(dst + drow * K + 4 * c) = pk;
+    }
+}
+// f32 vector placement (biases, norm weights): dst[map(i)] = f32(src[i])
+template <bool SRC_F32>
+__global__ void place_vec_kernel(float* dst, const void* src, int64_t n, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t s = src_row_of(i, mode);
+    dst[i] = SRC_F32 ? ((const float*)src)[s] : bf16_to_f32(((const bf16_t*)src)[s]);
+}
+__global__ void rope_table_kernel(float* cosb, float* sinb, int n_pos, int half, float theta, int head_dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos * half) return;
+    const int p = i / half, k = i - p * half;
+    // modeling_qwen2_flash.py:112: inv_freq = 1 / theta^(2k/d) in f32; :120-125 angle = pos * inv_freq in f32
+    const float inv = 1.0f / powf(theta, (float)(2 * k) / (float)head_dim);
+    const float ang = (float)p * inv;
+    cosb[i] = cosf(ang);
+    sinb[i] = sinf(ang);
+}
+__global__ void dense_batch_kernel(int32_t* pos, int32_t* seq_start, int32_t* seq_len, int32_t* pfx, int32_t* blk_seq, int32_t* blk_q0,
+                                   int B, int L, int nblk_per_seq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * L) pos[i] = i % L;
+    if (i < B) { seq_start[i] = i * L; seq_len[i] = L; pfx[i] = 0; }
+    if (i < B * nblk_per_seq) { blk_seq[i] = i / nblk_per_seq; blk_q0[i] = 32 * (i % nblk_per_seq); }
+}
+
+// ---------------------------------------------------------------------------- create / destroy
+extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
+    ARG_CHECK(cfg && out);
+    ARG_CHECK(cfg->hidden_size > 0 && cfg->num_heads > 0 && cfg->num_kv_heads > 0 && cfg->num_layers > 0);
+    ARG_CHECK(cfg->hidden_size % cfg->num_heads == 0);
+    if (cfg->hidden_size / cfg->num_heads != 128) {
+        blim_set_error("head_dim %d unsupported: the attention / RoPE kernels are built for head_dim 128", cfg->hidden_size / cfg->num_heads);
+        return BLIM_ERR_ARG;
+    }
+    ARG_CHECK(cfg->num_heads % cfg->num_kv_heads == 0 && cfg->num_heads / cfg->num_kv_heads <= 8);
+    ARG_CHECK(cfg->hidden_size % 64 == 0 && cfg->intermediate_size % 64 == 0 && cfg->mm_hidden_size % 64 == 0);
+    ARG_CHECK(cfg->vocab_size > 0 && cfg->max_positions > 0 && cfg->num_clips > 0);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        blim_set_error("no HIP device visible: the BLiM engine has no CPU fallback");
+        return BLIM_ERR_HIP;
+    }
+    blim_engine* e = new blim_engine();
+    e->c = *cfg;
+    const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
+    e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
+    e->L.resize(cfg->num_layers);
+    int rc = BLIM_OK;
+#define A(ptr, count, type) do { if (rc == BLIM_OK) rc = dev_alloc(e, (void**)&(ptr), (size_t)(count) * sizeof(type)); } while (0)
+    A(e->embed, (int64_t)V * H, bf16_t);
+    A(e->lm_head, (int64_t)V * H, bf16_t);
+    A(e->visual_head, (int64_t)M * H, bf16_t);
+    A(e->final_norm, H, float);
+    for (int w = 0; w < 2; ++w) {
+        A(e->mlp_w0[w], (int64_t)H * M, bf16_t); A(e->mlp_b0[w], H, float);
+        A(e->mlp_w2[w], (int64_t)H * H, bf16_t); A(e->mlp_b2[w], H, float);
+    }
+    for (auto& l : e->L) {
+        A(l.norm1, H, float); A(l.norm2, H, float);
+        A(l.wqkv, (int64_t)e->qkv_n * H, bf16_t); A(l.bqkv, e->qkv_n, float);
+        A(l.wo, (int64_t)H * H, bf16_t);
+        A(l.wgu, (int64_t)2 * I * H, bf16_t);
+        A(l.wd, (int64_t)H * I, bf16_t);
+    }
+    A(e->rope_cos, (int64_t)cfg->max_positions * 64, float);
+    A(e->rope_sin, (int64_t)cfg->max_positions * 64, float);
+#undef A
+    if (rc != BLIM_OK) { blim_destroy(e); return rc; }
+    const int n = cfg->max_positions * 64;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, e->rope_cos, e->rope_sin, cfg->max_positions, 64, cfg->rope_theta, 128);
+    if (hipDeviceSynchronize() != hipSuccess) { blim_set_error("rope table init failed"); blim_destroy(e); return BLIM_ERR_HIP; }
+    *out = e;
+    return BLIM_OK;
+}
+
+extern "C" void blim_destroy(blim_engine* e) {
+    if (!e) return;
+    hipDeviceSynchronize();
+    for (void* p : e->owned) hipFree(p);
+    DevBuf* bufs[] = {&e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx};
+    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    delete e;
+}
+
+// ---------------------------------------------------------------------------- weights
+struct WeightSlot { int kind; /*0 matrix->bf16, 1 vector->f32*/ void* dst; int64_t rows; int64_t cols; int mode; int64_t dst_row_off; };
+
+static bool find_slot(blim_engine* e, const std::string& name, WeightSlot& s) {
+    const blim_config& c = e->c;
+    const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, M = c.mm_hidden_size;
+    const int64_t qn = (int64_t)c.num_heads * 128, kn = (int64_t)c.num_kv_heads * 128;
+    auto mat = [&](void* d, int64_t r, int64_t k, int mode, int64_t off) { s = {0, d, r, k, mode, off}; return true; };
+    auto vec = [&](void* d, int64_t n, int mode, int64_t off) { s = {1, d, n, 1, mode, off}; return true; };
+    if (name == "embed_tokens") return mat(e->embed, V, H, 0, 0);
+    if (name == "lm_head") return mat(e->lm_head, V, H, 0, 0);
+    if (name == "visual_head") return mat(e->visual_head, M, H, 0, 0);
+    if (name == "final_norm") return vec(e->final_norm, H, 0, 0);
+    for (int w = 0; w < 2; ++w) {
+        const std::string p = w ? "tvg_mlp." : "mlp.";
+        if (name == p + "0.w") return mat(e->mlp_w0[w], H, M, 0, 0);
+        if (name == p + "0.b") return vec(e->mlp_b0[w], H, 0, 0);
+        if (name == p + "2.w") return mat(e->mlp_w2[w], H, H, 0, 0);
+        if (name == p + "2.b") return vec(e->mlp_b2[w], H, 0, 0);
+    }
+    int li = -1; char rest[64] = "";
+    if (sscanf(name.c_str(), "layers.%d.%63s", &li, rest) == 2 && li >= 0 && li < c.num_layers) {
+        LayerW& l = e->L[li];
+        const std::string r(rest);
+        if (r == "input_norm") return vec(l.norm1, H, 0, 0);
+        if (r == "post_norm") return vec(l.norm2, H, 0, 0);
+        if (r == "q_proj.w") return mat(l.wqkv, qn, H, 1, 0);
+        if (r == "k_proj.w") return mat(l.wqkv, kn, H, 1, qn);
+        if (r == "v_proj.w") return mat(l.wqkv, kn, H, 0, qn + kn);
+        if (r == "q_proj.b") return vec(l.bqkv, qn, 1, 0);
+        if (r == "k_proj.b") return vec(l.bqkv, kn, 1, qn);
+        if (r == "v_proj.b") return vec(l.bqkv, kn, 0, qn + kn);
+        if (r == "o_proj.w") return mat(l.wo, H, H, 0, 0);
+        if (r == "gate_proj.w") return mat(l.wgu, I, H, 2, 0);
+        if (r == "up_proj.w") return mat(l.wgu, I, H, 3, 0);
+        if (r == "down_proj.w") return mat(l.wd, H, I, 0, 0);
+    }
+    return false;
+}
+
+static int place_weight(blim_engine* e, const std::string& name, const void* dev_src, int dtype) {
+    WeightSlot s;
+    if (!find_slot(e, name, s)) { blim_set_error("unknown weight name '%s'", name.c_str()); return BLIM_ERR_ARG; }
+    if (s.kind == 0) {
+        ARG_CHECK(s.cols % 4 == 0);
+        bf16_t* dst = (bf16_t*)s.dst + s.dst_row_off * s.cols;
+        const int64_t total = s.rows * (s.cols / 4);
+        const int grid = (int)std::min<int64_t>((total + 255) / 256, 16384);
+        if (dtype == BLIM_DTYPE_F32) hipLaunchKernelGGL(place_rows_kernel<true>, dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
+        else hipLaunchKernelGGL(place_rows_kernel<false>, dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
+    } else {
+        float* dst = (float*)s.dst + s.dst_row_off;
+        const int grid = (int)((s.rows + 255) / 256);
+        if (dtype == BLIM_DTYPE_F32) hipLaunchKernelGGL(place_vec_kernel<true>, dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, s.mode);
+        else hipLaunchKernelGGL(place_vec_kernel<false>, dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, s.mode);
+    }
+    HIP_TRY(hipGetLastError());
+    e->loaded[name] = true;
+    return BLIM_OK;
+}
+
+static std::vector<std::string> all_weight_names(const blim_engine* e) {
+    std::vector<std::string> n = {"embed_tokens", "final_norm", "lm_head", "visual_head"};
+    for (const char* p : {"mlp", "tvg_mlp"}) for (const char* t : {"0.w", "0.b", "2.w", "2.b"}) n.push_back(std::string(p) + "." + t);
+    for (int i = 0; i < e->c.num_layers; ++i)
+        for (const char* t : {"input_norm", "post_norm", "q_proj.w", "q_proj.b", "k_proj.w", "k_proj.b", "v_proj.w", "v_proj.b", "o_proj.w",
+                              "gate_proj.w", "up_proj.w", "down_proj.w"})
+            n.push_back("layers." + std::to_string(i) + "." + t);
+    return n;
+}
+
+extern "C" int blim_load_weight(blim_engine* e, const char* name, const void* data, int32_t dtype, int32_t on_device) {
+    ARG_CHECK(e && name && data && (dtype == BLIM_DTYPE_F32 || dtype == BLIM_DTYPE_BF16));
+    WeightSlot s;
+    if (!find_slot(e, name, s)) { blim_set_error("unknown weight name '%s'", name); return BLIM_ERR_ARG; }
+    const void* src = data;
+    if (!on_device) {
+        const size_t bytes = (size_t)s.rows * s.cols * (dtype == BLIM_DTYPE_F32 ? 4 : 2);
+        TRY(ensure(e->stage, bytes));
+        HIP_TRY(hipMemcpy(e->stage.p, data, bytes, hipMemcpyHostToDevice));
+        src = e->stage.p;
+    }
+    TRY(place_weight(e, name, src, dtype));
+    HIP_TRY(hipDeviceSynchronize());
+    return BLIM_OK;
+}
+
+static uint64_t fnv1a64(const char* s) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (; *s; ++s) { h ^= (uint8_t)*s; h *= 0x100000001B3ull; }
+    return h;
+}
+static const double kSigma4 = 37837.22723328507;  // sqrt(4 * (65536^2 - 1) / 12)
+
+extern "C" int blim_init_synthetic_weights(blim_engine* e, uint64_t seed) {
+    ARG_CHECK(e);
+    for (const std::string& name : all_weight_names(e)) {
+        WeightSlot s;
+        if (!find_slot(e, name, s)) { blim_set_error("internal: no slot for %s", name.c_str()); return BLIM_ERR_STATE; }
+        const int64_t n = s.rows * s.cols;
+        const bool is_norm = name.size() >= 4 && name.compare(name.size() - 4, 4, "norm") == 0;
+        const float std_ = is_norm ? 0.1f : 0.02f, mean = is_norm ? 1.0f : 0.0f;
+        const float scale = (float)((double)std_ / kSigma4);
+        if (s.kind == 0) {
+            TRY(ensure(e->stage, (size_t)n * 2));
+            TRY(launch_fill_bell_bf16((bf16_t*)e->stage.p, n, seed, fnv1a64(name.c_str()), scale, mean, 0));
+            TRY(place_weight(e, name, e->stage.p, BLIM_DTYPE_BF16));
+        } else {
+            TRY(ensure(e->stage, (size_t)n * 4));
+            TRY(launch_fill_bell_f32((float*)e->stage.p, n, seed, fnv1a64(name.c_str()), scale, mean, 1, 0));
+            TRY(place_weight(e, name, e->stage.p, BLIM_DTYPE_F32));
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return BLIM_OK;
+}
+
+extern "C" int blim_weights_ready(const blim_engine* e) {
+    ARG_CHECK(e);
+    for (const std::string& n : all_weight_names(e)) {
+        auto it = e->loaded.find(n);
+        if (it == e->loaded.end()) { blim_set_error("weight '%s' not loaded", n.c_str()); return BLIM_ERR_STATE; }
+    }
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- workspaces
+static int reserve_tokens(blim_engine* e, int64_t T) {
+    const blim_config& c = e->c;
+    const int64_t Tp = round_up(T, 256);
+    TRY(ensure(e->resid, (size_t)Tp * c.hidden_size * 4));
+    TRY(ensure(e->xn, (size_t)Tp * c.hidden_size * 2));
+    TRY(ensure(e->qkv, (size_t)Tp * e->qkv_n * 2));
+    TRY(ensure(e->attn, (size_t)Tp * c.hidden_size * 2));
+    TRY(ensure(e->act, (size_t)Tp * c.intermediate_size * 2));
+    return BLIM_OK;
+}
+static int reserve_rows(blim_engine* e, int64_t R) {
+    const blim_config& c = e->c;
+    const int64_t Rp = round_up(R, 256);
+    const int ntn = (c.vocab_size + 255) / 256;
+    TRY(ensure(e->hsel, (size_t)Rp * c.hidden_size * 2));
+    TRY(ensure(e->lse_part, (size_t)Rp * ntn * sizeof(float2)));
+    TRY(ensure(e->lab_logit, (size_t)Rp * 4));
+    TRY(ensure(e->logprob, (size_t)Rp * 4));
+    return BLIM_OK;
+}
+extern "C" int blim_reserve(blim_engine* e, int64_t max_tokens, int64_t max_rows) {
+    ARG_CHECK(e && max_tokens >= 0 && max_rows >= 0);
+    if (max_tokens) TRY(reserve_tokens(e, max_tokens));
+    if (max_rows) TRY(reserve_rows(e, max_rows));
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- component ops
+static GemmParams gp(const void* A, int64_t lda, const void* W, int64_t M, int N, int K, void* C, int64_t ldc) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.M = (int)M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.scale = 1.0f;
+    return p;
+}
+
+extern "C" int blim_project_video(blim_engine* e, const void* feats, int64_t n_rows, int32_t which, void* out, void* stream) {
+    ARG_CHECK(e && feats && out && n_rows > 0 && (which == 0 || which == 1));
+    TRY(blim_weights_ready(e));
+    hipStream_t s = (hipStream_t)stream;
+    const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
+    TRY(ensure(e->proj_tmp, (size_t)round_up(n_rows, 256) * H * 2));
+    SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_rows * ((double)M * H + (double)H * H));
+    GemmParams p1 = gp(feats, M, e->mlp_w0[which], n_rows, H, M, e->proj_tmp.p, H);
+    p1.bias = e->mlp_b0[which]; p1.act = 1;
+    TRY(launch_gemm(EPI_BF16, p1, s));
+    GemmParams p2 = gp(e->proj_tmp.p, H, e->mlp_w2[which], n_rows, H, H, out, H);
+    p2.bias = e->mlp_b2[which];
+    TRY(launch_gemm(EPI_BF16, p2, s));
+    return BLIM_OK;
+}
+
+extern "C" int blim_group_mean(blim_engine* e, const void* in, int64_t n_out, int32_t group, void* out, void* stream) {
+    ARG_CHECK(e && in && out);
+    return launch_group_mean_bf16((bf16_t*)out, (const bf16_t*)in, n_out, group, e->c.hidden_size, (hipStream_t)stream);
+}
+
+extern "C" int blim_assemble(blim_engine* e, const int32_t* src_index, int64_t n_tokens, const void* feats, void* out_embeds, void* stream) {
+    ARG_CHECK(e && src_index && out_embeds && n_tokens > 0);
+    TRY(blim_weights_ready(e));
+    SpanGuard g(e, (hipStream_t)stream, TC_MISC, 0);
+    return launch_assemble((bf16_t*)out_embeds, src_index, n_tokens, e->c.hidden_size, e->embed, (const bf16_t*)feats, (hipStream_t)stream);
+}
+
+static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, hipStream_t s) {
+    const blim_config& c = e->c;
+    const int H = c.hidden_size, I = c.intermediate_size;
+    const int64_t T = b->n_tokens;
+    TRY(reserve_tokens(e, T));
+    float* resid = (float*)e->resid.p;
+    bf16_t* xn = (bf16_t*)e->xn.p; bf16_t* qkv = (bf16_t*)e->qkv.p; bf16_t* attn = (bf16_t*)e->attn.p; bf16_t* act = (bf16_t*)e->act.p;
+    { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_bf16_to_f32(resid, (const bf16_t*)embeds, T * H, s)); }
+    const double tok = (double)T;
+    for (int li = 0; li < c.num_layers; ++li) {
+        const LayerW& l = e->L[li];
+        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, nullptr, s)); }
+        {
+            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n);
+            GemmParams p = gp(xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
+            p.bias = l.bqkv; p.pos = b->positions; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
+            p.rope_cols = (c.num_heads + c.num_kv_heads) * 128;
+            TRY(launch_gemm(EPI_QKV, p, s));
+        }
+        {
+            SpanGuard g(e, s, TC_ATTN, 0);
+            AttnParams a;
+            a.qkv = qkv; a.ldq = e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
+            a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
+            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = H; a.scale = 0.08838834764831845f;
+            TRY(launch_attention(a, e->attn_tr, s));
+        }
+        {
+            SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H);
+            GemmParams p = gp(attn, H, l.wo, T, H, H, resid, H);
+            TRY(launch_gemm(EPI_RESID, p, s));
+        }
+        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, nullptr, s)); }
+        {
+            SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I);
+            GemmParams p = gp(xn, H, l.wgu, T, 2 * I, H, act, I);
+            TRY(launch_gemm(EPI_SWIGLU, p, s));
+        }
+        {
+            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I);
+            GemmParams p = gp(act, I, l.wd, T, H, I, resid, H);
+            TRY(launch_gemm(EPI_RESID, p, s));
+        }
+    }
+    return BLIM_OK;
+}
+
+static int check_batch(const blim_batch* b) {
+    ARG_CHECK(b && b->n_tokens > 0 && b->n_seqs > 0 && b->n_blocks > 0);
+    ARG_CHECK(b->positions && b->key_visible && b->seq_start && b->seq_len && b->pfx_start && b->pfx_len && b->blk_seq && b->blk_q0);
+    return BLIM_OK;
+}
+
+extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
+                           void* out_hidden_bf16, float* out_hidden_f32, void* stream) {
+    ARG_CHECK(e && embeds && (out_hidden_bf16 || out_hidden_f32));
+    TRY(check_batch(b));
+    TRY(blim_weights_ready(e));
+    hipStream_t s = (hipStream_t)stream;
+    TRY(run_layers(e, b, embeds, s));
+    const int64_t n = out_rows ? n_out : b->n_tokens;
+    ARG_CHECK(n > 0);
+    SpanGuard g(e, s, TC_NORM, 0);
+    return launch_rmsnorm((const float*)e->resid.p, e->c.hidden_size, out_rows, n, e->c.hidden_size, e->final_norm, e->c.rms_eps,
+                          (bf16_t*)out_hidden_bf16, out_hidden_f32, s);
+}
+
+extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
+    ARG_CHECK(e && hidden_bf16 && labels && logprob && n_rows > 0);
+    TRY(blim_weights_ready(e));
+    hipStream_t s = (hipStream_t)stream;
+    const int H = e->c.hidden_size, V = e->c.vocab_size;
+    TRY(reserve_rows(e, n_rows));
+    const int ntn = (V + 255) / 256;
+    HIP_TRY(hipMemsetAsync(e->lab_logit.p, 0, (size_t)n_rows * 4, s));
+    {
+        SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)H * V);
+        GemmParams p = gp(hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
+        p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
+        TRY(launch_gemm(EPI_LSE, p, s));
+    }
+    SpanGuard g(e, s, TC_MISC, 0);
+    return launch_lse_combine((const float2*)e->lse_part.p, ntn, (const float*)e->lab_logit.p, labels, n_rows, logprob, s);
+}
+
+extern "C" int blim_segment_mean(blim_engine* e, const float* logprob, const int32_t* row_start, int32_t n_pairs, int32_t mode, float* score, void* stream) {
+    (void)e;
+    return launch_segment_mean(logprob, row_start, n_pairs, mode, score, (hipStream_t)stream);
+}
+
+extern "C" int blim_lm_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, float* logits, void* stream) {
+    ARG_CHECK(e && hidden_bf16 && logits && n_rows > 0);
+    TRY(blim_weights_ready(e));
+    const int H = e->c.hidden_size, V = e->c.vocab_size;
+    SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * V);
+    GemmParams p = gp(hidden_bf16, H, e->lm_head, n_rows, V, H, logits, V);
+    return launch_gemm(EPI_F32, p, (hipStream_t)stream);
+}
+
+extern "C" int blim_ce_rows(blim_engine* e, const float* logits, int64_t ld, int32_t n_cols, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
+    (void)e;
+    return launch_ce_rows(logits, ld, n_cols, labels, n_rows, logprob, (hipStream_t)stream);
+}
+
+extern "C" int blim_visual_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, void* out_bf16, void* stream) {
+    ARG_CHECK(e && hidden_bf16 && out_bf16 && n_rows > 0);
+    TRY(blim_weights_ready(e));
+    const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
+    SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * M);
+    GemmParams p = gp(hidden_bf16, H, e->visual_head, n_rows, M, H, out_bf16, M);
+    return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
+}
+
+extern "C" int blim_tvg_logits(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream) {
+    ARG_CHECK(e && vh_bf16 && vocab_bf16 && logits && n_vocab > 0 && n_pairs > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int M = e->c.mm_hidden_size, C = e->c.num_clips;
+    SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_pairs * C * (double)M * n_vocab);
+    for (int c = 0; c < C; ++c) {
+        GemmParams p = gp((const bf16_t*)vh_bf16 + (int64_t)c * M, (int64_t)C * M, (const bf16_t*)vocab_bf16 + (int64_t)c * n_vocab * M, n_pairs, n_vocab, M,
+                          logits + (int64_t)c * n_vocab, (int64_t)C * n_vocab);
+        p.scale = 1.0f / sqrtf((float)M);
+        TRY(launch_gemm(EPI_F32, p, s));
+    }
+    return BLIM_OK;
+}
+
+extern "C" int blim_tvg_scores(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, const int32_t* labels,
+                               int32_t n_pairs, float* score, void* stream) {
+    ARG_CHECK(e && labels && score && n_vocab > 0 && n_pairs > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = e->c.num_clips;
+    TRY(ensure(e->tvg_logits, (size_t)n_pairs * C * n_vocab * 4));
+    float* lg = (float*)e->tvg_logits.p;
+    TRY(blim_tvg_logits(e, vh_bf16, vocab_bf16, n_vocab, n_pairs, lg, stream));
+    SpanGuard g(e, s, TC_MISC, 0);
+    return launch_tvg_score(lg, n_vocab, n_vocab, labels, n_pairs, C, score, s);
+}
+
+// ---------------------------------------------------------------------------- fused scoring
+extern "C" int blim_score_vtg(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* rows, const int32_t* labels,
+                              int64_t n_rows, const int32_t* row_start, int32_t n_pairs, float* score, void* stream) {
+    ARG_CHECK(e && rows && labels && row_start && score && n_rows > 0 && n_pairs > 0);
+    TRY(reserve_rows(e, n_rows));
+    TRY(blim_decode(e, b, embeds, rows, n_rows, e->hsel.p, nullptr, stream));
+    TRY(blim_vtg_logprobs(e, e->hsel.p, labels, n_rows, (float*)e->logprob.p, stream));
+    return blim_segment_mean(e, (const float*)e->logprob.p, row_start, n_pairs, 0, score, stream);
+}
+
+extern "C" int blim_score_tvg(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* rows, const void* vocab_bf16,
+                              int32_t n_vocab, const int32_t* labels, int32_t n_pairs, float* score, void* stream) {
+    ARG_CHECK(e && rows && vocab_bf16 && labels && score && n_pairs > 0);
+    const int64_t n_rows = (int64_t)n_pairs * e->c.num_clips;
+    TRY(reserve_rows(e, n_rows));
+    TRY(ensure(e->vh, (size_t)round_up(n_rows, 256) * e->c.mm_hidden_size * 2));
+    TRY(blim_decode(e, b, embeds, rows, n_rows, e->hsel.p, nullptr, stream));
+    TRY(blim_visual_head(e, e->hsel.p, n_rows, e->vh.p, stream));
+    return blim_tvg_scores(e, e->vh.p, vocab_bf16, n_vocab, labels, n_pairs, score, stream);
+}
+
+// ---------------------------------------------------------------------------- literal forward
+extern "C" int blim_forward(blim_engine* e, const void* embeds, const uint8_t* mask, int32_t B, int32_t L, float* logits, float* hidden, void* stream) {
+    ARG_CHECK(e && embeds && mask && B > 0 && L > 0 && (logits || hidden));
+    ARG_CHECK(L <= e->c.max_positions);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t T = (int64_t)B * L;
+    const int nbs = (L + 31) / 32;
+    const size_t need = (size_t)(T + 3 * (size_t)B + 2 * (size_t)B * nbs) * 4;
+    TRY(ensure(e->dense_idx, need));
+    int32_t* pos = (int32_t*)e->dense_idx.p;
+    int32_t* seq_start = pos + T; int32_t* seq_len = seq_start + B; int32_t* pfx = seq_len + B;
+    int32_t* blk_seq = pfx + B; int32_t* blk_q0 = blk_seq + (int64_t)B * nbs;
+    const int64_t nthr = std::max<int64_t>(T, (int64_t)B * nbs);
+    hipLaunchKernelGGL(dense_batch_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, pos, seq_start, seq_len, pfx, blk_seq, blk_q0, B, L, nbs);
+    HIP_TRY(hipGetLastError());
+    blim_batch b;
+    b.n_tokens = T; b.n_seqs = B; b.n_blocks = B * nbs; b.positions = pos; b.key_visible = mask; b.seq_start = seq_start; b.seq_len = seq_len;
+    b.pfx_start = pfx; b.pfx_len = pfx; b.blk_seq = blk_seq; b.blk_q0 = blk_q0;
+    TRY(reserve_rows(e, T));
+    TRY(blim_decode(e, &b, embeds, nullptr, 0, e->hsel.p, hidden, stream));
+    if (logits) TRY(blim_lm_head(e, e->hsel.p, T, logits, stream));
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- synthetic data, plain GEMM
+extern "C" int blim_fill_bell_bf16(void* out, int64_t n, uint64_t seed, const char* name, float std_, float mean, void* stream) {
+    ARG_CHECK(out && name && n > 0);
+    return launch_fill_bell_bf16((bf16_t*)out, n, seed, fnv1a64(name), (float)((double)std_ / kSigma4), mean, (hipStream_t)stream);
+}
+extern "C" int blim_fill_bell_f32(float* out, int64_t n, uint64_t seed, const char* name, float std_, float mean, int32_t round_bf16, void* stream) {
+    ARG_CHECK(out && name && n > 0);
+    return launch_fill_bell_f32(out, n, seed, fnv1a64(name), (float)((double)std_ / kSigma4), mean, round_bf16, (hipStream_t)stream);
+}
+extern "C" int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream) {
+    GemmParams p = gp(A, lda, W, M, N, K, C, ldc);
+    return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------- timing / options
+extern "C" int blim_timing_enable(blim_engine* e, int32_t on) {
+    ARG_CHECK(e);
+    e->timing = on != 0;
+    return BLIM_OK;
+}
+extern "C" int blim_timing_num_classes(void) { return TC_COUNT; }
+extern "C" const char* blim_timing_class_name(int32_t cls) { return (cls >= 0 && cls < TC_COUNT) ? kTimeClassNames[cls] : ""; }
+extern "C" int blim_timing_report(blim_engine* e, double* ms, int64_t* calls, double* flops) {
+    ARG_CHECK(e && ms && calls && flops);
+    for (int i = 0; i < TC_COUNT; ++i) { ms[i] = 0; calls[i] = 0; flops[i] = 0; }
+    for (auto& s : e->spans) {
+        HIP_TRY(hipEventSynchronize(s.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, s.a, s.b));
+        ms[s.cls] += t; calls[s.cls] += 1; flops[s.cls] += s.flops;
+        hipEventDestroy(s.a); hipEventDestroy(s.b);
+    }
+    e->spans.clear();
+    return BLIM_OK;
+}
+extern "C" int blim_debug_read(blim_engine* e, const char* which, void* dst, int64_t bytes, void* stream) {
+    ARG_CHECK(e && which && dst && bytes > 0);
+    const DevBuf* b = nullptr;
+    if (!strcmp(which, "resid")) b = &e->resid;
+    else if (!strcmp(which, "xn")) b = &e->xn;
+    else if (!strcmp(which, "qkv")) b = &e->qkv;
+    else if (!strcmp(which, "attn")) b = &e->attn;
+    else if (!strcmp(which, "act")) b = &e->act;
+    if (!b || !b->p || (size_t)bytes > b->bytes) { blim_set_error("debug_read: no buffer '%s' of %lld bytes", which, (long long)bytes); return BLIM_ERR_ARG; }
+    HIP_TRY(hipMemcpyAsync(dst, b->p, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BLIM_OK;
+}
+extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
+    ARG_CHECK(e && key);
+    if (!strcmp(key, "attn_tr_read")) { e->attn_tr = value; return BLIM_OK; }
+    blim_set_error("unknown option '%s'", key);
+    return BLIM_ERR_ARG;
+}

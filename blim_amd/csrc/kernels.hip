@@ -196,7 +196,7 @@ int launch_group_mean_bf16(bf16_t* out, const bf16_t* in, int64_t n_out, int gro
 
 // ---------------------------------------------------------------------------- LSE combine (K11)
 // One wave per row: combine the per-tile (max, sumexp) partials.
-__global__ __launch_bounds__(256) void lse_combine_kernel(const float2* part, int n_tiles, const float* label_logit, int64_t n_rows, float* logprob) {
+__global__ __launch_bounds__(256) void lse_combine_kernel(const float2* part, int n_tiles, const float* label_logit, const int32_t* labels, int64_t n_rows, float* logprob) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
@@ -210,17 +210,17 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float2* part, in
         if (v.x > -INFINITY) sm += v.y * expf(v.x - mx);
     }
     sm = wave_sum(sm);
-    if (lane == 0) logprob[r] = label_logit[r] - (mx + logf(sm));
+    if (lane == 0) logprob[r] = labels[r] < 0 ? 0.f : label_logit[r] - (mx + logf(sm));
 }
-int launch_lse_combine(const float2* part, int n_tiles, const float* label_logit, int64_t n_rows, float* logprob, hipStream_t s) {
-    ARG_CHECK(part && label_logit && logprob && n_rows > 0 && n_tiles > 0);
-    hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, part, n_tiles, label_logit, n_rows, logprob);
+int launch_lse_combine(const float2* part, int n_tiles, const float* label_logit, const int32_t* labels, int64_t n_rows, float* logprob, hipStream_t s) {
+    ARG_CHECK(part && label_logit && labels && logprob && n_rows > 0 && n_tiles > 0);
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, part, n_tiles, label_logit, labels, n_rows, logprob);
     LAUNCH_CHECK("lse_combine");
     return BLIM_OK;
 }
 
 // score = sum / count_nonzero  (retrieval_utils.py:32, sign already folded: logprob = -loss)
-__global__ void segment_mean_kernel(const float* logprob, const int32_t* row_start, int n_pairs, float* score) {
+__global__ void segment_mean_kernel(const float* logprob, const int32_t* row_start, int n_pairs, int mode, float* score) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     float sm = 0.f;
@@ -230,11 +230,11 @@ __global__ void segment_mean_kernel(const float* logprob, const int32_t* row_sta
         sm += v;
         nz += (v != 0.f);
     }
-    score[p] = sm / (float)nz;
+    score[p] = sm / (float)(mode == 0 ? nz : row_start[p + 1] - row_start[p]);
 }
-int launch_segment_mean_nonzero(const float* logprob, const int32_t* row_start, int n_pairs, float* score, hipStream_t s) {
+int launch_segment_mean(const float* logprob, const int32_t* row_start, int n_pairs, int mode, float* score, hipStream_t s) {
     ARG_CHECK(logprob && row_start && score && n_pairs > 0);
-    hipLaunchKernelGGL(segment_mean_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, s, logprob, row_start, n_pairs, score);
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, s, logprob, row_start, n_pairs, mode, score);
     LAUNCH_CHECK("segment_mean");
     return BLIM_OK;
 }

@@ -21,11 +21,11 @@ int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_r
 // mean over groups of `group` consecutive rows: out[i,:] = mean_j in[i*group + j, :]   (bf16 in/out, f32 accumulate)
 int launch_group_mean_bf16(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, hipStream_t s);
 
-// logprob[r] = label_logit[r] - logsumexp over the n_tiles (max, sumexp) partials of row r
-int launch_lse_combine(const float2* part, int n_tiles, const float* label_logit, int64_t n_rows, float* logprob, hipStream_t s);
+// logprob[r] = labels[r] < 0 ? 0 : label_logit[r] - logsumexp over the n_tiles (max, sumexp) partials of row r
+int launch_lse_combine(const float2* part, int n_tiles, const float* label_logit, const int32_t* labels, int64_t n_rows, float* logprob, hipStream_t s);
 
-// score[p] = sum(logprob[rows of p]) / count_nonzero(...)  for rows [row_start[p], row_start[p+1])
-int launch_segment_mean_nonzero(const float* logprob, const int32_t* row_start, int n_pairs, float* score, hipStream_t s);
+// score[p] = sum(logprob[rows of p]) / (mode 0: count_nonzero, mode 1: row count)  for rows [row_start[p], row_start[p+1])
+int launch_segment_mean(const float* logprob, const int32_t* row_start, int n_pairs, int mode, float* score, hipStream_t s);
 
 // logprob[r] = log_softmax(logits[r, :V])[label[r]] (label < 0 -> 0), one workgroup per row
 int launch_ce_rows(const float* logits, int64_t ld, int V, const int32_t* labels, int64_t n_rows, float* logprob, hipStream_t s);

@@ -1,0 +1,84 @@
+"""Process-group glue for the scoring path (one process per GPU, torch.distributed over RCCL).
+
+The reference shards query rows in contiguous blocks and merges the -100-filled [N, N] matrices with
+all_reduce(SUM) (retrieval_utils.py:213-215, 233-235, 252-262; backend 'nccl' at util/misc.py:225).
+Here each rank contributes only its own [step, N] row block to ONE all_gather per matrix (504 KB per
+rank at N=1000, W=8 instead of 4 MB all-reduced), and the result equals the single-process matrix for
+any world size.  `compat_offset=True` reproduces the reference's W-dependent offsets instead.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def is_dist_avail_and_initialized() -> bool:           # util/misc.py:170-175
+    d = _dist()
+    return d.is_available() and d.is_initialized()
+
+
+def get_world_size() -> int:                           # util/misc.py:178-181
+    return _dist().get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank() -> int:                                 # util/misc.py:184-187
+    return _dist().get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process() -> bool:
+    return get_rank() == 0
+
+
+def init_distributed_mode(backend: str = None) -> Tuple[int, int, int]:
+    """util/misc.py:199-229: env:// rendezvous from RANK / WORLD_SIZE / LOCAL_RANK; returns (rank, world, local_rank).
+    backend defaults to 'nccl' (= RCCL on ROCm) when a GPU is visible, 'gloo' otherwise."""
+    import datetime
+    import torch
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        return 0, 1, 0
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if not _dist().is_initialized():
+        _dist().init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank,
+                                   timeout=datetime.timedelta(seconds=7200))
+    _dist().barrier()
+    return rank, world, local
+
+
+def row_block(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row block of `rank`: step = n // W + 1 (retrieval_utils.py:213-215)."""
+    step = n // world + 1
+    start = min(n, rank * step)
+    return start, min(n, start + step)
+
+
+def merge_row_blocks(S, block: Tuple[int, int], world: int, compat_offset: bool = False):
+    """S: [N, M] f32 tensor whose rows block[0]:block[1] this rank computed (others -100).
+    Returns the merged matrix on every rank."""
+    import torch
+    d = _dist()
+    if world == 1 or not is_dist_avail_and_initialized():
+        return S
+    N, M = S.shape
+    step = N // world + 1
+    mine = torch.full((step, M), -100.0, dtype=S.dtype, device=S.device)
+    s, e = block
+    if e > s:
+        mine[: e - s] = S[s:e]
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    d.all_gather(gathered, mine)
+    out = torch.cat(gathered, dim=0)[:N].contiguous()
+    if compat_offset:
+        # all_reduce(SUM) of W matrices that hold -100 wherever the rank did not compute (retrieval_utils.py:252-262)
+        out = torch.where(out == -100.0, out * world, out - 100.0 * (world - 1))
+    return out

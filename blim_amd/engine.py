@@ -1,0 +1,354 @@
+"""ctypes binding of libblim_hip.so (include/blim.h).
+
+PyTorch is used only for device memory / streams: every tensor handed to the engine is a CUDA(HIP)
+tensor whose data_ptr() goes through the C ABI.  There is NO CPU fallback: importing works without a
+GPU (so the CPU test-suite can check symbols and host logic), but creating an engine or launching a
+kernel without the library or without a device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .synth import ModelDims, weight_shapes
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblim_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "blim.h")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+
+class BlimError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32),
+                ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+                ("mm_hidden_size", C.c_int32), ("num_clips", C.c_int32), ("max_positions", C.c_int32),
+                ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_tokens", C.c_int64), ("n_seqs", C.c_int32), ("n_blocks", C.c_int32),
+                ("positions", C.c_void_p), ("key_visible", C.c_void_p), ("seq_start", C.c_void_p),
+                ("seq_len", C.c_void_p), ("pfx_start", C.c_void_p), ("pfx_len", C.c_void_p),
+                ("blk_seq", C.c_void_p), ("blk_q0", C.c_void_p)]
+
+
+def declared_symbols(header: str = HEADER_PATH) -> Sequence[str]:
+    """Names of every function include/blim.h declares."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(blim_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Loads the shared library (raises BlimError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise BlimError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"(or `make -C blim_amd/csrc`). The BLiM engine has no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+    sig = {
+        "blim_abi_version": ([], C.c_int),
+        "blim_last_error": ([], C.c_char_p),
+        "blim_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
+        "blim_destroy": ([vp], None),
+        "blim_load_weight": ([vp, C.c_char_p, vp, i32, i32], C.c_int),
+        "blim_init_synthetic_weights": ([vp, u64], C.c_int),
+        "blim_weights_ready": ([vp], C.c_int),
+        "blim_reserve": ([vp, i64, i64], C.c_int),
+        "blim_project_video": ([vp, vp, i64, i32, vp, vp], C.c_int),
+        "blim_group_mean": ([vp, vp, i64, i32, vp, vp], C.c_int),
+        "blim_assemble": ([vp, vp, i64, vp, vp, vp], C.c_int),
+        "blim_decode": ([vp, C.POINTER(Batch), vp, vp, i64, vp, vp, vp], C.c_int),
+        "blim_vtg_logprobs": ([vp, vp, vp, i64, vp, vp], C.c_int),
+        "blim_segment_mean": ([vp, vp, vp, i32, i32, vp, vp], C.c_int),
+        "blim_lm_head": ([vp, vp, i64, vp, vp], C.c_int),
+        "blim_ce_rows": ([vp, vp, i64, i32, vp, i64, vp, vp], C.c_int),
+        "blim_visual_head": ([vp, vp, i64, vp, vp], C.c_int),
+        "blim_tvg_scores": ([vp, vp, vp, i32, vp, i32, vp, vp], C.c_int),
+        "blim_tvg_logits": ([vp, vp, vp, i32, i32, vp, vp], C.c_int),
+        "blim_score_vtg": ([vp, C.POINTER(Batch), vp, vp, vp, i64, vp, i32, vp, vp], C.c_int),
+        "blim_score_tvg": ([vp, C.POINTER(Batch), vp, vp, vp, i32, vp, i32, vp, vp], C.c_int),
+        "blim_forward": ([vp, vp, vp, i32, i32, vp, vp, vp], C.c_int),
+        "blim_fill_bell_bf16": ([vp, i64, u64, C.c_char_p, f32, f32, vp], C.c_int),
+        "blim_fill_bell_f32": ([vp, i64, u64, C.c_char_p, f32, f32, i32, vp], C.c_int),
+        "blim_gemm_bf16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
+        "blim_timing_enable": ([vp, i32], C.c_int),
+        "blim_timing_num_classes": ([], C.c_int),
+        "blim_timing_class_name": ([i32], C.c_char_p),
+        "blim_timing_report": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)], C.c_int),
+        "blim_set_option": ([vp, C.c_char_p, i32], C.c_int),
+        "blim_debug_read": ([vp, C.c_char_p, vp, i64, vp], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise BlimError(f"{what} failed (code {rc}): {load_library().blim_last_error().decode()}")
+
+
+def _ptr(t) -> int:
+    """data_ptr of a contiguous device tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "engine buffers must be contiguous device tensors"
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+class PackedBatch:
+    """Device-side description of packed sequences (blim_batch).  Built from host numpy arrays."""
+
+    def __init__(self, positions: np.ndarray, key_visible: np.ndarray, seq_start: np.ndarray, seq_len: np.ndarray,
+                 pfx_start: Optional[np.ndarray] = None, pfx_len: Optional[np.ndarray] = None, device="cuda"):
+        import torch
+        n_seqs = len(seq_start)
+        if pfx_start is None:
+            pfx_start = np.zeros(n_seqs, dtype=np.int32)
+            pfx_len = np.zeros(n_seqs, dtype=np.int32)
+        seq_len = np.asarray(seq_len, dtype=np.int32)
+        nblk = (seq_len + 31) // 32
+        blk_seq = np.repeat(np.arange(n_seqs, dtype=np.int32), nblk)
+        blk_q0 = (np.concatenate([np.arange(n, dtype=np.int32) for n in nblk]) * 32).astype(np.int32) if n_seqs else np.zeros(0, np.int32)
+        self.n_tokens = int(len(positions))
+        self.n_seqs = int(n_seqs)
+        self.n_blocks = int(len(blk_seq))
+        # one host->device copy for all index arrays
+        parts = [np.asarray(positions, np.int32), np.asarray(seq_start, np.int32), seq_len, np.asarray(pfx_start, np.int32),
+                 np.asarray(pfx_len, np.int32), blk_seq, blk_q0]
+        offs = np.cumsum([0] + [len(p) for p in parts])
+        flat = torch.from_numpy(np.concatenate(parts)).to(device)
+        self._flat = flat
+        self.positions, self.seq_start, self.seq_len, self.pfx_start, self.pfx_len, self.blk_seq, self.blk_q0 = \
+            [flat[offs[i]:offs[i + 1]] for i in range(7)]
+        self.key_visible = torch.from_numpy(np.ascontiguousarray(key_visible, dtype=np.uint8)).to(device)
+
+    def struct(self) -> Batch:
+        b = Batch()
+        b.n_tokens, b.n_seqs, b.n_blocks = self.n_tokens, self.n_seqs, self.n_blocks
+        b.positions = self.positions.data_ptr(); b.key_visible = self.key_visible.data_ptr()
+        b.seq_start = self.seq_start.data_ptr(); b.seq_len = self.seq_len.data_ptr()
+        b.pfx_start = self.pfx_start.data_ptr(); b.pfx_len = self.pfx_len.data_ptr()
+        b.blk_seq = self.blk_seq.data_ptr(); b.blk_q0 = self.blk_q0.data_ptr()
+        return b
+
+
+class Engine:
+    """One scoring engine on the current HIP device."""
+
+    def __init__(self, dims: ModelDims, max_positions: int = 4096):
+        import torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise BlimError("no HIP device visible: the BLiM engine has no CPU fallback")
+        self.dims = dims
+        cfg = Config(dims.vocab_size, dims.hidden_size, dims.intermediate_size, dims.num_layers, dims.num_heads, dims.num_kv_heads,
+                     dims.mm_hidden_size, dims.num_clips, max_positions, dims.rms_eps, dims.rope_theta)
+        h = C.c_void_p()
+        _check(self.lib.blim_create(C.byref(cfg), C.byref(h)), "blim_create")
+        self.h = h
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.blim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights
+    def load_weights(self, weights: Dict[str, np.ndarray]):
+        """weights: canonical name -> float32 numpy array (natural [out, in] layout)."""
+        shapes = weight_shapes(self.dims)
+        for name, arr in weights.items():
+            assert tuple(arr.shape) == tuple(shapes[name]), (name, arr.shape, shapes[name])
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            _check(self.lib.blim_load_weight(self.h, name.encode(), a.ctypes.data, DTYPE_F32, 0), f"blim_load_weight({name})")
+        _check(self.lib.blim_weights_ready(self.h), "blim_weights_ready")
+
+    def init_synthetic_weights(self, seed: int):
+        _check(self.lib.blim_init_synthetic_weights(self.h, seed), "blim_init_synthetic_weights")
+
+    def reserve(self, max_tokens: int, max_rows: int):
+        _check(self.lib.blim_reserve(self.h, max_tokens, max_rows), "blim_reserve")
+
+    def set_option(self, key: str, value: int):
+        _check(self.lib.blim_set_option(self.h, key.encode(), value), "blim_set_option")
+
+    # ---- component ops (torch device tensors in/out)
+    def project_video(self, feats, which: int):
+        import torch
+        n = feats.shape[0]
+        out = torch.empty((n, self.dims.hidden_size), dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.blim_project_video(self.h, _ptr(feats), n, which, _ptr(out), _stream()), "blim_project_video")
+        return out
+
+    def group_mean(self, x, group: int):
+        import torch
+        n_out = x.shape[0] // group
+        out = torch.empty((n_out, x.shape[1]), dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.blim_group_mean(self.h, _ptr(x), n_out, group, _ptr(out), _stream()), "blim_group_mean")
+        return out
+
+    def assemble(self, src_index, feats=None):
+        import torch
+        n = src_index.shape[0]
+        out = torch.empty((n, self.dims.hidden_size), dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.blim_assemble(self.h, _ptr(src_index), n, _ptr(feats), _ptr(out), _stream()), "blim_assemble")
+        return out
+
+    def decode(self, batch: PackedBatch, embeds, out_rows=None, want_f32=False, want_bf16=True):
+        import torch
+        n = batch.n_tokens if out_rows is None else out_rows.shape[0]
+        H = self.dims.hidden_size
+        ob = torch.empty((n, H), dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        of = torch.empty((n, H), dtype=torch.float32, device=self.device) if want_f32 else None
+        bs = batch.struct()
+        _check(self.lib.blim_decode(self.h, C.byref(bs), _ptr(embeds), _ptr(out_rows), n, _ptr(ob), _ptr(of), _stream()), "blim_decode")
+        return ob, of
+
+    def vtg_logprobs(self, hidden_bf16, labels):
+        import torch
+        n = hidden_bf16.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _check(self.lib.blim_vtg_logprobs(self.h, _ptr(hidden_bf16), _ptr(labels), n, _ptr(out), _stream()), "blim_vtg_logprobs")
+        return out
+
+    def tvg_logits(self, vh_bf16, vocab_clip_major, n_pairs: int):
+        import torch
+        out = torch.empty((n_pairs, self.dims.num_clips, vocab_clip_major.shape[1]), dtype=torch.float32, device=self.device)
+        _check(self.lib.blim_tvg_logits(self.h, _ptr(vh_bf16), _ptr(vocab_clip_major), vocab_clip_major.shape[1], n_pairs, _ptr(out), _stream()),
+               "blim_tvg_logits")
+        return out
+
+    def lm_head(self, hidden_bf16):
+        import torch
+        n = hidden_bf16.shape[0]
+        out = torch.empty((n, self.dims.vocab_size), dtype=torch.float32, device=self.device)
+        _check(self.lib.blim_lm_head(self.h, _ptr(hidden_bf16), n, _ptr(out), _stream()), "blim_lm_head")
+        return out
+
+    def visual_head(self, hidden_bf16):
+        import torch
+        n = hidden_bf16.shape[0]
+        out = torch.empty((n, self.dims.mm_hidden_size), dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.blim_visual_head(self.h, _ptr(hidden_bf16), n, _ptr(out), _stream()), "blim_visual_head")
+        return out
+
+    def tvg_scores(self, vh_bf16, vocab_clip_major, labels):
+        """vh [n_pairs*clips, M] bf16; vocab [clips, n_vocab, M] bf16; labels [n_pairs] int32."""
+        import torch
+        n_pairs = labels.shape[0]
+        out = torch.empty(n_pairs, dtype=torch.float32, device=self.device)
+        _check(self.lib.blim_tvg_scores(self.h, _ptr(vh_bf16), _ptr(vocab_clip_major), vocab_clip_major.shape[1], _ptr(labels), n_pairs,
+                                        _ptr(out), _stream()), "blim_tvg_scores")
+        return out
+
+    def score_vtg(self, batch: PackedBatch, embeds, rows, labels, row_start):
+        import torch
+        n_pairs = row_start.shape[0] - 1
+        out = torch.empty(n_pairs, dtype=torch.float32, device=self.device)
+        bs = batch.struct()
+        _check(self.lib.blim_score_vtg(self.h, C.byref(bs), _ptr(embeds), _ptr(rows), _ptr(labels), rows.shape[0], _ptr(row_start), n_pairs,
+                                       _ptr(out), _stream()), "blim_score_vtg")
+        return out
+
+    def score_tvg(self, batch: PackedBatch, embeds, rows, vocab_clip_major, labels):
+        import torch
+        n_pairs = labels.shape[0]
+        out = torch.empty(n_pairs, dtype=torch.float32, device=self.device)
+        bs = batch.struct()
+        _check(self.lib.blim_score_tvg(self.h, C.byref(bs), _ptr(embeds), _ptr(rows), _ptr(vocab_clip_major), vocab_clip_major.shape[1],
+                                       _ptr(labels), n_pairs, _ptr(out), _stream()), "blim_score_tvg")
+        return out
+
+    def forward(self, embeds, mask, want_logits=True, want_hidden=True):
+        """Literal forward: embeds [B,L,H] bf16, mask [B,L] uint8 -> (logits f32 [B,L,V] | None, hidden f32 [B,L,H] | None)."""
+        import torch
+        B, L, H = embeds.shape
+        lg = torch.empty((B, L, self.dims.vocab_size), dtype=torch.float32, device=self.device) if want_logits else None
+        hd = torch.empty((B, L, H), dtype=torch.float32, device=self.device) if want_hidden else None
+        _check(self.lib.blim_forward(self.h, _ptr(embeds), _ptr(mask), B, L, _ptr(lg), _ptr(hd), _stream()), "blim_forward")
+        return lg, hd
+
+    def debug_read(self, which: str, shape, dtype):
+        """Copy of an internal workspace as the last decode left it (bring-up aid)."""
+        import torch
+        out = torch.empty(shape, dtype=dtype, device=self.device)
+        _check(self.lib.blim_debug_read(self.h, which.encode(), _ptr(out), out.numel() * out.element_size(), _stream()), "blim_debug_read")
+        return out
+
+    # ---- timing
+    def timing_enable(self, on: bool):
+        _check(self.lib.blim_timing_enable(self.h, int(on)), "blim_timing_enable")
+
+    def timing_report(self) -> Dict[str, Dict[str, float]]:
+        n = self.lib.blim_timing_num_classes()
+        ms = (C.c_double * n)(); calls = (C.c_int64 * n)(); fl = (C.c_double * n)()
+        _check(self.lib.blim_timing_report(self.h, ms, calls, fl), "blim_timing_report")
+        return {self.lib.blim_timing_class_name(i).decode(): {"ms": ms[i], "calls": int(calls[i]), "flops": fl[i]} for i in range(n)}
+
+
+def ce_rows(logits, labels):
+    """logprob[r] = log_softmax(logits[r])[labels[r]] (0 where labels[r] < 0); logits f32 [n, V], labels int32 [n]."""
+    import torch
+    lib = load_library()
+    n, v = logits.shape
+    out = torch.empty(n, dtype=torch.float32, device=logits.device)
+    _check(lib.blim_ce_rows(None, _ptr(logits), v, v, _ptr(labels), n, _ptr(out), _stream()), "blim_ce_rows")
+    return out
+
+
+def segment_mean(logprob, row_start, mode: int = 0):
+    """mode 0: sum / count_nonzero (VTG), mode 1: plain mean (TVG)."""
+    import torch
+    lib = load_library()
+    n = row_start.shape[0] - 1
+    out = torch.empty(n, dtype=torch.float32, device=logprob.device)
+    _check(lib.blim_segment_mean(None, _ptr(logprob), _ptr(row_start), n, mode, _ptr(out), _stream()), "blim_segment_mean")
+    return out
+
+
+def fill_bell_bf16(out, seed: int, name: str, std: float, mean: float = 0.0):
+    lib = load_library()
+    _check(lib.blim_fill_bell_bf16(_ptr(out), out.numel(), seed, name.encode(), std, mean, _stream()), "blim_fill_bell_bf16")
+    return out
+
+
+def gemm_bf16(a, w):
+    """a [M,K] bf16, w [N,K] bf16 -> [M,N] bf16 (plain epilogue)."""
+    import torch
+    lib = load_library()
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    _check(lib.blim_gemm_bf16(_ptr(a), K, _ptr(w), M, N, K, _ptr(out), N, _stream()), "blim_gemm_bf16")
+    return out

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's model surface for the scoring path.
+
+`BlimModel` plays the role of VideoChatFlashQwenForCausalLM on the eval path
+(videochat_flash/modeling_videochat_flash.py:572-629): same method names, argument meaning and return
+shapes for the calls retrieval_utils.py makes, with every tensor op executed by the HIP engine
+(blim_amd/engine.py -> libblim_hip.so).  `DDPLike` provides the `.module` attribute the reference's
+loops expect from DistributedDataParallel (retrieval_utils.py:66, 105, 210).
+
+Only the `inputs_embeds` + `attention_mask` form of forward() is functional;
+other argument combinations raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+
+from .engine import Engine
+from .synth import IGNORE_INDEX, IMAGE_TOKEN_INDEX, ModelDims
+
+
+class BlimModel:
+    def __init__(self, dims: ModelDims, max_positions: int = 4096, tokenizer_model_max_length: Optional[int] = None):
+        self.dims = dims
+        self.engine = Engine(dims, max_positions=max_positions)
+        self.device = self.engine.device
+        self.tvg_prefix_length = 0
+        self.video_vocab = None
+        self.tokenizer_model_max_length = tokenizer_model_max_length
+        self.training = False
+        self._proj_cache = {}
+
+    # ---- nn.Module-ish surface used by the eval loop
+    def eval(self):
+        self.training = False
+        return self
+
+    def set_video_vocab(self, video_vocab):                      # modeling_videochat_flash.py:589-590
+        self.video_vocab = video_vocab
+
+    def set_tvg_prefix_length(self, n: int):                     # modeling_videochat_flash.py:592-593
+        self.tvg_prefix_length = int(n)
+
+    def clear_cache(self):
+        self._proj_cache.clear()
+
+    # ---- K1 with a per-video cache (the reference re-projects identical copies, retrieval_utils.py:60)
+    def project(self, feat, tvg: bool):
+        """feat: [clips, T, mm_hidden] device tensor -> bf16 [clips*T, H] (vtg) or [clips, H] (tvg: mean over T)."""
+        import torch
+        key = (feat.data_ptr(), tuple(feat.shape), bool(tvg), feat._version)
+        hit = self._proj_cache.get(key)
+        if hit is not None:
+            return hit
+        if feat.ndim == 4:                                       # :195 unsqueeze(0) / :157 squeeze(0)
+            feat = feat.squeeze(0)
+        clips, T, M = feat.shape
+        x = feat.to(device=self.device, dtype=torch.bfloat16).reshape(clips * T, M).contiguous()
+        y = self.engine.project_video(x, 1 if tvg else 0)
+        if tvg:
+            y = self.engine.group_mean(y, T)                     # :243 frame_feature.mean(1)
+        if len(self._proj_cache) > 4096:
+            self._proj_cache.clear()
+        self._proj_cache[key] = y
+        return y
+
+    def forward_visual(self, visual_token_embeds):               # modeling_videochat_flash.py:598-599
+        import torch
+        shp = visual_token_embeds.shape
+        x = visual_token_embeds.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
+        return self.engine.visual_head(x).float().reshape(*shp[:-1], self.dims.mm_hidden_size)
+
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images,
+                                             modalities=["image"], image_sizes=None, video_feature=False, tvg=False, cpn=False):
+        """modeling_videochat_flash.py:185-515, eval branch (video_feature=True, one <image> per row).
+
+        input_ids / attention_mask / labels: LEFT-padded [B, Lt] device tensors; images: list of B feature tensors.
+        Returns (None, position_ids, mask | (mask, cpn_mask), past_key_values, embeds [B,L,H] bf16, labels [B,L])."""
+        import torch
+        if not video_feature:
+            raise NotImplementedError("only pre-extracted video features (video_feature=True) are supported")
+        if images is None or input_ids.shape[1] == 1:
+            raise NotImplementedError("text-only / single-token inputs are outside the scoring path")
+        ids_h = input_ids.detach().cpu().numpy()
+        msk_h = (attention_mask.detach().cpu().numpy() != 0) if attention_mask is not None else np.ones_like(ids_h, dtype=bool)
+        lab_h = labels.detach().cpu().numpy() if labels is not None else np.full_like(ids_h, IGNORE_INDEX)
+        B = ids_h.shape[0]
+        feats, feat_off = [], []
+        n_feat_rows = 0
+        for b in range(B):
+            f = self.project(images[b], tvg)
+            feats.append(f); feat_off.append(n_feat_rows); n_feat_rows += f.shape[0]
+        rows_src, rows_lab, rows_cpn = [], [], []
+        for b in range(B):
+            ids = ids_h[b][msk_h[b]]; lab = lab_h[b][msk_h[b]]              # :333-334 strip the left pad
+            where = np.nonzero(ids == IMAGE_TOKEN_INDEX)[0]
+            if len(where) != 1:
+                raise NotImplementedError(f"row {b}: expected exactly one <image> placeholder, found {len(where)}")
+            w = int(where[0]); nf = feats[b].shape[0]
+            src = np.concatenate([ids[:w], -(1 + feat_off[b] + np.arange(nf)), ids[w + 1:]])
+            lb = np.concatenate([lab[:w], np.full(nf, IGNORE_INDEX), lab[w + 1:]])
+            first = np.zeros(w, dtype=np.int64)
+            if tvg:
+                first[: self.tvg_prefix_length] = 1                      # :414-417
+            else:
+                first[:] = 1                                             # :419
+            cm = np.concatenate([first, np.full(nf, 1 if tvg else 0), np.ones(len(ids) - w - 1, dtype=np.int64)])  # :431-433
+            if self.tokenizer_model_max_length is not None:              # :452-457
+                n = self.tokenizer_model_max_length
+                src, lb, cm = src[:n], lb[:n], cm[:n]
+            rows_src.append(src); rows_lab.append(lb); rows_cpn.append(cm)
+        L = max(len(r) for r in rows_src)
+        zero_row = n_feat_rows
+        src = np.full((B, L), -(1 + zero_row), dtype=np.int32)          # right padding with zero rows, :472-485
+        out_lab = np.full((B, L), IGNORE_INDEX, dtype=np.int64)
+        mask = np.zeros((B, L), dtype=np.int64); cpn_mask = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):
+            n = len(rows_src[b])
+            src[b, :n] = rows_src[b]; out_lab[b, :n] = rows_lab[b]; mask[b, :n] = 1; cpn_mask[b, :n] = rows_cpn[b]
+        feat_all = torch.cat(feats + [torch.zeros((1, self.dims.hidden_size), dtype=torch.bfloat16, device=self.device)], dim=0)
+        embeds = self.engine.assemble(torch.from_numpy(src.reshape(-1)).to(self.device), feat_all).reshape(B, L, -1)
+        mdt = attention_mask.dtype if attention_mask is not None else torch.long
+        new_labels = torch.from_numpy(out_lab).to(self.device) if labels is not None else None
+        if attention_mask is None:
+            m_t, c_t = None, torch.from_numpy(cpn_mask).to(self.device)
+        else:
+            m_t = torch.from_numpy(mask).to(self.device).to(mdt); c_t = torch.from_numpy(cpn_mask).to(self.device).to(mdt)
+        if cpn:
+            return None, position_ids, (m_t, c_t), past_key_values, embeds, new_labels
+        return None, position_ids, m_t, past_key_values, embeds, new_labels
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, images=None, image_sizes=None, return_dict=None,
+                modalities=["image"], dpo_forward=False, cache_position=None, want_logits: bool = True):
+        """modeling_videochat_flash.py:601-629 -> modeling_qwen2_flash.py:1392-1478.
+        Returns an object with .logits [B,L,V] f32 and .hidden_states [B,L,H] (final-norm last hidden state)."""
+        import torch
+        if inputs_embeds is None or input_ids is not None:
+            raise NotImplementedError("forward(): only inputs_embeds=... is supported on the scoring path")
+        if position_ids is not None or past_key_values is not None or labels is not None or use_cache or output_attentions or dpo_forward:
+            raise NotImplementedError("forward(): position_ids / cache / labels / attentions are outside the scoring path")
+        B, L, _ = inputs_embeds.shape
+        emb = inputs_embeds.to(torch.bfloat16).contiguous()
+        if attention_mask is None:
+            m8 = torch.ones((B, L), dtype=torch.uint8, device=self.device)
+        else:
+            m8 = (attention_mask != 0).to(torch.uint8).contiguous()
+        logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
+        return SimpleNamespace(loss=None, logits=logits, past_key_values=None, hidden_states=hidden, attentions=None)
+
+    __call__ = forward
+
+
+class DDPLike:
+    """Stand-in for DistributedDataParallel: the eval loop calls model.module.* and model(...)."""
+
+    def __init__(self, module: BlimModel):
+        self.module = module
+
+    def eval(self):
+        self.module.eval()
+        return self
+
+    def __call__(self, *a, **k):
+        return self.module(*a, **k)

@@ -1,0 +1,488 @@
+"""Scoring API of the reference (retrieval_utils.py) on the MI355X engine.
+
+Two layers:
+
+* The literal surface -- `compute_v2t_scores_x`, `compute_t2v_scores_x`, `padding_ids`,
+  `vtg_criterion`, `tvg_criterion`, `evaluation` -- keeps the reference's names, arguments and
+  per-query / per-batch control flow (retrieval_utils.py:18-281) so its eval loop is a drop-in.
+  All tensor work goes through the HIP engine (no torch math on the hot path).
+
+* `PairScorer` -- the fused fast path `evaluation` uses by default.  A likelihood is a function of the
+  (video, text) pair only, so pairs from many queries are packed into large token batches; tokens that
+  are identical for every candidate of a query (the video+prompt prefix for VTG, the caption prompt
+  for TVG) are computed once and their K/V reused (SURVEY.md section 7 "prefix-KV reuse"); hidden
+  states that no score reads (tail tokens) are not computed; priors that do not depend on the query
+  (v2t VTG-CPN) are computed once per candidate.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import distributed as dist_utils
+from . import engine as eng
+from .engine import PackedBatch
+from .synth import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+
+IMAGE_TOKEN_ID = 151645  # <|im_end|>, videochat_flash/conversation.py:13
+
+
+# ----------------------------------------------------------------------------- criteria (literal)
+
+class VTGCriterion:
+    """retrieval_utils.py:18-33 on materialised logits [B, L, V] (device f32) and labels [B, L]."""
+
+    def __call__(self, logits, labels):
+        import torch
+        B, L, V = logits.shape
+        shift = torch.full((B, L), IGNORE_INDEX, dtype=torch.int32, device=logits.device)
+        shift[:, :-1] = labels[:, 1:].to(torch.int32)                       # :24-25
+        lp = eng.ce_rows(logits.reshape(B * L, V), shift.reshape(-1).contiguous())
+        row_start = (torch.arange(B + 1, dtype=torch.int32, device=logits.device) * L).contiguous()
+        return eng.segment_mean(lp, row_start, mode=0)                       # -loss.sum / loss.bool().sum, :32-33
+
+    forward = __call__
+
+
+class TVGCriterion:
+    """retrieval_utils.py:35-43 on logits [B, clips, N] and labels [B, clips]."""
+
+    def __call__(self, logits, labels):
+        import torch
+        B, Cn, N = logits.shape
+        lp = eng.ce_rows(logits.reshape(B * Cn, N).contiguous(), labels.reshape(-1).to(torch.int32).contiguous())
+        row_start = (torch.arange(B + 1, dtype=torch.int32, device=logits.device) * Cn).contiguous()
+        return eng.segment_mean(lp, row_start, mode=1)
+
+    forward = __call__
+
+
+vtg_criterion = VTGCriterion()
+tvg_criterion = TVGCriterion()
+
+
+def _clip_major_vocab(video_vocab, device):
+    """[N, clips, M] -> bf16 [clips, N, M] on device (layout blim_tvg_* expects)."""
+    import torch
+    return video_vocab.to(device=device, dtype=torch.bfloat16).permute(1, 0, 2).contiguous()
+
+
+def _tvg_logits_literal(model, hidden_states, tvg_labels, video_vocab, num_clips, device):
+    """retrieval_utils.py:99, 104-106: gather 4 hidden rows, visual_head, scaled dot with the video vocabulary."""
+    import torch
+    idx = (tvg_labels == IMAGE_TOKEN_ID).nonzero()[:, 1][:, None].repeat(1, num_clips) + (torch.arange(num_clips) - (num_clips + 1)).to(device)
+    emb = torch.gather(hidden_states, 1, idx[..., None].repeat(1, 1, hidden_states.shape[-1]))
+    emb = model.module.forward_visual(emb)                                    # [B, clips, M] f32
+    vh = emb.to(torch.bfloat16).reshape(-1, emb.shape[-1]).contiguous()
+    return model.module.engine.tvg_logits(vh, _clip_major_vocab(video_vocab, device), emb.shape[0])
+
+
+def compute_v2t_scores_x(v2t_scores_x, iterator, start, input_ids, attention_masks, labels, video, video_vocab, tvg_video_labels,
+                         model, device, args, forward_type=None, cpn=False):
+    """retrieval_utils.py:48-111 (same arguments; mutates and returns v2t_scores_x)."""
+    import torch
+    for i, sims in enumerate(iterator):
+        k = min(len(sims), args.topk)
+        bs = args.batch_size_eval
+        _, topk_idx = sims.topk(k=k, dim=0)
+        topk_idx = topk_idx.cpu()
+        enc = video[start + i].to(device, non_blocking=True)
+        out = []
+        for j in range(0, len(topk_idx), bs):
+            sel = topk_idx[j:j + bs]
+            n = len(sel)
+            tvg = forward_type == "tvg"
+            (_, _, (masks, cpn_masks), _, embeds, lab) = model.module.prepare_inputs_labels_for_multimodal(
+                input_ids[sel].to(device), None, attention_masks[sel].to(device), None, labels[sel].to(device), [enc for _ in range(n)],
+                ["video" for _ in range(n)], image_sizes=[(448, 448) for _ in range(n)], video_feature=True, tvg=tvg, cpn=True)
+            outputs = model(inputs_embeds=embeds, attention_mask=cpn_masks if cpn else masks)
+            if forward_type == "vtg":
+                out.append(vtg_criterion(outputs.logits, lab))
+            else:
+                lg = _tvg_logits_literal(model, outputs.hidden_states, lab, video_vocab, args.num_clips, device)
+                out.append(tvg_criterion(lg, tvg_video_labels[start + i].repeat(n, args.num_clips).to(device)))
+        v2t_scores_x[start + i, topk_idx] = torch.cat(out, dim=0).to(v2t_scores_x.dtype)
+    return v2t_scores_x
+
+
+def compute_t2v_scores_x(t2v_scores_x, iterator, start, input_ids, attention_masks, labels, video, video_vocab, tvg_video_labels,
+                         model, device, args, forward_type=None, cpn=False):
+    """retrieval_utils.py:113-153 (text row repeated, candidate videos vary)."""
+    import torch
+    for i, sims in enumerate(iterator):
+        k = min(len(sims), args.topk)
+        bs = args.batch_size_eval
+        _, topk_idx = sims.topk(k=k, dim=0)
+        topk_idx = topk_idx.cpu()
+        out = []
+        for j in range(0, len(topk_idx), bs):
+            sel = topk_idx[j:j + bs]
+            enc = [video[int(v)].to(device) for v in sel]
+            n = len(enc)
+            tvg = forward_type == "tvg"
+            (_, _, (masks, cpn_masks), _, embeds, lab) = model.module.prepare_inputs_labels_for_multimodal(
+                input_ids[start + i].repeat(n, 1).to(device), None, attention_masks[start + i].repeat(n, 1).to(device), None,
+                labels[start + i].repeat(n, 1).to(device), enc, ["video" for _ in range(n)], image_sizes=[(448, 448) for _ in range(n)],
+                video_feature=True, tvg=tvg, cpn=True)
+            outputs = model(inputs_embeds=embeds, attention_mask=cpn_masks if cpn else masks)
+            if forward_type == "vtg":
+                out.append(vtg_criterion(outputs.logits, lab))
+            else:
+                lg = _tvg_logits_literal(model, outputs.hidden_states, lab, video_vocab, args.num_clips, device)
+                out.append(tvg_criterion(lg, tvg_video_labels[sel][:, None].repeat(1, args.num_clips).to(device)))
+        t2v_scores_x[start + i, topk_idx] = torch.cat(out, dim=0).to(t2v_scores_x.dtype)
+    return t2v_scores_x
+
+
+def padding_ids(input_ids, labels, masks, tokenizer=None):
+    """retrieval_utils.py:155-167: LEFT-pad ids (pad id), labels (-100), masks (0) to the longest row."""
+    import torch
+    n = len(input_ids)
+    L = max(len(x) for x in input_ids)
+    ids_p = torch.full((n, L), tokenizer.pad_token_id, dtype=torch.long)
+    lab_p = torch.full((n, L), IGNORE_INDEX, dtype=torch.long)
+    msk_p = torch.zeros((n, L), dtype=torch.long)
+    for i in range(n):
+        c = len(input_ids[i])
+        ids_p[i, L - c:] = torch.as_tensor(input_ids[i])
+        lab_p[i, L - c:] = torch.as_tensor(labels[i])
+        msk_p[i, L - c:] = torch.as_tensor(masks[i])
+    return ids_p, lab_p, msk_p
+
+
+# ----------------------------------------------------------------------------- fused path
+
+@dataclass
+class Plan:
+    """One engine call: packed batch + row bookkeeping, all device-resident."""
+    kind: str                  # "vtg" | "tvg"
+    batch: PackedBatch
+    src_index: object          # int32 [n_tokens]  (assemble input)
+    feats: object              # bf16 [n_feat_rows, H]
+    rows: object               # int32
+    labels: object             # int32 (vtg: [n_rows] token ids; tvg: [n_pairs] video labels)
+    row_start: Optional[object]
+    n_pairs: int
+    out_index: np.ndarray      # host: which requested pair each scored pair answers (many-to-one allowed)
+    n_tokens: int
+    n_rows: int
+
+
+def _split_prompt_response(ids: np.ndarray, labels: np.ndarray):
+    """ids/labels of one row (left pad stripped) -> (prompt ids, response ids) with labels == -100 on the prompt."""
+    resp = labels != IGNORE_INDEX
+    n_prompt = int(np.argmax(resp)) if resp.any() else len(ids)
+    assert resp[n_prompt:].all(), "response must be one trailing span"
+    return ids[:n_prompt], ids[n_prompt:]
+
+
+class PairScorer:
+    """Fused scoring of arbitrary (video, text) pairs.  See the module docstring for what is shared."""
+
+    def __init__(self, model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video: Sequence, video_vocab,
+                 tvg_video_labels, num_clips: int, max_tokens: int = 24576):
+        import torch
+        self.m = model.module if hasattr(model, "module") else model
+        self.engine = self.m.engine
+        self.device = self.m.device
+        self.max_tokens = int(max_tokens)
+        self.num_clips = int(num_clips)
+        strip = lambda ids, msk, lab: [(np.asarray(ids[i])[np.asarray(msk[i]) != 0], np.asarray(lab[i])[np.asarray(msk[i]) != 0])
+                                       for i in range(len(ids))]
+        self.vtg_rows = strip(vtg_ids, vtg_masks, vtg_labels)
+        self.tvg_rows = strip(tvg_ids, tvg_masks, tvg_labels)
+        self.video = video
+        self.tvg_video_labels = np.asarray(tvg_video_labels).astype(np.int32)
+        self.vocab_cm = _clip_major_vocab(video_vocab, self.device) if video_vocab is not None else None
+        self._vfeat: Dict[Tuple[int, bool], object] = {}
+        # per-text splits
+        self.vtg_split = []
+        for ids, lab in self.vtg_rows:
+            prompt, resp = _split_prompt_response(ids, lab)
+            w = np.nonzero(prompt == IMAGE_TOKEN_INDEX)[0]
+            assert len(w) == 1, "VTG prompt must hold exactly one <image> placeholder"
+            self.vtg_split.append((prompt[: w[0]].astype(np.int64), prompt[w[0] + 1:].astype(np.int64), resp.astype(np.int64)))
+        self.tvg_split = []
+        for ids, lab in self.tvg_rows:
+            prompt, resp = _split_prompt_response(ids, lab)
+            assert len(resp) >= 1 and resp[0] == IMAGE_TOKEN_INDEX, "TVG response must start with the <image> placeholder"
+            self.tvg_split.append(prompt.astype(np.int64))
+
+    # ---- projected video features, cached on device (K1 once per video instead of once per pair)
+    def video_feat(self, j: int, tvg: bool):
+        key = (int(j), bool(tvg))
+        f = self._vfeat.get(key)
+        if f is None:
+            f = self.m.project(self.video[j].to(self.device), tvg)
+            self._vfeat[key] = f
+        return f
+
+    # ---- planning (host) ------------------------------------------------------------------------
+    def plan_vtg(self, pairs: np.ndarray, cpn: bool = False) -> List[Plan]:
+        """pairs: [P, 2] (video j, text i).  cpn=True: video keys masked -> the score depends on the text only."""
+        pairs = np.asarray(pairs, dtype=np.int64)
+        plans: List[Plan] = []
+        if cpn:
+            texts, inv = np.unique(pairs[:, 1], return_inverse=True)
+            nv = int(np.prod(self.video[int(pairs[0, 0])].shape[:2]))
+            groups: Dict[Tuple, List[int]] = {}
+            for ti, i in enumerate(texts):
+                pre, post, _ = self.vtg_split[int(i)]
+                groups.setdefault((pre.tobytes(), post.tobytes()), []).append(ti)
+            items = [(None, nv, [int(texts[t]) for t in g], [np.nonzero(inv == t)[0] for t in g]) for g in groups.values()]
+        else:
+            order = np.lexsort((pairs[:, 1], pairs[:, 0]))
+            items = []
+            j_prev, cur = None, None
+            for idx in order:
+                j, i = int(pairs[idx, 0]), int(pairs[idx, 1])
+                pre, post, _ = self.vtg_split[i]
+                key = (j, pre.tobytes(), post.tobytes())
+                if key != j_prev:
+                    cur = (j, None, [], [])
+                    items.append(cur); j_prev = key
+                cur[2].append(i); cur[3].append(np.array([idx]))
+        # pack groups into super-batches
+        st = _PackState(self, "vtg")
+        for (j, nv, texts_g, outs_g) in items:
+            pre, post, _ = self.vtg_split[texts_g[0]]
+            n_vid = nv if j is None else int(self.video_feat(j, False).shape[0])
+            need = len(pre) + (0 if j is None else n_vid) + len(post) + sum(max(len(self.vtg_split[i][2]) - 1, 0) for i in texts_g)
+            if st.n_tok and st.n_tok + need > self.max_tokens:
+                plans.append(st.finish()); st = _PackState(self, "vtg")
+            # prefix sequence
+            if j is None:
+                ptoks = np.concatenate([pre, post]); ppos = np.concatenate([np.arange(len(pre)), len(pre) + n_vid + np.arange(len(post))])
+                p0 = st.add_seq(ptoks, ppos, np.ones(len(ptoks), np.uint8), None)
+            else:
+                fo = st.add_feat(self.video_feat(j, False))
+                ptoks = np.concatenate([pre, -(1 + fo + np.arange(n_vid)), post])
+                p0 = st.add_seq(ptoks, np.arange(len(ptoks)), np.ones(len(ptoks), np.uint8), None)
+            plen = len(ptoks); ppos_end = len(pre) + n_vid + len(post)
+            for i, outs in zip(texts_g, outs_g):
+                resp = self.vtg_split[i][2]
+                body = resp[:-1]                                           # the last response token predicts nothing
+                rows = [p0 + plen - 1]
+                if len(body):
+                    s0 = st.add_seq(body, ppos_end + np.arange(len(body)), np.ones(len(body), np.uint8), (p0, plen))
+                    rows += list(range(s0, s0 + len(body)))
+                st.add_pair(rows, resp.astype(np.int32), outs)
+        if st.n_pairs:
+            plans.append(st.finish())
+        return plans
+
+    def plan_tvg(self, pairs: np.ndarray, cpn: bool = False) -> List[Plan]:
+        """pairs: [P, 2] (video j, text i); score = log P(video j | text i) (mean over clips)."""
+        pairs = np.asarray(pairs, dtype=np.int64)
+        C = self.num_clips
+        plans: List[Plan] = []
+        st = _PackState(self, "tvg")
+        if cpn:
+            # prior depends on (prompt length, last prompt token, first tvg_prefix_length tokens, video) only
+            tp = self.m.tvg_prefix_length
+            keyed: Dict[Tuple, List[int]] = {}
+            for idx, (j, i) in enumerate(pairs):
+                pr = self.tvg_split[int(i)]
+                keyed.setdefault((pr[:tp].tobytes(), len(pr), int(pr[-1]), int(j)), []).append(idx)
+            by_prefix: Dict[bytes, List[Tuple]] = {}
+            for k, v in keyed.items():
+                by_prefix.setdefault(k[0], []).append((k, v))
+            for pbytes, lst in by_prefix.items():
+                ptoks = np.frombuffer(pbytes, dtype=np.int64)
+                p0 = None
+                for (k, outs) in lst:
+                    _, plen_full, last_tok, j = k
+                    if p0 is None or st.n_tok + 4 > self.max_tokens:
+                        if st.n_pairs:
+                            plans.append(st.finish()); st = _PackState(self, "tvg")
+                        p0 = st.add_seq(ptoks, np.arange(len(ptoks)), np.ones(len(ptoks), np.uint8), None)
+                    fo = st.add_feat(self.video_feat(j, True))
+                    toks = np.concatenate([[last_tok], -(1 + fo + np.arange(C - 1))])
+                    vis = np.concatenate([[1 if plen_full - 1 < tp else 0], np.ones(C - 1)]).astype(np.uint8)
+                    s0 = st.add_seq(toks, plen_full - 1 + np.arange(C), vis, (p0, len(ptoks)))
+                    st.add_pair(list(range(s0, s0 + C)), np.array([self.tvg_video_labels[j]], np.int32), np.array(outs))
+        else:
+            order = np.lexsort((pairs[:, 0], pairs[:, 1]))
+            i_prev, p0, plen = None, None, 0
+            for idx in order:
+                j, i = int(pairs[idx, 0]), int(pairs[idx, 1])
+                pr = self.tvg_split[i]
+                if i != i_prev or st.n_tok + (C - 1) > self.max_tokens:
+                    if st.n_tok and st.n_tok + len(pr) + (C - 1) > self.max_tokens:
+                        plans.append(st.finish()); st = _PackState(self, "tvg")
+                    p0 = st.add_seq(pr, np.arange(len(pr)), np.ones(len(pr), np.uint8), None); plen = len(pr); i_prev = i
+                fo = st.add_feat(self.video_feat(j, True))
+                rows = [p0 + plen - 1]
+                if C > 1:
+                    s0 = st.add_seq(-(1 + fo + np.arange(C - 1)), plen + np.arange(C - 1), np.ones(C - 1, np.uint8), (p0, plen))
+                    rows += list(range(s0, s0 + C - 1))
+                st.add_pair(rows, np.array([self.tvg_video_labels[j]], np.int32), np.array([idx]))
+        if st.n_pairs:
+            plans.append(st.finish())
+        return plans
+
+    # ---- execution (device) ---------------------------------------------------------------------
+    def run(self, plan: Plan):
+        """One engine call; returns a device f32 tensor [plan.n_pairs]."""
+        embeds = self.engine.assemble(plan.src_index, plan.feats)
+        if plan.kind == "vtg":
+            return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
+        return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)
+
+    def score(self, plans: List[Plan], n_requested: int) -> np.ndarray:
+        out = np.full(n_requested, np.nan, dtype=np.float32)
+        results = [self.run(p) for p in plans]
+        for p, r in zip(plans, results):
+            sc = r.float().cpu().numpy()
+            for k, outs in enumerate(p.out_index):
+                out[outs] = sc[k]
+        return out
+
+    def vtg(self, pairs, cpn=False) -> np.ndarray:
+        return self.score(self.plan_vtg(pairs, cpn), len(pairs))
+
+    def tvg(self, pairs, cpn=False) -> np.ndarray:
+        return self.score(self.plan_tvg(pairs, cpn), len(pairs))
+
+
+class _PackState:
+    """Accumulates sequences / rows of one super-batch on the host, then uploads once."""
+
+    def __init__(self, scorer: PairScorer, kind: str):
+        self.s, self.kind = scorer, kind
+        self.tok: List[np.ndarray] = []; self.pos: List[np.ndarray] = []; self.vis: List[np.ndarray] = []
+        self.seq_start: List[int] = []; self.seq_len: List[int] = []; self.pfx_start: List[int] = []; self.pfx_len: List[int] = []
+        self.feats: List[object] = []; self.feat_key: Dict[int, int] = {}; self.n_feat = 0
+        self.rows: List[int] = []; self.labels: List[np.ndarray] = []; self.row_start: List[int] = [0]
+        self.out_index: List[np.ndarray] = []
+        self.n_tok = 0; self.n_pairs = 0
+
+    def add_feat(self, f) -> int:
+        k = f.data_ptr()
+        if k in self.feat_key:
+            return self.feat_key[k]
+        off = self.n_feat
+        self.feats.append(f); self.feat_key[k] = off; self.n_feat += int(f.shape[0])
+        return off
+
+    def add_seq(self, toks, pos, vis, prefix) -> int:
+        start = self.n_tok
+        self.tok.append(np.asarray(toks, np.int64)); self.pos.append(np.asarray(pos, np.int64)); self.vis.append(np.asarray(vis, np.uint8))
+        self.seq_start.append(start); self.seq_len.append(len(toks))
+        self.pfx_start.append(prefix[0] if prefix else 0); self.pfx_len.append(prefix[1] if prefix else 0)
+        self.n_tok += len(toks)
+        return start
+
+    def add_pair(self, rows, labels, outs):
+        self.rows += rows
+        self.labels.append(np.asarray(labels, np.int32))
+        self.row_start.append(len(self.rows))
+        self.out_index.append(np.asarray(outs))
+        self.n_pairs += 1
+
+    def finish(self) -> Plan:
+        import torch
+        dev = self.s.device
+        src = np.concatenate(self.tok).astype(np.int32)
+        batch = PackedBatch(np.concatenate(self.pos), np.concatenate(self.vis), np.array(self.seq_start), np.array(self.seq_len),
+                            np.array(self.pfx_start), np.array(self.pfx_len), device=dev)
+        H = self.s.m.dims.hidden_size
+        feats = torch.cat(self.feats, dim=0) if self.feats else torch.zeros((1, H), dtype=torch.bfloat16, device=dev)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        labels = np.concatenate(self.labels)
+        return Plan(kind=self.kind, batch=batch, src_index=t(src), feats=feats, rows=t(np.array(self.rows)), labels=t(labels),
+                    row_start=t(np.array(self.row_start)) if self.kind == "vtg" else None, n_pairs=self.n_pairs,
+                    out_index=self.out_index, n_tokens=self.n_tok, n_rows=len(self.rows))
+
+
+def _topk_pairs(sims_rows, start: int, topk: int, query_is_video: bool) -> np.ndarray:
+    """(video, text) pairs of the top-k candidates of each local query row (sims.topk, retrieval_utils.py:52, 117)."""
+    import torch
+    sims = torch.as_tensor(sims_rows)
+    k = min(sims.shape[1], topk)
+    idx = sims.topk(k=k, dim=1).indices.cpu().numpy()
+    q = np.repeat(np.arange(start, start + sims.shape[0]), k)
+    c = idx.reshape(-1)
+    return np.stack([q, c], axis=1) if query_is_video else np.stack([c, q], axis=1)
+
+
+def evaluation(model, data_loader, device, tokenizer, args):
+    """retrieval_utils.py:169-281.  Returns (t2v_dict, v2t_dict) of numpy [N, N] matrices (W=1-equivalent for any
+    world size: row blocks are merged with an all-gather, not the reference's all_reduce(SUM) of -100-filled
+    matrices -- SURVEY.md section 5 'the -100 offset quirk'; args.compat_allreduce_offset reproduces the offset)."""
+    import torch
+    model.eval()
+    t_start = time.time()
+    video, tvg_video_labels = [], []
+    vtg_ids, vtg_labels, vtg_masks, tvg_ids, tvg_labels, tvg_masks = [], [], [], [], [], []
+    for data in data_loader:                                                # :182-193
+        video += [v for v in data["video"]]
+        vtg_ids += data["vtg_ids"]; vtg_labels += data["vtg_labels"]; vtg_masks += data["vtg_masks"]
+        tvg_ids += data["tvg_ids"]; tvg_labels += data["tvg_labels"]; tvg_masks += data["tvg_masks"]
+        tvg_video_labels.append(torch.as_tensor(data["tvg_video_labels"]))
+    vtg_ids, vtg_labels, vtg_masks = padding_ids(vtg_ids, vtg_labels, vtg_masks, tokenizer)      # :195-196
+    tvg_ids, tvg_labels, tvg_masks = padding_ids(tvg_ids, tvg_labels, tvg_masks, tokenizer)
+    tvg_video_labels = torch.cat(tvg_video_labels, dim=0)
+
+    finetuned = (getattr(args, "resume", "") != "") or not getattr(args, "eval", True)          # :199, 227, 242
+    scores = getattr(args, "iv2_scores", None)
+    if scores is None:
+        path = f"./scores/{args.dataset.lower()}{'' if finetuned else '_zeroshot'}.pth"          # :199-203
+        scores = torch.load(path, weights_only=True)
+    v2t_iv2, t2v_iv2 = torch.as_tensor(scores["v2t"]), torch.as_tensor(scores["t2v"])
+    num_texts, num_videos = t2v_iv2.shape
+    W, rank = dist_utils.get_world_size(), dist_utils.get_rank()
+    video_vocab = data_loader.dataset.video_vocab
+    model.module.set_tvg_prefix_length(data_loader.dataset.tvg_prefix_length)                     # :210
+
+    literal = bool(getattr(args, "literal", False))
+    full = lambda n, m: torch.full((n, m), -100.0, dtype=torch.float32, device=device)
+    scorer = None if literal else PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
+                                             tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
+
+    def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):
+        if literal:
+            fn = compute_v2t_scores_x if query_is_video else compute_t2v_scores_x
+            ids, msk, lab = (vtg_ids, vtg_masks, vtg_labels) if ftype == "vtg" else (tvg_ids, tvg_masks, tvg_labels)
+            return fn(S, sims_rows, start, ids, msk, lab, video, video_vocab.to(device), tvg_video_labels, model, device, args,
+                      forward_type=ftype, cpn=cpn)
+        if sims_rows.shape[0] == 0:
+            return S
+        pairs = _topk_pairs(sims_rows, start, args.topk, query_is_video)
+        sc = scorer.vtg(pairs, cpn) if ftype == "vtg" else scorer.tvg(pairs, cpn)
+        r, c = (pairs[:, 0], pairs[:, 1]) if query_is_video else (pairs[:, 1], pairs[:, 0])
+        S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = torch.from_numpy(sc).to(device)
+        return S
+
+    v2t, t2v = {}, {}
+    start, end = dist_utils.row_block(num_videos, W, rank)                                       # :213-215
+    v2t["candidate_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", False)
+    if args.cpn:
+        v2t["candidate_prior"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", True)
+    if finetuned:
+        v2t["query_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "tvg", False)
+    v_block = (start, end)
+    start, end = dist_utils.row_block(num_texts, W, rank)                                        # :233-235
+    t2v["query_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "vtg", False)
+    if finetuned:
+        t2v["candidate_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", False)
+        if args.cpn:
+            t2v["candidate_prior"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", True)
+    t_block = (start, end)
+
+    if W > 1:                                                                                    # :252-262
+        compat = bool(getattr(args, "compat_allreduce_offset", False))
+        for d, blk in ((v2t, v_block), (t2v, t_block)):
+            for k in list(d):
+                d[k] = dist_utils.merge_row_blocks(d[k], blk, W, compat_offset=compat)
+    t2v_dict = {k: v.cpu().numpy() for k, v in t2v.items()}                                      # :264-276
+    v2t_dict = {k: v.cpu().numpy() for k, v in v2t.items()}
+    t2v_dict["internvideo2"] = t2v_iv2.cpu().numpy()
+    v2t_dict["internvideo2"] = v2t_iv2.cpu().numpy()
+    if getattr(args, "verbose", False) and rank == 0:
+        print(f"Evaluation time {time.time() - t_start:.1f}s")
+    return t2v_dict, v2t_dict

@@ -1,0 +1,69 @@
+"""Rank / metric math of the reference's eval epoch (training_utils.py:106-221): CPN subtraction,
+the two linear ensembles and R@1/5/10.  Host-side numpy on the [N, N] score matrices."""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from . import distributed as dist_utils
+from .retrieval_utils import evaluation
+
+
+def _recall_one(m: np.ndarray, ids) -> tuple:
+    if np.count_nonzero(m == 0) != 0:                               # zero sentinel, training_utils.py:174-175, 195-196
+        return 0.0, 0.0, 0.0
+    ranks = np.zeros(m.shape[0])
+    for index, score in enumerate(m):
+        inds = np.argsort(score)[::-1]
+        gt = ids[index]
+        if isinstance(gt, (int, np.integer)):
+            ranks[index] = np.where(inds == gt)[0][0]
+        else:
+            ranks[index] = min(np.where(inds == g)[0][0] for g in gt)
+    n = len(ranks)
+    return tuple(100.0 * len(np.where(ranks < t)[0]) / n for t in (1, 5, 10))
+
+
+def get_recall(t2v, v2t, t2v_ids, v2t_ids) -> Dict[str, float]:
+    """training_utils.py:173-221."""
+    v1, v5, v10 = _recall_one(v2t, v2t_ids)
+    t1, t5, t10 = _recall_one(t2v, t2v_ids)
+    vm, tm = (v1 + v5 + v10) / 3, (t1 + t5 + t10) / 3
+    res = {"t2v_r1": t1, "t2v_r5": t5, "t2v_r10": t10, "t2v_r_mean": tm, "v2t_r1": v1, "v2t_r5": v5, "v2t_r10": v10,
+           "v2t_r_mean": vm, "r_mean": (vm + tm) / 2}
+    return {k: round(v, 2) for k, v in res.items()}
+
+
+def combine_and_rank(t2v_dict, v2t_dict, args, n: int) -> Dict[str, Dict[str, float]]:
+    """training_utils.py:145-169 (rank 0 part of val_one_epoch)."""
+    ids = {i: i for i in range(n)}
+    finetuned = (getattr(args, "resume", "") != "") or not getattr(args, "eval", True)
+    results = {}
+    z = lambda: np.zeros((n, n))
+    for name in ["internvideo2", "candidate_likelihood", "query_likelihood", "cpn_candidate_likelihood", "blim"]:
+        if name == "cpn_candidate_likelihood":
+            if args.cpn:
+                cpn_t2v = t2v_dict["candidate_likelihood"] - args.alpha[0] * t2v_dict["candidate_prior"] if finetuned else z()
+                cpn_v2t = v2t_dict["candidate_likelihood"] - args.alpha[1] * v2t_dict["candidate_prior"]
+                results[name] = get_recall(cpn_t2v, cpn_v2t, ids, ids)
+            else:
+                cpn_t2v = t2v_dict["candidate_likelihood"] if finetuned else z()
+                cpn_v2t = v2t_dict["candidate_likelihood"]
+        elif name == "blim":
+            blim_t2v = args.c[0] * t2v_dict["query_likelihood"] + (1 - args.c[0]) * cpn_t2v
+            blim_v2t = args.c[1] * v2t_dict["query_likelihood"] + (1 - args.c[1]) * cpn_v2t if finetuned else cpn_v2t
+            blim_t2v = args.c[2] * blim_t2v + (1 - args.c[2]) * t2v_dict["internvideo2"]
+            blim_v2t = args.c[3] * blim_v2t + (1 - args.c[3]) * v2t_dict["internvideo2"]
+            results[name] = get_recall(blim_t2v, blim_v2t, ids, ids)
+        else:
+            results[name] = get_recall(t2v_dict.get(name, z()), v2t_dict.get(name, z()), ids, ids)
+    return results
+
+
+def val_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler, tokenizer=None, args=None):
+    """training_utils.py:140-169 (no autocast: the engine computes in bf16 with f32 accumulation)."""
+    t2v_dict, v2t_dict = evaluation(model, data_loader, device, tokenizer, args)
+    if dist_utils.is_main_process():
+        return combine_and_rank(t2v_dict, v2t_dict, args, len(data_loader.dataset))
+    return None

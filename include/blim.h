@@ -1,0 +1,157 @@
+/* blim.h -- C ABI of the MI355X-native BLiM likelihood-scoring engine (libblim_hip.so).
+ *
+ * The reference (mlvlab/BLiM) is pure Python/PyTorch and has no FFI layer; its boundary for the hot path
+ * is the duck-typed Python surface that retrieval_utils.py calls.  This header is
+ * the C-ABI the host-side mirror of that surface (blim_amd/modeling.py, blim_amd/retrieval_utils.py)
+ * binds with ctypes; every entry point names the reference code it replaces.  INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success or a negative BLIM_ERR_* code and never throws;
+ * blim_last_error() returns a message for the calling thread.  All data pointers are DEVICE pointers
+ * (HIP) unless the parameter is documented as host; the caller owns every buffer passed in.  Calls are
+ * asynchronous on the given hipStream_t (passed as void*; NULL = default stream); the caller synchronises.
+ * An engine handle is not thread-safe; distinct handles are independent.  bf16 = raw 16-bit brain floats.
+ */
+#ifndef BLIM_H_
+#define BLIM_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLIM_ABI_VERSION 1
+#define BLIM_ERR_ARG (-1)
+#define BLIM_ERR_HIP (-2)
+#define BLIM_ERR_STATE (-3)
+#define BLIM_ERR_NOMEM (-4)
+
+#define BLIM_DTYPE_F32 0
+#define BLIM_DTYPE_BF16 1
+
+typedef struct blim_engine blim_engine;
+
+/* Model dimensions: Qwen2Config + mm_* fields of the checkpoint the reference loads (main.py:96-97). */
+typedef struct blim_config {
+    int32_t vocab_size, hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads;
+    int32_t mm_hidden_size; /* projector input width (1024) */
+    int32_t num_clips;      /* --num_clips, main.py:59 (4) */
+    int32_t max_positions;  /* RoPE table length */
+    float rms_eps, rope_theta;
+} blim_config;
+
+/* A batch of packed token sequences.  Sequence s owns tokens [seq_start[s], seq_start[s]+seq_len[s]) of the
+ * packed arrays and may name a shared prefix [pfx_start[s], +pfx_len[s]) (another sequence's tokens, e.g. the
+ * video+prompt prefix shared by all text candidates of one query).  Token i of s attends to every prefix token
+ * and to own tokens 0..i, restricted to key_visible != 0 (causal AND key-padding AND CPN mask of
+ * modeling_qwen2_flash.py:1025-1040 / modeling_videochat_flash.py:409-433).  blk_* list the 32-query blocks:
+ * for every sequence, q0 = 0, 32, 64, ... < seq_len. */
+typedef struct blim_batch {
+    int64_t n_tokens;
+    int32_t n_seqs;
+    int32_t n_blocks;
+    const int32_t* positions;   /* [n_tokens] RoPE position (modeling_qwen2_flash.py:998-1003) */
+    const uint8_t* key_visible; /* [n_tokens] */
+    const int32_t* seq_start;   /* [n_seqs] */
+    const int32_t* seq_len;     /* [n_seqs] */
+    const int32_t* pfx_start;   /* [n_seqs] */
+    const int32_t* pfx_len;     /* [n_seqs] (0 = no prefix) */
+    const int32_t* blk_seq;     /* [n_blocks] */
+    const int32_t* blk_q0;      /* [n_blocks] */
+} blim_batch;
+
+int blim_abi_version(void);
+const char* blim_last_error(void);
+
+/* ---- lifetime.  Replaces VideoChatFlashQwenForCausalLM.from_pretrained(...).half().to(device), main.py:96-97. */
+int blim_create(const blim_config* cfg, blim_engine** out);
+void blim_destroy(blim_engine* e);
+
+/* ---- weights.  `name` is a canonical tensor name (blim_amd/synth.py:weight_shapes); `data` holds the tensor in
+ * the checkpoint's natural [out, in] layout as f32 or bf16, on host (on_device = 0) or device.  The engine keeps
+ * its own bf16 copy in kernel layout (fused q|k|v with RoPE pair interleave, interleaved gate|up).
+ * Replaces load_state_dict / util/misc.py:303-311. */
+int blim_load_weight(blim_engine* e, const char* name, const void* data, int32_t dtype, int32_t on_device);
+/* Seeded synthetic weights generated on device by the rule of blim_amd/synth.py (no checkpoint available offline). */
+int blim_init_synthetic_weights(blim_engine* e, uint64_t seed);
+/* 0 when every tensor has been loaded, BLIM_ERR_STATE (message lists a missing tensor) otherwise. */
+int blim_weights_ready(const blim_engine* e);
+
+/* Pre-size workspaces (optional; they grow on demand, which synchronises the device). */
+int blim_reserve(blim_engine* e, int64_t max_tokens, int64_t max_rows);
+
+/* ---- K1: projector.  feats bf16 [n_rows, mm_hidden] -> out bf16 [n_rows, hidden]; which = 0 `mlp`, 1 `tvg_mlp`.
+ * Replaces ToMe16_mlp_hd64.forward(video_feature=True), mm_projector_builder.py:156-159. */
+int blim_project_video(blim_engine* e, const void* feats, int64_t n_rows, int32_t which, void* out, void* stream);
+/* mean over groups of `group` consecutive rows (TVG clip tokens, modeling_videochat_flash.py:243). */
+int blim_group_mean(blim_engine* e, const void* in, int64_t n_out, int32_t group, void* out, void* stream);
+
+/* ---- K2: sequence assembly.  out[t] = src_index[t] >= 0 ? embed_tokens[src_index[t]] : feats[-(src_index[t]+1)].
+ * Replaces embed_tokens + the splice of modeling_videochat_flash.py:388-440. */
+int blim_assemble(blim_engine* e, const int32_t* src_index, int64_t n_tokens, const void* feats, void* out_embeds, void* stream);
+
+/* ---- K3-K9: Qwen2 decoder over a packed batch; writes the final-norm hidden state of rows out_rows[0..n_out)
+ * (out_rows = NULL: all tokens) as bf16 and/or f32 (either may be NULL).
+ * Replaces Qwen2Model_Flash.forward, modeling_qwen2_flash.py:952-1156. */
+int blim_decode(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
+                void* out_hidden_bf16, float* out_hidden_f32, void* stream);
+
+/* ---- K10+K11: log P(label | hidden) without materialising logits: logprob[r] = log_softmax(lm_head(hidden[r]))[labels[r]],
+ * 0 where labels[r] < 0.  Replaces lm_head + .float() (modeling_qwen2_flash.py:1452-1453) + CrossEntropyLoss of
+ * VTGCriterion (retrieval_utils.py:23-31). */
+int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const int32_t* labels, int64_t n_rows, float* logprob, void* stream);
+/* score[p] = sum(logprob[row_start[p] .. row_start[p+1])) / d, d = count_nonzero(...) for mode 0 (VTGCriterion,
+ * retrieval_utils.py:32-33) or the row count for mode 1 (TVGCriterion's mean, :42).  e may be NULL. */
+int blim_segment_mean(blim_engine* e, const float* logprob, const int32_t* row_start, int32_t n_pairs, int32_t mode, float* score, void* stream);
+
+/* Literal path: logits f32 [n_rows, vocab] = lm_head(hidden) and the criterion on materialised logits. */
+int blim_lm_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, float* logits, void* stream);
+/* (e may be NULL for blim_ce_rows) */
+int blim_ce_rows(blim_engine* e, const float* logits, int64_t ld, int32_t n_cols, const int32_t* labels, int64_t n_rows, float* logprob, void* stream);
+
+/* ---- K13: visual_head, bf16 [n_rows, hidden] -> bf16 [n_rows, mm_hidden] (modeling_videochat_flash.py:598-599). */
+int blim_visual_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, void* out_bf16, void* stream);
+/* ---- K14+K15: vh bf16 [n_pairs, clips, mm_hidden]; vocab bf16 [clips, n_vocab, mm_hidden] (clip-major copy of
+ * video_vocab); score[p] = mean_c log_softmax_n(vh[p,c].vocab[c,n] / sqrt(mm_hidden))[labels[p]].
+ * Replaces the bmm + TVGCriterion of retrieval_utils.py:106-107, 40-43. */
+int blim_tvg_scores(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, const int32_t* labels,
+                    int32_t n_pairs, float* score, void* stream);
+/* the logits alone: f32 [n_pairs, clips, n_vocab] (literal path, retrieval_utils.py:106) */
+int blim_tvg_logits(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream);
+
+/* ---- Fused scoring: decode + head + criterion in one call.
+ * VTG: rows[r] = packed token whose hidden state predicts labels[r]; pair p owns rows [row_start[p], row_start[p+1]). */
+int blim_score_vtg(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* rows, const int32_t* labels,
+                   int64_t n_rows, const int32_t* row_start, int32_t n_pairs, float* score, void* stream);
+/* TVG: rows[p*clips + c] = packed token whose hidden state predicts clip c of pair p. */
+int blim_score_tvg(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* rows, const void* vocab_bf16,
+                   int32_t n_vocab, const int32_t* labels, int32_t n_pairs, float* score, void* stream);
+
+/* ---- Literal model.forward(inputs_embeds=[B,L,H] bf16, attention_mask=[B,L] u8) -> logits f32 [B,L,V] (may be NULL),
+ * hidden f32 [B,L,H] (may be NULL).  Replaces VideoChatFlashQwenForCausalLM.forward, modeling_videochat_flash.py:601-629. */
+int blim_forward(blim_engine* e, const void* embeds, const uint8_t* mask, int32_t B, int32_t L, float* logits, float* hidden, void* stream);
+
+/* ---- synthetic data + plain GEMM (bench / tests) */
+int blim_fill_bell_bf16(void* out, int64_t n, uint64_t seed, const char* name, float std, float mean, void* stream);
+int blim_fill_bell_f32(float* out, int64_t n, uint64_t seed, const char* name, float std, float mean, int32_t round_bf16, void* stream);
+/* C bf16 [M, ldc] = A bf16 [M, lda] . W bf16 [N, K]^T */
+int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
+
+/* ---- per-kernel-class timing (hipEvents on the launch stream).  Classes: see blim_timing_class_name. */
+int blim_timing_enable(blim_engine* e, int32_t on);
+int blim_timing_num_classes(void);
+const char* blim_timing_class_name(int32_t cls);
+/* Synchronises the recorded events; ms[c] = total ms, calls[c] = launches, flops[c] = FLOPs issued (host arrays of
+ * blim_timing_num_classes() entries); then clears the record. */
+int blim_timing_report(blim_engine* e, double* ms, int64_t* calls, double* flops);
+
+/* Bring-up aid: copies the first `bytes` bytes of an internal workspace ("resid" f32 [T,H], "xn" bf16 [T,H],
+ * "qkv" bf16 [T,(nh+2nkv)*128], "attn" bf16 [T,H], "act" bf16 [T,I]) as the last blim_decode left it. */
+int blim_debug_read(blim_engine* e, const char* which, void* dst, int64_t bytes, void* stream);
+
+/* tuning switches (0/1): "attn_tr_read" */
+int blim_set_option(blim_engine* e, const char* key, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLIM_H_ */

@@ -215,8 +215,9 @@ class OracleModel:
         return mask, cpn, embeds, out_lab
 
     # --- decoder, modeling_qwen2_flash.py:952-1156 + 1392-1478
-    def decoder_layer(self, i: int, x: np.ndarray, add_mask: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
-        """modeling_qwen2_flash.py:742-800 with eager attention :247-326."""
+    def decoder_layer(self, i: int, x: np.ndarray, add_mask: np.ndarray, cos: np.ndarray, sin: np.ndarray, parts: Optional[dict] = None) -> np.ndarray:
+        """modeling_qwen2_flash.py:742-800 with eager attention :247-326.  `parts` (optional dict) receives the
+        intermediates q/k/v (after RoPE, [B,L,heads*hd]), attn, act for bring-up comparisons."""
         c, w = self.cfg, self.w
         P = f"layers.{i}."
         B, L, H = x.shape
@@ -227,6 +228,9 @@ class OracleModel:
         v = (h @ w[P + "v_proj.w"].T + w[P + "v_proj.b"]).reshape(B, L, nkv, hd).transpose(0, 2, 1, 3)
         q = apply_rope(q, cos, sin)
         k = apply_rope(k, cos, sin)
+        if parts is not None:
+            flat = lambda t: t.transpose(0, 2, 1, 3).reshape(B, L, -1)
+            parts["xn1"] = h; parts["q"] = flat(q); parts["k"] = flat(k); parts["v"] = flat(v)
         rep = nh // nkv                                                 # repeat_kv :192-201
         k = np.repeat(k, rep, axis=1)
         v = np.repeat(v, rep, axis=1)
@@ -238,6 +242,8 @@ class OracleModel:
         x = x + a @ w[P + "o_proj.w"].T
         h = rms_norm(x, w[P + "post_norm"], c.rms_eps)
         g = silu(h @ w[P + "gate_proj.w"].T) * (h @ w[P + "up_proj.w"].T)
+        if parts is not None:
+            parts["attn"] = a; parts["resid_mid"] = x; parts["act"] = g
         return (x + g @ w[P + "down_proj.w"].T).astype(np.float32)
 
     def forward_hidden(self, embeds: np.ndarray, key_mask: np.ndarray, n_layers: Optional[int] = None) -> np.ndarray:
