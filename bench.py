@@ -1,0 +1,167 @@
+"""Benchmark of the likelihood-scoring hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one engine pass over one device-resident super-batch of synthetic (query, candidate) pairs of
+BASELINE.json's headline shape: Qwen2-7B dims, 96 video tokens + 32 text tokens per pair, top-16 candidates per
+video query (v2t VTG pass).  The 96-token video prefix of a query is computed once and its K/V reused by the 16
+candidates (identical scores, fewer executed FLOPs); `roofline` is priced on the FLOPs actually executed.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, I, V, LAYERS = 3584, 18944, 152064, 28
+FLOP_TOKEN_LAYER = 2 * H * (H + 2 * 512) + 2 * H * H + 6 * H * I      # 466,092,032
+FLOP_HEAD_ROW = 2 * H * V                                           # 1,089,994,752
+PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def f_pair(L, t_lab):
+    """Algorithmic FLOPs of one pair scored on its own."""
+    return LAYERS * (FLOP_TOKEN_LAYER * L + 2 * H * L * L) + FLOP_HEAD_ROW * t_lab
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The numpy oracle (fp32) on a bounded sample of the same workload, timed on this host's cores:
+    ONE decoder layer at 7B width on 16 pairs x 128 tokens (no prefix sharing, as the reference runs it) plus the
+    lm_head + log-softmax on 64 label rows; extrapolated to 28 layers and 16 x 32 label rows."""
+    from oracle import blim_oracle as O
+    cfg = O.OracleConfig(num_layers=1)
+    rs = np.random.default_rng(0)
+    shapes = O.weight_shapes(cfg)
+    w = {}
+    for n, s in shapes.items():
+        if n.startswith("layers.0.") or n == "final_norm":
+            w[n] = (rs.standard_normal(s, dtype=np.float32) * (0.02 if not n.endswith("norm") else 0.0) + (1.0 if n.endswith("norm") else 0.0)).astype(np.float32)
+    m = O.OracleModel(cfg, w)
+    B, L = 16, 128
+    x = (rs.standard_normal((B, L, cfg.hidden_size), dtype=np.float32) * 0.02)
+    cos, sin = O.rope_tables(cfg.head_dim, cfg.rope_theta, L)
+    am = O.additive_mask(np.ones((B, L), dtype=np.int64), L)
+    m.decoder_layer(0, x[:2], am[:2], cos, sin)        # warm up BLAS threads
+    t0 = time.time(); y = m.decoder_layer(0, x, am, cos, sin); t_layer = time.time() - t0
+    wl = rs.standard_normal((cfg.vocab_size, cfg.hidden_size), dtype=np.float32) * 0.02
+    rows = 64
+    t0 = time.time(); lg = y.reshape(-1, cfg.hidden_size)[:rows] @ wl.T; O.log_softmax(lg); t_head = (time.time() - t0) * (B * 32 / rows)
+    t_batch = LAYERS * t_layer + t_head
+    return {"value": round(B / t_batch, 4), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle (numpy fp32, BLAS threads = host cores): 1 decoder layer at 7B width on 16 pairs x 128 tokens = {t_layer:.2f}s, "
+                      f"lm_head+log-softmax on {rows} rows scaled to 512 = {t_head:.2f}s; x28 layers extrapolated; no prefix sharing"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--queries", type=int, default=53, help="video queries per step per GPU (53 x 608 tokens ~ 32768 = 128 row tiles)")
+    ap.add_argument("--topk", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from blim_amd import distributed as D
+    from blim_amd import retrieval_utils as RU
+    from blim_amd import synth
+    from blim_amd.modeling import BlimModel, DDPLike
+
+    rank, world, local = D.init_distributed_mode() if a.gpus > 1 else (0, 1, 0)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    dims = synth.ModelDims()
+    model = BlimModel(dims, max_positions=1024)
+    model.engine.init_synthetic_weights(0)                       # torch seed 0 of BASELINE.md -> engine seed 0
+    Q, K = a.queries, a.topk
+    n_plans = max(1, min(3, a.steps))
+    plans = []
+    tok = type("T", (), {"pad_token_id": synth.PAD_ID})()
+    for pi in range(n_plans):
+        prob = synth.make_problem(1000 + 17 * rank + pi, Q, dims, tok_per_clip=24, text_len=(32, 32), reference_layout=False)
+        Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+        vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+        tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+        scorer = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video],
+                               torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels), dims.num_clips, max_tokens=1 << 20)
+        pairs = RU._topk_pairs(torch.from_numpy(prob.v2t_sims), 0, K, True)
+        (plan,) = scorer.plan_vtg(pairs)
+        plans.append((scorer, plan))
+    plan0 = plans[0][1]
+    n_pairs, n_tok, n_rows = plan0.n_pairs, plan0.n_tokens, plan0.n_rows
+    model.engine.reserve(n_tok, n_rows)
+
+    def step(i):
+        sc, pl = plans[i % n_plans]
+        return sc.run(pl)
+
+    for i in range(a.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [step(i) for i in range(a.steps)]
+    mine = torch.stack(outs)                                      # [steps, pairs] score rows of this rank
+    if world > 1:
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(gathered, mine)              # RCCL all-gather of the score rows (north_star)
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(mine).all(), "non-finite scores"
+
+    # ---- per-kernel timing (HIP events on the launch stream) of one more step, for the roofline object
+    model.engine.timing_enable(True)
+    step(0)
+    rep = model.engine.timing_report()
+    model.engine.timing_enable(False)
+
+    if rank == 0:
+        total_pairs = n_pairs * a.steps * world
+        value = total_pairs / dt
+        exec_flops_step = LAYERS * (FLOP_TOKEN_LAYER * n_tok) + FLOP_HEAD_ROW * n_rows      # attention excluded (<1 %)
+        dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
+        d = rep[dom]
+        ach = d["flops"] / d["calls"] / (d["ms"] / d["calls"] * 1e-3) / 1e12
+        out = {
+            "metric": "candidate-pairs/sec (7B, 96+32 tok)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SYN v2t-VTG re-rank: Qwen2-7B dims (28 layers), seeded synthetic bf16 weights, 96 video + 32 text tokens per pair, "
+                                   f"top-{K} text candidates per video query, {Q} queries ({n_pairs} pairs, {n_tok} packed tokens, {n_rows} label rows) per step per GPU",
+                       "prefix_reuse": True, "pairs_per_step_per_gpu": n_pairs, "tokens_per_step_per_gpu": n_tok,
+                       "parallelism": f"query rows sharded over {world} GPU(s); RCCL all-gather of score rows at the end"},
+            "algorithmic_gflop_per_pair": round(f_pair(128, 32) / 1e9, 1),
+            "executed_gflop_per_pair": round(exec_flops_step / n_pairs / 1e9, 1),
+            "executed_tflops_per_gpu": round(exec_flops_step * a.steps / dt / 1e12, 1),
+            "frac_mfma_peak_whole_step": round(exec_flops_step * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(d["ms"] / d["calls"], 4), "flop_per_launch": d["flops"] / d["calls"]},
+            "kernel_classes_ms": {k: round(v["ms"], 3) for k, v in rep.items() if v["calls"]},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

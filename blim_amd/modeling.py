@@ -46,23 +46,27 @@ class BlimModel:
         self._proj_cache.clear()
 
     # ---- K1 with a per-video cache (the reference re-projects identical copies, retrieval_utils.py:60)
-    def project(self, feat, tvg: bool):
-        """feat: [clips, T, mm_hidden] device tensor -> bf16 [clips*T, H] (vtg) or [clips, H] (tvg: mean over T)."""
+    def project(self, feat, tvg: bool, cache: bool = True):
+        """feat: [clips, T, mm_hidden] device tensor -> bf16 [clips*T, H] (vtg) or [clips, H] (tvg: mean over T).
+
+        The cache is keyed on the tensor's storage address AND keeps a reference to the tensor, so the address
+        cannot be recycled for different data while the entry lives."""
         import torch
-        key = (feat.data_ptr(), tuple(feat.shape), bool(tvg), feat._version)
-        hit = self._proj_cache.get(key)
-        if hit is not None:
-            return hit
-        if feat.ndim == 4:                                       # :195 unsqueeze(0) / :157 squeeze(0)
-            feat = feat.squeeze(0)
-        clips, T, M = feat.shape
-        x = feat.to(device=self.device, dtype=torch.bfloat16).reshape(clips * T, M).contiguous()
+        key = (feat.data_ptr(), tuple(feat.shape), feat.dtype, bool(tvg), feat._version)
+        if cache:
+            hit = self._proj_cache.get(key)
+            if hit is not None:
+                return hit[1]
+        x = feat.squeeze(0) if feat.ndim == 4 else feat          # :195 unsqueeze(0) / :157 squeeze(0)
+        clips, T, M = x.shape
+        x = x.to(device=self.device, dtype=torch.bfloat16).reshape(clips * T, M).contiguous()
         y = self.engine.project_video(x, 1 if tvg else 0)
         if tvg:
             y = self.engine.group_mean(y, T)                     # :243 frame_feature.mean(1)
-        if len(self._proj_cache) > 4096:
-            self._proj_cache.clear()
-        self._proj_cache[key] = y
+        if cache:
+            if len(self._proj_cache) >= 256:
+                self._proj_cache.pop(next(iter(self._proj_cache)))
+            self._proj_cache[key] = (feat, y)
         return y
 
     def forward_visual(self, visual_token_embeds):               # modeling_videochat_flash.py:598-599

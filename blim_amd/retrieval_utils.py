@@ -217,7 +217,7 @@ class PairScorer:
         key = (int(j), bool(tvg))
         f = self._vfeat.get(key)
         if f is None:
-            f = self.m.project(self.video[j].to(self.device), tvg)
+            f = self.m.project(self.video[j].to(self.device), tvg, cache=False)
             self._vfeat[key] = f
         return f
 

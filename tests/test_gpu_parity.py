@@ -1,0 +1,281 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI, against the numpy oracle and the golden vectors recorded
+from the reference.  Tolerances: scores 1e-3 relative per entry (BASELINE.json north_star); intermediate bf16
+tensors 2e-2 of the tensor's max (one bf16 rounding is 2^-9 = 2e-3 relative; a few stack up per stage)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from blim_amd import engine as eng
+from blim_amd import retrieval_utils as RU
+from blim_amd import synth
+from blim_amd import training_utils as TU
+from blim_amd.modeling import BlimModel, DDPLike
+from oracle import blim_oracle as O
+from oracle.gen_golden import CASES
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SCORE_RTOL = 1e-3
+
+
+def bf(x):
+    return torch.from_numpy(synth.bf16_bits(np.asarray(x, np.float32)).view(np.int16)).view(torch.bfloat16)
+
+
+def relmax(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _build(case, layers=None, device_synth=False):
+    spec = CASES[case]
+    d = dict(spec["dims"])
+    if layers is not None:
+        d["num_layers"] = layers
+    dims = synth.ModelDims(**d)
+    model = BlimModel(dims, max_positions=1024)
+    w = None
+    if device_synth:
+        model.engine.init_synthetic_weights(spec["wseed"])
+    else:
+        w = synth.synthetic_weights(dims, spec["wseed"])
+        model.engine.load_weights(w)
+    prob = synth.make_problem(spec["pseed"], spec["n"], dims, tok_per_clip=spec["tok_per_clip"], text_len=spec["text_len"])
+    model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    return types.SimpleNamespace(spec=spec, dims=dims, model=model, w=w, prob=prob, d=d)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    t = _build("tiny")
+    yield t
+    t.model.engine.close()
+
+
+@pytest.fixture(scope="module")
+def tiny1():
+    t = _build("tiny", layers=1)
+    yield t
+    t.model.engine.close()
+
+
+@pytest.fixture(scope="module")
+def wide():
+    t = _build("wide", device_synth=True)
+    yield t
+    t.model.engine.close()
+
+
+def test_native_library_is_the_thing_under_test():
+    lib = eng.load_library()
+    assert os.path.samefile(lib._name, eng.LIB_PATH)
+    assert torch.cuda.is_available()
+
+
+def test_device_fill_is_bit_exact_with_the_numpy_rule():
+    for n, std, mean in ((1000, 0.02, 0.0), (4099, 0.1, 1.0), (7, 1.0, 0.0)):
+        out = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        eng.fill_bell_bf16(out, 7, "layers.3.q_proj.w", std, mean)
+        got = out.view(torch.int16).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, synth.bf16_bits(synth.bell_f32(7, "layers.3.q_proj.w", n, std, mean)))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1, 4, 64), (300, 500, 128), (1000, 260, 256), (513, 1028, 3584), (2048, 512, 18944)])
+def test_gemm_vs_numpy(M, N, K):
+    rs = np.random.RandomState(M + N)
+    a = synth.bf16_round(rs.randn(M, K).astype(np.float32)); w = synth.bf16_round(rs.randn(N, K).astype(np.float32) * 0.05)
+    got = eng.gemm_bf16(bf(a).cuda(), bf(w).cuda()).float().cpu().numpy()
+    want = a @ w.T
+    assert relmax(got, want) < 6e-3        # one bf16 rounding of the output
+
+
+def test_layer_stages_against_oracle(tiny1):
+    """QKV+bias+RoPE, attention (key mask incl. CPN), SwiGLU and both residual GEMMs, one stage at a time."""
+    t = tiny1
+    ocfg = O.OracleConfig(**t.d)
+    om = O.OracleModel(ocfg, t.w); om.set_tvg_prefix_length(t.prob.tvg_prefix_length)
+    vtg = O.padding_ids(t.prob.vtg_ids, t.prob.vtg_labels, t.prob.vtg_masks, synth.PAD_ID)
+    sel = [0, 1, 2]
+    mask, cpn, emb, lab = om.prepare_inputs_labels_for_multimodal(vtg[0][sel], vtg[2][sel], vtg[1][sel], [t.prob.video[i] for i in sel])
+    B, L, H = emb.shape
+    E = t.model.engine
+    e_t = bf(emb).cuda()
+    nq, nk = t.dims.num_heads * 128, t.dims.num_kv_heads * 128
+    for mm in (mask, cpn):
+        parts = {}
+        cos, sin = O.rope_tables(ocfg.head_dim, ocfg.rope_theta, L)
+        x1 = om.decoder_layer(0, synth.bf16_round(emb), O.additive_mask(mm, L), cos, sin, parts)
+        for tr in (1, 0):
+            E.set_option("attn_tr_read", tr)
+            _, hd = E.forward(e_t, torch.from_numpy(mm.astype(np.uint8)).cuda(), want_logits=False, want_hidden=True)
+            valid = mask.astype(bool)
+            qkv = E.debug_read("qkv", (B * L, nq + 2 * nk), torch.bfloat16).float().cpu().numpy().reshape(B, L, -1)
+            assert relmax(qkv[..., :nq][valid], parts["q"][valid]) < 2e-2
+            assert relmax(qkv[..., nq:nq + nk][valid], parts["k"][valid]) < 2e-2
+            assert relmax(qkv[..., nq + nk:][valid], parts["v"][valid]) < 2e-2
+            at = E.debug_read("attn", (B * L, H), torch.bfloat16).float().cpu().numpy().reshape(B, L, H)
+            assert relmax(at[valid], parts["attn"][valid]) < 2e-2
+            ac = E.debug_read("act", (B * L, t.dims.intermediate_size), torch.bfloat16).float().cpu().numpy().reshape(B, L, -1)
+            assert relmax(ac[valid], parts["act"][valid]) < 2e-2
+            rs = E.debug_read("resid", (B * L, H), torch.float32).cpu().numpy().reshape(B, L, H)
+            assert relmax(rs[valid], x1[valid]) < 1e-2
+            assert relmax(hd.cpu().numpy()[valid], O.rms_norm(x1, om.w["final_norm"], ocfg.rms_eps)[valid]) < 1e-2
+    E.set_option("attn_tr_read", 1)
+
+
+def test_projector_and_sequence_assembly(tiny):
+    t = tiny
+    g = np.load(os.path.join(GOLD, "tiny.npz"))
+    T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    sel = [0, 1, 2]
+    for kind in ("vtg", "tvg"):
+        r = t.model.prepare_inputs_labels_for_multimodal(T(g[f"pad_{kind}_ids"][sel]), None, T(g[f"pad_{kind}_masks"][sel]), None,
+                                                         T(g[f"pad_{kind}_labels"][sel]), [T(t.prob.video[i]) for i in sel], ["video"] * 3,
+                                                         image_sizes=None, video_feature=True, tvg=(kind == "tvg"), cpn=True)
+        (none0, pos, (m_t, c_t), pkv, e_t, l_t) = r
+        assert none0 is None and pos is None and pkv is None
+        assert np.array_equal(m_t.cpu().numpy(), g[f"prep_{kind}_mask"]) and m_t.dtype == torch.long
+        assert np.array_equal(c_t.cpu().numpy(), g[f"prep_{kind}_cpn_mask"])
+        assert np.array_equal(l_t.cpu().numpy(), g[f"prep_{kind}_labels"])
+        assert relmax(e_t.float().cpu().numpy(), g[f"prep_{kind}_embeds"]) < 1e-2
+        # cpn=False returns the plain mask, not the pair (modeling_videochat_flash.py:512-515)
+        r2 = t.model.prepare_inputs_labels_for_multimodal(T(g[f"pad_{kind}_ids"][sel]), None, T(g[f"pad_{kind}_masks"][sel]), None,
+                                                          T(g[f"pad_{kind}_labels"][sel]), [T(t.prob.video[i]) for i in sel], ["video"] * 3,
+                                                          video_feature=True, tvg=(kind == "tvg"))
+        assert torch.equal(r2[2], m_t)
+
+
+def test_forward_surface_and_hidden_states(tiny):
+    t = tiny
+    g = np.load(os.path.join(GOLD, "tiny.npz"))
+    ddp = DDPLike(t.model).eval()
+    for kind in ("vtg", "tvg"):
+        emb = bf(g[f"prep_{kind}_embeds"]).cuda()
+        valid = g[f"prep_{kind}_mask"].astype(bool)
+        for tag, mk in (("", f"prep_{kind}_mask"), ("_cpn", f"prep_{kind}_cpn_mask")):
+            out = ddp(inputs_embeds=emb, attention_mask=torch.from_numpy(g[mk]).cuda())
+            assert out.logits.dtype == torch.float32 and out.logits.shape == (3, emb.shape[1], t.dims.vocab_size)
+            assert out.hidden_states.shape == emb.shape
+            assert relmax(out.hidden_states.cpu().numpy()[valid], g[f"fwd_{kind}{tag}_hidden"][valid]) < 1e-2
+            if kind == "vtg":
+                sc = RU.vtg_criterion(out.logits, torch.from_numpy(g["prep_vtg_labels"]).cuda()).cpu().numpy()
+                np.testing.assert_allclose(sc, g[f"fwd_vtg{tag}_score"], rtol=SCORE_RTOL)
+                if tag == "":
+                    pos = torch.from_numpy(g["fwd_vtg_logits_row0_pos"]).cuda()
+                    assert relmax(out.logits[0, pos][:, ::997].cpu().numpy(), g["fwd_vtg_logits_row0_sub"]) < 1e-2
+    with pytest.raises(NotImplementedError):
+        t.model(input_ids=torch.zeros((1, 4), dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        t.model(inputs_embeds=emb, labels=torch.zeros((3, 4), dtype=torch.long))
+
+
+def test_criteria_on_golden_logits():
+    g = np.load(os.path.join(GOLD, "tiny.npz"))
+    sc = RU.vtg_criterion(torch.from_numpy(g["crit_vtg_logits"]).cuda(), torch.from_numpy(g["crit_vtg_labels"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(sc, g["crit_vtg_out"], rtol=1e-5)
+    sc = RU.tvg_criterion(torch.from_numpy(g["crit_tvg_logits"]).cuda(), torch.from_numpy(g["crit_tvg_labels"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(sc, g["crit_tvg_out"], rtol=1e-5)
+
+
+PASSES = [("v2t_vtg", True, "vtg", False), ("v2t_vtg_cpn", True, "vtg", True), ("v2t_tvg", True, "tvg", False),
+          ("t2v_vtg", False, "vtg", False), ("t2v_tvg", False, "tvg", False), ("t2v_tvg_cpn", False, "tvg", True)]
+
+
+def _six_passes(t, literal):
+    ddp = DDPLike(t.model)
+    dev = t.model.device
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(t.prob.vtg_ids), Tt(t.prob.vtg_labels), Tt(t.prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(t.prob.tvg_ids), Tt(t.prob.tvg_labels), Tt(t.prob.tvg_masks), tok)
+    video = [torch.from_numpy(v) for v in t.prob.video]
+    vocab = torch.from_numpy(t.prob.video_vocab); vlab = torch.from_numpy(t.prob.tvg_video_labels)
+    n = t.spec["n"]
+    args = types.SimpleNamespace(topk=t.spec["topk"], batch_size_eval=t.spec["bs"], num_clips=t.dims.num_clips)
+    out = {}
+    scorer = None if literal else RU.PairScorer(ddp, vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], video, vocab, vlab, t.dims.num_clips, max_tokens=4096)
+    for name, qv, ft, cpn in PASSES:
+        sims = torch.from_numpy(t.prob.v2t_sims if qv else t.prob.t2v_sims)
+        S = torch.full((n, n), -100.0, device=dev)
+        if literal:
+            fn = RU.compute_v2t_scores_x if qv else RU.compute_t2v_scores_x
+            ids, lab, msk = vtg if ft == "vtg" else tvg
+            S = fn(S, sims, 0, ids, msk, lab, video, vocab.to(dev), vlab, ddp, dev, args, forward_type=ft, cpn=cpn)
+        else:
+            pairs = RU._topk_pairs(sims, 0, args.topk, qv)
+            sc = scorer.vtg(pairs, cpn) if ft == "vtg" else scorer.tvg(pairs, cpn)
+            r, c = (pairs[:, 0], pairs[:, 1]) if qv else (pairs[:, 1], pairs[:, 0])
+            S[torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev)] = torch.from_numpy(sc).to(dev)
+        out[name] = S.cpu().numpy()
+    return out
+
+
+def _check_passes(got, g):
+    for name, S in got.items():
+        G = g[f"S_{name}"]
+        assert np.array_equal(S == -100.0, G == -100.0), name          # same entries computed (top-k, leftover batch)
+        m = G != -100.0
+        np.testing.assert_allclose(S[m], G[m], rtol=SCORE_RTOL, err_msg=name)
+
+
+@pytest.mark.parametrize("literal", [True, False], ids=["literal-api", "fused-pairscorer"])
+def test_six_passes_tiny_vs_reference_golden(tiny, literal):
+    g = np.load(os.path.join(GOLD, "tiny.npz"))
+    got = _six_passes(tiny, literal)
+    _check_passes(got, g)
+    # R@k of the full BLiM ensemble: identical to the reference's matrices'
+    n = tiny.spec["n"]
+    args = types.SimpleNamespace(cpn=True, alpha=[0.4, 0.8], c=[0.3, 0.6, 0.9, 0.7], resume="ckpt", eval=True)
+    mk = lambda src, pre: ({"candidate_likelihood": src[f"{pre}t2v_tvg"], "candidate_prior": src[f"{pre}t2v_tvg_cpn"], "query_likelihood": src[f"{pre}t2v_vtg"],
+                            "internvideo2": tiny.prob.t2v_sims},
+                           {"candidate_likelihood": src[f"{pre}v2t_vtg"], "candidate_prior": src[f"{pre}v2t_vtg_cpn"], "query_likelihood": src[f"{pre}v2t_tvg"],
+                            "internvideo2": tiny.prob.v2t_sims})
+    assert TU.combine_and_rank(*mk(got, ""), args, n) == TU.combine_and_rank(*mk(g, "S_"), args, n)
+
+
+@pytest.mark.parametrize("literal", [False, True], ids=["fused-pairscorer", "literal-api"])
+def test_six_passes_7b_width_vs_reference_golden(wide, literal):
+    """Qwen2-7B width (H=3584, 28/4 heads, I=18944, V=152064), one layer; weights generated ON DEVICE from the seed."""
+    g = np.load(os.path.join(GOLD, "wide.npz"))
+    _check_passes(_six_passes(wide, literal), g)
+
+
+def test_full_size_properties_7b():
+    """Size-independent properties at the full 28-layer 7B configuration: a pair's score does not depend on what else is in
+    the batch (bitwise), nor on the order of the pairs; shared-prefix scoring equals per-pair scoring (1e-3)."""
+    dims = synth.ModelDims()
+    model = BlimModel(dims, max_positions=1024)
+    model.engine.init_synthetic_weights(0)
+    prob = synth.make_problem(21, 6, dims, tok_per_clip=24, text_len=(5, 32), reference_layout=True)
+    model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    sc = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video],
+                       torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels), dims.num_clips)
+    pairs = np.array([[j, i] for j in range(3) for i in range(6)])
+    full = sc.vtg(pairs)
+    assert np.isfinite(full).all() and (full < 0).all()
+    perm = np.random.RandomState(0).permutation(len(pairs))
+    assert np.array_equal(sc.vtg(pairs[perm]), full[perm])                       # order invariance, bitwise
+    alone = np.array([sc.vtg(pairs[k:k + 1])[0] for k in (0, 7, 17)])
+    np.testing.assert_allclose(alone, full[[0, 7, 17]], rtol=SCORE_RTOL)          # batch-composition invariance
+    tv = sc.tvg(pairs)
+    assert np.array_equal(sc.tvg(pairs[perm]), tv[perm])
+    # the v2t prior does not depend on the video
+    pr = sc.vtg(pairs, cpn=True).reshape(3, 6)
+    assert np.ptp(pr, axis=0).max() == 0.0
+    # shared-prefix scoring == the literal per-pair forward (no sharing), through the reference-shaped API
+    ddp = DDPLike(model)
+    dev = model.device
+    j, i = 1, 4
+    r = model.prepare_inputs_labels_for_multimodal(vtg[0][[i]].to(dev), None, vtg[2][[i]].to(dev), None, vtg[1][[i]].to(dev),
+                                                   [torch.from_numpy(prob.video[j]).to(dev)], ["video"], video_feature=True, cpn=True)
+    out = ddp(inputs_embeds=r[4], attention_mask=r[2][0])
+    lit = RU.vtg_criterion(out.logits, r[5]).cpu().numpy()[0]
+    np.testing.assert_allclose(full[j * 6 + i], lit, rtol=SCORE_RTOL)
+    model.engine.close()

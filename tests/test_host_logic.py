@@ -1,0 +1,174 @@
+"""CPU: host-side mirror (padding, recall, ensemble, sharding, packing plans) and the C-ABI library's symbols."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from blim_amd import distributed as D
+from blim_amd import engine as eng
+from blim_amd import retrieval_utils as RU
+from blim_amd import synth
+from blim_amd import training_utils as TU
+from oracle import blim_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    lib = eng.load_library()
+    syms = eng.declared_symbols()
+    assert len(syms) >= 25
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.blim_abi_version() == 1
+    assert lib.blim_timing_num_classes() >= 8
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    with pytest.raises(eng.BlimError):
+        eng.Engine(synth.ModelDims(num_layers=1))
+    # and at the C level
+    lib = eng.load_library()
+    import ctypes as C
+    cfg = eng.Config(152064, 3584, 18944, 1, 28, 4, 1024, 4, 128, 1e-6, 1e6)
+    h = C.c_void_p()
+    assert lib.blim_create(C.byref(cfg), C.byref(h)) < 0
+    assert b"no HIP device" in lib.blim_last_error() or b"failed" in lib.blim_last_error()
+
+
+def test_padding_ids_matches_golden():
+    g = np.load(os.path.join(GOLD, "tiny.npz"))
+    from oracle.gen_golden import CASES
+    spec = CASES["tiny"]
+    prob = synth.make_problem(spec["pseed"], spec["n"], synth.ModelDims(**spec["dims"]), tok_per_clip=spec["tok_per_clip"], text_len=spec["text_len"])
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    T = lambda rows: [torch.from_numpy(r) for r in rows]
+    ids, lab, msk = RU.padding_ids(T(prob.vtg_ids), T(prob.vtg_labels), T(prob.vtg_masks), tok)
+    assert np.array_equal(ids.numpy(), g["pad_vtg_ids"]) and np.array_equal(lab.numpy(), g["pad_vtg_labels"]) and np.array_equal(msk.numpy(), g["pad_vtg_masks"])
+    # ragged / single-row edge cases
+    ids, lab, msk = RU.padding_ids([torch.tensor([5])], [torch.tensor([-100])], [torch.tensor([1])], tok)
+    assert ids.shape == (1, 1)
+
+
+def test_get_recall_matches_golden():
+    g = np.load(os.path.join(GOLD, "tiny.npz"))
+    ids = {i: i for i in range(50)}
+    rec = TU.get_recall(g["recall_t2v"], g["recall_v2t"], ids, ids)
+    assert [rec[k] for k in g["recall_keys"]] == list(g["recall_vals"])
+    bz = g["recall_v2t"].copy(); bz[3, 4] = 0.0
+    rec0 = TU.get_recall(g["recall_t2v"], bz, ids, ids)
+    assert [rec0[k] for k in g["recall_keys"]] == list(g["recall_zero_vals"])
+    assert rec0["v2t_r1"] == 0.0 and rec0["t2v_r1"] == rec["t2v_r1"]
+
+
+def test_combine_matches_oracle():
+    rs = np.random.RandomState(0)
+    n = 12
+    mk = lambda: (rs.randn(n, n) - 5).astype(np.float32)
+    t2v = {k: mk() for k in ("candidate_likelihood", "candidate_prior", "query_likelihood", "internvideo2")}
+    v2t = {k: mk() for k in ("candidate_likelihood", "candidate_prior", "query_likelihood", "internvideo2")}
+    for finetuned in (True, False):
+        args = types.SimpleNamespace(cpn=True, alpha=[0.4, 0.8], c=[0.3, 0.6, 0.9, 0.7], resume="x" if finetuned else "", eval=True)
+        res = TU.combine_and_rank(t2v, v2t, args, n)
+        cpn_t2v, cpn_v2t, bt, bv = O.combine_scores(t2v, v2t, args.alpha, args.c, True, finetuned)
+        assert res["blim"] == O.get_recall(bt, bv)
+        assert res["cpn_candidate_likelihood"] == O.get_recall(cpn_t2v, cpn_v2t)
+        if not finetuned:
+            assert res["cpn_candidate_likelihood"]["t2v_r1"] == 0.0   # np.zeros placeholder -> zero sentinel
+
+
+def test_row_block_is_the_reference_partition():
+    for n, w in ((1000, 8), (1000, 1), (7, 8), (4917, 8), (16, 4)):
+        blocks = [D.row_block(n, w, r) for r in range(w)]
+        step = n // w + 1
+        assert blocks[0] == (0, min(n, step))
+        covered = sorted(i for s, e in blocks for i in range(s, e))
+        assert covered == list(range(n))
+    assert D.row_block(1000, 8, 7) == (882, 1000) and D.row_block(1000, 8, 0) == (0, 126)
+
+
+def test_packed_batch_blocks():
+    b = eng.PackedBatch(np.arange(100), np.ones(100), np.array([0, 40, 45]), np.array([40, 5, 55]), np.array([0, 0, 0]), np.array([0, 40, 40]), device="cpu")
+    assert b.n_blocks == 2 + 1 + 2
+    assert b.blk_seq.tolist() == [0, 0, 1, 2, 2] and b.blk_q0.tolist() == [0, 32, 0, 0, 32]
+    st = b.struct()
+    assert st.n_tokens == 100 and st.n_seqs == 3
+
+
+class _FakeModel:
+    """Planning needs only .project / .device / .dims / .tvg_prefix_length."""
+
+    def __init__(self, dims, tp):
+        self.dims, self.device, self.tvg_prefix_length, self.engine = dims, torch.device("cpu"), tp, None
+
+    def project(self, feat, tvg, cache=True):
+        clips, T, _ = feat.shape
+        return torch.zeros((clips if tvg else clips * T, self.dims.hidden_size), dtype=torch.bfloat16)
+
+
+def _scorer(n=6, layout=True):
+    dims = synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+    prob = synth.make_problem(5, n, dims, tok_per_clip=8, text_len=(3, 9), reference_layout=layout)
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    T = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(T(prob.vtg_ids), T(prob.vtg_labels), T(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(T(prob.tvg_ids), T(prob.tvg_labels), T(prob.tvg_masks), tok)
+    sc = RU.PairScorer(_FakeModel(dims, prob.tvg_prefix_length), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1],
+                       [torch.from_numpy(v) for v in prob.video], None, torch.from_numpy(prob.tvg_video_labels), dims.num_clips, max_tokens=4096)
+    return sc, prob
+
+
+def test_vtg_plan_shares_the_video_prefix():
+    sc, prob = _scorer()
+    pairs = np.array([[0, 0], [0, 1], [0, 2], [3, 1]])
+    (plan,) = sc.plan_vtg(pairs)
+    nv = 4 * 8
+    pre_post = len(prob.vtg_ids[0]) - 1 - (len(prob.vtg_labels[0]) - int((prob.vtg_labels[0] == -100).sum()))
+    resp = [int((prob.vtg_labels[i] != -100).sum()) for i in range(6)]
+    expect = 2 * (pre_post + nv) + (resp[0] - 1) + (resp[1] - 1) + (resp[2] - 1) + (resp[1] - 1)
+    assert plan.n_tokens == expect                       # two prefixes (videos 0 and 3), four suffixes
+    assert plan.n_pairs == 4 and plan.n_rows == resp[0] + resp[1] + resp[2] + resp[1]
+    assert plan.batch.n_seqs == 2 + 4
+    pl = plan.batch.pfx_len.numpy()
+    assert sorted(pl.tolist()) == [0, 0] + [pre_post + nv] * 4
+    # labels are the response tokens, rows start at the last prefix token
+    rows = plan.rows.numpy(); rs = plan.row_start.numpy()
+    first_rows = rows[rs[:-1]]
+    assert set(first_rows.tolist()) <= {pre_post + nv - 1, plan.batch.seq_start.numpy()[np.nonzero(pl == 0)[0][1]] + pre_post + nv - 1}
+
+
+def test_vtg_cpn_plan_scores_each_text_once():
+    sc, prob = _scorer()
+    pairs = np.array([[0, 1], [2, 1], [3, 1], [4, 5]])
+    (plan,) = sc.plan_vtg(pairs, cpn=True)
+    assert plan.n_pairs == 2                            # texts 1 and 5
+    fan = sorted(len(o) for o in plan.out_index)
+    assert fan == [1, 3]
+    # the (masked) video tokens are not even packed; positions skip over them
+    pos = plan.batch.positions.numpy()
+    assert pos.max() >= 4 * 8 + 14
+
+
+def test_tvg_plan_needs_three_tokens_per_pair():
+    sc, prob = _scorer()
+    pairs = np.array([[0, 2], [1, 2], [5, 2]])
+    (plan,) = sc.plan_tvg(pairs)
+    prompt = len(prob.tvg_ids[2]) - 3
+    assert plan.n_tokens == prompt + 3 * 3 and plan.n_rows == 12 and plan.n_pairs == 3
+    (planc,) = sc.plan_tvg(np.array([[0, 2], [1, 2], [0, 3]]), cpn=True)
+    # prior = f(prompt length, video): texts 2 and 3 differ in length here, so 3 scored pairs; prefix = tvg_prefix_length tokens
+    assert planc.n_pairs == len({(len(prob.tvg_ids[i]), j) for j, i in [(0, 2), (1, 2), (0, 3)]})
+    assert planc.batch.seq_len.numpy()[0] == prob.tvg_prefix_length
+
+
+def test_plans_split_at_the_token_budget():
+    sc, prob = _scorer()
+    sc.max_tokens = 150
+    pairs = np.array([[j, i] for j in range(6) for i in range(6)])
+    plans = sc.plan_vtg(pairs)
+    assert len(plans) > 1 and sum(p.n_pairs for p in plans) == 36
+    covered = sorted(int(o[0]) for p in plans for o in p.out_index)
+    assert covered == list(range(36))
