@@ -39,7 +39,10 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-template <int EPI>
+// PIPE 0: all 8 waves in lock step, one barrier per K-step (bring-up structure, kept for A/B runs).
+// PIPE 1: ping-pong -- waves 0-3 and 4-7 (SIMD partners) alternate {LDS fragment reads} and {64 MFMAs} so each SIMD's
+//         matrix pipe always has one wave computing; LDS-DMA for K-step k+2 is issued one full K-step ahead.
+template <int EPI, int PIPE>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // 128 KiB
 
@@ -65,23 +68,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 
     // ---- per-lane LDS-DMA source pointers: wave w stages blocks w, w+8, w+16, w+24 of A and of B
     const int sq = lane >> 4, sr = (lane >> 1) & 7, sc = 2 * sq + (lane & 1);  // LDS slot lane -> (row sr, chunk sc)
-    const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
+    // 32-bit byte offsets from the (wave-uniform, scalar) operand bases: the K-step advance is then a scalar add
+    // on the base and the LDS-DMA uses the saddr + voffset form (no per-step vector address arithmetic).
+    uint32_t offA[4], offB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int b = wave + 8 * i;
         const int ra = min(row0 + 8 * b + sr, p.M - 1);
         const int rb = min(col0 + 8 * b + sr, p.N - 1);
-        srcA[i] = p.A + (int64_t)ra * p.lda + 8 * sc;
-        srcB[i] = p.W + (int64_t)rb * p.K + 8 * sc;
+        offA[i] = (uint32_t)(((int64_t)ra * p.lda + 8 * sc) * 2);
+        offB[i] = (uint32_t)(((int64_t)rb * p.K + 8 * sc) * 2);
     }
-    auto stage = [&](int buf, int kt) {
+    const char* baseA = (const char*)p.A;
+    const char* baseW = (const char*)p.W;
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         char* base = smem + buf * BUF_BYTES;
+        const char* ga = baseA + (int64_t)kt * (BK * 2);
+        const char* gw = baseW + (int64_t)kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int b = wave + 8 * i;
-            glds16(srcA[i] + (int64_t)kt * BK, base + b * 1024);
-            glds16(srcB[i] + (int64_t)kt * BK, base + TILE_BYTES + b * 1024);
+            glds16(ga + offA[i], base + b * 1024);
+            glds16(gw + offB[i], base + TILE_BYTES + b * 1024);
         }
     };
 
@@ -98,28 +106,95 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* base = smem + cur * BUF_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[8], b[4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(base + b_off + ni * 2048 + ks * 512);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) a[mi] = *(const bf16x8*)(base + a_off + mi * 2048 + ks * 512);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
+    if constexpr (PIPE == 0) {
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            const char* base = smem + cur * BUF_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[8], b[4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(base + b_off + ni * 2048 + ks * 512);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) a[mi] = *(const bf16x8*)(base + a_off + mi * 2048 + ks * 512);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        const int grp = wave >> 2;  // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
+        bf16x8 fa[2][8], fb[2][4];
+        auto load_frags = [&](int st) __attribute__((always_inline)) {
+            const char* base = smem + st * BUF_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) fb[ks][ni] = *(const bf16x8*)(base + b_off + ni * 2048 + ks * 512);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) fa[ks][mi] = *(const bf16x8*)(base + a_off + mi * 2048 + ks * 512);
+            }
+        };
+        auto compute = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][mi], fb[ks][ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // a phase boundary: own LDS reads complete (WAR on the stage about to be refilled), then rendezvous
+#define PHASE_BARRIER()                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                      \
+        asm volatile("" ::: "memory")
+
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-step 0 landed (8 LDS-DMA per wave per step)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHASE_BARRIER();
+        // Two straight-line loops (one per wave group) that execute the SAME barrier sequence.
+        //   phase A(kt): group 0 computes step kt          | group 1 reads its fragments of step kt
+        //   phase B(kt): stage kt&1 is free -> refill with step kt+2;  group 0 reads step kt+1 | group 1 computes step kt
+        if (grp == 0) {
+            load_frags(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // K-step 1 landed
+            PHASE_BARRIER();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                compute();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // step kt+1 (issued one K-step ago) landed
+                PHASE_BARRIER();
+                if (kt + 2 < nk) stage(cur, kt + 2);
+                if (kt + 1 < nk) load_frags(cur ^ 1);
+                PHASE_BARRIER();
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PHASE_BARRIER();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                load_frags(cur);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PHASE_BARRIER();
+                if (kt + 2 < nk) stage(cur, kt + 2);
+                compute();
+                PHASE_BARRIER();
+            }
+        }
+#undef PHASE_BARRIER
     }
 
     // =========================================================================== epilogues
@@ -284,10 +359,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     }
 }
 
+#include <stdlib.h>
+static int g_gemm_pipe = getenv("BLIM_GEMM_PIPE") ? atoi(getenv("BLIM_GEMM_PIPE")) : 1;
+void gemm_set_pipe(int pipe) { g_gemm_pipe = pipe; }
+
 template <int EPI>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
+    if (g_gemm_pipe == 0) hipLaunchKernelGGL((gemm_kernel<EPI, 0>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<EPI, 1>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         blim_set_error("gemm launch failed: %s", hipGetErrorString(e));
@@ -301,6 +381,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
     ARG_CHECK(p.K % BK == 0);
     ARG_CHECK(p.lda % 8 == 0);
     ARG_CHECK(p.A && p.W);
+    ARG_CHECK((int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
         case EPI_BF16: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_BF16>(p, stream);
         case EPI_F32: ARG_CHECK(p.C); return launch_t<EPI_F32>(p, stream);

@@ -39,6 +39,8 @@ struct GemmParams {
 // 256x256x64 tiles, 512 threads.  K % 64 == 0, lda % 8 == 0.  Rows/cols beyond M/N are clamped on
 // load and masked on store, so neither A nor W needs padding.
 int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream);
+// main-loop variant: 0 lock-step, 1 ping-pong (default)
+void gemm_set_pipe(int pipe);
 
 // Row permutation used for q/k heads so that RoPE partners (d, d+64) land in the same lane:
 // stored row c' (0..127 within a head) holds natural row d = 16*(c'>>5) + (c'&15) + 64*((c'>>4)&1).
