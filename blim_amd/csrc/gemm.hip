@@ -39,12 +39,16 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-// PIPE 0: all 8 waves in lock step, one barrier per K-step (bring-up structure, kept for A/B runs).
+// PIPE 0: all 8 waves in lock step, two 64-KB LDS stages, one barrier per K-step (bring-up structure, kept for A/B runs).
 // PIPE 1: ping-pong -- waves 0-3 and 4-7 (SIMD partners) alternate {LDS fragment reads} and {64 MFMAs} so each SIMD's
-//         matrix pipe always has one wave computing; LDS-DMA for K-step k+2 is issued one full K-step ahead.
+//         matrix pipe always has one wave computing; two 64-KB stages, LDS-DMA for K-step k+2 issued as one 64-KB burst.
+// PIPE 2: ping-pong over a RING of five 32-KB operand slots (A or W tile of one K-step): one operand tile is issued per
+//         half K-step (A(k+2) at the start of phase A(k), W(k+2) at the start of phase B(k)) and waited for with a
+//         counted vmcnt, so the L2->LDS pipe never drains (measured: a drained 64-KB burst per step moves 44 GB/s per
+//         CU, the same bytes issued as alternating 32-KB tiles 62 GB/s -- tools/dma_bench.hip).
 template <int EPI, int PIPE>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];  // 128 KiB
+    __shared__ __attribute__((aligned(16))) char smem[PIPE == 2 ? 5 * TILE_BYTES : 2 * BUF_BYTES];  // 160 / 128 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,10 +70,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const int tn = (pid % width) / gsz;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // ---- per-lane LDS-DMA source pointers: wave w stages blocks w, w+8, w+16, w+24 of A and of B
+    // ---- per-lane LDS-DMA sources: wave w stages blocks w, w+8, w+16, w+24 of A and of W.
+    // 32-bit byte offsets from the (wave-uniform, scalar) operand bases: the K-step advance is a scalar add on the
+    // base and the LDS-DMA uses the saddr + voffset form (no per-step vector address arithmetic).
     const int sq = lane >> 4, sr = (lane >> 1) & 7, sc = 2 * sq + (lane & 1);  // LDS slot lane -> (row sr, chunk sc)
-    // 32-bit byte offsets from the (wave-uniform, scalar) operand bases: the K-step advance is then a scalar add
-    // on the base and the LDS-DMA uses the saddr + voffset form (no per-step vector address arithmetic).
     uint32_t offA[4], offB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -81,23 +85,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     }
     const char* baseA = (const char*)p.A;
     const char* baseW = (const char*)p.W;
-    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
-        char* base = smem + buf * BUF_BYTES;
-        const char* ga = baseA + (int64_t)kt * (BK * 2);
-        const char* gw = baseW + (int64_t)kt * (BK * 2);
+    // one operand tile (32 KiB, 4 LDS-DMA per wave) of K-step kt into the LDS tile at byte offset `dst`
+    auto stage_tile = [&](bool isW, int dst, int kt) __attribute__((always_inline)) {
+        const char* g = (isW ? baseW : baseA) + (int64_t)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int b = wave + 8 * i;
-            glds16(ga + offA[i], base + b * 1024);
-            glds16(gw + offB[i], base + TILE_BYTES + b * 1024);
-        }
+        for (int i = 0; i < 4; ++i) glds16(g + (isW ? offB[i] : offA[i]), smem + dst + (wave + 8 * i) * 1024);
     };
 
-    // ---- fragment read offsets (bytes) inside a tile
+    // ---- fragment read offsets (bytes) inside an operand tile
     const int fr = lane & 15, fc = lane >> 4;
     const int frag_off = (fr >> 3) * 1024 + (fr & 7) * 32 + (fc >> 1) * 256 + (fc & 1) * 16;
-    const int a_off = (16 * wm) * 1024 + frag_off;                 // + mi*2048 + ks*512
-    const int b_off = TILE_BYTES + (8 * wn) * 1024 + frag_off;     // + ni*2048 + ks*512
+    const int a_off = (16 * wm) * 1024 + frag_off;   // + mi*2048 + ks*512
+    const int b_off = (8 * wn) * 1024 + frag_off;    // + ni*2048 + ks*512
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -107,18 +106,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 
     const int nk = p.K / BK;
     if constexpr (PIPE == 0) {
-        stage(0, 0);
+        stage_tile(false, 0, 0); stage_tile(true, TILE_BYTES, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            if (kt + 1 < nk) { stage_tile(false, (cur ^ 1) * BUF_BYTES, kt + 1); stage_tile(true, (cur ^ 1) * BUF_BYTES + TILE_BYTES, kt + 1); }
             const char* base = smem + cur * BUF_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 a[8], b[4];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(base + b_off + ni * 2048 + ks * 512);
+                for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(base + TILE_BYTES + b_off + ni * 2048 + ks * 512);
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) a[mi] = *(const bf16x8*)(base + a_off + mi * 2048 + ks * 512);
 #pragma unroll
@@ -133,14 +132,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     } else {
         const int grp = wave >> 2;  // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
         bf16x8 fa[2][8], fb[2][4];
-        auto load_frags = [&](int st) __attribute__((always_inline)) {
-            const char* base = smem + st * BUF_BYTES;
+        auto load_frags = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
+            const char* ba = smem + offA_tile + a_off;
+            const char* bb = smem + offB_tile + b_off;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) fb[ks][ni] = *(const bf16x8*)(base + b_off + ni * 2048 + ks * 512);
+                for (int ni = 0; ni < 4; ++ni) fb[ks][ni] = *(const bf16x8*)(bb + ni * 2048 + ks * 512);
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) fa[ks][mi] = *(const bf16x8*)(base + a_off + mi * 2048 + ks * 512);
+                for (int mi = 0; mi < 8; ++mi) fa[ks][mi] = *(const bf16x8*)(ba + mi * 2048 + ks * 512);
             }
         };
         auto compute = [&]() __attribute__((always_inline)) {
@@ -154,44 +154,90 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][mi], fb[ks][ni], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        // a phase boundary: own LDS reads complete (WAR on the stage about to be refilled), then rendezvous
+        // a phase boundary: own LDS reads complete (WAR on the tile about to be refilled), then rendezvous
 #define PHASE_BARRIER()                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_s_barrier();                      \
         asm volatile("" ::: "memory")
 
-        stage(0, 0);
-        if (nk > 1) stage(1, 1);
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-step 0 landed (8 LDS-DMA per wave per step)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PHASE_BARRIER();
-        // Two straight-line loops (one per wave group) that execute the SAME barrier sequence.
-        //   phase A(kt): group 0 computes step kt          | group 1 reads its fragments of step kt
-        //   phase B(kt): stage kt&1 is free -> refill with step kt+2;  group 0 reads step kt+1 | group 1 computes step kt
-        if (grp == 0) {
-            load_frags(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // K-step 1 landed
+        // Both variants run two straight-line loops (one per wave group) that execute the SAME barrier sequence:
+        //   phase A(kt): group 0 computes step kt              | group 1 reads its fragments of step kt
+        //   phase B(kt): group 0 reads its fragments of kt+1   | group 1 computes step kt
+        if constexpr (PIPE == 1) {
+            stage_tile(false, 0, 0); stage_tile(true, TILE_BYTES, 0);
+            if (nk > 1) { stage_tile(false, BUF_BYTES, 1); stage_tile(true, BUF_BYTES + TILE_BYTES, 1); }
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-step 0 landed (8 LDS-DMA per wave per step)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();
-            for (int kt = 0; kt < nk; ++kt) {
-                const int cur = kt & 1;
-                compute();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // step kt+1 (issued one K-step ago) landed
+            if (grp == 0) {
+                load_frags(0, TILE_BYTES);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // K-step 1 landed
                 PHASE_BARRIER();
-                if (kt + 2 < nk) stage(cur, kt + 2);
-                if (kt + 1 < nk) load_frags(cur ^ 1);
-                PHASE_BARRIER();
-            }
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PHASE_BARRIER();
-            for (int kt = 0; kt < nk; ++kt) {
-                const int cur = kt & 1;
-                load_frags(cur);
+                for (int kt = 0; kt < nk; ++kt) {
+                    const int cur = (kt & 1) * BUF_BYTES, nxt = BUF_BYTES - cur;
+                    compute();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // step kt+1 (issued one K-step ago) landed
+                    PHASE_BARRIER();
+                    if (kt + 2 < nk) { stage_tile(false, cur, kt + 2); stage_tile(true, cur + TILE_BYTES, kt + 2); }
+                    if (kt + 1 < nk) load_frags(nxt, nxt + TILE_BYTES);
+                    PHASE_BARRIER();
+                }
+            } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PHASE_BARRIER();
-                if (kt + 2 < nk) stage(cur, kt + 2);
-                compute();
+                for (int kt = 0; kt < nk; ++kt) {
+                    const int cur = (kt & 1) * BUF_BYTES;
+                    load_frags(cur, cur + TILE_BYTES);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PHASE_BARRIER();
+                    if (kt + 2 < nk) { stage_tile(false, cur, kt + 2); stage_tile(true, cur + TILE_BYTES, kt + 2); }
+                    compute();
+                    PHASE_BARRIER();
+                }
+            }
+        } else {
+            // ---- ring of five operand tiles.  Operand n = 2*step + isW lives in slot n % 5.
+            // Issue order A0 W0 A1 W1 | A2 W2 A3 W3 ... : A(k+2) at the start of phase A(k) (into the slot W(k-1) left),
+            // W(k+2) at the start of phase B(k) (into the slot A(k) left).  At the end of phase A(k) the step k+1 tiles
+            // must have landed; the only younger LDS-DMA is A(k+2) (4 per wave) -> s_waitcnt vmcnt(4), or vmcnt(0) once
+            // nothing younger is issued any more.
+            constexpr int RING = 5 * TILE_BYTES;
+            auto adv = [](int s, int j) { const int x = s + j * TILE_BYTES; return x >= RING ? x - RING : x; };
+            stage_tile(false, 0, 0); stage_tile(true, TILE_BYTES, 0);
+            if (nk > 1) { stage_tile(false, 2 * TILE_BYTES, 1); stage_tile(true, 3 * TILE_BYTES, 1); }
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A0 W0 landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PHASE_BARRIER();
+            int sa = 0;   // slot (byte offset) of A(kt); W(kt) = adv(sa,1), A(kt+1) = adv(sa,2), W(kt+1) = adv(sa,3), A(kt+2) = adv(sa,4), W(kt+2) = sa
+            if (grp == 0) {
+                load_frags(0, TILE_BYTES);
                 PHASE_BARRIER();
+                for (int kt = 0; kt < nk; ++kt) {
+                    // phase A(kt)
+                    if (kt + 2 < nk) stage_tile(false, adv(sa, 4), kt + 2);
+                    compute();
+                    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // A(kt+1) W(kt+1) landed
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PHASE_BARRIER();
+                    // phase B(kt)
+                    if (kt + 2 < nk) stage_tile(true, sa, kt + 2);
+                    if (kt + 1 < nk) load_frags(adv(sa, 2), adv(sa, 3));
+                    PHASE_BARRIER();
+                    sa = adv(sa, 2);
+                }
+            } else {
+                PHASE_BARRIER();
+                for (int kt = 0; kt < nk; ++kt) {
+                    if (kt + 2 < nk) stage_tile(false, adv(sa, 4), kt + 2);
+                    load_frags(sa, adv(sa, 1));
+                    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PHASE_BARRIER();
+                    if (kt + 2 < nk) stage_tile(true, sa, kt + 2);
+                    compute();
+                    PHASE_BARRIER();
+                    sa = adv(sa, 2);
+                }
             }
         }
 #undef PHASE_BARRIER
@@ -360,14 +406,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 }
 
 #include <stdlib.h>
-static int g_gemm_pipe = getenv("BLIM_GEMM_PIPE") ? atoi(getenv("BLIM_GEMM_PIPE")) : 1;
+static int g_gemm_pipe = getenv("BLIM_GEMM_PIPE") ? atoi(getenv("BLIM_GEMM_PIPE")) : 2;
 void gemm_set_pipe(int pipe) { g_gemm_pipe = pipe; }
 
 template <int EPI>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     if (g_gemm_pipe == 0) hipLaunchKernelGGL((gemm_kernel<EPI, 0>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel<EPI, 1>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
+    else if (g_gemm_pipe == 1) hipLaunchKernelGGL((gemm_kernel<EPI, 1>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<EPI, 2>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         blim_set_error("gemm launch failed: %s", hipGetErrorString(e));
