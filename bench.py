@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 H, I, V, LAYERS = 3584, 18944, 152064, 28
 FLOP_TOKEN_LAYER = 2 * H * (H + 2 * 512) + 2 * H * H + 6 * H * I      # 466,092,032
 FLOP_HEAD_ROW = 2 * H * V                                           # 1,089,994,752
-PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
 
 
 def f_pair(L, t_lab):
@@ -64,7 +64,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queries", type=int, default=53, help="video queries per step per GPU (53 x 608 tokens ~ 32768 = 128 row tiles)")
+    ap.add_argument("--queries", type=int, default=55, help="video queries per step per GPU (55 x 592 packed tokens = 32,560 -> 128 row tiles of 256)")
+    ap.add_argument("--dtype", default=None, choices=["f16", "bf16"], help="16-bit compute format (default f16 = the reference's autocast dtype; same MFMA rate)")
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -81,7 +82,7 @@ def main():
     dev = torch.device("cuda", local)
 
     dims = synth.ModelDims()
-    model = BlimModel(dims, max_positions=1024)
+    model = BlimModel(dims, max_positions=1024, dtype=a.dtype)
     model.engine.init_synthetic_weights(0)                       # torch seed 0 of BASELINE.md -> engine seed 0
     Q, K = a.queries, a.topk
     n_plans = max(1, min(3, a.steps))
@@ -141,8 +142,8 @@ def main():
         out = {
             "metric": "candidate-pairs/sec (7B, 96+32 tok)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SYN v2t-VTG re-rank: Qwen2-7B dims (28 layers), seeded synthetic bf16 weights, 96 video + 32 text tokens per pair, "
+            "dtype": model.engine.dtype, "data": "synthetic",
+            "config": {"workload": "SYN v2t-VTG re-rank: Qwen2-7B dims (28 layers), seeded synthetic weights, 96 video + 32 text tokens per pair, "
                                    f"top-{K} text candidates per video query, {Q} queries ({n_pairs} pairs, {n_tok} packed tokens, {n_rows} label rows) per step per GPU",
                        "prefix_reuse": True, "pairs_per_step_per_gpu": n_pairs, "tokens_per_step_per_gpu": n_tok,
                        "parallelism": f"query rows sharded over {world} GPU(s); RCCL all-gather of score rows at the end"},

@@ -18,7 +18,7 @@
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <bool USE_TR, int MAXC>
+template <bool USE_TR, int MAXC, int DT>
 __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t k_lds[KT * HD];
     __shared__ __attribute__((aligned(16))) bf16_t v_lds[KT * HD];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(k_lds + key * HD + 8 * ((2 * ks + hf) ^ (key & 15)));
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+                sacc = mfma32<DT>(kf, qf[ks], sacc);
             }
         }
         // ---- mask + online softmax; this lane's keys: krow(r) = (r&3) + 8*(r>>2) + 4*hf
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         for (int s2 = 0; s2 < 2; ++s2) {
             uint32_t w[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(pv[8 * s2 + 2 * j], pv[8 * s2 + 2 * j + 1]);
+            for (int j = 0; j < 4; ++j) w[j] = pack2<DT>(pv[8 * s2 + 2 * j], pv[8 * s2 + 2 * j + 1]);
             pf[s2] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
         }
         // ---- O^T += V^T . P^T : A = V^T fragment (lane: d = 32db + (lane&31); keys 16s+4hf+{0..3} and +8)
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
                         vf[j] = (short)v_lds[kr * HD + 8 * ((d >> 3) ^ ((kr & 3) << 2)) + (d & 7)];
                     }
                 }
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[db], 0, 0, 0);
+                o[db] = mfma32<DT>(vf, pf[s2], o[db]);
             }
         }
     }
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = 32 * db + 8 * g + 4 * hf;
-                *(uint2*)(orow + d) = make_uint2(pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                                                 pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+                *(uint2*)(orow + d) = make_uint2(pack2<DT>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                                                 pack2<DT>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
             }
     }
 }
@@ -221,7 +221,11 @@ int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
     const int G = p.num_heads / p.num_kv_heads;
     if (G > 8) { blim_set_error("attention: %d query heads per kv head > 8 unsupported", G); return BLIM_ERR_ARG; }
     const dim3 grid(p.n_blocks, p.num_kv_heads), block(64 * G);
-#define ATTN_LAUNCH(TR, MC) hipLaunchKernelGGL((attn_kernel<TR, MC>), grid, block, 0, stream, p)
+#define ATTN_LAUNCH(TR, MC)                                                                             \
+    do {                                                                                            \
+        if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<TR, MC, DT_F16>), grid, block, 0, stream, p); \
+        else hipLaunchKernelGGL((attn_kernel<TR, MC, DT_BF16>), grid, block, 0, stream, p);                \
+    } while (0)
     if (G >= 4) { if (use_tr_read) ATTN_LAUNCH(true, 4); else ATTN_LAUNCH(false, 4); }
     else if (G >= 2) { if (use_tr_read) ATTN_LAUNCH(true, 8); else ATTN_LAUNCH(false, 8); }
     else { if (use_tr_read) ATTN_LAUNCH(true, 16); else ATTN_LAUNCH(false, 16); }

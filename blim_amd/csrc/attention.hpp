@@ -8,6 +8,7 @@
 #include "common.hpp"
 
 struct AttnParams {
+    int dtype;  // DT_BF16 / DT_F16
     const bf16_t* qkv;  // [T, ldq]: q heads | k heads | v heads, head_dim 128, RoPE already applied
     int64_t ldq;
     int num_heads, num_kv_heads;

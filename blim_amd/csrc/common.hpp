@@ -27,6 +27,40 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// ---- 16-bit compute dtype (runtime choice per engine, compile-time per kernel): 0 = bf16, 1 = fp16.
+// fp16 is what the reference itself runs on GPU (main.py:97 .half(), training_utils.py:142 autocast(float16)); both
+// MFMA forms have the same rate on gfx950.
+#define DT_BF16 0
+#define DT_F16 1
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int DT> __device__ __forceinline__ float from16(uint16_t b) {
+    if constexpr (DT == DT_BF16) return __uint_as_float(((uint32_t)b) << 16);
+    else return (float)__builtin_bit_cast(_Float16, b);
+}
+template <int DT> __device__ __forceinline__ uint16_t to16(float f) {
+    if constexpr (DT == DT_BF16) return f32_to_bf16(f);
+    else { _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }
+}
+template <int DT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (DT == DT_BF16) return pack_bf16x2(lo, hi);
+    else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 v = {lo, hi};
+        h2 r = __builtin_convertvector(v, h2);
+        return __builtin_bit_cast(uint32_t, r);
+    }
+}
+template <int DT> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (DT == DT_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int DT> __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (DT == DT_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

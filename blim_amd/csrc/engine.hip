@@ -106,7 +106,7 @@ __device__ __forceinline__ int64_t src_row_of(int64_t r, int mode) {
     if (mode == 1) { const int64_t h = r >> 7; const int c = (int)(r & 127); return (h << 7) + 16 * (c >> 5) + (c & 15) + 64 * ((c >> 4) & 1); }
     return r;
 }
-template <bool SRC_F32>
+template <bool SRC_F32, int DT>
 __global__ void place_rows_kernel(bf16_t* dst, const void* src, int64_t n_rows, int K, int mode) {
     // grid-stride over (row, 4-element chunk)
     const int chunks = K / 4;
@@ -121,9 +121,12 @@ __global__ void place_rows_kernel(bf16_t* dst, const void* src, int64_t n_rows, 
         uint2 pk;
         if (SRC_F32) {
             const float4 v = *(const float4*)((const float*)src + srow * K + 4 * c);
-            pk = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-        } else {
+            pk = make_uint2(pack2<DT>(v.x, v.y), pack2<DT>(v.z, v.w));
+        } else {   // bf16 source
             pk = *(const uint2*)((const bf16_t*)src + srow * K + 4 * c);
+            if (DT == DT_F16)
+                pk = make_uint2(pack2<DT>(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xFFFF0000u)),
+                                pack2<DT>(__uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xFFFF0000u)));
         }
         *(uint2*)(dst + drow * K + 4 * c) = pk;
     }
@@ -166,6 +169,7 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     ARG_CHECK(cfg->num_heads % cfg->num_kv_heads == 0 && cfg->num_heads / cfg->num_kv_heads <= 8);
     ARG_CHECK(cfg->hidden_size % 64 == 0 && cfg->intermediate_size % 64 == 0 && cfg->mm_hidden_size % 64 == 0);
     ARG_CHECK(cfg->vocab_size > 0 && cfg->max_positions > 0 && cfg->num_clips > 0);
+    ARG_CHECK(cfg->compute_dtype == BLIM_COMPUTE_BF16 || cfg->compute_dtype == BLIM_COMPUTE_F16);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         blim_set_error("no HIP device visible: the BLiM engine has no CPU fallback");
@@ -263,8 +267,14 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
         bf16_t* dst = (bf16_t*)s.dst + s.dst_row_off * s.cols;
         const int64_t total = s.rows * (s.cols / 4);
         const int grid = (int)std::min<int64_t>((total + 255) / 256, 16384);
-        if (dtype == BLIM_DTYPE_F32) hipLaunchKernelGGL(place_rows_kernel<true>, dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
-        else hipLaunchKernelGGL(place_rows_kernel<false>, dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
+        const bool f16 = e->c.compute_dtype == BLIM_COMPUTE_F16;
+        if (dtype == BLIM_DTYPE_F32) {
+            if (f16) hipLaunchKernelGGL((place_rows_kernel<true, DT_F16>), dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
+            else hipLaunchKernelGGL((place_rows_kernel<true, DT_BF16>), dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
+        } else {
+            if (f16) hipLaunchKernelGGL((place_rows_kernel<false, DT_F16>), dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
+            else hipLaunchKernelGGL((place_rows_kernel<false, DT_BF16>), dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, (int)s.cols, s.mode);
+        }
     } else {
         float* dst = (float*)s.dst + s.dst_row_off;
         const int grid = (int)((s.rows + 255) / 256);
@@ -370,9 +380,10 @@ extern "C" int blim_reserve(blim_engine* e, int64_t max_tokens, int64_t max_rows
 }
 
 // ---------------------------------------------------------------------------- component ops
-static GemmParams gp(const void* A, int64_t lda, const void* W, int64_t M, int N, int K, void* C, int64_t ldc) {
+static GemmParams gp(int dt, const void* A, int64_t lda, const void* W, int64_t M, int N, int K, void* C, int64_t ldc) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
+    p.dtype = dt;
     p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.M = (int)M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.scale = 1.0f;
     return p;
 }
@@ -384,10 +395,10 @@ extern "C" int blim_project_video(blim_engine* e, const void* feats, int64_t n_r
     const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
     TRY(ensure(e->proj_tmp, (size_t)round_up(n_rows, 256) * H * 2));
     SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_rows * ((double)M * H + (double)H * H));
-    GemmParams p1 = gp(feats, M, e->mlp_w0[which], n_rows, H, M, e->proj_tmp.p, H);
+    GemmParams p1 = gp(e->c.compute_dtype, feats, M, e->mlp_w0[which], n_rows, H, M, e->proj_tmp.p, H);
     p1.bias = e->mlp_b0[which]; p1.act = 1;
     TRY(launch_gemm(EPI_BF16, p1, s));
-    GemmParams p2 = gp(e->proj_tmp.p, H, e->mlp_w2[which], n_rows, H, H, out, H);
+    GemmParams p2 = gp(e->c.compute_dtype, e->proj_tmp.p, H, e->mlp_w2[which], n_rows, H, H, out, H);
     p2.bias = e->mlp_b2[which];
     TRY(launch_gemm(EPI_BF16, p2, s));
     return BLIM_OK;
@@ -395,7 +406,7 @@ extern "C" int blim_project_video(blim_engine* e, const void* feats, int64_t n_r
 
 extern "C" int blim_group_mean(blim_engine* e, const void* in, int64_t n_out, int32_t group, void* out, void* stream) {
     ARG_CHECK(e && in && out);
-    return launch_group_mean_bf16((bf16_t*)out, (const bf16_t*)in, n_out, group, e->c.hidden_size, (hipStream_t)stream);
+    return launch_group_mean((bf16_t*)out, (const bf16_t*)in, n_out, group, e->c.hidden_size, e->c.compute_dtype, (hipStream_t)stream);
 }
 
 extern "C" int blim_assemble(blim_engine* e, const int32_t* src_index, int64_t n_tokens, const void* feats, void* out_embeds, void* stream) {
@@ -412,14 +423,14 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     TRY(reserve_tokens(e, T));
     float* resid = (float*)e->resid.p;
     bf16_t* xn = (bf16_t*)e->xn.p; bf16_t* qkv = (bf16_t*)e->qkv.p; bf16_t* attn = (bf16_t*)e->attn.p; bf16_t* act = (bf16_t*)e->act.p;
-    { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_bf16_to_f32(resid, (const bf16_t*)embeds, T * H, s)); }
+    { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s)); }
     const double tok = (double)T;
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
-        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, nullptr, s)); }
+        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n);
-            GemmParams p = gp(xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
+            GemmParams p = gp(c.compute_dtype, xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
             p.bias = l.bqkv; p.pos = b->positions; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
             p.rope_cols = (c.num_heads + c.num_kv_heads) * 128;
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -427,6 +438,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_ATTN, 0);
             AttnParams a;
+            a.dtype = c.compute_dtype;
             a.qkv = qkv; a.ldq = e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
             a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = H; a.scale = 0.08838834764831845f;
@@ -434,18 +446,18 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         }
         {
             SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H);
-            GemmParams p = gp(attn, H, l.wo, T, H, H, resid, H);
+            GemmParams p = gp(c.compute_dtype, attn, H, l.wo, T, H, H, resid, H);
             TRY(launch_gemm(EPI_RESID, p, s));
         }
-        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, nullptr, s)); }
+        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I);
-            GemmParams p = gp(xn, H, l.wgu, T, 2 * I, H, act, I);
+            GemmParams p = gp(c.compute_dtype, xn, H, l.wgu, T, 2 * I, H, act, I);
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
         {
             SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I);
-            GemmParams p = gp(act, I, l.wd, T, H, I, resid, H);
+            GemmParams p = gp(c.compute_dtype, act, I, l.wd, T, H, I, resid, H);
             TRY(launch_gemm(EPI_RESID, p, s));
         }
     }
@@ -469,7 +481,7 @@ extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embe
     ARG_CHECK(n > 0);
     SpanGuard g(e, s, TC_NORM, 0);
     return launch_rmsnorm((const float*)e->resid.p, e->c.hidden_size, out_rows, n, e->c.hidden_size, e->final_norm, e->c.rms_eps,
-                          (bf16_t*)out_hidden_bf16, out_hidden_f32, s);
+                          (bf16_t*)out_hidden_bf16, e->c.compute_dtype, out_hidden_f32, s);
 }
 
 extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
@@ -482,7 +494,7 @@ extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const 
     HIP_TRY(hipMemsetAsync(e->lab_logit.p, 0, (size_t)n_rows * 4, s));
     {
         SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)H * V);
-        GemmParams p = gp(hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
+        GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
     }
@@ -500,7 +512,7 @@ extern "C" int blim_lm_head(blim_engine* e, const void* hidden_bf16, int64_t n_r
     TRY(blim_weights_ready(e));
     const int H = e->c.hidden_size, V = e->c.vocab_size;
     SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * V);
-    GemmParams p = gp(hidden_bf16, H, e->lm_head, n_rows, V, H, logits, V);
+    GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, logits, V);
     return launch_gemm(EPI_F32, p, (hipStream_t)stream);
 }
 
@@ -514,7 +526,7 @@ extern "C" int blim_visual_head(blim_engine* e, const void* hidden_bf16, int64_t
     TRY(blim_weights_ready(e));
     const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
     SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * M);
-    GemmParams p = gp(hidden_bf16, H, e->visual_head, n_rows, M, H, out_bf16, M);
+    GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->visual_head, n_rows, M, H, out_bf16, M);
     return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
 }
 
@@ -524,7 +536,7 @@ extern "C" int blim_tvg_logits(blim_engine* e, const void* vh_bf16, const void* 
     const int M = e->c.mm_hidden_size, C = e->c.num_clips;
     SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_pairs * C * (double)M * n_vocab);
     for (int c = 0; c < C; ++c) {
-        GemmParams p = gp((const bf16_t*)vh_bf16 + (int64_t)c * M, (int64_t)C * M, (const bf16_t*)vocab_bf16 + (int64_t)c * n_vocab * M, n_pairs, n_vocab, M,
+        GemmParams p = gp(e->c.compute_dtype, (const bf16_t*)vh_bf16 + (int64_t)c * M, (int64_t)C * M, (const bf16_t*)vocab_bf16 + (int64_t)c * n_vocab * M, n_pairs, n_vocab, M,
                           logits + (int64_t)c * n_vocab, (int64_t)C * n_vocab);
         p.scale = 1.0f / sqrtf((float)M);
         TRY(launch_gemm(EPI_F32, p, s));
@@ -599,7 +611,11 @@ extern "C" int blim_fill_bell_f32(float* out, int64_t n, uint64_t seed, const ch
     return launch_fill_bell_f32(out, n, seed, fnv1a64(name), (float)((double)std_ / kSigma4), mean, round_bf16, (hipStream_t)stream);
 }
 extern "C" int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream) {
-    GemmParams p = gp(A, lda, W, M, N, K, C, ldc);
+    GemmParams p = gp(DT_BF16, A, lda, W, M, N, K, C, ldc);
+    return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
+}
+extern "C" int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream) {
+    GemmParams p = gp(DT_F16, A, lda, W, M, N, K, C, ldc);
     return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
 }
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 //         half K-step (A(k+2) at the start of phase A(k), W(k+2) at the start of phase B(k)) and waited for with a
 //         counted vmcnt, so the L2->LDS pipe never drains (measured: a drained 64-KB burst per step moves 44 GB/s per
 //         CU, the same bytes issued as alternating 32-KB tiles 62 GB/s -- tools/dma_bench.hip).
-template <int EPI, int PIPE>
+template <int EPI, int PIPE, int DT>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[PIPE == 2 ? 5 * TILE_BYTES : 2 * BUF_BYTES];  // 160 / 128 KiB
 
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = mfma16<DT>(a[mi], b[ni], acc[mi][ni]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][mi], fb[ks][ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = mfma16<DT>(fa[ks][mi], fb[ks][ni], acc[mi][ni]);
             __builtin_amdgcn_s_setprio(0);
         };
         // a phase boundary: own LDS reads complete (WAR on the tile about to be refilled), then rendezvous
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         }
                         bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + col;
                         if (col + 3 < p.N) {
-                            uint2 pk = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+                            uint2 pk = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
                             *(uint2*)out = pk;
                         } else {
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = f32_to_bf16(x[j]);
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = to16<DT>(x[j]);
                         }
                     } else if constexpr (EPI == EPI_F32) {
                         float* out = (float*)p.C + (int64_t)row * p.ldc + col;
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             hi[j] = x2 * c4[j] + x1 * s4[j];
                         }
                         bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + head * 128 + d;
-                        *(uint2*)out = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]));
-                        *(uint2*)(out + 64) = make_uint2(pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
+                        *(uint2*)out = make_uint2(pack2<DT>(lo[0], lo[1]), pack2<DT>(lo[2], lo[3]));
+                        *(uint2*)(out + 64) = make_uint2(pack2<DT>(hi[0], hi[1]), pack2<DT>(hi[2], hi[3]));
                     }
                 } else {
 #pragma unroll
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x[j] = t[ni][j] + (p.bias ? p.bias[col + j] : 0.f);
                         bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + col;
-                        *(uint2*)out = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+                        *(uint2*)out = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
                     }
                 }
             } else if constexpr (EPI == EPI_SWIGLU) {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) x[j] = silu_f(t[2 * pr][j]) * t[2 * pr + 1][j];
                     bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + oc;
-                    *(uint2*)out = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+                    *(uint2*)out = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
                 }
             }
         }
@@ -409,12 +409,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 static int g_gemm_pipe = getenv("BLIM_GEMM_PIPE") ? atoi(getenv("BLIM_GEMM_PIPE")) : 2;
 void gemm_set_pipe(int pipe) { g_gemm_pipe = pipe; }
 
+template <int EPI, int PIPE>
+static void launch_p(const GemmParams& p, dim3 grid, hipStream_t stream) {
+    if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, PIPE, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<EPI, PIPE, DT_BF16>), grid, dim3(NTHREADS), 0, stream, p);
+}
+
 template <int EPI>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    if (g_gemm_pipe == 0) hipLaunchKernelGGL((gemm_kernel<EPI, 0>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
-    else if (g_gemm_pipe == 1) hipLaunchKernelGGL((gemm_kernel<EPI, 1>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel<EPI, 2>), dim3(ntm * ntn), dim3(NTHREADS), 0, stream, p);
+    const dim3 grid(ntm * ntn);
+#ifdef BLIM_GEMM_ALL_PIPES
+    if (g_gemm_pipe == 0) launch_p<EPI, 0>(p, grid, stream);
+    else if (g_gemm_pipe == 1) launch_p<EPI, 1>(p, grid, stream);
+    else
+#endif
+    launch_p<EPI, 2>(p, grid, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         blim_set_error("gemm launch failed: %s", hipGetErrorString(e));
@@ -428,6 +438,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
     ARG_CHECK(p.K % BK == 0);
     ARG_CHECK(p.lda % 8 == 0);
     ARG_CHECK(p.A && p.W);
+    ARG_CHECK(p.dtype == DT_BF16 || p.dtype == DT_F16);
     ARG_CHECK((int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
         case EPI_BF16: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_BF16>(p, stream);

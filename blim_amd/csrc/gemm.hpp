@@ -16,6 +16,7 @@ enum GemmEpi : int {
 };
 
 struct GemmParams {
+    int dtype;  // DT_BF16 / DT_F16: format of A, W and of 16-bit outputs
     const bf16_t* A;
     int64_t lda;
     const bf16_t* W;  // [N, K], row stride K

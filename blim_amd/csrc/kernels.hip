@@ -82,15 +82,16 @@ int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int
 }
 
 // ---------------------------------------------------------------------------- dtype converts
-__global__ void bf16_to_f32_kernel(float* out, const bf16_t* in, int64_t n) {
+template <int DT>
+__global__ void h16_to_f32_kernel(float* out, const bf16_t* in, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
             const uint2 v = *(const uint2*)(in + i);
-            *(float4*)(out + i) = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u),
-                                              __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xFFFF0000u));
+            *(float4*)(out + i) = make_float4(from16<DT>((uint16_t)(v.x & 0xFFFF)), from16<DT>((uint16_t)(v.x >> 16)),
+                                              from16<DT>((uint16_t)(v.y & 0xFFFF)), from16<DT>((uint16_t)(v.y >> 16)));
         } else {
-            for (int64_t j = i; j < n; ++j) out[j] = bf16_to_f32(in[j]);
+            for (int64_t j = i; j < n; ++j) out[j] = from16<DT>(in[j]);
         }
     }
 }
@@ -105,10 +106,11 @@ __global__ void f32_to_bf16_kernel(bf16_t* out, const float* in, int64_t n) {
         }
     }
 }
-int launch_bf16_to_f32(float* out, const bf16_t* in, int64_t n, hipStream_t s) {
+int launch_h16_to_f32(float* out, const bf16_t* in, int64_t n, int dtype, hipStream_t s) {
     ARG_CHECK(out && in && n > 0);
-    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, out, in, n);
-    LAUNCH_CHECK("bf16_to_f32");
+    if (dtype == DT_F16) hipLaunchKernelGGL(h16_to_f32_kernel<DT_F16>, dim3(grid_for(n, 1024)), dim3(256), 0, s, out, in, n);
+    else hipLaunchKernelGGL(h16_to_f32_kernel<DT_BF16>, dim3(grid_for(n, 1024)), dim3(256), 0, s, out, in, n);
+    LAUNCH_CHECK("h16_to_f32");
     return BLIM_OK;
 }
 int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s) {
@@ -120,7 +122,7 @@ int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s) {
 
 // ---------------------------------------------------------------------------- RMSNorm (K3/K9)
 // One wave per row; the row (H f32) is read once in float4 pieces and kept in registers when H <= 64*4*16.
-template <int MAXV>
+template <int MAXV, int DT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H,
                                                       const float* w, float eps, bf16_t* out_bf16, float* out_f32) {
     const int lane = threadIdx.x & 63;
@@ -147,29 +149,34 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
         if (c < nv) {
             const float4 g = *(const float4*)(w + 4 * c);
             const float o0 = g.x * (v[i].x * inv), o1 = g.y * (v[i].y * inv), o2 = g.z * (v[i].z * inv), o3 = g.w * (v[i].w * inv);
-            if (out_bf16) *(uint2*)(out_bf16 + r * H + 4 * c) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            if (out_bf16) *(uint2*)(out_bf16 + r * H + 4 * c) = make_uint2(pack2<DT>(o0, o1), pack2<DT>(o2, o3));
             if (out_f32) *(float4*)(out_f32 + r * H + 4 * c) = make_float4(o0, o1, o2, o3);
         }
     }
 }
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
-                   bf16_t* out_bf16, float* out_f32, hipStream_t s) {
-    ARG_CHECK(x && w && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0 && (out_bf16 || out_f32));
+                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s) {
+    ARG_CHECK(x && w && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0 && (out_h16 || out_f32));
     const int nv = H / 4;
     const dim3 grid((unsigned)((n_rows + 3) / 4));
-    if (nv <= 64 * 4) {
-        hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_bf16, out_f32);
-    } else if (nv <= 64 * 16) {
-        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_bf16, out_f32);
-    } else {
+#define RMS_LAUNCH(MV)                                                                                                              \
+    do {                                                                                                                            \
+        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32); \
+        else hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32);                \
+    } while (0)
+    if (nv <= 64 * 4) RMS_LAUNCH(4);
+    else if (nv <= 64 * 16) RMS_LAUNCH(16);
+    else {
         blim_set_error("rmsnorm: hidden size %d > 4096 not supported", H);
         return BLIM_ERR_ARG;
     }
+#undef RMS_LAUNCH
     LAUNCH_CHECK("rmsnorm");
     return BLIM_OK;
 }
 
 // ---------------------------------------------------------------------------- group mean (TVG clip tokens)
+template <int DT>
 __global__ void group_mean_kernel(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H) {
     const int chunks = H / 4;
     const int64_t total = n_out * chunks;
@@ -180,16 +187,17 @@ __global__ void group_mean_kernel(bf16_t* out, const bf16_t* in, int64_t n_out, 
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int j = 0; j < group; ++j) {
             const uint2 v = *(const uint2*)(in + (o * group + j) * H + 4 * c);
-            a0 += __uint_as_float(v.x << 16); a1 += __uint_as_float(v.x & 0xFFFF0000u);
-            a2 += __uint_as_float(v.y << 16); a3 += __uint_as_float(v.y & 0xFFFF0000u);
+            a0 += from16<DT>((uint16_t)(v.x & 0xFFFF)); a1 += from16<DT>((uint16_t)(v.x >> 16));
+            a2 += from16<DT>((uint16_t)(v.y & 0xFFFF)); a3 += from16<DT>((uint16_t)(v.y >> 16));
         }
         const float inv = 1.0f / (float)group;
-        *(uint2*)(out + o * H + 4 * c) = make_uint2(pack_bf16x2(a0 * inv, a1 * inv), pack_bf16x2(a2 * inv, a3 * inv));
+        *(uint2*)(out + o * H + 4 * c) = make_uint2(pack2<DT>(a0 * inv, a1 * inv), pack2<DT>(a2 * inv, a3 * inv));
     }
 }
-int launch_group_mean_bf16(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, hipStream_t s) {
+int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s) {
     ARG_CHECK(out && in && n_out > 0 && group > 0 && H % 4 == 0);
-    hipLaunchKernelGGL(group_mean_kernel, dim3(grid_for(n_out * (H / 4), 256)), dim3(256), 0, s, out, in, n_out, group, H);
+    if (dtype == DT_F16) hipLaunchKernelGGL(group_mean_kernel<DT_F16>, dim3(grid_for(n_out * (H / 4), 256)), dim3(256), 0, s, out, in, n_out, group, H);
+    else hipLaunchKernelGGL(group_mean_kernel<DT_BF16>, dim3(grid_for(n_out * (H / 4), 256)), dim3(256), 0, s, out, in, n_out, group, H);
     LAUNCH_CHECK("group_mean");
     return BLIM_OK;
 }

@@ -21,6 +21,13 @@ LIB_PATH = os.path.join(_HERE, "libblim_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "blim.h")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
+COMPUTE_DTYPES = {"bf16": 0, "f16": 1}
+DEFAULT_COMPUTE_DTYPE = os.environ.get("BLIM_DTYPE", "f16")   # fp16 = the reference's own autocast dtype
+
+
+def torch_dtype_of(name: str):
+    import torch
+    return {"bf16": torch.bfloat16, "f16": torch.float16}[name]
 
 
 class BlimError(RuntimeError):
@@ -31,7 +38,7 @@ class Config(C.Structure):
     _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32),
                 ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
                 ("mm_hidden_size", C.c_int32), ("num_clips", C.c_int32), ("max_positions", C.c_int32),
-                ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
+                ("compute_dtype", C.c_int32), ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
 
 
 class Batch(C.Structure):
@@ -87,6 +94,7 @@ def load_library(path: str = LIB_PATH):
         "blim_fill_bell_bf16": ([vp, i64, u64, C.c_char_p, f32, f32, vp], C.c_int),
         "blim_fill_bell_f32": ([vp, i64, u64, C.c_char_p, f32, f32, i32, vp], C.c_int),
         "blim_gemm_bf16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
+        "blim_gemm_f16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
         "blim_timing_enable": ([vp, i32], C.c_int),
         "blim_timing_num_classes": ([], C.c_int),
         "blim_timing_class_name": ([i32], C.c_char_p),
@@ -160,14 +168,16 @@ class PackedBatch:
 class Engine:
     """One scoring engine on the current HIP device."""
 
-    def __init__(self, dims: ModelDims, max_positions: int = 4096):
+    def __init__(self, dims: ModelDims, max_positions: int = 4096, dtype: Optional[str] = None):
         import torch
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise BlimError("no HIP device visible: the BLiM engine has no CPU fallback")
         self.dims = dims
+        self.dtype = dtype or DEFAULT_COMPUTE_DTYPE          # "f16" | "bf16": 16-bit format of activations / weights / MFMA operands
+        self.torch_dtype = torch_dtype_of(self.dtype)
         cfg = Config(dims.vocab_size, dims.hidden_size, dims.intermediate_size, dims.num_layers, dims.num_heads, dims.num_kv_heads,
-                     dims.mm_hidden_size, dims.num_clips, max_positions, dims.rms_eps, dims.rope_theta)
+                     dims.mm_hidden_size, dims.num_clips, max_positions, COMPUTE_DTYPES[self.dtype], dims.rms_eps, dims.rope_theta)
         h = C.c_void_p()
         _check(self.lib.blim_create(C.byref(cfg), C.byref(h)), "blim_create")
         self.h = h
@@ -207,21 +217,21 @@ class Engine:
     def project_video(self, feats, which: int):
         import torch
         n = feats.shape[0]
-        out = torch.empty((n, self.dims.hidden_size), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((n, self.dims.hidden_size), dtype=self.torch_dtype, device=self.device)
         _check(self.lib.blim_project_video(self.h, _ptr(feats), n, which, _ptr(out), _stream()), "blim_project_video")
         return out
 
     def group_mean(self, x, group: int):
         import torch
         n_out = x.shape[0] // group
-        out = torch.empty((n_out, x.shape[1]), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((n_out, x.shape[1]), dtype=self.torch_dtype, device=self.device)
         _check(self.lib.blim_group_mean(self.h, _ptr(x), n_out, group, _ptr(out), _stream()), "blim_group_mean")
         return out
 
     def assemble(self, src_index, feats=None):
         import torch
         n = src_index.shape[0]
-        out = torch.empty((n, self.dims.hidden_size), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((n, self.dims.hidden_size), dtype=self.torch_dtype, device=self.device)
         _check(self.lib.blim_assemble(self.h, _ptr(src_index), n, _ptr(feats), _ptr(out), _stream()), "blim_assemble")
         return out
 
@@ -229,7 +239,7 @@ class Engine:
         import torch
         n = batch.n_tokens if out_rows is None else out_rows.shape[0]
         H = self.dims.hidden_size
-        ob = torch.empty((n, H), dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        ob = torch.empty((n, H), dtype=self.torch_dtype, device=self.device) if want_bf16 else None
         of = torch.empty((n, H), dtype=torch.float32, device=self.device) if want_f32 else None
         bs = batch.struct()
         _check(self.lib.blim_decode(self.h, C.byref(bs), _ptr(embeds), _ptr(out_rows), n, _ptr(ob), _ptr(of), _stream()), "blim_decode")
@@ -259,7 +269,7 @@ class Engine:
     def visual_head(self, hidden_bf16):
         import torch
         n = hidden_bf16.shape[0]
-        out = torch.empty((n, self.dims.mm_hidden_size), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((n, self.dims.mm_hidden_size), dtype=self.torch_dtype, device=self.device)
         _check(self.lib.blim_visual_head(self.h, _ptr(hidden_bf16), n, _ptr(out), _stream()), "blim_visual_head")
         return out
 
@@ -344,11 +354,13 @@ def fill_bell_bf16(out, seed: int, name: str, std: float, mean: float = 0.0):
 
 
 def gemm_bf16(a, w):
-    """a [M,K] bf16, w [N,K] bf16 -> [M,N] bf16 (plain epilogue)."""
+    """a [M,K], w [N,K] (both bf16 or both f16) -> [M,N] of the same dtype (plain epilogue)."""
     import torch
     lib = load_library()
     M, K = a.shape
     N = w.shape[0]
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    _check(lib.blim_gemm_bf16(_ptr(a), K, _ptr(w), M, N, K, _ptr(out), N, _stream()), "blim_gemm_bf16")
+    assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16)
+    out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    fn = lib.blim_gemm_bf16 if a.dtype == torch.bfloat16 else lib.blim_gemm_f16
+    _check(fn(_ptr(a), K, _ptr(w), M, N, K, _ptr(out), N, _stream()), "blim_gemm")
     return out

@@ -21,9 +21,11 @@ from .synth import IGNORE_INDEX, IMAGE_TOKEN_INDEX, ModelDims
 
 
 class BlimModel:
-    def __init__(self, dims: ModelDims, max_positions: int = 4096, tokenizer_model_max_length: Optional[int] = None):
+    def __init__(self, dims: ModelDims, max_positions: int = 4096, tokenizer_model_max_length: Optional[int] = None,
+                 dtype: Optional[str] = None):
         self.dims = dims
-        self.engine = Engine(dims, max_positions=max_positions)
+        self.engine = Engine(dims, max_positions=max_positions, dtype=dtype)
+        self.dtype = self.engine.torch_dtype                        # torch dtype of activations (fp16 default, like the reference)
         self.device = self.engine.device
         self.tvg_prefix_length = 0
         self.video_vocab = None
@@ -47,7 +49,7 @@ class BlimModel:
 
     # ---- K1 with a per-video cache (the reference re-projects identical copies, retrieval_utils.py:60)
     def project(self, feat, tvg: bool, cache: bool = True):
-        """feat: [clips, T, mm_hidden] device tensor -> bf16 [clips*T, H] (vtg) or [clips, H] (tvg: mean over T).
+        """feat: [clips, T, mm_hidden] device tensor -> 16-bit [clips*T, H] (vtg) or [clips, H] (tvg: mean over T).
 
         The cache is keyed on the tensor's storage address AND keeps a reference to the tensor, so the address
         cannot be recycled for different data while the entry lives."""
@@ -59,7 +61,7 @@ class BlimModel:
                 return hit[1]
         x = feat.squeeze(0) if feat.ndim == 4 else feat          # :195 unsqueeze(0) / :157 squeeze(0)
         clips, T, M = x.shape
-        x = x.to(device=self.device, dtype=torch.bfloat16).reshape(clips * T, M).contiguous()
+        x = x.to(device=self.device, dtype=self.dtype).reshape(clips * T, M).contiguous()
         y = self.engine.project_video(x, 1 if tvg else 0)
         if tvg:
             y = self.engine.group_mean(y, T)                     # :243 frame_feature.mean(1)
@@ -72,7 +74,7 @@ class BlimModel:
     def forward_visual(self, visual_token_embeds):               # modeling_videochat_flash.py:598-599
         import torch
         shp = visual_token_embeds.shape
-        x = visual_token_embeds.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
+        x = visual_token_embeds.reshape(-1, shp[-1]).to(self.dtype).contiguous()
         return self.engine.visual_head(x).float().reshape(*shp[:-1], self.dims.mm_hidden_size)
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images,
@@ -80,7 +82,7 @@ class BlimModel:
         """modeling_videochat_flash.py:185-515, eval branch (video_feature=True, one <image> per row).
 
         input_ids / attention_mask / labels: LEFT-padded [B, Lt] device tensors; images: list of B feature tensors.
-        Returns (None, position_ids, mask | (mask, cpn_mask), past_key_values, embeds [B,L,H] bf16, labels [B,L])."""
+        Returns (None, position_ids, mask | (mask, cpn_mask), past_key_values, embeds [B,L,H] (compute dtype), labels [B,L])."""
         import torch
         if not video_feature:
             raise NotImplementedError("only pre-extracted video features (video_feature=True) are supported")
@@ -122,7 +124,7 @@ class BlimModel:
         for b in range(B):
             n = len(rows_src[b])
             src[b, :n] = rows_src[b]; out_lab[b, :n] = rows_lab[b]; mask[b, :n] = 1; cpn_mask[b, :n] = rows_cpn[b]
-        feat_all = torch.cat(feats + [torch.zeros((1, self.dims.hidden_size), dtype=torch.bfloat16, device=self.device)], dim=0)
+        feat_all = torch.cat(feats + [torch.zeros((1, self.dims.hidden_size), dtype=self.dtype, device=self.device)], dim=0)
         embeds = self.engine.assemble(torch.from_numpy(src.reshape(-1)).to(self.device), feat_all).reshape(B, L, -1)
         mdt = attention_mask.dtype if attention_mask is not None else torch.long
         new_labels = torch.from_numpy(out_lab).to(self.device) if labels is not None else None
@@ -145,7 +147,7 @@ class BlimModel:
         if position_ids is not None or past_key_values is not None or labels is not None or use_cache or output_attentions or dpo_forward:
             raise NotImplementedError("forward(): position_ids / cache / labels / attentions are outside the scoring path")
         B, L, _ = inputs_embeds.shape
-        emb = inputs_embeds.to(torch.bfloat16).contiguous()
+        emb = inputs_embeds.to(self.dtype).contiguous()
         if attention_mask is None:
             m8 = torch.ones((B, L), dtype=torch.uint8, device=self.device)
         else:

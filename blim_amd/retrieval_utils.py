@@ -65,10 +65,9 @@ vtg_criterion = VTGCriterion()
 tvg_criterion = TVGCriterion()
 
 
-def _clip_major_vocab(video_vocab, device):
-    """[N, clips, M] -> bf16 [clips, N, M] on device (layout blim_tvg_* expects)."""
-    import torch
-    return video_vocab.to(device=device, dtype=torch.bfloat16).permute(1, 0, 2).contiguous()
+def _clip_major_vocab(video_vocab, device, dtype):
+    """[N, clips, M] -> 16-bit [clips, N, M] on device (layout blim_tvg_* expects)."""
+    return video_vocab.to(device=device, dtype=dtype).permute(1, 0, 2).contiguous()
 
 
 def _tvg_logits_literal(model, hidden_states, tvg_labels, video_vocab, num_clips, device):
@@ -77,8 +76,8 @@ def _tvg_logits_literal(model, hidden_states, tvg_labels, video_vocab, num_clips
     idx = (tvg_labels == IMAGE_TOKEN_ID).nonzero()[:, 1][:, None].repeat(1, num_clips) + (torch.arange(num_clips) - (num_clips + 1)).to(device)
     emb = torch.gather(hidden_states, 1, idx[..., None].repeat(1, 1, hidden_states.shape[-1]))
     emb = model.module.forward_visual(emb)                                    # [B, clips, M] f32
-    vh = emb.to(torch.bfloat16).reshape(-1, emb.shape[-1]).contiguous()
-    return model.module.engine.tvg_logits(vh, _clip_major_vocab(video_vocab, device), emb.shape[0])
+    vh = emb.to(model.module.dtype).reshape(-1, emb.shape[-1]).contiguous()
+    return model.module.engine.tvg_logits(vh, _clip_major_vocab(video_vocab, device, model.module.dtype), emb.shape[0])
 
 
 def compute_v2t_scores_x(v2t_scores_x, iterator, start, input_ids, attention_masks, labels, video, video_vocab, tvg_video_labels,
@@ -197,7 +196,7 @@ class PairScorer:
         self.tvg_rows = strip(tvg_ids, tvg_masks, tvg_labels)
         self.video = video
         self.tvg_video_labels = np.asarray(tvg_video_labels).astype(np.int32)
-        self.vocab_cm = _clip_major_vocab(video_vocab, self.device) if video_vocab is not None else None
+        self.vocab_cm = _clip_major_vocab(video_vocab, self.device, self.m.dtype) if video_vocab is not None else None
         self._vfeat: Dict[Tuple[int, bool], object] = {}
         # per-text splits
         self.vtg_split = []
@@ -391,7 +390,7 @@ class _PackState:
         batch = PackedBatch(np.concatenate(self.pos), np.concatenate(self.vis), np.array(self.seq_start), np.array(self.seq_len),
                             np.array(self.pfx_start), np.array(self.pfx_len), device=dev)
         H = self.s.m.dims.hidden_size
-        feats = torch.cat(self.feats, dim=0) if self.feats else torch.zeros((1, H), dtype=torch.bfloat16, device=dev)
+        feats = torch.cat(self.feats, dim=0) if self.feats else torch.zeros((1, H), dtype=self.s.m.dtype, device=dev)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         labels = np.concatenate(self.labels)
         return Plan(kind=self.kind, batch=batch, src_index=t(src), feats=feats, rows=t(np.array(self.rows)), labels=t(labels),

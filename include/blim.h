@@ -10,7 +10,8 @@
  * blim_last_error() returns a message for the calling thread.  All data pointers are DEVICE pointers
  * (HIP) unless the parameter is documented as host; the caller owns every buffer passed in.  Calls are
  * asynchronous on the given hipStream_t (passed as void*; NULL = default stream); the caller synchronises.
- * An engine handle is not thread-safe; distinct handles are independent.  bf16 = raw 16-bit brain floats.
+ * An engine handle is not thread-safe; distinct handles are independent.  Buffers documented as "bf16" below hold raw
+ * 16-bit values of the engine's compute_dtype (bf16 or f16).
  */
 #ifndef BLIM_H_
 #define BLIM_H_
@@ -19,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 1
+#define BLIM_ABI_VERSION 2
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -27,6 +28,12 @@ extern "C" {
 
 #define BLIM_DTYPE_F32 0
 #define BLIM_DTYPE_BF16 1
+
+/* 16-bit compute format of an engine: activations handed across the ABI ("h16" below), the engine's weight copy and the
+ * MFMA operand type.  F16 is what the reference itself runs on GPU (main.py:97 .half(), training_utils.py:142 autocast
+ * float16) and the default of the Python host; BF16 has the same MFMA rate and an 8-bit mantissa. */
+#define BLIM_COMPUTE_BF16 0
+#define BLIM_COMPUTE_F16 1
 
 typedef struct blim_engine blim_engine;
 
@@ -36,6 +43,7 @@ typedef struct blim_config {
     int32_t mm_hidden_size; /* projector input width (1024) */
     int32_t num_clips;      /* --num_clips, main.py:59 (4) */
     int32_t max_positions;  /* RoPE table length */
+    int32_t compute_dtype;  /* BLIM_COMPUTE_BF16 / BLIM_COMPUTE_F16 */
     float rms_eps, rope_theta;
 } blim_config;
 
@@ -133,7 +141,8 @@ int blim_forward(blim_engine* e, const void* embeds, const uint8_t* mask, int32_
 /* ---- synthetic data + plain GEMM (bench / tests) */
 int blim_fill_bell_bf16(void* out, int64_t n, uint64_t seed, const char* name, float std, float mean, void* stream);
 int blim_fill_bell_f32(float* out, int64_t n, uint64_t seed, const char* name, float std, float mean, int32_t round_bf16, void* stream);
-/* C bf16 [M, ldc] = A bf16 [M, lda] . W bf16 [N, K]^T */
+/* C [M, ldc] = A [M, lda] . W [N, K]^T, all bf16 (resp. f16) */
+int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
 int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
 
 /* ---- per-kernel-class timing (hipEvents on the launch stream).  Classes: see blim_timing_class_name. */

@@ -1,6 +1,11 @@
 """GPU (-m gpu): the HIP engine, called through the C ABI, against the numpy oracle and the golden vectors recorded
-from the reference.  Tolerances: scores 1e-3 relative per entry (BASELINE.json north_star); intermediate bf16
-tensors 2e-2 of the tensor's max (one bf16 rounding is 2^-9 = 2e-3 relative; a few stack up per stage)."""
+from the reference.
+
+Tolerances.  Scores: 1e-3 relative per entry (BASELINE.json north_star) in the default fp16 compute mode (the
+reference's own autocast dtype) for every pass kind and both model sizes.  In bf16 mode (8-bit mantissa: each of the
+eight 16-bit roundings per layer adds 1.1e-3 rms) the VTG passes hold 1e-3 too; the TVG passes, whose scores are ~10x
+smaller in magnitude, hold 1e-3 on the tiny model and 4e-3 at 7B width (measured 2.4e-3; a numpy simulation of the same
+roundings gives 2.7e-3 - 3.5e-3, fp16 3.1e-4).  Intermediate 16-bit tensors: 2e-2 of the tensor's max."""
 import os
 import types
 
@@ -21,8 +26,18 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SCORE_RTOL = 1e-3
 
 
-def bf(x):
-    return torch.from_numpy(synth.bf16_bits(np.asarray(x, np.float32)).view(np.int16)).view(torch.bfloat16)
+def h16(x, dtype):
+    """float32 numpy -> torch tensor of the engine's 16-bit compute dtype (round to nearest even)."""
+    if dtype == torch.bfloat16:
+        return torch.from_numpy(synth.bf16_bits(np.asarray(x, np.float32)).view(np.int16)).view(torch.bfloat16)
+    return torch.from_numpy(np.asarray(x, np.float32)).to(torch.float16)
+
+
+DTYPES = ["f16", "bf16"]
+
+
+def tvg_rtol(dtype: str, case: str) -> float:
+    return 4e-3 if (dtype == "bf16" and case == "wide") else SCORE_RTOL
 
 
 def relmax(a, b):
@@ -30,13 +45,13 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def _build(case, layers=None, device_synth=False):
+def _build(case, layers=None, device_synth=False, dtype="f16"):
     spec = CASES[case]
     d = dict(spec["dims"])
     if layers is not None:
         d["num_layers"] = layers
     dims = synth.ModelDims(**d)
-    model = BlimModel(dims, max_positions=1024)
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
     w = None
     if device_synth:
         model.engine.init_synthetic_weights(spec["wseed"])
@@ -45,26 +60,26 @@ def _build(case, layers=None, device_synth=False):
         model.engine.load_weights(w)
     prob = synth.make_problem(spec["pseed"], spec["n"], dims, tok_per_clip=spec["tok_per_clip"], text_len=spec["text_len"])
     model.set_tvg_prefix_length(prob.tvg_prefix_length)
-    return types.SimpleNamespace(spec=spec, dims=dims, model=model, w=w, prob=prob, d=d)
+    return types.SimpleNamespace(spec=spec, dims=dims, model=model, w=w, prob=prob, d=d, dtype=dtype, case=case)
 
 
-@pytest.fixture(scope="module")
-def tiny():
-    t = _build("tiny")
+@pytest.fixture(scope="module", params=DTYPES)
+def tiny(request):
+    t = _build("tiny", dtype=request.param)
     yield t
     t.model.engine.close()
 
 
-@pytest.fixture(scope="module")
-def tiny1():
-    t = _build("tiny", layers=1)
+@pytest.fixture(scope="module", params=DTYPES)
+def tiny1(request):
+    t = _build("tiny", layers=1, dtype=request.param)
     yield t
     t.model.engine.close()
 
 
-@pytest.fixture(scope="module")
-def wide():
-    t = _build("wide", device_synth=True)
+@pytest.fixture(scope="module", params=DTYPES)
+def wide(request):
+    t = _build("wide", device_synth=True, dtype=request.param)
     yield t
     t.model.engine.close()
 
@@ -83,13 +98,14 @@ def test_device_fill_is_bit_exact_with_the_numpy_rule():
         assert np.array_equal(got, synth.bf16_bits(synth.bell_f32(7, "layers.3.q_proj.w", n, std, mean)))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1, 4, 64), (300, 500, 128), (1000, 260, 256), (513, 1028, 3584), (2048, 512, 18944)])
-def test_gemm_vs_numpy(M, N, K):
+def test_gemm_vs_numpy(M, N, K, dtype):
     rs = np.random.RandomState(M + N)
     a = synth.bf16_round(rs.randn(M, K).astype(np.float32)); w = synth.bf16_round(rs.randn(N, K).astype(np.float32) * 0.05)
-    got = eng.gemm_bf16(bf(a).cuda(), bf(w).cuda()).float().cpu().numpy()
+    got = eng.gemm_bf16(h16(a, dtype).cuda(), h16(w, dtype).cuda()).float().cpu().numpy()
     want = a @ w.T
-    assert relmax(got, want) < 6e-3        # one bf16 rounding of the output
+    assert relmax(got, want) < (6e-3 if dtype == torch.bfloat16 else 1e-3)        # one 16-bit rounding of the output
 
 
 def test_layer_stages_against_oracle(tiny1):
@@ -102,23 +118,23 @@ def test_layer_stages_against_oracle(tiny1):
     mask, cpn, emb, lab = om.prepare_inputs_labels_for_multimodal(vtg[0][sel], vtg[2][sel], vtg[1][sel], [t.prob.video[i] for i in sel])
     B, L, H = emb.shape
     E = t.model.engine
-    e_t = bf(emb).cuda()
+    e_t = h16(emb, t.model.dtype).cuda()
     nq, nk = t.dims.num_heads * 128, t.dims.num_kv_heads * 128
     for mm in (mask, cpn):
         parts = {}
         cos, sin = O.rope_tables(ocfg.head_dim, ocfg.rope_theta, L)
-        x1 = om.decoder_layer(0, synth.bf16_round(emb), O.additive_mask(mm, L), cos, sin, parts)
+        x1 = om.decoder_layer(0, h16(emb, t.model.dtype).float().numpy(), O.additive_mask(mm, L), cos, sin, parts)
         for tr in (1, 0):
             E.set_option("attn_tr_read", tr)
             _, hd = E.forward(e_t, torch.from_numpy(mm.astype(np.uint8)).cuda(), want_logits=False, want_hidden=True)
             valid = mask.astype(bool)
-            qkv = E.debug_read("qkv", (B * L, nq + 2 * nk), torch.bfloat16).float().cpu().numpy().reshape(B, L, -1)
+            qkv = E.debug_read("qkv", (B * L, nq + 2 * nk), t.model.dtype).float().cpu().numpy().reshape(B, L, -1)
             assert relmax(qkv[..., :nq][valid], parts["q"][valid]) < 2e-2
             assert relmax(qkv[..., nq:nq + nk][valid], parts["k"][valid]) < 2e-2
             assert relmax(qkv[..., nq + nk:][valid], parts["v"][valid]) < 2e-2
-            at = E.debug_read("attn", (B * L, H), torch.bfloat16).float().cpu().numpy().reshape(B, L, H)
+            at = E.debug_read("attn", (B * L, H), t.model.dtype).float().cpu().numpy().reshape(B, L, H)
             assert relmax(at[valid], parts["attn"][valid]) < 2e-2
-            ac = E.debug_read("act", (B * L, t.dims.intermediate_size), torch.bfloat16).float().cpu().numpy().reshape(B, L, -1)
+            ac = E.debug_read("act", (B * L, t.dims.intermediate_size), t.model.dtype).float().cpu().numpy().reshape(B, L, -1)
             assert relmax(ac[valid], parts["act"][valid]) < 2e-2
             rs = E.debug_read("resid", (B * L, H), torch.float32).cpu().numpy().reshape(B, L, H)
             assert relmax(rs[valid], x1[valid]) < 1e-2
@@ -153,7 +169,7 @@ def test_forward_surface_and_hidden_states(tiny):
     g = np.load(os.path.join(GOLD, "tiny.npz"))
     ddp = DDPLike(t.model).eval()
     for kind in ("vtg", "tvg"):
-        emb = bf(g[f"prep_{kind}_embeds"]).cuda()
+        emb = h16(g[f"prep_{kind}_embeds"], t.model.dtype).cuda()
         valid = g[f"prep_{kind}_mask"].astype(bool)
         for tag, mk in (("", f"prep_{kind}_mask"), ("_cpn", f"prep_{kind}_cpn_mask")):
             out = ddp(inputs_embeds=emb, attention_mask=torch.from_numpy(g[mk]).cuda())
@@ -213,19 +229,20 @@ def _six_passes(t, literal):
     return out
 
 
-def _check_passes(got, g):
+def _check_passes(got, g, t):
     for name, S in got.items():
         G = g[f"S_{name}"]
         assert np.array_equal(S == -100.0, G == -100.0), name          # same entries computed (top-k, leftover batch)
         m = G != -100.0
-        np.testing.assert_allclose(S[m], G[m], rtol=SCORE_RTOL, err_msg=name)
+        rtol = tvg_rtol(t.dtype, t.case) if "tvg" in name else SCORE_RTOL
+        np.testing.assert_allclose(S[m], G[m], rtol=rtol, err_msg=f"{name} [{t.dtype}]")
 
 
 @pytest.mark.parametrize("literal", [True, False], ids=["literal-api", "fused-pairscorer"])
 def test_six_passes_tiny_vs_reference_golden(tiny, literal):
     g = np.load(os.path.join(GOLD, "tiny.npz"))
     got = _six_passes(tiny, literal)
-    _check_passes(got, g)
+    _check_passes(got, g, tiny)
     # R@k of the full BLiM ensemble: identical to the reference's matrices'
     n = tiny.spec["n"]
     args = types.SimpleNamespace(cpn=True, alpha=[0.4, 0.8], c=[0.3, 0.6, 0.9, 0.7], resume="ckpt", eval=True)
@@ -240,14 +257,15 @@ def test_six_passes_tiny_vs_reference_golden(tiny, literal):
 def test_six_passes_7b_width_vs_reference_golden(wide, literal):
     """Qwen2-7B width (H=3584, 28/4 heads, I=18944, V=152064), one layer; weights generated ON DEVICE from the seed."""
     g = np.load(os.path.join(GOLD, "wide.npz"))
-    _check_passes(_six_passes(wide, literal), g)
+    _check_passes(_six_passes(wide, literal), g, wide)
 
 
-def test_full_size_properties_7b():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_full_size_properties_7b(dtype):
     """Size-independent properties at the full 28-layer 7B configuration: a pair's score does not depend on what else is in
     the batch (bitwise), nor on the order of the pairs; shared-prefix scoring equals per-pair scoring (1e-3)."""
     dims = synth.ModelDims()
-    model = BlimModel(dims, max_positions=1024)
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
     model.engine.init_synthetic_weights(0)
     prob = synth.make_problem(21, 6, dims, tok_per_clip=24, text_len=(5, 32), reference_layout=True)
     model.set_tvg_prefix_length(prob.tvg_prefix_length)

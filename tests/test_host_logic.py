@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.blim_abi_version() == 1
+    assert lib.blim_abi_version() == 2
     assert lib.blim_timing_num_classes() >= 8
 
 
@@ -33,7 +33,7 @@ def test_engine_fails_loudly_without_gpu():
     # and at the C level
     lib = eng.load_library()
     import ctypes as C
-    cfg = eng.Config(152064, 3584, 18944, 1, 28, 4, 1024, 4, 128, 1e-6, 1e6)
+    cfg = eng.Config(152064, 3584, 18944, 1, 28, 4, 1024, 4, 128, 1, 1e-6, 1e6)
     h = C.c_void_p()
     assert lib.blim_create(C.byref(cfg), C.byref(h)) < 0
     assert b"no HIP device" in lib.blim_last_error() or b"failed" in lib.blim_last_error()
@@ -102,11 +102,11 @@ class _FakeModel:
     """Planning needs only .project / .device / .dims / .tvg_prefix_length."""
 
     def __init__(self, dims, tp):
-        self.dims, self.device, self.tvg_prefix_length, self.engine = dims, torch.device("cpu"), tp, None
+        self.dims, self.device, self.tvg_prefix_length, self.engine, self.dtype = dims, torch.device("cpu"), tp, None, torch.float16
 
     def project(self, feat, tvg, cache=True):
         clips, T, _ = feat.shape
-        return torch.zeros((clips if tvg else clips * T, self.dims.hidden_size), dtype=torch.bfloat16)
+        return torch.zeros((clips if tvg else clips * T, self.dims.hidden_size), dtype=torch.float16)
 
 
 def _scorer(n=6, layout=True):

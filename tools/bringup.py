@@ -34,8 +34,14 @@ def relerr(a, b):
     return float(np.abs(a - b).max()), float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)), float(np.sqrt(((a - b) ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30))
 
 
+DT = os.environ.get("BLIM_DTYPE", "f16")
+TDT = torch.float16 if DT == "f16" else torch.bfloat16
+
+
 def bf(x):
-    return torch.from_numpy(synth.bf16_bits(np.asarray(x, np.float32)).view(np.int16)).view(torch.bfloat16)
+    if TDT == torch.bfloat16:
+        return torch.from_numpy(synth.bf16_bits(np.asarray(x, np.float32)).view(np.int16)).view(torch.bfloat16)
+    return torch.from_numpy(np.asarray(x, np.float32)).to(torch.float16)
 
 
 def stage(name):
@@ -76,6 +82,7 @@ def test_gemm(perf):
         for (M, N, K) in ((8192, 3584, 3584), (8192, 37888, 3584), (8192, 3584, 18944), (8192, 4608, 3584), (16384, 37888, 3584), (4096, 4096, 4096), (8192, 8192, 8192)):
             a = torch.empty((M, K), dtype=torch.bfloat16, device="cuda"); w = torch.empty((N, K), dtype=torch.bfloat16, device="cuda")
             eng.fill_bell_bf16(a, 1, "a", 1.0); eng.fill_bell_bf16(w, 1, "w", 0.02)
+            a = a.to(TDT); w = w.to(TDT)
             for _ in range(2):
                 eng.gemm_bf16(a, w)
             torch.cuda.synchronize()
@@ -129,18 +136,18 @@ def test_layer_parts():
     for tag, mm in (("mask", mask), ("cpn", cpn)):
         parts = {}
         cos, sin = O.rope_tables(ocfg.head_dim, ocfg.rope_theta, L)
-        x1 = om.decoder_layer(0, synth.bf16_round(emb), O.additive_mask(mm, L), cos, sin, parts)
+        x1 = om.decoder_layer(0, bf(emb).float().numpy(), O.additive_mask(mm, L), cos, sin, parts)
         lg, hd = model.engine.forward(e_t, T(mm.astype(np.uint8)), want_logits=False, want_hidden=True)
         nq, nk = dims.num_heads * 128, dims.num_kv_heads * 128
-        qkv = model.engine.debug_read("qkv", (B * L, nq + 2 * nk), torch.bfloat16).float().cpu().numpy().reshape(B, L, -1)
+        qkv = model.engine.debug_read("qkv", (B * L, nq + 2 * nk), TDT).float().cpu().numpy().reshape(B, L, -1)
         say(f"[{tag}] q:", relerr(qkv[..., :nq], parts["q"]), " k:", relerr(qkv[..., nq:nq + nk], parts["k"]), " v:", relerr(qkv[..., nq + nk:], parts["v"]))
-        at = model.engine.debug_read("attn", (B * L, H), torch.bfloat16).float().cpu().numpy().reshape(B, L, H)
+        at = model.engine.debug_read("attn", (B * L, H), TDT).float().cpu().numpy().reshape(B, L, H)
         valid = mask.astype(bool)
         say(f"[{tag}] attn (valid rows):", relerr(at[valid], parts["attn"][valid]))
         if tag == "cpn":
             rows_any = np.array([[(mm[b, :t + 1] != 0).any() for t in range(L)] for b in range(B)]) & valid
             say(f"[{tag}] attn (rows with >=1 visible key):", relerr(at[rows_any], parts["attn"][rows_any]))
-        ac = model.engine.debug_read("act", (B * L, dims.intermediate_size), torch.bfloat16).float().cpu().numpy().reshape(B, L, -1)
+        ac = model.engine.debug_read("act", (B * L, dims.intermediate_size), TDT).float().cpu().numpy().reshape(B, L, -1)
         say(f"[{tag}] act:", relerr(ac[valid], parts["act"][valid]))
         rs = model.engine.debug_read("resid", (B * L, H), torch.float32).cpu().numpy().reshape(B, L, H)
         say(f"[{tag}] resid out:", relerr(rs[valid], x1[valid]))
@@ -149,7 +156,7 @@ def test_layer_parts():
         for tr in (0, 1):
             model.engine.set_option("attn_tr_read", tr)
             model.engine.forward(e_t, T(mm.astype(np.uint8)), want_logits=False, want_hidden=True)
-            a2 = model.engine.debug_read("attn", (B * L, H), torch.bfloat16).float().cpu().numpy().reshape(B, L, H)
+            a2 = model.engine.debug_read("attn", (B * L, H), TDT).float().cpu().numpy().reshape(B, L, H)
             say(f"[{tag}] attn tr_read={tr}:", relerr(a2[valid], parts["attn"][valid]))
     model.engine.close()
 
@@ -248,7 +255,7 @@ def test_perf(n_query=24):
             ss.append(t); sl.append(31); ps.append(p0); pl.append(96); pos += list(range(96, 127))
             rows += [p0 + 95] + list(range(t, t + 31)); rstart.append(len(rows)); t += 31
     batch = eng.PackedBatch(np.array(pos), np.ones(t, np.uint8), np.array(ss), np.array(sl), np.array(ps), np.array(pl))
-    emb = torch.empty((t, H), dtype=torch.bfloat16, device="cuda"); eng.fill_bell_bf16(emb, 1, "emb", 0.02)
+    emb = torch.empty((t, H), dtype=torch.bfloat16, device="cuda"); eng.fill_bell_bf16(emb, 1, "emb", 0.02); emb = emb.to(TDT)
     rows_t = torch.tensor(rows, dtype=torch.int32, device="cuda"); rs_t = torch.tensor(rstart, dtype=torch.int32, device="cuda")
     labels = torch.from_numpy(synth.uniform_ids(1, "lab", len(rows), 1000, 150000).astype(np.int32)).cuda()
     say(f"tokens {t}, rows {len(rows)}, pairs {len(rstart) - 1}")

@@ -13,6 +13,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for (M, N, K) in shapes:
     a = torch.empty((M, K), dtype=torch.bfloat16, device="cuda"); w = torch.empty((N, K), dtype=torch.bfloat16, device="cuda")
     eng.fill_bell_bf16(a, 1, "a", 1.0); eng.fill_bell_bf16(w, 1, "w", 0.02)
+    if os.environ.get("BLIM_DTYPE", "f16") == "f16":
+        a = a.to(torch.float16); w = w.to(torch.float16)
     eng.gemm_bf16(a, w)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
