@@ -652,10 +652,13 @@ extern "C" int blim_debug_read(blim_engine* e, const char* which, void* dst, int
     HIP_TRY(hipMemcpyAsync(dst, b->p, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BLIM_OK;
 }
+extern "C" int blim_debug_gemm_stamps(void* device_buf) {
+    gemm_set_debug_stamps((unsigned long long*)device_buf);
+    return BLIM_OK;
+}
 extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     ARG_CHECK(e && key);
     if (!strcmp(key, "attn_tr_read")) { e->attn_tr = value; return BLIM_OK; }
-    if (!strcmp(key, "gemm_pipe")) { gemm_set_pipe(value); return BLIM_OK; }
     blim_set_error("unknown option '%s'", key);
     return BLIM_ERR_ARG;
 }

@@ -24,36 +24,55 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 }
 
 // 4x4 transpose inside each quad of lanes: in: lane c holds v[j] = X[row j][col c];
-// out: lane c holds v[j] = X[row c][col j].
+// out: lane c holds v[j] = X[row c][col j].  Two butterfly stages of DPP quad_perm moves (no LDS traffic).
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+}
 __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int lane) {
     const bool odd = lane & 1;
     float s0 = odd ? v0 : v1, s1 = odd ? v2 : v3;
-    float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
     if (odd) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
     const bool hi = lane & 2;
     s0 = hi ? v0 : v2; s1 = hi ? v1 : v3;
-    r0 = __shfl_xor(s0, 2); r1 = __shfl_xor(s1, 2);
+    r0 = quad_xor2(s0); r1 = quad_xor2(s1);
     if (hi) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-// PIPE 0: all 8 waves in lock step, two 64-KB LDS stages, one barrier per K-step (bring-up structure, kept for A/B runs).
-// PIPE 1: ping-pong -- waves 0-3 and 4-7 (SIMD partners) alternate {LDS fragment reads} and {64 MFMAs} so each SIMD's
-//         matrix pipe always has one wave computing; two 64-KB stages, LDS-DMA for K-step k+2 issued as one 64-KB burst.
-// PIPE 2: ping-pong over a RING of five 32-KB operand slots (A or W tile of one K-step): one operand tile is issued per
-//         half K-step (A(k+2) at the start of phase A(k), W(k+2) at the start of phase B(k)) and waited for with a
-//         counted vmcnt, so the L2->LDS pipe never drains (measured: a drained 64-KB burst per step moves 44 GB/s per
-//         CU, the same bytes issued as alternating 32-KB tiles 62 GB/s -- tools/dma_bench.hip).
-template <int EPI, int PIPE, int DT>
+// Main loop ("ring" structure; measured ladder in DESIGN.md section 3):
+//  * waves 0-3 / 4-7 (the SIMD partners) ping-pong: while one group issues its 64 MFMAs of K-step k back to back, the other
+//    reads its 24 LDS fragments of the next step, so each SIMD's matrix pipe always has one wave computing;
+//  * LDS is a RING of five 32-KB operand slots (A or W tile of one K-step).  One operand tile is staged per half K-step
+//    and waited for with a counted vmcnt, so the L2->LDS pipe never drains (a drained 64-KB burst per step moves
+//    44 GB/s per CU, the same bytes as alternating 32-KB tiles 62 GB/s: tools/dma_bench.hip);
+//  * only the fragment-READING group issues LDS-DMA (group 1 every A tile, group 0 every W tile, after its LDS reads):
+//    the computing group issues nothing but MFMAs.
+template <int EPI, int DT>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[PIPE == 2 ? 5 * TILE_BYTES : 2 * BUF_BYTES];  // 160 / 128 KiB
+    __shared__ __attribute__((aligned(16))) char smem[5 * TILE_BYTES];  // 160 KiB ring / 136 KiB (two stages, or the staged C tile)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)blockIdx.x * 4 + k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    // Stagger the XCDs (blocks b, b+8, ... share one) by a few microseconds in the first dispatch round so that their
+    // epilogue write bursts (and LDS-DMA bursts) do not coincide chip-wide: 256 CUs x 128-512 KB written in the same
+    // microsecond is HBM-write-bound (measured epilogue 10-14 us per tile); within an XCD the blocks stay in lock step,
+    // which is what keeps their shared A/W panels L2-resident.
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const int n = (blockIdx.x & 7) * p.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- tile mapping: XCD-contiguous chunks (blocks b, b+8, ... share an XCD), then grouped M order
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
@@ -70,27 +89,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const int tn = (pid % width) / gsz;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // ---- per-lane LDS-DMA sources: wave w stages blocks w, w+8, w+16, w+24 of A and of W.
+    // ---- per-lane LDS-DMA sources (see the main loop: each wave stages 8 blocks of ONE operand)
     // 32-bit byte offsets from the (wave-uniform, scalar) operand bases: the K-step advance is a scalar add on the
     // base and the LDS-DMA uses the saddr + voffset form (no per-step vector address arithmetic).
-    const int sq = lane >> 4, sr = (lane >> 1) & 7, sc = 2 * sq + (lane & 1);  // LDS slot lane -> (row sr, chunk sc)
-    uint32_t offA[4], offB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int b = wave + 8 * i;
-        const int ra = min(row0 + 8 * b + sr, p.M - 1);
-        const int rb = min(col0 + 8 * b + sr, p.N - 1);
-        offA[i] = (uint32_t)(((int64_t)ra * p.lda + 8 * sc) * 2);
-        offB[i] = (uint32_t)(((int64_t)rb * p.K + 8 * sc) * 2);
-    }
+    const int sq = lane >> 4, sr = (lane >> 1) & 7, sc = 2 * sq + (lane & 1);  // LDS slot lane -> (row sr, 16-B chunk sc)
     const char* baseA = (const char*)p.A;
     const char* baseW = (const char*)p.W;
-    // one operand tile (32 KiB, 4 LDS-DMA per wave) of K-step kt into the LDS tile at byte offset `dst`
-    auto stage_tile = [&](bool isW, int dst, int kt) __attribute__((always_inline)) {
-        const char* g = (isW ? baseW : baseA) + (int64_t)kt * (BK * 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(g + (isW ? offB[i] : offA[i]), smem + dst + (wave + 8 * i) * 1024);
-    };
 
     // ---- fragment read offsets (bytes) inside an operand tile
     const int fr = lane & 15, fc = lane >> 4;
@@ -105,31 +109,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    if constexpr (PIPE == 0) {
-        stage_tile(false, 0, 0); stage_tile(true, TILE_BYTES, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) { stage_tile(false, (cur ^ 1) * BUF_BYTES, kt + 1); stage_tile(true, (cur ^ 1) * BUF_BYTES + TILE_BYTES, kt + 1); }
-            const char* base = smem + cur * BUF_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[8], b[4];
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(base + TILE_BYTES + b_off + ni * 2048 + ks * 512);
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) a[mi] = *(const bf16x8*)(base + a_off + mi * 2048 + ks * 512);
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = mfma16<DT>(a[mi], b[ni], acc[mi][ni]);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    } else {
+    stamp(1);
+    {
         const int grp = wave >> 2;  // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
         bf16x8 fa[2][8], fb[2][4];
         auto load_frags = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
@@ -160,90 +141,74 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         __builtin_amdgcn_s_barrier();                      \
         asm volatile("" ::: "memory")
 
-        // Both variants run two straight-line loops (one per wave group) that execute the SAME barrier sequence:
-        //   phase A(kt): group 0 computes step kt              | group 1 reads its fragments of step kt
-        //   phase B(kt): group 0 reads its fragments of kt+1   | group 1 computes step kt
-        if constexpr (PIPE == 1) {
-            stage_tile(false, 0, 0); stage_tile(true, TILE_BYTES, 0);
-            if (nk > 1) { stage_tile(false, BUF_BYTES, 1); stage_tile(true, BUF_BYTES + TILE_BYTES, 1); }
-            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-step 0 landed (8 LDS-DMA per wave per step)
+        // Two straight-line loops (one per wave group) that execute the SAME barrier sequence:
+        //   phase A(kt): group 0 computes step kt              | group 1 reads its fragments of step kt, stages A(kt+2)
+        //   phase B(kt): group 0 reads its fragments of kt+1, stages W(kt+2) | group 1 computes step kt
+        // Operand n = 2*step + isW lives in ring slot n % 5: A(kt) at `sa`, W(kt) = adv(sa,1), A(kt+1) = adv(sa,2),
+        // W(kt+1) = adv(sa,3), A(kt+2) = adv(sa,4) (the slot W(kt-1) left), W(kt+2) = sa (the slot A(kt) left).
+        constexpr int RING = 5 * TILE_BYTES;
+        auto adv = [](int s, int j) { const int x = s + j * TILE_BYTES; return x >= RING ? x - RING : x; };
+        const int wg = wave & 3;
+        uint32_t off8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = wg + 4 * i;   // 1-KiB block (8 rows) of the operand tile
+            if (grp == 1) off8[i] = (uint32_t)(((int64_t)min(row0 + 8 * b + sr, p.M - 1) * p.lda + 8 * sc) * 2);
+            else off8[i] = (uint32_t)(((int64_t)min(col0 + 8 * b + sr, p.N - 1) * p.K + 8 * sc) * 2);
+        }
+        const char* gbase = grp == 1 ? baseA : baseW;
+        auto stage8 = [&](int dst, int kt) __attribute__((always_inline)) {   // one operand tile share: 8 LDS-DMA per wave
+            const char* g = gbase + (int64_t)kt * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) glds16(g + off8[i], smem + dst + (wg + 4 * i) * 1024);
+        };
+        int sa = 0;
+        if (grp == 0) {
+            stage8(TILE_BYTES, 0);                                   // W0
+            if (nk > 1) stage8(3 * TILE_BYTES, 1);                   // W1
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PHASE_BARRIER();                                         // A0 W0 landed (every wave waited for its own DMA)
+            load_frags(0, TILE_BYTES);
             PHASE_BARRIER();
-            if (grp == 0) {
-                load_frags(0, TILE_BYTES);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // K-step 1 landed
+            for (int kt = 0; kt < nk; ++kt) {
+                compute();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of W(kt+1) landed
                 PHASE_BARRIER();
-                for (int kt = 0; kt < nk; ++kt) {
-                    const int cur = (kt & 1) * BUF_BYTES, nxt = BUF_BYTES - cur;
-                    compute();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // step kt+1 (issued one K-step ago) landed
-                    PHASE_BARRIER();
-                    if (kt + 2 < nk) { stage_tile(false, cur, kt + 2); stage_tile(true, cur + TILE_BYTES, kt + 2); }
-                    if (kt + 1 < nk) load_frags(nxt, nxt + TILE_BYTES);
-                    PHASE_BARRIER();
-                }
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (kt + 1 < nk) load_frags(adv(sa, 2), adv(sa, 3));
+                if (kt + 2 < nk) stage8(sa, kt + 2);                 // W(kt+2)
                 PHASE_BARRIER();
-                for (int kt = 0; kt < nk; ++kt) {
-                    const int cur = (kt & 1) * BUF_BYTES;
-                    load_frags(cur, cur + TILE_BYTES);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    PHASE_BARRIER();
-                    if (kt + 2 < nk) { stage_tile(false, cur, kt + 2); stage_tile(true, cur + TILE_BYTES, kt + 2); }
-                    compute();
-                    PHASE_BARRIER();
-                }
+                sa = adv(sa, 2);
             }
         } else {
-            // ---- ring of five operand tiles.  Operand n = 2*step + isW lives in slot n % 5.
-            // Issue order A0 W0 A1 W1 | A2 W2 A3 W3 ... : A(k+2) at the start of phase A(k) (into the slot W(k-1) left),
-            // W(k+2) at the start of phase B(k) (into the slot A(k) left).  At the end of phase A(k) the step k+1 tiles
-            // must have landed; the only younger LDS-DMA is A(k+2) (4 per wave) -> s_waitcnt vmcnt(4), or vmcnt(0) once
-            // nothing younger is issued any more.
-            constexpr int RING = 5 * TILE_BYTES;
-            auto adv = [](int s, int j) { const int x = s + j * TILE_BYTES; return x >= RING ? x - RING : x; };
-            stage_tile(false, 0, 0); stage_tile(true, TILE_BYTES, 0);
-            if (nk > 1) { stage_tile(false, 2 * TILE_BYTES, 1); stage_tile(true, 3 * TILE_BYTES, 1); }
-            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A0 W0 landed
+            stage8(0, 0);                                            // A0
+            if (nk > 1) stage8(2 * TILE_BYTES, 1);                   // A1
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();
-            int sa = 0;   // slot (byte offset) of A(kt); W(kt) = adv(sa,1), A(kt+1) = adv(sa,2), W(kt+1) = adv(sa,3), A(kt+2) = adv(sa,4), W(kt+2) = sa
-            if (grp == 0) {
-                load_frags(0, TILE_BYTES);
+            PHASE_BARRIER();
+            for (int kt = 0; kt < nk; ++kt) {
+                load_frags(sa, adv(sa, 1));
+                if (kt + 2 < nk) { stage8(adv(sa, 4), kt + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // my share of A(kt+1) landed
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PHASE_BARRIER();
-                for (int kt = 0; kt < nk; ++kt) {
-                    // phase A(kt)
-                    if (kt + 2 < nk) stage_tile(false, adv(sa, 4), kt + 2);
-                    compute();
-                    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // A(kt+1) W(kt+1) landed
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    PHASE_BARRIER();
-                    // phase B(kt)
-                    if (kt + 2 < nk) stage_tile(true, sa, kt + 2);
-                    if (kt + 1 < nk) load_frags(adv(sa, 2), adv(sa, 3));
-                    PHASE_BARRIER();
-                    sa = adv(sa, 2);
-                }
-            } else {
+                compute();
                 PHASE_BARRIER();
-                for (int kt = 0; kt < nk; ++kt) {
-                    if (kt + 2 < nk) stage_tile(false, adv(sa, 4), kt + 2);
-                    load_frags(sa, adv(sa, 1));
-                    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    PHASE_BARRIER();
-                    if (kt + 2 < nk) stage_tile(true, sa, kt + 2);
-                    compute();
-                    PHASE_BARRIER();
-                    sa = adv(sa, 2);
-                }
+                sa = adv(sa, 2);
             }
         }
 #undef PHASE_BARRIER
     }
 
+    stamp(2);
     // =========================================================================== epilogues
+    if (p.debug_skip_epilogue) {   // timing aid (tools/gemm_k_sweep.py): keep the accumulators live, store nothing
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     const int wrow0 = row0 + 128 * wm;  // wave's first row
     const int wcol0 = col0 + 64 * wn;   // wave's first column (in W's row order)
 
@@ -292,139 +257,169 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 p.lse_part[(int64_t)row * ntn + tn] = make_float2(mx, sm);
             }
         }
+        stamp(3);
         return;
     } else {
+        // ---- C tile staged through LDS so that global stores are whole rows (512 B / 1 KiB per row), 16 B per lane.
+        // (Direct stores from the MFMA layout touch 32-B row segments: measured 10-13 us per tile, 12 % of a K=3584 tile.)
         const int tq = (lane & 15) >> 2;        // which 4-col group of the fragment this lane owns after the transpose
         const int rsub = 4 * (lane >> 4) + (lane & 3);
+        __syncthreads();                        // every wave is out of the main loop: LDS is reusable
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV || EPI == EPI_SWIGLU) {
+            constexpr int NC = (EPI == EPI_SWIGLU) ? 128 : 256;   // output columns of this tile
+            constexpr int RS = NC * 2 + 32;                       // LDS row stride (bytes), = 32 mod 128: conflict-free ds_write_b64
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int row = wrow0 + 16 * mi + rsub;
-            float t[4][4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
-                quad_transpose(v0, v1, v2, v3, lane);
-                t[ni][0] = v0; t[ni][1] = v1; t[ni][2] = v2; t[ni][3] = v3;
-            }
-            if (row >= p.M) continue;
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_RESID) {
+            for (int mi = 0; mi < 8; ++mi) {
+                const int rl = 128 * wm + 16 * mi + rsub;         // row inside the tile
+                const int row = min(row0 + rl, p.M - 1);
+                float t[4][4];
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const int col = wcol0 + 16 * ni + 4 * tq;
-                    if (col >= p.N) continue;
-                    float x[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) x[j] = t[ni][j];
-                    if constexpr (EPI != EPI_RESID) {
-                        if (p.bias) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) x[j] += (col + j < p.N) ? p.bias[col + j] : 0.f;
-                        }
-                    }
-                    if constexpr (EPI == EPI_BF16) {
-                        if (p.act == 1) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) x[j] = gelu_erf(x[j]);
-                        }
-                        bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + col;
-                        if (col + 3 < p.N) {
-                            uint2 pk = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
-                            *(uint2*)out = pk;
-                        } else {
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = to16<DT>(x[j]);
-                        }
-                    } else if constexpr (EPI == EPI_F32) {
-                        float* out = (float*)p.C + (int64_t)row * p.ldc + col;
-                        if (col + 3 < p.N && (p.ldc & 3) == 0) {
-                            *(float4*)out = make_float4(x[0] * p.scale, x[1] * p.scale, x[2] * p.scale, x[3] * p.scale);
-                        } else {
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = x[j] * p.scale;
-                        }
-                    } else {  // EPI_RESID
-                        float* out = (float*)p.C + (int64_t)row * p.ldc + col;
-                        if (col + 3 < p.N) {
-                            float4 o = *(float4*)out;
-                            o.x += x[0]; o.y += x[1]; o.z += x[2]; o.w += x[3];
-                            *(float4*)out = o;
-                        } else {
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j];
-                        }
-                    }
+                    float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
+                    quad_transpose(v0, v1, v2, v3, lane);
+                    t[ni][0] = v0; t[ni][1] = v1; t[ni][2] = v2; t[ni][3] = v3;
                 }
-            } else if constexpr (EPI == EPI_QKV) {
-                // fragments (2p, 2p+1) hold RoPE partners d and d+64 for q/k heads; v heads are in natural order.
-                const int head = wcol0 >> 7;
-                if (wcol0 < p.rope_cols) {
-                    const int pos = p.pos[row];
-                    const int gbase = ((wcol0 & 127) >> 5);  // 0 or 2
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const int cst = wcol0 + 32 * pr + 4 * tq;       // stored col of the lo element
-                        const int d = 16 * (gbase + pr) + 4 * tq;      // natural d of the lo element (0..63)
-                        const float4 cs = *(const float4*)(p.rope_cos + (int64_t)pos * 64 + d);
-                        const float4 sn = *(const float4*)(p.rope_sin + (int64_t)pos * 64 + d);
-                        const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
-                        float lo[4], hi[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float x1 = t[2 * pr][j] + (p.bias ? p.bias[cst + j] : 0.f);
-                            const float x2 = t[2 * pr + 1][j] + (p.bias ? p.bias[cst + 16 + j] : 0.f);
-                            lo[j] = x1 * c4[j] - x2 * s4[j];
-                            hi[j] = x2 * c4[j] + x1 * s4[j];
-                        }
-                        bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + head * 128 + d;
-                        *(uint2*)out = make_uint2(pack2<DT>(lo[0], lo[1]), pack2<DT>(lo[2], lo[3]));
-                        *(uint2*)(out + 64) = make_uint2(pack2<DT>(hi[0], hi[1]), pack2<DT>(hi[2], hi[3]));
-                    }
-                } else {
+                char* lrow = smem + rl * RS;
+                if constexpr (EPI == EPI_BF16) {
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
-                        const int col = wcol0 + 16 * ni + 4 * tq;
-                        if (col >= p.N) continue;
+                        const int cl = 64 * wn + 16 * ni + 4 * tq;
+                        const int col = col0 + cl;
                         float x[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) x[j] = t[ni][j] + (p.bias ? p.bias[col + j] : 0.f);
-                        bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + col;
-                        *(uint2*)out = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
+                        for (int j = 0; j < 4; ++j) {
+                            x[j] = t[ni][j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f);
+                            if (p.act == 1) x[j] = gelu_erf(x[j]);
+                        }
+                        *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
+                    }
+                } else if constexpr (EPI == EPI_QKV) {
+                    // fragments (2p, 2p+1) hold RoPE partners d and d+64 for q/k heads; v heads are in natural order.
+                    if (wcol0 < p.rope_cols) {
+                        const int pos = p.pos[row];
+                        const int hl = wn >> 1;                    // head inside the tile
+                        const int gbase = (wn & 1) * 2;            // first 32-group of this wave inside the head
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const int cst = wcol0 + 32 * pr + 4 * tq;       // stored col of the lo element
+                            const int d = 16 * (gbase + pr) + 4 * tq;      // natural d of the lo element (0..63)
+                            const float4 cs = *(const float4*)(p.rope_cos + (int64_t)pos * 64 + d);
+                            const float4 sn = *(const float4*)(p.rope_sin + (int64_t)pos * 64 + d);
+                            const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+                            float lo[4], hi[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float x1 = t[2 * pr][j] + (p.bias ? p.bias[cst + j] : 0.f);
+                                const float x2 = t[2 * pr + 1][j] + (p.bias ? p.bias[cst + 16 + j] : 0.f);
+                                lo[j] = x1 * c4[j] - x2 * s4[j];
+                                hi[j] = x2 * c4[j] + x1 * s4[j];
+                            }
+                            char* o = lrow + (hl * 128 + d) * 2;
+                            *(uint2*)o = make_uint2(pack2<DT>(lo[0], lo[1]), pack2<DT>(lo[2], lo[3]));
+                            *(uint2*)(o + 128) = make_uint2(pack2<DT>(hi[0], hi[1]), pack2<DT>(hi[2], hi[3]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const int cl = 64 * wn + 16 * ni + 4 * tq;
+                            float x[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) x[j] = t[ni][j] + (p.bias ? p.bias[col0 + cl + j] : 0.f);
+                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
+                        }
+                    }
+                } else {  // EPI_SWIGLU: fragments (2p, 2p+1) = gate / up of the same 16 intermediate columns
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int cl = (2 * wn + pr) * 16 + 4 * tq;
+                        float x[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[j] = silu_f(t[2 * pr][j]) * t[2 * pr + 1][j];
+                        *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
                     }
                 }
-            } else if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int cst = wcol0 + 32 * pr;  // stored col of this 32-group
-                    if (cst >= p.N) continue;
-                    const int oc = (cst >> 5) * 16 + 4 * tq;  // output (intermediate) column
-                    float x[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) x[j] = silu_f(t[2 * pr][j]) * t[2 * pr + 1][j];
-                    bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + oc;
-                    *(uint2*)out = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
+            }
+            __syncthreads();
+            constexpr int LPR = NC * 2 / 16;                      // lanes (16 B each) per output row
+            const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
+            const int oc0 = (EPI == EPI_SWIGLU) ? col0 / 2 : col0;
+            const int seg = tid % LPR;
+            const int oc = oc0 + 8 * seg;
+#pragma unroll 4
+            for (int rl = tid / LPR; rl < 256; rl += NTHREADS / LPR) {
+                const int row = row0 + rl;
+                if (row >= p.M || oc >= n_out) continue;
+                const uint4 v = *(const uint4*)(smem + rl * RS + seg * 16);
+                bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + oc;
+                if (oc + 7 < n_out && (p.ldc & 7) == 0) *(uint4*)out = v;
+                else {
+                    const bf16_t* e = (const bf16_t*)&v;
+                    for (int j = 0; j < 8 && oc + j < n_out; ++j) out[j] = e[j];
                 }
             }
+        } else {  // EPI_RESID / EPI_F32: f32 tile, two passes of 128 rows
+            constexpr int RS = 1024 + 32;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if (wm == h) {
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        char* lrow = smem + (16 * mi + rsub) * RS;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
+                            quad_transpose(v0, v1, v2, v3, lane);
+                            *(float4*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 4) = make_float4(v0, v1, v2, v3);
+                        }
+                    }
+                }
+                __syncthreads();
+                const int col = col0 + 4 * lane;
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int rl = wave + 8 * i;
+                    const int row = row0 + 128 * h + rl;
+                    if (row >= p.M || col >= p.N) continue;
+                    float4 v = *(const float4*)(smem + rl * RS + lane * 16);
+                    float* out = (float*)p.C + (int64_t)row * p.ldc + col;
+                    const bool vec = (col + 3 < p.N) && ((p.ldc & 3) == 0);
+                    if constexpr (EPI == EPI_RESID) {
+                        if (vec) {
+                            float4 o = *(float4*)out;
+                            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                            *(float4*)out = o;
+                        } else {
+                            const float x[4] = {v.x, v.y, v.z, v.w};
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j];
+                        }
+                    } else {
+                        float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x[j] = (x[j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f)) * p.scale;
+                        if (vec) *(float4*)out = make_float4(x[0], x[1], x[2], x[3]);
+                        else for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = x[j];
+                    }
+                }
+                __syncthreads();
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);
     }
 }
 
 #include <stdlib.h>
-static int g_gemm_pipe = getenv("BLIM_GEMM_PIPE") ? atoi(getenv("BLIM_GEMM_PIPE")) : 2;
-void gemm_set_pipe(int pipe) { g_gemm_pipe = pipe; }
-
-template <int EPI, int PIPE>
-static void launch_p(const GemmParams& p, dim3 grid, hipStream_t stream) {
-    if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, PIPE, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel<EPI, PIPE, DT_BF16>), grid, dim3(NTHREADS), 0, stream, p);
-}
+static int g_gemm_stagger = getenv("BLIM_GEMM_STAGGER") ? atoi(getenv("BLIM_GEMM_STAGGER")) : 0;
+static int g_gemm_skip_epi = getenv("BLIM_GEMM_SKIP_EPI") ? atoi(getenv("BLIM_GEMM_SKIP_EPI")) : 0;
+static unsigned long long* g_gemm_stamps = nullptr;
+void gemm_set_debug_stamps(unsigned long long* buf) { g_gemm_stamps = buf; }
 
 template <int EPI>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     const dim3 grid(ntm * ntn);
-#ifdef BLIM_GEMM_ALL_PIPES
-    if (g_gemm_pipe == 0) launch_p<EPI, 0>(p, grid, stream);
-    else if (g_gemm_pipe == 1) launch_p<EPI, 1>(p, grid, stream);
-    else
-#endif
-    launch_p<EPI, 2>(p, grid, stream);
+    if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<EPI, DT_BF16>), grid, dim3(NTHREADS), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         blim_set_error("gemm launch failed: %s", hipGetErrorString(e));
@@ -433,7 +428,11 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     return BLIM_OK;
 }
 
-int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
+int launch_gemm(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.debug_skip_epilogue = g_gemm_skip_epi;
+    p.stagger = g_gemm_stagger;
+    p.debug_stamps = g_gemm_stamps;
     ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0);
     ARG_CHECK(p.K % BK == 0);
     ARG_CHECK(p.lda % 8 == 0);

@@ -35,13 +35,15 @@ struct GemmParams {
     const int32_t* labels;   // [M] target column per row (or < 0)
     float2* lse_part;        // [M, ceil(N/256)] (max, sumexp)
     float* label_logit;      // [M]
+    int stagger;             // first-round start delay per XCD index, in units of s_sleep(127) (~4 us); BLIM_GEMM_STAGGER
+    int debug_skip_epilogue; // timing aid only (set from BLIM_GEMM_SKIP_EPI)
+    unsigned long long* debug_stamps;  // timing aid: [n_workgroups][4] s_memtime at {entry, main loop start, main loop end, exit}
 };
+void gemm_set_debug_stamps(unsigned long long* buf);
 
 // 256x256x64 tiles, 512 threads.  K % 64 == 0, lda % 8 == 0.  Rows/cols beyond M/N are clamped on
 // load and masked on store, so neither A nor W needs padding.
 int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream);
-// main-loop variant: 0 lock-step, 1 ping-pong (default)
-void gemm_set_pipe(int pipe);
 
 // Row permutation used for q/k heads so that RoPE partners (d, d+64) land in the same lane:
 // stored row c' (0..127 within a head) holds natural row d = 16*(c'>>5) + (c'&15) + 64*((c'>>4)&1).

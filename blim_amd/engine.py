@@ -101,6 +101,7 @@ def load_library(path: str = LIB_PATH):
         "blim_timing_report": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)], C.c_int),
         "blim_set_option": ([vp, C.c_char_p, i32], C.c_int),
         "blim_debug_read": ([vp, C.c_char_p, vp, i64, vp], C.c_int),
+        "blim_debug_gemm_stamps": ([vp], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
