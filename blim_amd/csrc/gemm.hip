@@ -62,7 +62,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     auto stamp = [&](int k) __attribute__((always_inline)) {
-        if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)blockIdx.x * 4 + k] = __builtin_amdgcn_s_memrealtime();
+        if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
     // Stagger the XCDs (blocks b, b+8, ... share one) by a few microseconds in the first dispatch round so that their
@@ -281,17 +281,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 }
                 char* lrow = smem + rl * RS;
                 if constexpr (EPI == EPI_BF16) {
+                    if (p.bias == nullptr && p.act == 0) {         // wave-uniform fast path: convert and stage
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
-                        const int cl = 64 * wn + 16 * ni + 4 * tq;
-                        const int col = col0 + cl;
-                        float x[4];
+                        for (int ni = 0; ni < 4; ++ni)
+                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(pack2<DT>(t[ni][0], t[ni][1]), pack2<DT>(t[ni][2], t[ni][3]));
+                    } else {
+#pragma unroll 1
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const int cl = 64 * wn + 16 * ni + 4 * tq;
+                            const int col = col0 + cl;
+                            float x[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            x[j] = t[ni][j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f);
-                            if (p.act == 1) x[j] = gelu_erf(x[j]);
+                            for (int j = 0; j < 4; ++j) {
+                                x[j] = t[ni][j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f);
+                                if (p.act == 1) x[j] = gelu_erf(x[j]);
+                            }
+                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
                         }
-                        *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
                     }
                 } else if constexpr (EPI == EPI_QKV) {
                     // fragments (2p, 2p+1) hold RoPE partners d and d+64 for q/k heads; v heads are in natural order.
@@ -306,11 +312,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             const float4 cs = *(const float4*)(p.rope_cos + (int64_t)pos * 64 + d);
                             const float4 sn = *(const float4*)(p.rope_sin + (int64_t)pos * 64 + d);
                             const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+                            const float4 b0 = *(const float4*)(p.bias + cst), b1 = *(const float4*)(p.bias + cst + 16);
+                            const float bl[4] = {b0.x, b0.y, b0.z, b0.w}, bh[4] = {b1.x, b1.y, b1.z, b1.w};
                             float lo[4], hi[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float x1 = t[2 * pr][j] + (p.bias ? p.bias[cst + j] : 0.f);
-                                const float x2 = t[2 * pr + 1][j] + (p.bias ? p.bias[cst + 16 + j] : 0.f);
+                                const float x1 = t[2 * pr][j] + bl[j];
+                                const float x2 = t[2 * pr + 1][j] + bh[j];
                                 lo[j] = x1 * c4[j] - x2 * s4[j];
                                 hi[j] = x2 * c4[j] + x1 * s4[j];
                             }
@@ -322,10 +330,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
                             const int cl = 64 * wn + 16 * ni + 4 * tq;
-                            float x[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) x[j] = t[ni][j] + (p.bias ? p.bias[col0 + cl + j] : 0.f);
-                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
+                            const float4 bv = *(const float4*)(p.bias + col0 + cl);
+                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(t[ni][0] + bv.x, t[ni][1] + bv.y), pack2<DT>(t[ni][2] + bv.z, t[ni][3] + bv.w));
                         }
                     }
                 } else {  // EPI_SWIGLU: fragments (2p, 2p+1) = gate / up of the same 16 intermediate columns
@@ -340,6 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 }
             }
             __syncthreads();
+            stamp(4);
             constexpr int LPR = NC * 2 / 16;                      // lanes (16 B each) per output row
             const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
             const int oc0 = (EPI == EPI_SWIGLU) ? col0 / 2 : col0;
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     for (int j = 0; j < 8 && oc + j < n_out; ++j) out[j] = e[j];
                 }
             }
+            stamp(5);
         } else {  // EPI_RESID / EPI_F32: f32 tile, two passes of 128 rows
             constexpr int RS = 1024 + 32;
 #pragma unroll 1
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     } else {
                         float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) x[j] = (x[j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f)) * p.scale;
+                        for (int j = 0; j < 4; ++j) x[j] *= p.scale;
                         if (vec) *(float4*)out = make_float4(x[0], x[1], x[2], x[3]);
                         else for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = x[j];
                     }
@@ -441,10 +449,10 @@ int launch_gemm(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK((int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
         case EPI_BF16: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_BF16>(p, stream);
-        case EPI_F32: ARG_CHECK(p.C); return launch_t<EPI_F32>(p, stream);
+        case EPI_F32: ARG_CHECK(p.C && p.bias == nullptr); return launch_t<EPI_F32>(p, stream);
         case EPI_RESID: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_RESID>(p, stream);
         case EPI_QKV:
-            ARG_CHECK(p.C && p.pos && p.rope_cos && p.rope_sin && p.N % 128 == 0 && p.rope_cols % 128 == 0 && p.ldc % 4 == 0);
+            ARG_CHECK(p.C && p.bias && p.pos && p.rope_cos && p.rope_sin && p.N % 128 == 0 && p.rope_cols % 128 == 0 && p.ldc % 4 == 0);
             return launch_t<EPI_QKV>(p, stream);
         case EPI_SWIGLU: ARG_CHECK(p.C && p.N % 32 == 0 && p.ldc % 4 == 0); return launch_t<EPI_SWIGLU>(p, stream);
         case EPI_LSE: ARG_CHECK(p.labels && p.lse_part && p.label_logit); return launch_t<EPI_LSE>(p, stream);

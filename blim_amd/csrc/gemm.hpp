@@ -7,7 +7,7 @@
 
 enum GemmEpi : int {
     EPI_BF16 = 0,    // C bf16 [M,ldc] = act(acc + bias)
-    EPI_F32 = 1,     // C f32  [M,ldc] = (acc + bias) * scale
+    EPI_F32 = 1,     // C f32  [M,ldc] = acc * scale
     EPI_RESID = 2,   // C f32  [M,ldc] += acc                       (residual stream)
     EPI_QKV = 3,     // C bf16 [M,ldc] = rope(acc + bias) for cols < rope_cols, acc + bias otherwise;
                      //   W rows of every q/k head are stored pair-interleaved (see qkv_perm_row)
@@ -37,7 +37,7 @@ struct GemmParams {
     float* label_logit;      // [M]
     int stagger;             // first-round start delay per XCD index, in units of s_sleep(127) (~4 us); BLIM_GEMM_STAGGER
     int debug_skip_epilogue; // timing aid only (set from BLIM_GEMM_SKIP_EPI)
-    unsigned long long* debug_stamps;  // timing aid: [n_workgroups][4] s_memtime at {entry, main loop start, main loop end, exit}
+    unsigned long long* debug_stamps;  // timing aid: [n_workgroups][8] s_memrealtime at {entry, main loop start, main loop end, exit, C staged in LDS, stores issued}
 };
 void gemm_set_debug_stamps(unsigned long long* buf);
 

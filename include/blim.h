@@ -157,8 +157,8 @@ int blim_timing_report(blim_engine* e, double* ms, int64_t* calls, double* flops
  * "qkv" bf16 [T,(nh+2nkv)*128], "attn" bf16 [T,H], "act" bf16 [T,I]) as the last blim_decode left it. */
 int blim_debug_read(blim_engine* e, const char* which, void* dst, int64_t bytes, void* stream);
 
-/* Bring-up aid: when non-NULL, every GEMM workgroup writes 4 s_memtime stamps {entry, main loop start, main loop end, exit}
- * to device_buf[workgroup*4 ..] (u64); NULL turns it off. */
+/* Bring-up aid: when non-NULL, every GEMM workgroup writes s_memrealtime stamps {entry, main loop start, main loop end, exit,
+ * C staged in LDS, stores issued} to device_buf[workgroup*8 ..] (u64, 100 MHz); NULL turns it off. */
 int blim_debug_gemm_stamps(void* device_buf);
 
 /* tuning switches: "attn_tr_read" (0/1) */
