@@ -31,6 +31,22 @@ def f_pair(L, t_lab):
     return LAYERS * (FLOP_TOKEN_LAYER * L + 2 * H * L * L) + FLOP_HEAD_ROW * t_lab
 
 
+def measured_traffic(kernel_class, dtype):
+    """HBM-side bytes per launch of a kernel class from the newest committed PMC summary (profiles/*_traffic.json, made by
+    tools/collect_profiles.sh + tools/parse_profiles.py with separate --pmc FETCH_SIZE / WRITE_SIZE passes); None if absent."""
+    import glob
+    epi = {"gemm_qkv_rope": 3, "gemm_o_resid": 2, "gemm_down_resid": 2, "gemm_gateup_swiglu": 4, "lm_head_lse": 5}.get(kernel_class)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if epi is None or not files:
+        return None
+    name = f"void gemm_kernel<{epi}, {1 if dtype == 'f16' else 0}>(GemmParams)"
+    try:
+        d = json.load(open(files[-1]))
+        return d[name]["hbm_bytes_per_launch"] if name in d else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds_budget=30.0):
     """The numpy oracle (fp32) on a bounded sample of the same workload, timed on this host's cores:
     ONE decoder layer at 7B width on 16 pairs x 128 tokens (no prefix sharing, as the reference runs it) plus the
@@ -152,7 +168,7 @@ def main():
             "executed_tflops_per_gpu": round(exec_flops_step * a.steps / dt / 1e12, 1),
             "frac_mfma_peak_whole_step": round(exec_flops_step * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(dom, model.engine.dtype),
                          "avg_launch_ms": round(d["ms"] / d["calls"], 4), "flop_per_launch": d["flops"] / d["calls"]},
             "kernel_classes_ms": {k: round(v["ms"], 3) for k, v in rep.items() if v["calls"]},
         }

@@ -297,3 +297,62 @@ def test_full_size_properties_7b(dtype):
     lit = RU.vtg_criterion(out.logits, r[5]).cpu().numpy()[0]
     np.testing.assert_allclose(full[j * 6 + i], lit, rtol=SCORE_RTOL)
     model.engine.close()
+
+
+class _SynthDataset:
+    """Minimal stand-in for dataloader/base_dataset.py's eval side: what evaluation() reads from it."""
+
+    def __init__(self, prob):
+        self.prob = prob
+        self.video_vocab = torch.from_numpy(prob.video_vocab)
+        self.tvg_prefix_length = prob.tvg_prefix_length
+
+    def __len__(self):
+        return len(self.prob.video)
+
+
+class _SynthLoader:
+    """Yields the eval collate format of base_dataset.py:119-163 (lists of 1-D tensors per batch)."""
+
+    def __init__(self, prob, bs):
+        self.dataset = _SynthDataset(prob)
+        self.prob, self.bs = prob, bs
+
+    def __len__(self):
+        return (len(self.prob.video) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        p, T = self.prob, torch.from_numpy
+        for s in range(0, len(p.video), self.bs):
+            e = min(len(p.video), s + self.bs)
+            yield {"video": [T(v) for v in p.video[s:e]],
+                   "vtg_ids": [T(x) for x in p.vtg_ids[s:e]], "vtg_labels": [T(x) for x in p.vtg_labels[s:e]], "vtg_masks": [T(x) for x in p.vtg_masks[s:e]],
+                   "tvg_ids": [T(x) for x in p.tvg_ids[s:e]], "tvg_labels": [T(x) for x in p.tvg_labels[s:e]], "tvg_masks": [T(x) for x in p.tvg_masks[s:e]],
+                   "tvg_video_labels": T(p.tvg_video_labels[s:e])}
+
+
+@pytest.mark.parametrize("literal", [False, True], ids=["fused", "literal"])
+def test_evaluation_and_val_one_epoch_end_to_end(tiny, literal):
+    """evaluation() / val_one_epoch() with the reference's argument names on a loader in the reference's collate format:
+    all six matrices equal the reference's golden ones, recall dicts identical (fine-tuned mode with CPN)."""
+    g = np.load(os.path.join(GOLD, "tiny.npz"))
+    t = tiny
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    args = types.SimpleNamespace(topk=t.spec["topk"], batch_size_eval=t.spec["bs"], num_clips=t.dims.num_clips, cpn=True, resume="ckpt", eval=True,
+                                 dataset="SYNTH", alpha=[0.4, 0.8], c=[0.3, 0.6, 0.9, 0.7], literal=literal,
+                                 iv2_scores={"v2t": torch.from_numpy(t.prob.v2t_sims), "t2v": torch.from_numpy(t.prob.t2v_sims)})
+    loader = _SynthLoader(t.prob, bs=4)
+    ddp = DDPLike(t.model)
+    t2v, v2t = RU.evaluation(ddp, loader, t.model.device, tok, args)
+    assert set(t2v) == {"candidate_likelihood", "query_likelihood", "internvideo2", "candidate_prior"} and set(v2t) == set(t2v)
+    got = {"v2t_vtg": v2t["candidate_likelihood"], "v2t_vtg_cpn": v2t["candidate_prior"], "v2t_tvg": v2t["query_likelihood"],
+           "t2v_vtg": t2v["query_likelihood"], "t2v_tvg": t2v["candidate_likelihood"], "t2v_tvg_cpn": t2v["candidate_prior"]}
+    _check_passes(got, g, t)
+    res = TU.val_one_epoch(ddp, loader, None, t.model.device, 0, None, tokenizer=tok, args=args)
+    ref_t2v = {"candidate_likelihood": g["S_t2v_tvg"], "candidate_prior": g["S_t2v_tvg_cpn"], "query_likelihood": g["S_t2v_vtg"], "internvideo2": t.prob.t2v_sims}
+    ref_v2t = {"candidate_likelihood": g["S_v2t_vtg"], "candidate_prior": g["S_v2t_vtg_cpn"], "query_likelihood": g["S_v2t_tvg"], "internvideo2": t.prob.v2t_sims}
+    assert res == TU.combine_and_rank(ref_t2v, ref_v2t, args, t.spec["n"])
+    # zero-shot mode (no --resume): only v2t VTG, its prior and t2v VTG are computed (retrieval_utils.py:227, 242)
+    args.resume = ""
+    t2v0, v2t0 = RU.evaluation(ddp, loader, t.model.device, tok, args)
+    assert set(t2v0) == {"query_likelihood", "internvideo2"} and set(v2t0) == {"candidate_likelihood", "candidate_prior", "internvideo2"}
