@@ -42,6 +42,16 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
     if (hi) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
 }
 
+// all-reduce over the 16 lanes of a DPP row (lanes sharing lane>>4) by rotations 8,4,2,1: no LDS crossbar traffic
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); return fmaxf(v, row_ror<1>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); return v + row_ror<1>(v);
+}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
@@ -232,15 +242,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     if (col == lab) p.label_logit[row] = v[ni];
                     mx = fmaxf(mx, v[ni]);
                 }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                mx = row16_max(mx);
                 float sm = 0.f;
                 if (mx > -INFINITY) {
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) sm += __expf(v[ni] - mx);
                 }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                sm = row16_sum(sm);
                 if (fr == 0) red[wn * 256 + rl] = make_float2(mx, sm);
             }
         }
@@ -383,27 +391,43 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 }
                 __syncthreads();
                 const int col = col0 + 4 * lane;
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i) {
-                    const int rl = wave + 8 * i;
-                    const int row = row0 + 128 * h + rl;
-                    if (row >= p.M || col >= p.N) continue;
-                    float4 v = *(const float4*)(smem + rl * RS + lane * 16);
-                    float* out = (float*)p.C + (int64_t)row * p.ldc + col;
-                    const bool vec = (col + 3 < p.N) && ((p.ldc & 3) == 0);
-                    if constexpr (EPI == EPI_RESID) {
-                        if (vec) {
-                            float4 o = *(float4*)out;
-                            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-                            *(float4*)out = o;
-                        } else {
-                            const float x[4] = {v.x, v.y, v.z, v.w};
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j];
+                const bool vec = (col + 3 < p.N) && ((p.ldc & 3) == 0);
+                if constexpr (EPI == EPI_RESID) {
+                    if (vec) {   // common case: 16 independent 1-KiB row loads in flight, then add + store
+                        float4 o[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int row = min(row0 + 128 * h + wave + 8 * i, p.M - 1);
+                            o[i] = *(const float4*)((const float*)p.C + (int64_t)row * p.ldc + col);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int rl = wave + 8 * i;
+                            const int row = row0 + 128 * h + rl;
+                            const float4 v = *(const float4*)(smem + rl * RS + lane * 16);
+                            if (row < p.M) *(float4*)((float*)p.C + (int64_t)row * p.ldc + col) = make_float4(o[i].x + v.x, o[i].y + v.y, o[i].z + v.z, o[i].w + v.w);
                         }
                     } else {
-                        float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) x[j] *= p.scale;
+#pragma unroll 1
+                        for (int i = 0; i < 16; ++i) {
+                            const int rl = wave + 8 * i;
+                            const int row = row0 + 128 * h + rl;
+                            if (row >= p.M || col >= p.N) continue;
+                            const float4 v = *(const float4*)(smem + rl * RS + lane * 16);
+                            const float x[4] = {v.x, v.y, v.z, v.w};
+                            float* out = (float*)p.C + (int64_t)row * p.ldc + col;
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j];
+                        }
+                    }
+                } else {
+#pragma unroll 4
+                    for (int i = 0; i < 16; ++i) {
+                        const int rl = wave + 8 * i;
+                        const int row = row0 + 128 * h + rl;
+                        if (row >= p.M || col >= p.N) continue;
+                        const float4 v = *(const float4*)(smem + rl * RS + lane * 16);
+                        float x[4] = {v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale};
+                        float* out = (float*)p.C + (int64_t)row * p.ldc + col;
                         if (vec) *(float4*)out = make_float4(x[0], x[1], x[2], x[3]);
                         else for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = x[j];
                     }
