@@ -71,10 +71,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    int stamp_vb = blockIdx.x;
     auto stamp = [&](int k) __attribute__((always_inline)) {
-        if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+        if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)stamp_vb * 8 + k] = __builtin_amdgcn_s_memrealtime();
     };
-    stamp(0);
     // Stagger the XCDs (blocks b, b+8, ... share one) by a few microseconds in the first dispatch round so that their
     // epilogue write bursts (and LDS-DMA bursts) do not coincide chip-wide: 256 CUs x 128-512 KB written in the same
     // microsecond is HBM-write-bound (measured epilogue 10-14 us per tile); within an XCD the blocks stay in lock step,
@@ -84,12 +84,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
-    // ---- tile mapping: XCD-contiguous chunks (blocks b, b+8, ... share an XCD), then grouped M order
+    // ---- persistent workgroups: grid = one workgroup per CU (a multiple of 8), each walks virtual block ids
+    // vb = blockIdx.x, + gridDim.x, ...  (vb % 8 == blockIdx.x % 8: a workgroup keeps its XCD's chunk of the tile order).
+    // No relaunch gap between tiles, and the next tile's first LDS-DMA overlaps the previous tile's store drain.
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     const int nwg = ntm * ntn;
+#pragma unroll 1
+    for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    // ---- tile mapping: XCD-contiguous chunks (blocks b, b+8, ... share an XCD), then grouped M order
+    stamp_vb = vb;
+    stamp(0);
     int pid;
     {
-        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int bid = vb, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int width = GROUP_M * ntn;
@@ -217,7 +224,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
+        __syncthreads();
+        continue;
     }
     const int wrow0 = row0 + 128 * wm;  // wave's first row
     const int wcol0 = col0 + 64 * wn;   // wave's first column (in W's row order)
@@ -266,7 +274,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }
         }
         stamp(3);
-        return;
+        __syncthreads();   // `red` (LDS) is reused by the next tile's ring
+        continue;
     } else {
         // ---- C tile staged through LDS so that global stores are whole rows (512 B / 1 KiB per row), 16 B per lane.
         // (Direct stores from the MFMA layout touch 32-B row segments: measured 10-13 us per tile, 12 % of a K=3584 tile.)
@@ -435,12 +444,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 __syncthreads();
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.debug_stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(3);
+        __syncthreads();   // the staged C tile (LDS) is reused by the next tile's ring
     }
+    }  // persistent tile loop
 }
 
 #include <stdlib.h>
+static int g_gemm_persistent = getenv("BLIM_GEMM_PERSISTENT") ? atoi(getenv("BLIM_GEMM_PERSISTENT")) : 1;
 static int g_gemm_stagger = getenv("BLIM_GEMM_STAGGER") ? atoi(getenv("BLIM_GEMM_STAGGER")) : 0;
 static int g_gemm_skip_epi = getenv("BLIM_GEMM_SKIP_EPI") ? atoi(getenv("BLIM_GEMM_SKIP_EPI")) : 0;
 static unsigned long long* g_gemm_stamps = nullptr;
@@ -449,7 +461,15 @@ void gemm_set_debug_stamps(unsigned long long* buf) { g_gemm_stamps = buf; }
 template <int EPI>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    const dim3 grid(ntm * ntn);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        n_cu = (n_cu / 8) * 8;   // virtual block ids must keep blockIdx % 8
+        if (n_cu < 8) n_cu = 8;
+    }
+    const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
+    const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
     if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((gemm_kernel<EPI, DT_BF16>), grid, dim3(NTHREADS), 0, stream, p);
     hipError_t e = hipGetLastError();
