@@ -1,0 +1,205 @@
+"""Checkpoint loading for the scoring engine.
+
+What the reference does at start-up (main.py:96-111, 125-128; util/misc.py:276-311):
+  1. `VideoChatFlashQwenForCausalLM.from_pretrained(model_path).half()` -- HF safetensors, keys `model.embed_tokens.weight`,
+     `model.layers.N.self_attn.q_proj.{weight,bias}`, ..., `model.mm_projector.mlp.{0,2}.{weight,bias}`, `lm_head.weight`;
+  2. LoRA (r = --lora_r 8, alpha = --lora_alpha 32) on the projector `mlp` Linear "0" and "2"; `tvg_mlp = deepcopy(mlp)`;
+     LoRA on every q/k/v/o_proj and lm_head; `visual_head` trainable in fp32;
+  3. `--resume`: a torch file whose `['model']` holds ONLY the trainable tensors (LoRA A/B, visual_head), loaded strict=False.
+The engine has no adapter path: deltas are merged at load time, W' = W + (alpha / r) * B @ A, and the merged matrix goes
+through `blim_load_weight` (which rounds to the engine's 16-bit format and lays it out for the kernels).
+
+Key naming of the resume file follows peft's convention (`base_model.model.<path>.lora_{A,B}.default.weight`, wrapped
+Linear at `<path>.base_layer`); the inner projector adapters sit under `mm_projector.{mlp,tvg_mlp}.base_model.model.{0,2}`.
+peft is not installed in the build image, so this naming is implemented from peft's documented layout and exercised with
+synthetic adapters (tests/test_checkpoint.py), not against a file written by the reference.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import re
+from typing import Callable, Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+from .synth import ModelDims, weight_shapes
+
+
+# ----------------------------------------------------------------------------- key mapping
+
+def canonical_to_hf(name: str) -> str:
+    """Canonical tensor name (blim_amd/synth.py:weight_shapes) -> key in the HF checkpoint / reference state_dict."""
+    if name == "embed_tokens":
+        return "model.embed_tokens.weight"
+    if name == "final_norm":
+        return "model.norm.weight"
+    if name == "lm_head":
+        return "lm_head.weight"
+    if name == "visual_head":
+        return "visual_head.weight"
+    m = re.fullmatch(r"(mlp|tvg_mlp)\.(\d)\.(w|b)", name)
+    if m:
+        return f"model.mm_projector.{m.group(1)}.{m.group(2)}.{'weight' if m.group(3) == 'w' else 'bias'}"
+    m = re.fullmatch(r"layers\.(\d+)\.(input_norm|post_norm)", name)
+    if m:
+        return f"model.layers.{m.group(1)}.{'input_layernorm' if m.group(2) == 'input_norm' else 'post_attention_layernorm'}.weight"
+    m = re.fullmatch(r"layers\.(\d+)\.(q_proj|k_proj|v_proj|o_proj|gate_proj|up_proj|down_proj)\.(w|b)", name)
+    if m:
+        grp = "self_attn" if m.group(2) in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp"
+        return f"model.layers.{m.group(1)}.{grp}.{m.group(2)}.{'weight' if m.group(3) == 'w' else 'bias'}"
+    raise KeyError(name)
+
+
+def hf_to_canonical(key: str) -> Optional[str]:
+    """Inverse of canonical_to_hf; None for tensors the scoring path does not use (vision tower, rotary buffers ...)."""
+    key = key.replace(".base_layer.", ".")
+    table = {"model.embed_tokens.weight": "embed_tokens", "model.norm.weight": "final_norm", "lm_head.weight": "lm_head",
+             "visual_head.weight": "visual_head"}
+    if key in table:
+        return table[key]
+    m = re.fullmatch(r"model\.mm_projector\.(mlp|tvg_mlp)\.(?:base_model\.model\.)?(\d)\.(weight|bias)", key)
+    if m:
+        return f"{m.group(1)}.{m.group(2)}.{'w' if m.group(3) == 'weight' else 'b'}"
+    m = re.fullmatch(r"model\.layers\.(\d+)\.(input_layernorm|post_attention_layernorm)\.weight", key)
+    if m:
+        return f"layers.{m.group(1)}.{'input_norm' if m.group(2) == 'input_layernorm' else 'post_norm'}"
+    m = re.fullmatch(r"model\.layers\.(\d+)\.(?:self_attn|mlp)\.(q_proj|k_proj|v_proj|o_proj|gate_proj|up_proj|down_proj)\.(weight|bias)", key)
+    if m:
+        return f"layers.{m.group(1)}.{m.group(2)}.{'w' if m.group(3) == 'weight' else 'b'}"
+    return None
+
+
+_PEFT_PREFIX = "base_model.model."
+
+
+def parse_resume_key(key: str) -> Optional[Tuple[str, str]]:
+    """Key of the reference's resume file -> (canonical weight name, kind) with kind in {'A', 'B', 'full'}."""
+    k = key
+    while k.startswith(_PEFT_PREFIX):
+        k = k[len(_PEFT_PREFIX):]
+    m = re.fullmatch(r"(.*)\.lora_(A|B)\.[^.]+\.weight", k)
+    if m:
+        base = m.group(1).replace(".base_model.model.", ".")       # inner projector adapter
+        name = hf_to_canonical(base + ".weight")
+        return (name, m.group(2)) if name else None
+    name = hf_to_canonical(k.replace(".base_model.model.", "."))
+    return (name, "full") if name else None
+
+
+# ----------------------------------------------------------------------------- tensor sources
+
+def _to_f32(t) -> np.ndarray:
+    import torch
+    if isinstance(t, np.ndarray):
+        return np.ascontiguousarray(t, dtype=np.float32)
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+def open_base_checkpoint(path: str) -> Tuple[Iterable[str], Callable[[str], np.ndarray]]:
+    """(keys, get(key) -> float32 ndarray) over a HF checkpoint directory (single or sharded *.safetensors, optionally with
+    model.safetensors.index.json) or a torch state-dict file."""
+    if os.path.isdir(path):
+        from safetensors import safe_open
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+        where: Dict[str, str] = {}
+        idx = os.path.join(path, "model.safetensors.index.json")
+        if os.path.exists(idx):
+            where = {k: os.path.join(path, v) for k, v in json.load(open(idx))["weight_map"].items()}
+        else:
+            for f in files:
+                with safe_open(f, framework="pt") as h:
+                    for k in h.keys():
+                        where[k] = f
+
+        def get(key: str) -> np.ndarray:
+            with safe_open(where[key], framework="pt") as h:
+                return _to_f32(h.get_tensor(key))
+        return list(where.keys()), get
+    import torch
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    sd = sd.get("model", sd) if isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict) else sd
+    return list(sd.keys()), lambda k: _to_f32(sd[k])
+
+
+def lora_delta(A: np.ndarray, B: np.ndarray, r: int, alpha: float) -> np.ndarray:
+    """(alpha / r) * B @ A with A [r, in], B [out, r] (peft LoRA Linear.get_delta_weight)."""
+    assert A.shape[0] == r and B.shape[1] == r, (A.shape, B.shape, r)
+    return (np.float32(alpha / r) * (B.astype(np.float32) @ A.astype(np.float32))).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- loader
+
+def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Optional[str] = None, lora_r: int = 8, lora_alpha: float = 32.0,
+                    allow_missing_visual_head: bool = True, verbose: bool = False) -> Dict[str, str]:
+    """Streams the base checkpoint (+ merged LoRA / visual_head of `resume_path`) into `engine`, one tensor at a time.
+    Returns {canonical name: provenance} for every tensor loaded."""
+    import torch
+    shapes = weight_shapes(dims)
+    keys, get = open_base_checkpoint(base_path)
+    have = {}
+    for k in keys:
+        n = hf_to_canonical(k)
+        if n is not None and n in shapes:
+            have[n] = k
+    adapters: Dict[str, Dict[str, np.ndarray]] = {}
+    full: Dict[str, np.ndarray] = {}
+    if resume_path:
+        ck = torch.load(resume_path, map_location="cpu", weights_only=False)
+        sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+        for k, v in sd.items():
+            parsed = parse_resume_key(k)
+            if parsed is None:
+                continue
+            name, kind = parsed
+            if kind == "full":
+                full[name] = _to_f32(v)
+            else:
+                adapters.setdefault(name, {})[kind] = _to_f32(v)
+    report: Dict[str, str] = {}
+    for name, shape in shapes.items():
+        src = name
+        prov = "base"
+        if name not in have and name.startswith("tvg_mlp."):
+            src = "mlp." + name[len("tvg_mlp."):]                     # tvg_mlp = deepcopy(mlp), main.py:102
+            prov = "base (copy of mlp)"
+        if name in full:
+            w = full[name]; prov = "resume"
+        elif src in have:
+            w = get(have[src])
+        elif name == "visual_head" and allow_missing_visual_head:
+            # the reference initialises visual_head randomly and only uses it after fine-tuning; zero-shot eval never reads it
+            w = np.zeros(shape, dtype=np.float32); prov = "absent (zeros; TVG passes need a fine-tuned checkpoint)"
+        else:
+            raise KeyError(f"tensor '{name}' ({canonical_to_hf(name)}) not found in {base_path}")
+        assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
+        ad = adapters.get(name)
+        if ad is not None:
+            if "A" not in ad or "B" not in ad:
+                raise KeyError(f"incomplete LoRA adapter for {name}")
+            w = w + lora_delta(ad["A"], ad["B"], lora_r, lora_alpha)
+            prov += " + LoRA"
+        engine.load_weight(name, w)
+        report[name] = prov
+        if verbose:
+            print(f"{name:32s} {str(tuple(shape)):20s} {prov}")
+    return report
+
+
+def save_hf_checkpoint(weights: Dict[str, np.ndarray], out_dir: str, shards: int = 2, dtype: str = "bf16") -> None:
+    """Writes canonical-name weights as a sharded HF-style safetensors checkpoint (tests / synthetic checkpoints)."""
+    import torch
+    from safetensors.torch import save_file
+    os.makedirs(out_dir, exist_ok=True)
+    td = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
+    names = [n for n in weights if not n.startswith("tvg_mlp.")]     # the base checkpoint has no tvg_mlp
+    weight_map = {}
+    for s in range(shards):
+        part = {canonical_to_hf(n): torch.from_numpy(np.ascontiguousarray(weights[n])).to(td).contiguous() for n in names[s::shards]}
+        fn = f"model-{s + 1:05d}-of-{shards:05d}.safetensors"
+        save_file(part, os.path.join(out_dir, fn))
+        weight_map.update({k: fn for k in part})
+    json.dump({"metadata": {}, "weight_map": weight_map}, open(os.path.join(out_dir, "model.safetensors.index.json"), "w"))

@@ -196,14 +196,21 @@ class Engine:
             pass
 
     # ---- weights
+    def load_weight(self, name: str, arr: np.ndarray):
+        """One tensor: canonical name, float32 numpy array in the checkpoint's natural [out, in] layout."""
+        shape = weight_shapes(self.dims)[name]
+        assert tuple(arr.shape) == tuple(shape), (name, arr.shape, shape)
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        _check(self.lib.blim_load_weight(self.h, name.encode(), a.ctypes.data, DTYPE_F32, 0), f"blim_load_weight({name})")
+
     def load_weights(self, weights: Dict[str, np.ndarray]):
-        """weights: canonical name -> float32 numpy array (natural [out, in] layout)."""
-        shapes = weight_shapes(self.dims)
+        """weights: canonical name -> float32 numpy array; every tensor of the model must be present."""
         for name, arr in weights.items():
-            assert tuple(arr.shape) == tuple(shapes[name]), (name, arr.shape, shapes[name])
-            a = np.ascontiguousarray(arr, dtype=np.float32)
-            _check(self.lib.blim_load_weight(self.h, name.encode(), a.ctypes.data, DTYPE_F32, 0), f"blim_load_weight({name})")
+            self.load_weight(name, arr)
         _check(self.lib.blim_weights_ready(self.h), "blim_weights_ready")
+
+    def weights_ready(self) -> bool:
+        return self.lib.blim_weights_ready(self.h) == 0
 
     def init_synthetic_weights(self, seed: int):
         _check(self.lib.blim_init_synthetic_weights(self.h, seed), "blim_init_synthetic_weights")
