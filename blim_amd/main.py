@@ -1,0 +1,108 @@
+"""Thin evaluation driver with the reference's flags (main.py:31-75, eval branch :146-174).
+
+    python -m blim_amd.main --eval --dataset MSRVTT --model_path ./pretrained/VideoChat-Flash-Qwen2-7B_res448 \\
+        --resume ./checkpoint/msrvtt.pth --topk 16 --batch_size_eval 16 --cpn --alpha 0.4 0.8 --c 0.3 0.6 0.9 0.7
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 -m blim_amd.main ...        (one process per GPU, RCCL)
+
+Reads ./data/<DS>/..., ./scores/<ds>[_zeroshot].pth exactly as the reference does.  `--synthetic N` replaces checkpoint,
+tokenizer, dataset and first-stage scores by seeded synthetic ones (no downloads): an end-to-end dry run of the same code path.
+Training (`main.py` without --eval) is out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser("BLiM evaluation on the MI355X engine", add_help=True)
+    p.add_argument("--batch_size_eval", default=16, type=int)
+    p.add_argument("--num_workers", default=2, type=int)
+    p.add_argument("--pin_mem", action="store_true")
+    p.add_argument("--model_path", default="./pretrained/VideoChat-Flash-Qwen2-7B_res448", type=str)
+    p.add_argument("--dataset", default="MSRVTT", type=str, choices=["MSRVTT", "DiDeMo", "ActivityNet", "LSMDC"])
+    p.add_argument("--output_dir", default="./output", type=str)
+    p.add_argument("--resume", default="", type=str, help="fine-tuned LoRA / visual_head checkpoint (empty = zero-shot)")
+    p.add_argument("--eval", action="store_true")
+    p.add_argument("--topk", default=16, type=int)
+    p.add_argument("--num_clips", default=4, type=int)
+    p.add_argument("--cpn", action="store_true")
+    p.add_argument("--alpha", default=[0.0, 0.0], type=float, nargs=2, help="CPN weights (t2v, v2t)")
+    p.add_argument("--c", default=[0.5, 0.5, 0.5, 0.5], type=float, nargs=4, help="ensemble weights")
+    p.add_argument("--lora_r", default=8, type=int)
+    p.add_argument("--lora_alpha", default=32, type=int)
+    # engine-side options
+    p.add_argument("--dtype", default=None, choices=["f16", "bf16"])
+    p.add_argument("--max_tokens", default=32768, type=int, help="packed tokens per engine call")
+    p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
+    p.add_argument("--compat_allreduce_offset", action="store_true")
+    p.add_argument("--synthetic", default=0, type=int, help="N > 0: dry run on N synthetic videos/texts (tiny model unless --synthetic_7b)")
+    p.add_argument("--synthetic_7b", action="store_true")
+    return p
+
+
+def dims_from_config(model_path: str):
+    from .synth import ModelDims
+    c = json.load(open(os.path.join(model_path, "config.json")))
+    if c.get("mm_llm_compress", False):
+        raise NotImplementedError("checkpoint enables PyramidDrop token compression (mm_llm_compress): outside the scoring path")
+    return ModelDims(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
+                     num_layers=c["num_hidden_layers"], num_heads=c["num_attention_heads"], num_kv_heads=c["num_key_value_heads"],
+                     rms_eps=c.get("rms_norm_eps", 1e-6), rope_theta=c.get("rope_theta", 1e6), mm_hidden_size=c.get("mm_hidden_size", 1024),
+                     num_clips=4)
+
+
+def main(args):
+    import numpy as np
+    import torch
+    from . import distributed as D
+    from . import synth
+    from .modeling import BlimModel, DDPLike
+    from .training_utils import val_one_epoch
+
+    rank, world, local = D.init_distributed_mode()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if not args.eval:
+        raise NotImplementedError("only --eval is supported: the training loop is outside the scoring path")
+    t0 = time.time()
+    if args.synthetic > 0:
+        dims = synth.ModelDims() if args.synthetic_7b else synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2,
+                                                                         num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+        model = BlimModel(dims, dtype=args.dtype)
+        model.engine.init_synthetic_weights(0)
+        prob = synth.make_problem(1, args.synthetic, dims, tok_per_clip=64 if args.synthetic_7b else 8)
+        T = torch.from_numpy
+        loader = synth.ProblemLoader(prob, args.batch_size_eval)
+        tokenizer = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+        args.iv2_scores = {"v2t": T(prob.v2t_sims), "t2v": T(prob.t2v_sims)}
+    else:
+        from transformers import AutoTokenizer
+        from .checkpoint import load_checkpoint
+        from .dataloader import load_data
+        tokenizer = AutoTokenizer.from_pretrained(args.model_path, trust_remote_code=True)
+        dims = dims_from_config(args.model_path)
+        model = BlimModel(dims, dtype=args.dtype)
+        load_checkpoint(model.engine, dims, args.model_path, args.resume or None, lora_r=args.lora_r, lora_alpha=args.lora_alpha)
+        loader = load_data(args, tokenizer=tokenizer, split="test")
+    if rank == 0:
+        print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")
+    results = val_one_epoch(DDPLike(model), loader, None, device, 0, None, tokenizer=tokenizer, args=args)
+    if rank == 0:
+        import pandas as pd
+        os.makedirs(args.output_dir, exist_ok=True)
+        table = pd.DataFrame(results).T                                                    # main.py:170-173
+        print(table.to_string())
+        with open(os.path.join(args.output_dir, "log.txt"), "a") as f:
+            f.write(table.to_string() + "\n")
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(get_args_parser().parse_args())

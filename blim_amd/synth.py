@@ -193,3 +193,35 @@ def make_problem(seed: int, n: int, dims: ModelDims, tok_per_clip: int = 64, tex
                    tvg_ids=tvg_ids, tvg_labels=tvg_labels, tvg_masks=ones(tvg_ids),
                    tvg_video_labels=np.arange(n, dtype=np.int64), tvg_prefix_length=len(sys_hdr) + len(usr_hdr) + len(tvg_instr),
                    v2t_sims=sims.astype(np.float32), t2v_sims=sims_t.astype(np.float32))
+
+
+class ProblemLoader:
+    """Iterates a synthetic Problem in the reference's eval collate format (dataloader/base_dataset.py:119-163: lists of 1-D
+    tensors per batch) and carries the two dataset attributes evaluation() reads (video_vocab, tvg_prefix_length)."""
+
+    class _Dataset:
+        def __init__(self, prob):
+            import torch
+            self.video_vocab = torch.from_numpy(prob.video_vocab)
+            self.tvg_prefix_length = prob.tvg_prefix_length
+            self._n = len(prob.video)
+
+        def __len__(self):
+            return self._n
+
+    def __init__(self, prob: Problem, batch_size: int):
+        self.prob, self.bs = prob, int(batch_size)
+        self.dataset = ProblemLoader._Dataset(prob)
+
+    def __len__(self):
+        return (len(self.prob.video) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        import torch
+        p, T = self.prob, torch.from_numpy
+        for s in range(0, len(p.video), self.bs):
+            e = min(len(p.video), s + self.bs)
+            out = {"video": [T(v) for v in p.video[s:e]], "tvg_video_labels": T(p.tvg_video_labels[s:e])}
+            for k in ("vtg_ids", "vtg_labels", "vtg_masks", "tvg_ids", "tvg_labels", "tvg_masks"):
+                out[k] = [T(x) for x in getattr(p, k)[s:e]]
+            yield out
