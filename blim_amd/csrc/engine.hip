@@ -481,7 +481,7 @@ extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embe
     ARG_CHECK(n > 0);
     SpanGuard g(e, s, TC_NORM, 0);
     return launch_rmsnorm((const float*)e->resid.p, e->c.hidden_size, out_rows, n, e->c.hidden_size, e->final_norm, e->c.rms_eps,
-                          (bf16_t*)out_hidden_bf16, e->c.compute_dtype, out_hidden_f32, s);
+                          (bf16_t*)out_hidden_bf16, e->c.compute_dtype, out_hidden_f32, s, b->n_tokens);
 }
 
 extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {

@@ -124,13 +124,21 @@ int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s) {
 // One wave per row; the row (H f32) is read once in float4 pieces and kept in registers when H <= 64*4*16.
 template <int MAXV, int DT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H,
-                                                      const float* w, float eps, bf16_t* out_bf16, float* out_f32) {
+                                                      const float* w, float eps, bf16_t* out_bf16, float* out_f32, int64_t n_src) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
     const int64_t src = rows ? rows[r] : r;
-    const float* xr = x + src * ldx;
     const int nv = H / 4;  // float4 per row
+    if (src < 0 || src >= n_src) {   // a gather index outside the packed batch: poison the row (NaN score) instead of reading wild memory
+        const float qnan = __builtin_nanf("");
+        for (int c = lane; c < nv; c += 64) {
+            if (out_bf16) *(uint2*)(out_bf16 + r * H + 4 * c) = make_uint2(pack2<DT>(qnan, qnan), pack2<DT>(qnan, qnan));
+            if (out_f32) *(float4*)(out_f32 + r * H + 4 * c) = make_float4(qnan, qnan, qnan, qnan);
+        }
+        return;
+    }
+    const float* xr = x + src * ldx;
     float4 v[MAXV];
     float ss = 0.f;
 #pragma unroll
@@ -155,14 +163,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
     }
 }
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
-                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s) {
+                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src) {
+    if (!rows) n_src = n_rows;
     ARG_CHECK(x && w && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0 && (out_h16 || out_f32));
     const int nv = H / 4;
     const dim3 grid((unsigned)((n_rows + 3) / 4));
 #define RMS_LAUNCH(MV)                                                                                                              \
     do {                                                                                                                            \
-        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32); \
-        else hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32);                \
+        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src); \
+        else hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src);                \
     } while (0)
     if (nv <= 64 * 4) RMS_LAUNCH(4);
     else if (nv <= 64 * 16) RMS_LAUNCH(16);

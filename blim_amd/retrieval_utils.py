@@ -255,6 +255,10 @@ class PairScorer:
                 plans.append(st.finish()); st = _PackState(self, "vtg")
             # prefix sequence
             if j is None:
+                if len(pre) + len(post) == 0:
+                    # the reference's rows always open with the ChatML header; with no visible token in front of the response the
+                    # prior's first factor would be read from a fully masked video position (undefined attention row)
+                    raise ValueError("VTG candidate prior (cpn=True) needs at least one prompt token besides the <image> placeholder")
                 ptoks = np.concatenate([pre, post]); ppos = np.concatenate([np.arange(len(pre)), len(pre) + n_vid + np.arange(len(post))])
                 p0 = st.add_seq(ptoks, ppos, np.ones(len(ptoks), np.uint8), None)
             else:

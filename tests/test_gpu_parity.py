@@ -188,6 +188,21 @@ def test_forward_surface_and_hidden_states(tiny):
         t.model(inputs_embeds=emb, labels=torch.zeros((3, 4), dtype=torch.long))
 
 
+def test_gather_rows_outside_the_batch_poison_the_score_instead_of_faulting(tiny):
+    """C-ABI robustness: a label-row index outside [0, n_tokens) must not read wild memory; its output row is NaN."""
+    t = tiny
+    L, Hd = 12, t.dims.hidden_size
+    batch = eng.PackedBatch(np.arange(L, dtype=np.int32), np.ones(L, np.uint8), np.array([0], np.int32), np.array([L], np.int32))
+    emb = (torch.randn((L, Hd), device="cuda") * 0.02).to(t.model.engine.torch_dtype)
+    rows = torch.tensor([0, -1, L - 1, L, 1 << 30], dtype=torch.int32, device="cuda")
+    hid, _ = t.model.engine.decode(batch, emb, out_rows=rows)
+    torch.cuda.synchronize()
+    bad = torch.isnan(hid.float()).all(dim=1).cpu().numpy()
+    assert bad.tolist() == [False, True, False, True, True]
+    ref, _ = t.model.engine.decode(batch, emb)
+    assert torch.equal(hid[0], ref[0]) and torch.equal(hid[2], ref[L - 1])
+
+
 def test_criteria_on_golden_logits():
     g = np.load(os.path.join(GOLD, "tiny.npz"))
     sc = RU.vtg_criterion(torch.from_numpy(g["crit_vtg_logits"]).cuda(), torch.from_numpy(g["crit_vtg_labels"]).cuda()).cpu().numpy()

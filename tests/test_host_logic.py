@@ -172,3 +172,13 @@ def test_plans_split_at_the_token_budget():
     assert len(plans) > 1 and sum(p.n_pairs for p in plans) == 36
     covered = sorted(int(o[0]) for p in plans for o in p.out_index)
     assert covered == list(range(36))
+
+
+def test_vtg_cpn_without_any_prompt_token_is_rejected():
+    """Headline-shaped rows ([<image>][text], no ChatML header): with the video keys masked nothing is visible in front of the
+    response, so the planner refuses instead of pointing the first label row in front of the packed batch."""
+    sc, prob = _scorer(layout=False)
+    with pytest.raises(ValueError, match="at least one prompt token"):
+        sc.plan_vtg(np.array([[0, 1], [2, 1]]), cpn=True)
+    (plan,) = sc.plan_vtg(np.array([[0, 1], [2, 1]]))              # the likelihood pass itself is fine
+    assert plan.n_pairs == 2 and int(plan.rows.numpy().min()) >= 0
