@@ -90,15 +90,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     const int nwg = ntm * ntn;
 #pragma unroll 1
-    for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
-    // ---- tile mapping: XCD-contiguous chunks (blocks b, b+8, ... share an XCD), then grouped M order
-    stamp_vb = vb;
-    stamp(0);
+    for (int vb = blockIdx.x; vb < (p.tile_map ? ((nwg + 255) & ~255) : nwg); vb += gridDim.x) {
+    // ---- tile mapping (blocks b, b+8, ... share an XCD), then grouped M order
     int pid;
-    {
+    if (p.tile_map) {
+        // groups of 32 consecutive tiles (8 M x 4 N) dealt round-robin to the XCDs: at any moment the eight XCDs work on 32
+        // neighbouring columns of ONE 8-tile row band, so its A panels are fetched from HBM once and served to the other
+        // seven XCDs by the memory-side cache (each XCD still sees the same 8 x 4 sharing in its own L2)
+        const int xcd = vb & 7, k = vb >> 3;
+        pid = ((k >> 5) * 8 + xcd) * 32 + (k & 31);
+        if (pid >= nwg) continue;
+    } else {
+        // XCD-contiguous chunks of the tile order
         const int bid = vb, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    stamp_vb = pid;
+    stamp(0);
     const int width = GROUP_M * ntn;
     const int first_m = (pid / width) * GROUP_M;
     const int gsz = min(ntm - first_m, GROUP_M);
@@ -152,12 +160,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         acc[mi][ni] = mfma16<DT>(fa[ks][mi], fb[ks][ni], acc[mi][ni]);
             __builtin_amdgcn_s_setprio(0);
         };
+        // (Measured dead end: issuing the last 4/8/16 MFMAs of a K-step behind the phase barrier, so that the rendezvous
+        // latency is covered by queued MFMAs: 0 / -8 / -9 % -- two waves feeding one SIMD's matrix pipe at once costs more
+        // than the bubble.)
         // a phase boundary: own LDS reads complete (WAR on the tile about to be refilled), then rendezvous
 #define PHASE_BARRIER()                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_s_barrier();                      \
         asm volatile("" ::: "memory")
 
+#ifdef GEMM_WAIT_PROF   // instrumented build only (tools/gemm_waits.py): where a wave's time goes inside one K-step
+        unsigned long long wp_t[6], wp_acc[5] = {0, 0, 0, 0, 0};
+#define WP_T(i) wp_t[i] = __builtin_readcyclecounter()
+#define WP_ACC() do { for (int q_ = 0; q_ < 5; ++q_) wp_acc[q_] += wp_t[q_ + 1] - wp_t[q_]; } while (0)
+#else
+#define WP_T(i)
+#define WP_ACC()
+#endif
         // Two straight-line loops (one per wave group) that execute the SAME barrier sequence:
         //   phase A(kt): group 0 computes step kt              | group 1 reads its fragments of step kt, stages A(kt+2)
         //   phase B(kt): group 0 reads its fragments of kt+1, stages W(kt+2) | group 1 computes step kt
@@ -177,7 +196,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         auto stage8 = [&](int dst, int kt) __attribute__((always_inline)) {   // one operand tile share: 8 LDS-DMA per wave
             const char* g = gbase + (int64_t)kt * (BK * 2);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) glds16(g + off8[i], smem + dst + (wg + 4 * i) * 1024);
+            for (int i = 0; i < 8; ++i) {
+                // keep the lane offset a 32-bit VGPR at the point of use: the zero-extension then folds into the LDS-DMA's
+                // saddr + voffset form (hoisted out of the K loop it becomes 8 VGPR pairs and the loop spills to scratch)
+                uint32_t o = off8[i];
+                asm volatile("" : "+v"(o));
+                glds16(g + o, smem + dst + (wg + 4 * i) * 1024);
+            }
         };
         int sa = 0;
         if (grp == 0) {
@@ -189,12 +214,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             load_frags(0, TILE_BYTES);
             PHASE_BARRIER();
             for (int kt = 0; kt < nk; ++kt) {
+                WP_T(0);
                 compute();
+                WP_T(1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of W(kt+1) landed
+                WP_T(2);
                 PHASE_BARRIER();
+                WP_T(3);
                 if (kt + 1 < nk) load_frags(adv(sa, 2), adv(sa, 3));
                 if (kt + 2 < nk) stage8(sa, kt + 2);                 // W(kt+2)
+#ifdef GEMM_WAIT_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                WP_T(4);
                 PHASE_BARRIER();
+                WP_T(5);
+                WP_ACC();
                 sa = adv(sa, 2);
             }
         } else {
@@ -205,16 +240,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             PHASE_BARRIER();
             PHASE_BARRIER();
             for (int kt = 0; kt < nk; ++kt) {
+                WP_T(0);
                 load_frags(sa, adv(sa, 1));
-                if (kt + 2 < nk) { stage8(adv(sa, 4), kt + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // my share of A(kt+1) landed
+                if (kt + 2 < nk) stage8(adv(sa, 4), kt + 2);
+#ifdef GEMM_WAIT_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                WP_T(1);
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // my share of A(kt+1) landed
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WP_T(2);
                 PHASE_BARRIER();
+                WP_T(3);
                 compute();
+                WP_T(4);
                 PHASE_BARRIER();
+                WP_T(5);
+                WP_ACC();
                 sa = adv(sa, 2);
             }
         }
 #undef PHASE_BARRIER
+#ifdef GEMM_WAIT_PROF
+        if (p.debug_stamps && lane == 0 && (wave & 3) == 0)
+            for (int q_ = 0; q_ < 5; ++q_) p.debug_stamps[((size_t)nwg + (size_t)stamp_vb * 2 + grp) * 8 + q_] = wp_acc[q_];
+#endif
     }
 
     stamp(2);
@@ -453,6 +503,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 
 #include <stdlib.h>
 static int g_gemm_persistent = getenv("BLIM_GEMM_PERSISTENT") ? atoi(getenv("BLIM_GEMM_PERSISTENT")) : 1;
+static int g_gemm_tile_map = getenv("BLIM_GEMM_TILE_MAP") ? atoi(getenv("BLIM_GEMM_TILE_MAP")) : -1;   // -1: by shape
 static int g_gemm_stagger = getenv("BLIM_GEMM_STAGGER") ? atoi(getenv("BLIM_GEMM_STAGGER")) : 0;
 static int g_gemm_skip_epi = getenv("BLIM_GEMM_SKIP_EPI") ? atoi(getenv("BLIM_GEMM_SKIP_EPI")) : 0;
 static unsigned long long* g_gemm_stamps = nullptr;
@@ -484,6 +535,9 @@ int launch_gemm(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
     p.stagger = g_gemm_stagger;
+    // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
+    // round-robin map, the wide ones (gate|up 37888, lm_head) lose 4 % -- there the XCDs already walk the same W columns in step
+    p.tile_map = g_gemm_tile_map >= 0 ? g_gemm_tile_map : ((p.N + BN - 1) / BN <= 32 ? 1 : 0);
     p.debug_stamps = g_gemm_stamps;
     ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0);
     ARG_CHECK(p.K % BK == 0);

@@ -17,7 +17,7 @@ import numpy as np
 from .synth import ModelDims, weight_shapes
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblim_hip.so")
+LIB_PATH = os.environ.get("BLIM_LIB_PATH") or os.path.join(_HERE, "libblim_hip.so")     # override: A/B of two builds (tools/)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "blim.h")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
