@@ -32,6 +32,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // MFMA forms have the same rate on gfx950.
 #define DT_BF16 0
 #define DT_F16 1
+// fp8 mode (BASELINE config 5): the five big decoder GEMMs and lm_head take OCP e4m3 operands (per-row f32 scales on both
+// sides, MX block scales fixed at 1) on the block-scaled MFMA; everything 16-bit around them is fp16.
+#define DT_F8 2
+#define FP8_MAX 448.0f
+template <int DT> struct out16 { static constexpr int value = DT == DT_F8 ? DT_F16 : DT; };
+
+// two floats -> two e4m3 bytes in the low (hi = false) or high half of `old` (round to nearest even, v_cvt_pk_fp8_f32)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int DT> __device__ __forceinline__ float from16(uint16_t b) {

@@ -33,9 +33,9 @@ extern "C" int blim_abi_version(void) { return BLIM_ABI_VERSION; }
     } while (0)
 
 // ---------------------------------------------------------------------------- timing classes
-enum TimeClass { TC_GEMM_QKV = 0, TC_ATTN, TC_GEMM_O, TC_GEMM_GATEUP, TC_GEMM_DOWN, TC_NORM, TC_LMHEAD_LSE, TC_GEMM_OTHER, TC_MISC, TC_COUNT };
+enum TimeClass { TC_GEMM_QKV = 0, TC_ATTN, TC_GEMM_O, TC_GEMM_GATEUP, TC_GEMM_DOWN, TC_NORM, TC_LMHEAD_LSE, TC_GEMM_OTHER, TC_MISC, TC_QUANT, TC_COUNT };
 static const char* kTimeClassNames[TC_COUNT] = {"gemm_qkv_rope", "attention", "gemm_o_resid", "gemm_gateup_swiglu", "gemm_down_resid",
-                                                "rmsnorm", "lm_head_lse", "gemm_other", "misc"};
+                                                "rmsnorm", "lm_head_lse", "gemm_other", "misc", "quantize_fp8"};
 
 struct TimedSpan { hipEvent_t a, b; int cls; double flops; };
 
@@ -49,6 +49,9 @@ struct LayerW {
     float* norm1 = nullptr; float* norm2 = nullptr;
     bf16_t* wqkv = nullptr; float* bqkv = nullptr;
     bf16_t* wo = nullptr; bf16_t* wgu = nullptr; bf16_t* wd = nullptr;
+    // fp8 mode: e4m3 copies of the four matrices (same stored row order) + one f32 scale per stored row
+    uint8_t* wqkv8 = nullptr; uint8_t* wo8 = nullptr; uint8_t* wgu8 = nullptr; uint8_t* wd8 = nullptr;
+    float* sqkv = nullptr; float* so = nullptr; float* sgu = nullptr; float* sd = nullptr;
 };
 
 struct blim_engine {
@@ -61,10 +64,14 @@ struct blim_engine {
     bf16_t* mlp_w0[2] = {nullptr, nullptr}; float* mlp_b0[2] = {nullptr, nullptr};
     bf16_t* mlp_w2[2] = {nullptr, nullptr}; float* mlp_b2[2] = {nullptr, nullptr};
     float* rope_cos = nullptr; float* rope_sin = nullptr;
+    bool f8 = false;              // BLIM_COMPUTE_F8: c.compute_dtype is then F16 (the 16-bit side of the mode)
+    bool f8_ready = false;        // fp8 copies are current
+    uint8_t* lm_head8 = nullptr; float* s_lm = nullptr;
     std::map<std::string, bool> loaded;
     std::vector<void*> owned;
     // workspaces
     DevBuf resid, xn, qkv, attn, act, hsel, lse_part, lab_logit, logprob, stage, proj_tmp, vh, tvg_logits, dense_idx;
+    DevBuf x8, a8, act8, hsel8, rscale;   // fp8 mode: quantised GEMM inputs and their per-row scales
     // options / timing
     int attn_tr = 1;
     bool timing = false;
@@ -169,7 +176,8 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     ARG_CHECK(cfg->num_heads % cfg->num_kv_heads == 0 && cfg->num_heads / cfg->num_kv_heads <= 8);
     ARG_CHECK(cfg->hidden_size % 64 == 0 && cfg->intermediate_size % 64 == 0 && cfg->mm_hidden_size % 64 == 0);
     ARG_CHECK(cfg->vocab_size > 0 && cfg->max_positions > 0 && cfg->num_clips > 0);
-    ARG_CHECK(cfg->compute_dtype == BLIM_COMPUTE_BF16 || cfg->compute_dtype == BLIM_COMPUTE_F16);
+    ARG_CHECK(cfg->compute_dtype == BLIM_COMPUTE_BF16 || cfg->compute_dtype == BLIM_COMPUTE_F16 || cfg->compute_dtype == BLIM_COMPUTE_F8);
+    ARG_CHECK(cfg->compute_dtype != BLIM_COMPUTE_F8 || (cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         blim_set_error("no HIP device visible: the BLiM engine has no CPU fallback");
@@ -177,6 +185,7 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     }
     blim_engine* e = new blim_engine();
     e->c = *cfg;
+    if (cfg->compute_dtype == BLIM_COMPUTE_F8) { e->f8 = true; e->c.compute_dtype = BLIM_COMPUTE_F16; }
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -196,7 +205,14 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
         A(l.wo, (int64_t)H * H, bf16_t);
         A(l.wgu, (int64_t)2 * I * H, bf16_t);
         A(l.wd, (int64_t)H * I, bf16_t);
+        if (e->f8) {
+            A(l.wqkv8, (int64_t)e->qkv_n * H, uint8_t); A(l.sqkv, e->qkv_n, float);
+            A(l.wo8, (int64_t)H * H, uint8_t); A(l.so, H, float);
+            A(l.wgu8, (int64_t)2 * I * H, uint8_t); A(l.sgu, 2 * I, float);
+            A(l.wd8, (int64_t)H * I, uint8_t); A(l.sd, H, float);
+        }
     }
+    if (e->f8) { A(e->lm_head8, (int64_t)V * H, uint8_t); A(e->s_lm, V, float); }
     A(e->rope_cos, (int64_t)cfg->max_positions * 64, float);
     A(e->rope_sin, (int64_t)cfg->max_positions * 64, float);
 #undef A
@@ -213,7 +229,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     hipDeviceSynchronize();
     for (void* p : e->owned) hipFree(p);
     DevBuf* bufs[] = {&e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -283,6 +299,7 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
     }
     HIP_TRY(hipGetLastError());
     e->loaded[name] = true;
+    e->f8_ready = false;
     return BLIM_OK;
 }
 
@@ -351,10 +368,34 @@ extern "C" int blim_weights_ready(const blim_engine* e) {
     return BLIM_OK;
 }
 
+// fp8 mode: (re)build the e4m3 copies of the big matrices from the placed 16-bit ones (per stored row: scale = absmax / 448)
+static int finalize_f8(blim_engine* e) {
+    if (!e->f8 || e->f8_ready) return BLIM_OK;
+    TRY(blim_weights_ready(e));
+    const blim_config& c = e->c;
+    const int H = c.hidden_size, I = c.intermediate_size;
+    for (auto& l : e->L) {
+        TRY(launch_quant_rows(l.wqkv, H, e->qkv_n, H, c.compute_dtype, l.wqkv8, l.sqkv, 0));
+        TRY(launch_quant_rows(l.wo, H, H, H, c.compute_dtype, l.wo8, l.so, 0));
+        TRY(launch_quant_rows(l.wgu, H, 2 * (int64_t)I, H, c.compute_dtype, l.wgu8, l.sgu, 0));
+        TRY(launch_quant_rows(l.wd, I, H, I, c.compute_dtype, l.wd8, l.sd, 0));
+    }
+    TRY(launch_quant_rows(e->lm_head, H, c.vocab_size, H, c.compute_dtype, e->lm_head8, e->s_lm, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    e->f8_ready = true;
+    return BLIM_OK;
+}
+
 // ---------------------------------------------------------------------------- workspaces
 static int reserve_tokens(blim_engine* e, int64_t T) {
     const blim_config& c = e->c;
     const int64_t Tp = round_up(T, 256);
+    if (e->f8) {
+        TRY(ensure(e->x8, (size_t)Tp * c.hidden_size));
+        TRY(ensure(e->a8, (size_t)Tp * c.hidden_size));
+        TRY(ensure(e->act8, (size_t)Tp * c.intermediate_size));
+        TRY(ensure(e->rscale, (size_t)Tp * 4 * 4));      // [x | attn | act | label rows] scales
+    }
     TRY(ensure(e->resid, (size_t)Tp * c.hidden_size * 4));
     TRY(ensure(e->xn, (size_t)Tp * c.hidden_size * 2));
     TRY(ensure(e->qkv, (size_t)Tp * e->qkv_n * 2));
@@ -367,6 +408,7 @@ static int reserve_rows(blim_engine* e, int64_t R) {
     const int64_t Rp = round_up(R, 256);
     const int ntn = (c.vocab_size + 255) / 256;
     TRY(ensure(e->hsel, (size_t)Rp * c.hidden_size * 2));
+    if (e->f8) TRY(ensure(e->hsel8, (size_t)Rp * c.hidden_size + (size_t)Rp * 4));   // e4m3 rows, then their scales
     TRY(ensure(e->lse_part, (size_t)Rp * ntn * sizeof(float2)));
     TRY(ensure(e->lab_logit, (size_t)Rp * 4));
     TRY(ensure(e->logprob, (size_t)Rp * 4));
@@ -416,21 +458,36 @@ extern "C" int blim_assemble(blim_engine* e, const int32_t* src_index, int64_t n
     return launch_assemble((bf16_t*)out_embeds, src_index, n_tokens, e->c.hidden_size, e->embed, (const bf16_t*)feats, (hipStream_t)stream);
 }
 
+static GemmParams gp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, const float* w_scale, int64_t M, int N, int K, void* C, int64_t ldc) {
+    GemmParams p = gp(DT_F8, A8, lda, W8, M, N, K, C, ldc);
+    p.row_scale = a_scale; p.col_scale = w_scale;
+    return p;
+}
+
 static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, hipStream_t s) {
     const blim_config& c = e->c;
     const int H = c.hidden_size, I = c.intermediate_size;
     const int64_t T = b->n_tokens;
     TRY(reserve_tokens(e, T));
+    TRY(finalize_f8(e));
     float* resid = (float*)e->resid.p;
     bf16_t* xn = (bf16_t*)e->xn.p; bf16_t* qkv = (bf16_t*)e->qkv.p; bf16_t* attn = (bf16_t*)e->attn.p; bf16_t* act = (bf16_t*)e->act.p;
+    // fp8 mode: quantised inputs of the four GEMMs and their per-token scales
+    const int64_t Tp = round_up(T, 256);
+    uint8_t* x8 = (uint8_t*)e->x8.p; uint8_t* a8 = (uint8_t*)e->a8.p; uint8_t* act8 = (uint8_t*)e->act8.p;
+    float* sx = (float*)e->rscale.p; float* sa = sx ? sx + Tp : nullptr; float* sact = sx ? sx + 2 * Tp : nullptr;
     { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s)); }
     const double tok = (double)T;
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
-        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s)); }
+        {
+            SpanGuard g(e, s, TC_NORM, 0);
+            if (e->f8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s));
+        }
         {
             SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n);
-            GemmParams p = gp(c.compute_dtype, xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
+            GemmParams p = e->f8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp(c.compute_dtype, xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
             p.bias = l.bqkv; p.pos = b->positions; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
             p.rope_cols = (c.num_heads + c.num_kv_heads) * 128;
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -444,20 +501,26 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = H; a.scale = 0.08838834764831845f;
             TRY(launch_attention(a, e->attn_tr, s));
         }
+        if (e->f8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H);
-            GemmParams p = gp(c.compute_dtype, attn, H, l.wo, T, H, H, resid, H);
+            GemmParams p = e->f8 ? gp8(a8, H, sa, l.wo8, l.so, T, H, H, resid, H) : gp(c.compute_dtype, attn, H, l.wo, T, H, H, resid, H);
             TRY(launch_gemm(EPI_RESID, p, s));
         }
-        { SpanGuard g(e, s, TC_NORM, 0); TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s)); }
         {
-            SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I);
-            GemmParams p = gp(c.compute_dtype, xn, H, l.wgu, T, 2 * I, H, act, I);
-            TRY(launch_gemm(EPI_SWIGLU, p, s));
+            SpanGuard g(e, s, TC_NORM, 0);
+            if (e->f8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s));
         }
         {
+            SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I);
+            GemmParams p = e->f8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp(c.compute_dtype, xn, H, l.wgu, T, 2 * I, H, act, I);
+            TRY(launch_gemm(EPI_SWIGLU, p, s));
+        }
+        if (e->f8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
+        {
             SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I);
-            GemmParams p = gp(c.compute_dtype, act, I, l.wd, T, H, I, resid, H);
+            GemmParams p = e->f8 ? gp8(act8, I, sact, l.wd8, l.sd, T, H, I, resid, H) : gp(c.compute_dtype, act, I, l.wd, T, H, I, resid, H);
             TRY(launch_gemm(EPI_RESID, p, s));
         }
     }
@@ -492,9 +555,16 @@ extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const 
     TRY(reserve_rows(e, n_rows));
     const int ntn = (V + 255) / 256;
     HIP_TRY(hipMemsetAsync(e->lab_logit.p, 0, (size_t)n_rows * 4, s));
+    uint8_t* h8 = nullptr; float* hs = nullptr;
+    if (e->f8) {
+        TRY(finalize_f8(e));
+        h8 = (uint8_t*)e->hsel8.p; hs = (float*)(h8 + (size_t)round_up(n_rows, 256) * H);
+        SpanGuard g(e, s, TC_QUANT, 0);
+        TRY(launch_quant_rows((const bf16_t*)hidden_bf16, H, n_rows, H, e->c.compute_dtype, h8, hs, s));
+    }
     {
         SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)H * V);
-        GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
+        GemmParams p = e->f8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0) : gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
     }
@@ -616,6 +686,15 @@ extern "C" int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t
 }
 extern "C" int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream) {
     GemmParams p = gp(DT_F16, A, lda, W, M, N, K, C, ldc);
+    return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
+}
+extern "C" int blim_quant_rows(const void* in16, int64_t ld, int64_t n_rows, int32_t K, int32_t dtype16, void* out8, float* scale, void* stream) {
+    ARG_CHECK(dtype16 == BLIM_COMPUTE_BF16 || dtype16 == BLIM_COMPUTE_F16);
+    return launch_quant_rows((const bf16_t*)in16, ld, n_rows, K, dtype16, (uint8_t*)out8, scale, (hipStream_t)stream);
+}
+extern "C" int blim_gemm_f8(const void* A8, int64_t lda, const float* a_scale, const void* W8, const float* w_scale, int32_t M, int32_t N, int32_t K,
+                            void* C, int64_t ldc, void* stream) {
+    GemmParams p = gp8(A8, lda, a_scale, W8, w_scale, M, N, K, C, ldc);
     return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
 }
 

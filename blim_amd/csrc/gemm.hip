@@ -122,10 +122,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const char* baseW = (const char*)p.W;
 
     // ---- fragment read offsets (bytes) inside an operand tile
+    // 16-bit: lane (row fr, k-chunk fc of 8 elements) reads 16 B per 32-deep MFMA step ks (quarter 2 ks + fc/2, half fc&1).
+    // fp8: lane (row fr, k-block fc of 32 elements) owns the whole 32-B quarter fc: two 16-B reads feed one 128-deep MFMA.
+    constexpr int ES = (DT == DT_F8) ? 1 : 2;            // operand element size
+    constexpr int KS_OFF = (DT == DT_F8) ? 16 : 512;     // byte distance of a fragment's second 16-B read
+    constexpr int ODT = out16<DT>::value;                // dtype of 16-bit outputs
     const int fr = lane & 15, fc = lane >> 4;
-    const int frag_off = (fr >> 3) * 1024 + (fr & 7) * 32 + (fc >> 1) * 256 + (fc & 1) * 16;
-    const int a_off = (16 * wm) * 1024 + frag_off;   // + mi*2048 + ks*512
-    const int b_off = (8 * wn) * 1024 + frag_off;    // + ni*2048 + ks*512
+    const int frag_off = (fr >> 3) * 1024 + (fr & 7) * 32 + (DT == DT_F8 ? fc * 256 : (fc >> 1) * 256 + (fc & 1) * 16);
+    const int a_off = (16 * wm) * 1024 + frag_off;   // + mi*2048 + ks*KS_OFF
+    const int b_off = (8 * wn) * 1024 + frag_off;    // + ni*2048 + ks*KS_OFF
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -133,31 +138,53 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = p.K * ES / (BK * 2);   // K-steps of 128 bytes per row
     stamp(1);
     {
         const int grp = wave >> 2;  // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
-        bf16x8 fa[2][8], fb[2][4];
+        typedef int i32x8 __attribute__((ext_vector_type(8)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        bf16x8 fa[2][8], fb[2][4];        // 16-bit fragments: [32-deep step][16-row block]
+        i32x8 fa8[8], fb8[4];             // fp8 fragments: 32 e4m3 per lane (the two 16-B reads land in the halves of one tuple)
         auto load_frags = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
             const char* ba = smem + offA_tile + a_off;
             const char* bb = smem + offB_tile + b_off;
+            if constexpr (DT == DT_F8) {
+                auto rd = [](const char* q) __attribute__((always_inline)) {
+                    const i32x4 l = *(const i32x4*)q, h = *(const i32x4*)(q + 16);
+                    return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+                };
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int ni = 0; ni < 4; ++ni) fb8[ni] = rd(bb + ni * 2048);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) fb[ks][ni] = *(const bf16x8*)(bb + ni * 2048 + ks * 512);
+                for (int mi = 0; mi < 8; ++mi) fa8[mi] = rd(ba + mi * 2048);
+            } else {
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) fa[ks][mi] = *(const bf16x8*)(ba + mi * 2048 + ks * 512);
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) fb[ks][ni] = *(const bf16x8*)(bb + ni * 2048 + ks * KS_OFF);
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) fa[ks][mi] = *(const bf16x8*)(ba + mi * 2048 + ks * KS_OFF);
+                }
             }
         };
         auto compute = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            if constexpr (DT == DT_F8) {
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = mfma16<DT>(fa[ks][mi], fb[ks][ni], acc[mi][ni]);
+                    for (int ni = 0; ni < 4; ++ni)   // e4m3 x e4m3, MX block scales 2^0 (0x7f): 32 MFMAs of 128-deep K per step
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa8[mi], fb8[ni], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            acc[mi][ni] = mfma16<DT>(fa[ks][mi], fb[ks][ni], acc[mi][ni]);
+            }
             __builtin_amdgcn_s_setprio(0);
         };
         // (Measured dead end: issuing the last 4/8/16 MFMAs of a K-step behind the phase barrier, so that the rendezvous
@@ -189,8 +216,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int b = wg + 4 * i;   // 1-KiB block (8 rows) of the operand tile
-            if (grp == 1) off8[i] = (uint32_t)(((int64_t)min(row0 + 8 * b + sr, p.M - 1) * p.lda + 8 * sc) * 2);
-            else off8[i] = (uint32_t)(((int64_t)min(col0 + 8 * b + sr, p.N - 1) * p.K + 8 * sc) * 2);
+            if (grp == 1) off8[i] = (uint32_t)((int64_t)min(row0 + 8 * b + sr, p.M - 1) * p.lda * ES + 16 * sc);
+            else off8[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr, p.N - 1) * p.K * ES + 16 * sc);
         }
         const char* gbase = grp == 1 ? baseA : baseW;
         auto stage8 = [&](int dst, int kt) __attribute__((always_inline)) {   // one operand tile share: 8 LDS-DMA per wave
@@ -211,6 +238,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();                                         // A0 W0 landed (every wave waited for its own DMA)
+            if constexpr (DT == DT_F8) {
+                // same barrier sequence, loop rotated so that a step's fragments are read and consumed inside one iteration:
+                // the fp8 fragments are 8-register tuples assembled from two 16-B reads, and carried across the back edge the
+                // register allocator keeps a second copy of all twelve (spilling ~200 VGPRs)
+                int sp = 0;                                          // slot of A(k-1)
+                for (int k = 0; k < nk; ++k) {
+                    load_frags(sa, adv(sa, 1));
+                    if (k >= 1 && k + 1 < nk) stage8(sp, k + 1);     // W(k+1) into the slot A(k-1) left
+                    PHASE_BARRIER();
+                    compute();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of W(k+1) landed
+                    PHASE_BARRIER();
+                    sp = sa; sa = adv(sa, 2);
+                }
+                PHASE_BARRIER();
+            } else {
             load_frags(0, TILE_BYTES);
             PHASE_BARRIER();
             for (int kt = 0; kt < nk; ++kt) {
@@ -231,6 +274,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_T(5);
                 WP_ACC();
                 sa = adv(sa, 2);
+            }
             }
         } else {
             stage8(0, 0);                                            // A0
@@ -279,6 +323,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     }
     const int wrow0 = row0 + 128 * wm;  // wave's first row
     const int wcol0 = col0 + 64 * wn;   // wave's first column (in W's row order)
+    if constexpr (DT == DT_F8) {
+        // dequantise: acc[row][col] *= row_scale[row] * col_scale[col].  The tile's 256 + 256 scales go through LDS (free now).
+        float* sc = (float*)smem;
+        sc[tid] = tid < 256 ? p.row_scale[min(row0 + tid, p.M - 1)] : p.col_scale[min(col0 + tid - 256, p.N - 1)];
+        __syncthreads();
+        float cs[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) cs[ni] = sc[256 + 64 * wn + 16 * ni + (lane & 15)];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const float4 rs = *(const float4*)(sc + 128 * wm + 16 * mi + 4 * (lane >> 4));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[mi][ni][0] *= rs.x * cs[ni]; acc[mi][ni][1] *= rs.y * cs[ni]; acc[mi][ni][2] *= rs.z * cs[ni]; acc[mi][ni][3] *= rs.w * cs[ni];
+            }
+        }
+        __syncthreads();
+    }
 
     if constexpr (EPI == EPI_LSE) {
         // accumulators as the MFMA leaves them: lane holds col (lane&15) of frag ni, rows 4*(lane>>4)+j of frag mi.
@@ -351,7 +413,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     if (p.bias == nullptr && p.act == 0) {         // wave-uniform fast path: convert and stage
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
-                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(pack2<DT>(t[ni][0], t[ni][1]), pack2<DT>(t[ni][2], t[ni][3]));
+                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(pack2<ODT>(t[ni][0], t[ni][1]), pack2<ODT>(t[ni][2], t[ni][3]));
                     } else {
 #pragma unroll 1
                         for (int ni = 0; ni < 4; ++ni) {
@@ -363,7 +425,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                                 x[j] = t[ni][j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f);
                                 if (p.act == 1) x[j] = gelu_erf(x[j]);
                             }
-                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
+                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<ODT>(x[0], x[1]), pack2<ODT>(x[2], x[3]));
                         }
                     }
                 } else if constexpr (EPI == EPI_QKV) {
@@ -390,15 +452,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                                 hi[j] = x2 * c4[j] + x1 * s4[j];
                             }
                             char* o = lrow + (hl * 128 + d) * 2;
-                            *(uint2*)o = make_uint2(pack2<DT>(lo[0], lo[1]), pack2<DT>(lo[2], lo[3]));
-                            *(uint2*)(o + 128) = make_uint2(pack2<DT>(hi[0], hi[1]), pack2<DT>(hi[2], hi[3]));
+                            *(uint2*)o = make_uint2(pack2<ODT>(lo[0], lo[1]), pack2<ODT>(lo[2], lo[3]));
+                            *(uint2*)(o + 128) = make_uint2(pack2<ODT>(hi[0], hi[1]), pack2<ODT>(hi[2], hi[3]));
                         }
                     } else {
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
                             const int cl = 64 * wn + 16 * ni + 4 * tq;
                             const float4 bv = *(const float4*)(p.bias + col0 + cl);
-                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(t[ni][0] + bv.x, t[ni][1] + bv.y), pack2<DT>(t[ni][2] + bv.z, t[ni][3] + bv.w));
+                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<ODT>(t[ni][0] + bv.x, t[ni][1] + bv.y), pack2<ODT>(t[ni][2] + bv.z, t[ni][3] + bv.w));
                         }
                     }
                 } else {  // EPI_SWIGLU: fragments (2p, 2p+1) = gate / up of the same 16 intermediate columns
@@ -408,7 +470,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         float x[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x[j] = silu_f(t[2 * pr][j]) * t[2 * pr + 1][j];
-                        *(uint2*)(lrow + cl * 2) = make_uint2(pack2<DT>(x[0], x[1]), pack2<DT>(x[2], x[3]));
+                        *(uint2*)(lrow + cl * 2) = make_uint2(pack2<ODT>(x[0], x[1]), pack2<ODT>(x[2], x[3]));
                     }
                 }
             }
@@ -521,7 +583,8 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     }
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
-    if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
+    if (p.dtype == DT_F8) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F8>), grid, dim3(NTHREADS), 0, stream, p);
+    else if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((gemm_kernel<EPI, DT_BF16>), grid, dim3(NTHREADS), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -540,11 +603,13 @@ int launch_gemm(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     p.tile_map = g_gemm_tile_map >= 0 ? g_gemm_tile_map : ((p.N + BN - 1) / BN <= 32 ? 1 : 0);
     p.debug_stamps = g_gemm_stamps;
     ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0);
-    ARG_CHECK(p.K % BK == 0);
-    ARG_CHECK(p.lda % 8 == 0);
     ARG_CHECK(p.A && p.W);
-    ARG_CHECK(p.dtype == DT_BF16 || p.dtype == DT_F16);
-    ARG_CHECK((int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32));  // 32-bit operand offsets
+    ARG_CHECK(p.dtype == DT_BF16 || p.dtype == DT_F16 || p.dtype == DT_F8);
+    const int es = p.dtype == DT_F8 ? 1 : 2;
+    ARG_CHECK((int64_t)p.K * es % 128 == 0);                  // whole 128-byte K-steps
+    ARG_CHECK(p.lda * es % 16 == 0);
+    ARG_CHECK(p.dtype != DT_F8 || (p.row_scale && p.col_scale));
+    ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * p.K * es < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
         case EPI_BF16: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_BF16>(p, stream);
         case EPI_F32: ARG_CHECK(p.C && p.bias == nullptr); return launch_t<EPI_F32>(p, stream);

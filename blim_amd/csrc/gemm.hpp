@@ -16,7 +16,9 @@ enum GemmEpi : int {
 };
 
 struct GemmParams {
-    int dtype;  // DT_BF16 / DT_F16: format of A, W and of 16-bit outputs
+    int dtype;  // DT_BF16 / DT_F16: format of A, W and of 16-bit outputs; DT_F8: A, W are e4m3 bytes (K-step 128), 16-bit outputs fp16
+    const float* row_scale;  // DT_F8: [M] dequantisation scale of every A row
+    const float* col_scale;  // DT_F8: [N] dequantisation scale of every W row (in W's stored row order)
     const bf16_t* A;
     int64_t lda;
     const bf16_t* W;  // [N, K], row stride K
@@ -42,7 +44,7 @@ struct GemmParams {
 };
 void gemm_set_debug_stamps(unsigned long long* buf);
 
-// 256x256x64 tiles, 512 threads.  K % 64 == 0, lda % 8 == 0.  Rows/cols beyond M/N are clamped on
+// 256x256 tiles x 128 bytes of K per step (64 16-bit / 128 fp8 elements), 512 threads.  K % 64 == 0 (fp8: % 128), lda % 8 == 0 (fp8: % 16).  Rows/cols beyond M/N are clamped on
 // load and masked on store, so neither A nor W needs padding.
 int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream);
 

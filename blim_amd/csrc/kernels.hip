@@ -315,3 +315,100 @@ int launch_tvg_score(const float* logits, int64_t ld, int n_vocab, const int32_t
     LAUNCH_CHECK("tvg_score");
     return BLIM_OK;
 }
+
+// ---------------------------------------------------------------------------- fp8 quantisers (DT_F8 mode)
+template <int DT>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, float* scale) {
+    constexpr int MAXC = 10;                      // 8-element chunks per thread: K <= 256 * 8 * 10
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const bf16_t* row = in + r * ld;
+    const int nchunk = K / 8;
+    uint4 v[MAXC];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nchunk) {
+            v[i] = *(const uint4*)(row + 8 * c);
+            const uint16_t* e = (const uint16_t*)&v[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(from16<DT>(e[j])));
+        }
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = mx > 0.f ? mx / FP8_MAX : 1.0f;
+    const float inv = 1.0f / sc;
+    if (threadIdx.x == 0) scale[r] = sc;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nchunk) {
+            const uint16_t* e = (const uint16_t*)&v[i];
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = from16<DT>(e[j]) * inv;
+            *(uint2*)(out8 + r * K + 8 * c) = make_uint2(pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7]));
+        }
+    }
+}
+int launch_quant_rows(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, float* scale, hipStream_t s) {
+    ARG_CHECK(in && out8 && scale && n_rows > 0 && K > 0 && K % 8 == 0 && ld % 8 == 0 && K <= 256 * 8 * 10);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, scale);
+    else hipLaunchKernelGGL((quant_rows_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, scale);
+    LAUNCH_CHECK("quant_rows");
+    return BLIM_OK;
+}
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_f8_kernel(const float* x, int64_t ldx, int64_t n_rows, int H, const float* w, float eps, uint8_t* out8, float* scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float* xr = x + r * ldx;
+    const int nv = H / 4;
+    float4 v[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = *(const float4*)(xr + 4 * c);
+            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 g = *(const float4*)(w + 4 * c);
+            v[i] = make_float4(g.x * (v[i].x * inv), g.y * (v[i].y * inv), g.z * (v[i].z * inv), g.w * (v[i].w * inv));
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+        }
+    }
+    mx = wave_max(mx);
+    const float sc = mx > 0.f ? mx / FP8_MAX : 1.0f;
+    const float qi = 1.0f / sc;
+    if (lane == 0) scale[r] = sc;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) *(uint32_t*)(out8 + r * H + 4 * c) = pack_fp8x4(v[i].x * qi, v[i].y * qi, v[i].z * qi, v[i].w * qi);
+    }
+}
+int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const float* w, float eps, uint8_t* out8, float* scale, hipStream_t s) {
+    ARG_CHECK(x && w && out8 && scale && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0);
+    const int nv = H / 4;
+    const dim3 grid((unsigned)((n_rows + 3) / 4));
+    if (nv <= 64 * 4) hipLaunchKernelGGL((rmsnorm_f8_kernel<4>), grid, dim3(256), 0, s, x, ldx, n_rows, H, w, eps, out8, scale);
+    else if (nv <= 64 * 16) hipLaunchKernelGGL((rmsnorm_f8_kernel<16>), grid, dim3(256), 0, s, x, ldx, n_rows, H, w, eps, out8, scale);
+    else { blim_set_error("rmsnorm_f8: hidden size %d > 4096 not supported", H); return BLIM_ERR_ARG; }
+    LAUNCH_CHECK("rmsnorm_f8");
+    return BLIM_OK;
+}

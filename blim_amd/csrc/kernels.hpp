@@ -32,3 +32,9 @@ int launch_ce_rows(const float* logits, int64_t ld, int V, const int32_t* labels
 
 // TVG criterion: logits [n_pairs*clips, n_vocab] f32 (row p*clips+c = pair p, clip c), label[p] -> score[p] = mean_c log_softmax[label]
 int launch_tvg_score(const float* logits, int64_t ld, int n_vocab, const int32_t* labels, int n_pairs, int clips, float* score, hipStream_t s);
+
+// ---- fp8 mode (DT_F8): per-row symmetric quantisation to OCP e4m3, scale = absmax / 448 (1 when the row is all zero)
+// in: 16-bit [n_rows, K] (row stride ld, dtype DT_BF16/DT_F16) -> out8 [n_rows, K] + scale [n_rows].  K % 8 == 0, K <= 20480.
+int launch_quant_rows(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, float* scale, hipStream_t s);
+// RMSNorm whose output is quantised per row (same arithmetic as launch_rmsnorm, then the rule above)
+int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const float* w, float eps, uint8_t* out8, float* scale, hipStream_t s);

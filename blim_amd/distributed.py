@@ -43,7 +43,9 @@ def init_distributed_mode(backend: str = None) -> Tuple[int, int, int]:
         return 0, 1, 0
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("BLIM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if "BLIM_FORCE_DEVICE" in os.environ:                 # test aid: several ranks on one GPU (gloo backend only)
+        local = int(os.environ["BLIM_FORCE_DEVICE"])
     if backend == "nccl":
         torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -21,13 +21,13 @@ LIB_PATH = os.environ.get("BLIM_LIB_PATH") or os.path.join(_HERE, "libblim_hip.s
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "blim.h")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
-COMPUTE_DTYPES = {"bf16": 0, "f16": 1}
+COMPUTE_DTYPES = {"bf16": 0, "f16": 1, "f8": 2}     # "f8": e4m3 operands for the big GEMMs + lm_head, fp16 everywhere else
 DEFAULT_COMPUTE_DTYPE = os.environ.get("BLIM_DTYPE", "f16")   # fp16 = the reference's own autocast dtype
 
 
 def torch_dtype_of(name: str):
     import torch
-    return {"bf16": torch.bfloat16, "f16": torch.float16}[name]
+    return {"bf16": torch.bfloat16, "f16": torch.float16, "f8": torch.float16}[name]
 
 
 class BlimError(RuntimeError):
@@ -95,6 +95,8 @@ def load_library(path: str = LIB_PATH):
         "blim_fill_bell_f32": ([vp, i64, u64, C.c_char_p, f32, f32, i32, vp], C.c_int),
         "blim_gemm_bf16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
         "blim_gemm_f16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
+        "blim_quant_rows": ([vp, i64, i64, i32, i32, vp, vp, vp], C.c_int),
+        "blim_gemm_f8": ([vp, i64, vp, vp, vp, i32, i32, i32, vp, i64, vp], C.c_int),
         "blim_timing_enable": ([vp, i32], C.c_int),
         "blim_timing_num_classes": ([], C.c_int),
         "blim_timing_class_name": ([i32], C.c_char_p),
@@ -358,6 +360,28 @@ def segment_mean(logprob, row_start, mode: int = 0):
 def fill_bell_bf16(out, seed: int, name: str, std: float, mean: float = 0.0):
     lib = load_library()
     _check(lib.blim_fill_bell_bf16(_ptr(out), out.numel(), seed, name.encode(), std, mean, _stream()), "blim_fill_bell_bf16")
+    return out
+
+
+def quant_rows(x):
+    """x [M,K] bf16/f16 -> (e4m3 bytes as uint8 [M,K], f32 scale [M] = absmax / 448)."""
+    import torch
+    lib = load_library()
+    M, K = x.shape
+    q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    _check(lib.blim_quant_rows(_ptr(x), x.stride(0), M, K, 0 if x.dtype == torch.bfloat16 else 1, _ptr(q), _ptr(sc), _stream()), "blim_quant_rows")
+    return q, sc
+
+
+def gemm_f8(a8, a_scale, w8, w_scale):
+    """(a8 [M,K] . w8 [N,K]^T) * a_scale[m] * w_scale[n] -> f16 [M,N]; a8 / w8 hold e4m3 bytes (uint8)."""
+    import torch
+    lib = load_library()
+    M, K = a8.shape
+    N = w8.shape[0]
+    out = torch.empty((M, N), dtype=torch.float16, device=a8.device)
+    _check(lib.blim_gemm_f8(_ptr(a8), K, _ptr(a_scale), _ptr(w8), _ptr(w_scale), M, N, K, _ptr(out), N, _stream()), "blim_gemm_f8")
     return out
 
 

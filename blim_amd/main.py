@@ -36,7 +36,7 @@ def get_args_parser():
     p.add_argument("--lora_r", default=8, type=int)
     p.add_argument("--lora_alpha", default=32, type=int)
     # engine-side options
-    p.add_argument("--dtype", default=None, choices=["f16", "bf16"])
+    p.add_argument("--dtype", default=None, choices=["f16", "bf16", "f8"])
     p.add_argument("--max_tokens", default=32768, type=int, help="packed tokens per engine call")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")

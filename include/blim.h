@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 2
+#define BLIM_ABI_VERSION 3
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -34,6 +34,13 @@ extern "C" {
  * float16) and the default of the Python host; BF16 has the same MFMA rate and an 8-bit mantissa. */
 #define BLIM_COMPUTE_BF16 0
 #define BLIM_COMPUTE_F16 1
+/* fp8 mode (BASELINE.json config 5, "fp8 weights on CDNA4 fp8 MFMA"): q/k/v, o, gate|up, down and
+ * lm_head weights are quantised at load to OCP e4m3 with one f32 scale per output row, their input activations per token
+ * (scale = absmax / 448), and multiplied on the block-scaled fp8 MFMA (unit MX block scales, the two f32 scales applied to
+ * the f32 accumulator).  Everything else -- attention, RoPE, residual stream, norms, projector, visual head, criteria -- and
+ * every 16-bit buffer crossing the ABI is fp16 as with BLIM_COMPUTE_F16.  Scores differ from the fp32 reference at the 1e-2
+ * level (reported, not asserted to 1e-3). */
+#define BLIM_COMPUTE_F8 2
 
 typedef struct blim_engine blim_engine;
 
@@ -43,7 +50,7 @@ typedef struct blim_config {
     int32_t mm_hidden_size; /* projector input width (1024) */
     int32_t num_clips;      /* --num_clips, main.py:59 (4) */
     int32_t max_positions;  /* RoPE table length */
-    int32_t compute_dtype;  /* BLIM_COMPUTE_BF16 / BLIM_COMPUTE_F16 */
+    int32_t compute_dtype;  /* BLIM_COMPUTE_BF16 / BLIM_COMPUTE_F16 / BLIM_COMPUTE_F8 */
     float rms_eps, rope_theta;
 } blim_config;
 
@@ -144,6 +151,12 @@ int blim_fill_bell_f32(float* out, int64_t n, uint64_t seed, const char* name, f
 /* C [M, ldc] = A [M, lda] . W [N, K]^T, all bf16 (resp. f16) */
 int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
 int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
+/* fp8 building blocks (tests / bench): per-row e4m3 quantisation of a 16-bit matrix (dtype16 = BLIM_COMPUTE_BF16 / _F16;
+ * out8 [n_rows, K] bytes, scale [n_rows] = absmax / 448, 1 for an all-zero row), and
+ * C f16 [M, ldc] = (A8 [M, lda] . W8 [N, K]^T) * a_scale[m] * w_scale[n] on the block-scaled fp8 MFMA.  K % 128 == 0. */
+int blim_quant_rows(const void* in16, int64_t ld, int64_t n_rows, int32_t K, int32_t dtype16, void* out8, float* scale, void* stream);
+int blim_gemm_f8(const void* A8, int64_t lda, const float* a_scale, const void* W8, const float* w_scale, int32_t M, int32_t N, int32_t K,
+                 void* C, int64_t ldc, void* stream);
 
 /* ---- per-kernel-class timing (hipEvents on the launch stream).  Classes: see blim_timing_class_name. */
 int blim_timing_enable(blim_engine* e, int32_t on);

@@ -13,15 +13,22 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for (M, N, K) in shapes:
     a = torch.empty((M, K), dtype=torch.bfloat16, device="cuda"); w = torch.empty((N, K), dtype=torch.bfloat16, device="cuda")
     eng.fill_bell_bf16(a, 1, "a", 1.0); eng.fill_bell_bf16(w, 1, "w", 0.02)
-    if os.environ.get("BLIM_DTYPE", "f16") == "f16":
+    mode = os.environ.get("BLIM_DTYPE", "f16")
+    if mode in ("f16", "f8"):
         a = a.to(torch.float16); w = w.to(torch.float16)
-    eng.gemm_bf16(a, w)
+    if mode == "f8":                                    # e4m3 operands, per-row scales, block-scaled MFMA (K-step 128)
+        (a8, sa), (w8, sw) = eng.quant_rows(a), eng.quant_rows(w)
+        del a, w
+        run = lambda: eng.gemm_f8(a8, sa, w8, sw)
+    else:
+        run = lambda: eng.gemm_bf16(a, w)
+    run()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        eng.gemm_bf16(a, w)
+        run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"gemm {M}x{N}x{K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s", flush=True)
-    del a, w
+    del run
