@@ -40,7 +40,7 @@ def measured_traffic(kernel_class, dtype):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if epi is None or not files:
         return None
-    name = f"void gemm_kernel<{epi}, {1 if dtype == 'f16' else 0}>(GemmParams)"
+    name = f"void gemm_kernel<{epi}, {dict(bf16=0, f16=1, f8=2)[dtype]}>(GemmParams)"
     try:
         d = json.load(open(files[-1]))
         return d[name]["hbm_bytes_per_launch"] if name in d else None

@@ -66,6 +66,7 @@ struct blim_engine {
     float* rope_cos = nullptr; float* rope_sin = nullptr;
     bool f8 = false;              // BLIM_COMPUTE_F8: c.compute_dtype is then F16 (the 16-bit side of the mode)
     bool f8_ready = false;        // fp8 copies are current
+    int f8_mask = 31;             // which GEMMs run in fp8 (option "f8_mask"): 1 qkv, 2 o_proj, 4 gate|up, 8 down, 16 lm_head
     uint8_t* lm_head8 = nullptr; float* s_lm = nullptr;
     std::map<std::string, bool> loaded;
     std::vector<void*> owned;
@@ -478,16 +479,17 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     float* sx = (float*)e->rscale.p; float* sa = sx ? sx + Tp : nullptr; float* sact = sx ? sx + 2 * Tp : nullptr;
     { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s)); }
     const double tok = (double)T;
+    const bool q8 = e->f8 && (e->f8_mask & 1), o8 = e->f8 && (e->f8_mask & 2), g8 = e->f8 && (e->f8_mask & 4), d8 = e->f8 && (e->f8_mask & 8);
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
         {
             SpanGuard g(e, s, TC_NORM, 0);
-            if (e->f8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
+            if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
             else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s));
         }
         {
             SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n);
-            GemmParams p = e->f8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp(c.compute_dtype, xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
+            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp(c.compute_dtype, xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
             p.bias = l.bqkv; p.pos = b->positions; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
             p.rope_cols = (c.num_heads + c.num_kv_heads) * 128;
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -501,26 +503,26 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = H; a.scale = 0.08838834764831845f;
             TRY(launch_attention(a, e->attn_tr, s));
         }
-        if (e->f8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
+        if (o8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H);
-            GemmParams p = e->f8 ? gp8(a8, H, sa, l.wo8, l.so, T, H, H, resid, H) : gp(c.compute_dtype, attn, H, l.wo, T, H, H, resid, H);
+            GemmParams p = o8 ? gp8(a8, H, sa, l.wo8, l.so, T, H, H, resid, H) : gp(c.compute_dtype, attn, H, l.wo, T, H, H, resid, H);
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         {
             SpanGuard g(e, s, TC_NORM, 0);
-            if (e->f8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
+            if (g8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
             else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s));
         }
         {
             SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I);
-            GemmParams p = e->f8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp(c.compute_dtype, xn, H, l.wgu, T, 2 * I, H, act, I);
+            GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp(c.compute_dtype, xn, H, l.wgu, T, 2 * I, H, act, I);
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
-        if (e->f8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
+        if (d8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I);
-            GemmParams p = e->f8 ? gp8(act8, I, sact, l.wd8, l.sd, T, H, I, resid, H) : gp(c.compute_dtype, act, I, l.wd, T, H, I, resid, H);
+            GemmParams p = d8 ? gp8(act8, I, sact, l.wd8, l.sd, T, H, I, resid, H) : gp(c.compute_dtype, act, I, l.wd, T, H, I, resid, H);
             TRY(launch_gemm(EPI_RESID, p, s));
         }
     }
@@ -556,7 +558,8 @@ extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const 
     const int ntn = (V + 255) / 256;
     HIP_TRY(hipMemsetAsync(e->lab_logit.p, 0, (size_t)n_rows * 4, s));
     uint8_t* h8 = nullptr; float* hs = nullptr;
-    if (e->f8) {
+    const bool l8 = e->f8 && (e->f8_mask & 16);
+    if (l8) {
         TRY(finalize_f8(e));
         h8 = (uint8_t*)e->hsel8.p; hs = (float*)(h8 + (size_t)round_up(n_rows, 256) * H);
         SpanGuard g(e, s, TC_QUANT, 0);
@@ -564,7 +567,7 @@ extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const 
     }
     {
         SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)H * V);
-        GemmParams p = e->f8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0) : gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
+        GemmParams p = l8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0) : gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
     }
@@ -738,6 +741,7 @@ extern "C" int blim_debug_gemm_stamps(void* device_buf) {
 extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     ARG_CHECK(e && key);
     if (!strcmp(key, "attn_tr_read")) { e->attn_tr = value; return BLIM_OK; }
+    if (!strcmp(key, "f8_mask")) { e->f8_mask = value & 31; return BLIM_OK; }
     blim_set_error("unknown option '%s'", key);
     return BLIM_ERR_ARG;
 }

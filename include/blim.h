@@ -174,7 +174,8 @@ int blim_debug_read(blim_engine* e, const char* which, void* dst, int64_t bytes,
  * C staged in LDS, stores issued} to device_buf[workgroup*8 ..] (u64, 100 MHz); NULL turns it off. */
 int blim_debug_gemm_stamps(void* device_buf);
 
-/* tuning switches: "attn_tr_read" (0/1) */
+/* tuning switches: "attn_tr_read" (0/1); "f8_mask" (BLIM_COMPUTE_F8 engines: which GEMMs take fp8 operands, bit 0 qkv, 1 o_proj,
+ * 2 gate|up, 3 down, 4 lm_head; default 31 = all; the others run in fp16 from the retained 16-bit weights) */
 int blim_set_option(blim_engine* e, const char* key, int32_t value);
 
 #ifdef __cplusplus
