@@ -444,8 +444,10 @@ def evaluation(model, data_loader, device, tokenizer, args):
 
     literal = bool(getattr(args, "literal", False))
     full = lambda n, m: torch.full((n, m), -100.0, dtype=torch.float32, device=device)
-    scorer = None if literal else PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
-                                             tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
+    scorer = getattr(args, "_scorer", None)              # test hook: any object with .vtg(pairs, cpn) / .tvg(pairs, cpn)
+    if scorer is None and not literal:
+        scorer = PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
+                            tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
 
     def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):
         if literal:
@@ -465,7 +467,26 @@ def evaluation(model, data_loader, device, tokenizer, args):
     start, end = dist_utils.row_block(num_videos, W, rank)                                       # :213-215
     v2t["candidate_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", False)
     if args.cpn:
-        v2t["candidate_prior"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", True)
+        if W > 1 and not literal:
+            # the v2t prior log P(text | masked video) does not depend on the query video: every rank scores its block of
+            # TEXTS once (N/W forwards instead of rows*k/W), the [N] vector is all-gathered and scattered into the rank's top-k
+            # entries
+            t0, t1 = dist_utils.row_block(num_texts, W, rank)
+            mine = torch.full((num_texts // W + 1,), -100.0, dtype=torch.float32, device=device)
+            if t1 > t0:
+                tp = np.stack([np.zeros(t1 - t0, dtype=np.int64), np.arange(t0, t1, dtype=np.int64)], axis=1)
+                mine[: t1 - t0] = torch.from_numpy(np.asarray(scorer.vtg(tp, True), dtype=np.float32)).to(device)
+            parts = [torch.empty_like(mine) for _ in range(W)]
+            torch.distributed.all_gather(parts, mine)
+            prior = torch.cat(parts)[:num_texts]
+            S = full(num_videos, num_texts)
+            if end > start:
+                pairs = _topk_pairs(v2t_iv2[start:end], start, args.topk, True)
+                r_, c_ = torch.from_numpy(pairs[:, 0]).to(device), torch.from_numpy(pairs[:, 1]).to(device)
+                S[r_, c_] = prior[c_]
+            v2t["candidate_prior"] = S
+        else:
+            v2t["candidate_prior"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", True)
     if finetuned:
         v2t["query_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "tvg", False)
     v_block = (start, end)

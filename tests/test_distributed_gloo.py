@@ -44,3 +44,90 @@ def test_all_gather_row_blocks_world2():
         assert p.exitcode == 0
     for rank, eq, compat_ok, w, r in res:
         assert eq and compat_ok and w == 2 and r == rank
+
+
+# ----------------------------------------------------------------------------- evaluation() control flow at W = 2
+class _FakeScorer:
+    """Deterministic stand-in for PairScorer: a score is a pure function of (pass kind, video, text), like the engine's."""
+
+    def __init__(self):
+        self.calls = []
+
+    def _f(self, pairs, salt, video_matters=True):
+        p = np.asarray(pairs, dtype=np.float64)
+        v = p[:, 0] if video_matters else 0.0
+        return (-(1.0 + salt) - 0.37 * np.sin(1.3 * v + 0.7 * p[:, 1] + salt) - 0.01 * p[:, 1]).astype(np.float32)
+
+    def vtg(self, pairs, cpn=False):
+        self.calls.append(("vtg", bool(cpn), len(pairs)))
+        return self._f(pairs, 5.0 if cpn else 0.0, video_matters=not cpn)
+
+    def tvg(self, pairs, cpn=False):
+        self.calls.append(("tvg", bool(cpn), len(pairs)))
+        return self._f(pairs, 9.0 if cpn else 2.0)
+
+
+class _Loader:
+    def __init__(self, n, bs=4):
+        import types
+        self.n, self.bs = n, bs
+        self.dataset = types.SimpleNamespace(video_vocab=torch.zeros(n, 4, 8), tvg_prefix_length=3)
+
+    def __iter__(self):
+        one = lambda: torch.ones(3, dtype=torch.long)
+        for s in range(0, self.n, self.bs):
+            k = min(self.bs, self.n - s)
+            yield {"video": [torch.zeros(4, 2, 8) for _ in range(k)], "vtg_ids": [one() for _ in range(k)], "vtg_labels": [one() for _ in range(k)],
+                   "vtg_masks": [one() for _ in range(k)], "tvg_ids": [one() for _ in range(k)], "tvg_labels": [one() for _ in range(k)],
+                   "tvg_masks": [one() for _ in range(k)], "tvg_video_labels": torch.arange(s, s + k)}
+
+
+def _eval_args(n, scorer):
+    import types
+    rs = np.random.RandomState(3)
+    sims = rs.randn(n, n).astype(np.float32) + 3 * np.eye(n, dtype=np.float32)
+    return types.SimpleNamespace(topk=3, batch_size_eval=4, num_clips=4, cpn=True, resume="ckpt", eval=True, dataset="MSRVTT",
+                                 iv2_scores={"v2t": torch.from_numpy(sims), "t2v": torch.from_numpy(sims.T.copy())}, _scorer=scorer)
+
+
+def _run_eval(n):
+    import types
+    from blim_amd import retrieval_utils as RU
+    scorer = _FakeScorer()
+    model = types.SimpleNamespace(eval=lambda: None, module=types.SimpleNamespace(set_tvg_prefix_length=lambda k: None))
+    tok = types.SimpleNamespace(pad_token_id=0)
+    t2v, v2t = RU.evaluation(model, _Loader(n), torch.device("cpu"), tok, _eval_args(n, scorer))
+    return t2v, v2t, scorer.calls
+
+
+def _eval_worker(rank, world, port, n, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D.init_distributed_mode(backend="gloo")
+    t2v, v2t, calls = _run_eval(n)
+    out_q.put((rank, {k: v for k, v in t2v.items()}, {k: v for k, v in v2t.items()}, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluation_world2_equals_single_process_and_shards_the_prior_over_texts():
+    n = 11
+    ref_t2v, ref_v2t, ref_calls = _run_eval(n)                       # W = 1 in this process
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, t2v, v2t, calls in res:
+        for k in ref_t2v:
+            assert np.array_equal(t2v[k], ref_t2v[k]), ("t2v", k, rank)
+        for k in ref_v2t:
+            assert np.array_equal(v2t[k], ref_v2t[k]), ("v2t", k, rank)
+        # the v2t prior pass scored this rank's TEXT block once (6 and 5 texts), not rows x topk pairs
+        prior_calls = [c for c in calls if c[0] == "vtg" and c[1]]
+        assert prior_calls == [("vtg", True, 6 if rank == 0 else 5)]
+    assert ("vtg", True, n * 3) in ref_calls                           # single process: all top-k pairs (deduplicated inside the scorer)
