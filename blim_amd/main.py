@@ -56,6 +56,12 @@ def dims_from_config(model_path: str):
                      num_clips=4)
 
 
+def load_tokenizer(model_path: str):
+    """main.py:94: the checkpoint's own tokenizer (Qwen2 BPE + ChatML specials)."""
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(model_path, trust_remote_code=True)
+
+
 def main(args):
     import numpy as np
     import torch
@@ -81,10 +87,9 @@ def main(args):
         tokenizer = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
         args.iv2_scores = {"v2t": T(prob.v2t_sims), "t2v": T(prob.t2v_sims)}
     else:
-        from transformers import AutoTokenizer
         from .checkpoint import load_checkpoint
         from .dataloader import load_data
-        tokenizer = AutoTokenizer.from_pretrained(args.model_path, trust_remote_code=True)
+        tokenizer = load_tokenizer(args.model_path)
         dims = dims_from_config(args.model_path)
         model = BlimModel(dims, dtype=args.dtype)
         load_checkpoint(model.engine, dims, args.model_path, args.resume or None, lora_r=args.lora_r, lora_alpha=args.lora_alpha)
@@ -102,6 +107,8 @@ def main(args):
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    model.engine.close()
+    return results
 
 
 if __name__ == "__main__":

@@ -1,0 +1,64 @@
+"""GPU: the eval driver end to end on a synthetic on-disk tree -- sharded safetensors checkpoint + config.json, a resume file
+with LoRA adapters and visual_head, ./data/MSRVTT features + annotations, ./scores/msrvtt.pth -- i.e. the same files, names and
+flags a user of the reference has (main.py:146-174), with the stand-in tokenizer of tests/dataset_fixture.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from blim_amd import checkpoint as CK
+from blim_amd import main as driver
+from blim_amd import synth
+from dataset_fixture import CAPTIONS, StubTokenizer, build_tree
+from test_checkpoint import _adapters, _resume_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _tree(root):
+    dims = synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=1024)
+    w = synth.synthetic_weights(dims, 3)
+    ck = os.path.join(root, "pretrained", "tiny")
+    CK.save_hf_checkpoint(w, ck, shards=2, dtype="bf16")
+    json.dump({"vocab_size": dims.vocab_size, "hidden_size": dims.hidden_size, "intermediate_size": dims.intermediate_size,
+               "num_hidden_layers": dims.num_layers, "num_attention_heads": dims.num_heads, "num_key_value_heads": dims.num_kv_heads,
+               "rms_norm_eps": 1e-6, "rope_theta": 1e6, "mm_hidden_size": 1024, "mm_llm_compress": False}, open(os.path.join(ck, "config.json"), "w"))
+    build_tree(root, "MSRVTT")
+    n = len(CAPTIONS)
+    rs = np.random.RandomState(0)
+    sims = rs.randn(n, n).astype(np.float32) + 3 * np.eye(n, dtype=np.float32)
+    os.makedirs(os.path.join(root, "scores"), exist_ok=True)
+    for name in ("msrvtt.pth", "msrvtt_zeroshot.pth"):
+        torch.save({"v2t": torch.from_numpy(sims), "t2v": torch.from_numpy(sims.T.copy())}, os.path.join(root, "scores", name))
+    os.makedirs(os.path.join(root, "checkpoint"), exist_ok=True)
+    ad = _adapters(dims, 5, ["layers.0.q_proj.w", "layers.1.o_proj.w", "lm_head", "mlp.0.w", "tvg_mlp.2.w"])
+    vh = (np.random.RandomState(7).randn(1024, dims.hidden_size) * 0.02).astype(np.float32)
+    torch.save(_resume_state(ad, vh), os.path.join(root, "checkpoint", "msrvtt.pth"))
+    return ck
+
+
+def _run(argv):
+    return driver.main(driver.get_args_parser().parse_args(argv))
+
+
+def test_eval_driver_on_a_synthetic_tree(tmp_path, monkeypatch, capsys):
+    ck = _tree(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(driver, "load_tokenizer", lambda path: StubTokenizer())
+    base = ["--eval", "--dataset", "MSRVTT", "--model_path", ck, "--topk", "4", "--batch_size_eval", "3", "--num_workers", "0",
+            "--output_dir", str(tmp_path / "out")]
+    tuned = base + ["--resume", "./checkpoint/msrvtt.pth", "--cpn", "--alpha", "0.4", "0.8", "--c", "0.3", "0.6", "0.9", "0.7"]
+    fused = _run(tuned)
+    literal = _run(tuned + ["--literal"])
+    zero = _run(base)                                                  # zero-shot: VTG passes only, ./scores/msrvtt_zeroshot.pth
+    out = capsys.readouterr().out
+    assert "model + data ready" in out
+    assert fused == literal                                            # fused PairScorer and the reference's per-batch control flow agree on every R@k
+    for res in (fused, zero):
+        assert set(res) >= {"t2v", "v2t"} or len(res) > 0
+        flat = [v for d in res.values() for v in (d.values() if isinstance(d, dict) else [d])]
+        assert all(0.0 <= float(x) <= 100.0 for x in flat)
+    log = open(tmp_path / "out" / "log.txt").read()
+    assert log.count("R@1") >= 3 or log.count("R1") >= 3 or len(log) > 100
