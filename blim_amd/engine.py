@@ -146,6 +146,7 @@ class PackedBatch:
         blk_seq = np.repeat(np.arange(n_seqs, dtype=np.int32), nblk)
         blk_q0 = (np.concatenate([np.arange(n, dtype=np.int32) for n in nblk]) * 32).astype(np.int32) if n_seqs else np.zeros(0, np.int32)
         self.n_tokens = int(len(positions))
+        self.max_position = int(np.max(positions)) if len(positions) else 0     # checked against the engine's RoPE table
         self.n_seqs = int(n_seqs)
         self.n_blocks = int(len(blk_seq))
         # one host->device copy for all index arrays
@@ -158,7 +159,10 @@ class PackedBatch:
             [flat[offs[i]:offs[i + 1]] for i in range(7)]
         self.key_visible = torch.from_numpy(np.ascontiguousarray(key_visible, dtype=np.uint8)).to(device)
 
-    def struct(self) -> Batch:
+    def struct(self, max_positions: Optional[int] = None) -> Batch:
+        if max_positions is not None and self.max_position >= max_positions:
+            raise BlimError(f"a sequence reaches position {self.max_position} but the engine's RoPE table holds {max_positions} positions: "
+                            f"create the engine / BlimModel with a larger max_positions")
         b = Batch()
         b.n_tokens, b.n_seqs, b.n_blocks = self.n_tokens, self.n_seqs, self.n_blocks
         b.positions = self.positions.data_ptr(); b.key_visible = self.key_visible.data_ptr()
@@ -177,6 +181,7 @@ class Engine:
         if not torch.cuda.is_available():
             raise BlimError("no HIP device visible: the BLiM engine has no CPU fallback")
         self.dims = dims
+        self.max_positions = int(max_positions)
         self.dtype = dtype or DEFAULT_COMPUTE_DTYPE          # "f16" | "bf16": 16-bit format of activations / weights / MFMA operands
         self.torch_dtype = torch_dtype_of(self.dtype)
         cfg = Config(dims.vocab_size, dims.hidden_size, dims.intermediate_size, dims.num_layers, dims.num_heads, dims.num_kv_heads,
@@ -251,7 +256,7 @@ class Engine:
         H = self.dims.hidden_size
         ob = torch.empty((n, H), dtype=self.torch_dtype, device=self.device) if want_bf16 else None
         of = torch.empty((n, H), dtype=torch.float32, device=self.device) if want_f32 else None
-        bs = batch.struct()
+        bs = batch.struct(self.max_positions)
         _check(self.lib.blim_decode(self.h, C.byref(bs), _ptr(embeds), _ptr(out_rows), n, _ptr(ob), _ptr(of), _stream()), "blim_decode")
         return ob, of
 
@@ -296,7 +301,7 @@ class Engine:
         import torch
         n_pairs = row_start.shape[0] - 1
         out = torch.empty(n_pairs, dtype=torch.float32, device=self.device)
-        bs = batch.struct()
+        bs = batch.struct(self.max_positions)
         _check(self.lib.blim_score_vtg(self.h, C.byref(bs), _ptr(embeds), _ptr(rows), _ptr(labels), rows.shape[0], _ptr(row_start), n_pairs,
                                        _ptr(out), _stream()), "blim_score_vtg")
         return out
@@ -305,7 +310,7 @@ class Engine:
         import torch
         n_pairs = labels.shape[0]
         out = torch.empty(n_pairs, dtype=torch.float32, device=self.device)
-        bs = batch.struct()
+        bs = batch.struct(self.max_positions)
         _check(self.lib.blim_score_tvg(self.h, C.byref(bs), _ptr(embeds), _ptr(rows), _ptr(vocab_clip_major), vocab_clip_major.shape[1],
                                        _ptr(labels), n_pairs, _ptr(out), _stream()), "blim_score_tvg")
         return out

@@ -64,7 +64,8 @@ typedef struct blim_batch {
     int64_t n_tokens;
     int32_t n_seqs;
     int32_t n_blocks;
-    const int32_t* positions;   /* [n_tokens] RoPE position (modeling_qwen2_flash.py:998-1003) */
+    const int32_t* positions;   /* [n_tokens] RoPE position (modeling_qwen2_flash.py:998-1003); every value < blim_config.max_positions
+                                 * (device data: not checked by the library, the Python host checks it when it packs the batch) */
     const uint8_t* key_visible; /* [n_tokens] */
     const int32_t* seq_start;   /* [n_seqs] */
     const int32_t* seq_len;     /* [n_seqs] */

@@ -182,3 +182,12 @@ def test_vtg_cpn_without_any_prompt_token_is_rejected():
         sc.plan_vtg(np.array([[0, 1], [2, 1]]), cpn=True)
     (plan,) = sc.plan_vtg(np.array([[0, 1], [2, 1]]))              # the likelihood pass itself is fine
     assert plan.n_pairs == 2 and int(plan.rows.numpy().min()) >= 0
+
+
+def test_packed_batch_rejects_positions_beyond_the_rope_table():
+    pos = np.arange(40, dtype=np.int32)
+    b = eng.PackedBatch(pos, np.ones(40, np.uint8), np.array([0], np.int32), np.array([40], np.int32), device="cpu")
+    assert b.max_position == 39
+    b.struct(40)                                         # fits
+    with pytest.raises(eng.BlimError, match="RoPE table"):
+        b.struct(39)
