@@ -1,0 +1,86 @@
+"""GPU (-m gpu): seeded random problem shapes through the fused PairScorer AND the literal reference-shaped API, each compared
+entry by entry with the numpy oracle's restatement of compute_*_scores_x (oracle/blim_oracle.py; itself pinned to the reference
+by tests/golden).  Covers the ragged edge cases the golden fixtures do not: a single video/text, top-k larger than N, one-token
+captions, one token per clip, batch size 1, headline-shaped rows without a prompt."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from blim_amd import retrieval_utils as RU
+from blim_amd import synth
+from blim_amd.modeling import BlimModel, DDPLike
+from oracle import blim_oracle as O
+
+pytestmark = pytest.mark.gpu
+D = dict(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+PASSES = [("v2t", "vtg", False), ("v2t", "vtg", True), ("v2t", "tvg", False), ("t2v", "vtg", False), ("t2v", "tvg", False), ("t2v", "tvg", True)]
+#        seed  n  tok/clip  text_len  topk  bs  reference_layout
+CASES = [(101, 1, 8, (3, 6), 4, 3, True),        # one video, one text; top-k > N
+         (102, 5, 1, (1, 1), 2, 1, True),        # one token per clip, one-token captions, batch size 1
+         (103, 4, 3, (1, 12), 7, 5, True),       # top-k > N, ragged lengths
+         (104, 6, 8, (2, 9), 3, 2, True),
+         (105, 3, 5, (4, 4), 3, 3, False),       # headline-shaped rows (no prompt tokens): VTG prior undefined -> skipped
+         (106, 7, 2, (1, 5), 5, 4, True),
+         (107, 3, 40, (33, 70), 3, 2, True),     # captions across the 32- and 64-token query-block boundaries, 160-token video prefix
+         (108, 2, 64, (60, 64), 2, 2, True),     # reference-sized rows: 256 video tokens
+         (109, 9, 4, (1, 33), 9, 4, True),       # dense: every candidate of every query
+         (110, 4, 8, (31, 33), 4, 3, False)]     # headline-shaped, suffixes straddling one query block
+
+
+@pytest.fixture(scope="module")
+def models():
+    dims = synth.ModelDims(**D)
+    w = synth.synthetic_weights(dims, 9)
+    model = BlimModel(dims, max_positions=512, dtype="f16")
+    model.engine.load_weights(w)
+    om = O.OracleModel(O.OracleConfig(**D), w)
+    yield dims, model, om
+    model.engine.close()
+
+
+@pytest.mark.parametrize("seed,n,tpc,tl,topk,bs,layout", CASES)
+def test_random_shapes_fused_and_literal_vs_oracle(models, seed, n, tpc, tl, topk, bs, layout):
+    dims, model, om = models
+    prob = synth.make_problem(seed, n, dims, tok_per_clip=tpc, text_len=tl, reference_layout=layout)
+    model.set_tvg_prefix_length(prob.tvg_prefix_length); om.set_tvg_prefix_length(prob.tvg_prefix_length)
+    model.clear_cache()
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    ov = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+    ot = O.padding_ids(prob.tvg_ids, prob.tvg_labels, prob.tvg_masks, synth.PAD_ID)
+    video = [torch.from_numpy(v) for v in prob.video]
+    vocab, vlab = torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels)
+    ddp, dev = DDPLike(model), model.device
+    args = types.SimpleNamespace(topk=topk, batch_size_eval=bs, num_clips=dims.num_clips)
+    scorer = RU.PairScorer(ddp, vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], video, vocab, vlab, dims.num_clips, max_tokens=600)
+    for direction, ft, cpn in PASSES:
+        if not layout and ft == "vtg" and cpn:
+            with pytest.raises(ValueError):
+                scorer.vtg(np.array([[0, 0]]), True)
+            continue
+        qv = direction == "v2t"
+        sims = prob.v2t_sims if qv else prob.t2v_sims
+        o_ids, o_lab, o_msk = ov if ft == "vtg" else ot
+        fn_o = O.compute_v2t_scores_x if qv else O.compute_t2v_scores_x
+        want = fn_o(np.full((n, n), -100.0, np.float32), sims, 0, o_ids, o_msk, o_lab, prob.video, prob.video_vocab, prob.tvg_video_labels,
+                    om, topk, bs, dims.num_clips, ft, cpn)
+        m = want != -100.0
+        # fused
+        pairs = RU._topk_pairs(torch.from_numpy(sims), 0, topk, qv)
+        sc = scorer.vtg(pairs, cpn) if ft == "vtg" else scorer.tvg(pairs, cpn)
+        S = np.full((n, n), -100.0, np.float32)
+        r, c = (pairs[:, 0], pairs[:, 1]) if qv else (pairs[:, 1], pairs[:, 0])
+        S[r, c] = sc
+        assert np.array_equal(S != -100.0, m), (direction, ft, cpn)
+        np.testing.assert_allclose(S[m], want[m], rtol=1e-3, err_msg=f"fused {direction} {ft} cpn={cpn}")
+        # literal API (the reference's per-batch control flow)
+        ids, lab, msk = vtg if ft == "vtg" else tvg
+        fn = RU.compute_v2t_scores_x if qv else RU.compute_t2v_scores_x
+        L = fn(torch.full((n, n), -100.0, device=dev), torch.from_numpy(sims), 0, ids, msk, lab, video, vocab.to(dev), vlab, ddp, dev, args,
+               forward_type=ft, cpn=cpn).cpu().numpy()
+        assert np.array_equal(L != -100.0, m), (direction, ft, cpn)
+        np.testing.assert_allclose(L[m], want[m], rtol=1e-3, err_msg=f"literal {direction} {ft} cpn={cpn}")
