@@ -222,9 +222,15 @@ class PairScorer:
 
     # ---- planning (host) ------------------------------------------------------------------------
     def plan_vtg(self, pairs: np.ndarray, cpn: bool = False) -> List[Plan]:
-        """pairs: [P, 2] (video j, text i).  cpn=True: video keys masked -> the score depends on the text only."""
+        return list(self.iter_vtg(pairs, cpn))
+
+    def plan_tvg(self, pairs: np.ndarray, cpn: bool = False) -> List[Plan]:
+        return list(self.iter_tvg(pairs, cpn))
+
+    def iter_vtg(self, pairs: np.ndarray, cpn: bool = False):
+        """pairs: [P, 2] (video j, text i).  cpn=True: video keys masked -> the score depends on the text only.
+        Yields one Plan per engine call, so that packing call k+1 (host) overlaps call k (device)."""
         pairs = np.asarray(pairs, dtype=np.int64)
-        plans: List[Plan] = []
         if cpn:
             texts, inv = np.unique(pairs[:, 1], return_inverse=True)
             nv = int(np.prod(self.video[int(pairs[0, 0])].shape[:2]))
@@ -252,7 +258,7 @@ class PairScorer:
             n_vid = nv if j is None else int(self.video_feat(j, False).shape[0])
             need = len(pre) + (0 if j is None else n_vid) + len(post) + sum(max(len(self.vtg_split[i][2]) - 1, 0) for i in texts_g)
             if st.n_tok and st.n_tok + need > self.max_tokens:
-                plans.append(st.finish()); st = _PackState(self, "vtg")
+                yield st.finish(); st = _PackState(self, "vtg")
             # prefix sequence
             if j is None:
                 if len(pre) + len(post) == 0:
@@ -275,14 +281,12 @@ class PairScorer:
                     rows += list(range(s0, s0 + len(body)))
                 st.add_pair(rows, resp.astype(np.int32), outs)
         if st.n_pairs:
-            plans.append(st.finish())
-        return plans
+            yield st.finish()
 
-    def plan_tvg(self, pairs: np.ndarray, cpn: bool = False) -> List[Plan]:
+    def iter_tvg(self, pairs: np.ndarray, cpn: bool = False):
         """pairs: [P, 2] (video j, text i); score = log P(video j | text i) (mean over clips)."""
         pairs = np.asarray(pairs, dtype=np.int64)
         C = self.num_clips
-        plans: List[Plan] = []
         st = _PackState(self, "tvg")
         if cpn:
             # prior depends on (prompt length, last prompt token, first tvg_prefix_length tokens, video) only
@@ -301,7 +305,7 @@ class PairScorer:
                     _, plen_full, last_tok, j = k
                     if p0 is None or st.n_tok + 4 > self.max_tokens:
                         if st.n_pairs:
-                            plans.append(st.finish()); st = _PackState(self, "tvg")
+                            yield st.finish(); st = _PackState(self, "tvg")
                         p0 = st.add_seq(ptoks, np.arange(len(ptoks)), np.ones(len(ptoks), np.uint8), None)
                     fo = st.add_feat(self.video_feat(j, True))
                     toks = np.concatenate([[last_tok], -(1 + fo + np.arange(C - 1))])
@@ -316,7 +320,7 @@ class PairScorer:
                 pr = self.tvg_split[i]
                 if i != i_prev or st.n_tok + (C - 1) > self.max_tokens:
                     if st.n_tok and st.n_tok + len(pr) + (C - 1) > self.max_tokens:
-                        plans.append(st.finish()); st = _PackState(self, "tvg")
+                        yield st.finish(); st = _PackState(self, "tvg")
                     p0 = st.add_seq(pr, np.arange(len(pr)), np.ones(len(pr), np.uint8), None); plen = len(pr); i_prev = i
                 fo = st.add_feat(self.video_feat(j, True))
                 rows = [p0 + plen - 1]
@@ -325,8 +329,7 @@ class PairScorer:
                     rows += list(range(s0, s0 + C - 1))
                 st.add_pair(rows, np.array([self.tvg_video_labels[j]], np.int32), np.array([idx]))
         if st.n_pairs:
-            plans.append(st.finish())
-        return plans
+            yield st.finish()
 
     # ---- execution (device) ---------------------------------------------------------------------
     def run(self, plan: Plan):
@@ -336,20 +339,22 @@ class PairScorer:
             return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
         return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)
 
-    def score(self, plans: List[Plan], n_requested: int) -> np.ndarray:
+    def score(self, plans, n_requested: int) -> np.ndarray:
+        """plans: list or generator of Plan.  Engine calls are asynchronous, so with a generator the host packs plan k+1 while
+        the device runs plan k; the scores are copied back once, at the end."""
         out = np.full(n_requested, np.nan, dtype=np.float32)
-        results = [self.run(p) for p in plans]
-        for p, r in zip(plans, results):
+        done = [(p.out_index, self.run(p)) for p in plans]
+        for out_index, r in done:
             sc = r.float().cpu().numpy()
-            for k, outs in enumerate(p.out_index):
+            for k, outs in enumerate(out_index):
                 out[outs] = sc[k]
         return out
 
     def vtg(self, pairs, cpn=False) -> np.ndarray:
-        return self.score(self.plan_vtg(pairs, cpn), len(pairs))
+        return self.score(self.iter_vtg(pairs, cpn), len(pairs))
 
     def tvg(self, pairs, cpn=False) -> np.ndarray:
-        return self.score(self.plan_tvg(pairs, cpn), len(pairs))
+        return self.score(self.iter_tvg(pairs, cpn), len(pairs))
 
 
 class _PackState:
