@@ -85,7 +85,10 @@ def main(args):
         T = torch.from_numpy
         loader = synth.ProblemLoader(prob, args.batch_size_eval)
         tokenizer = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
-        args.iv2_scores = {"v2t": T(prob.v2t_sims), "t2v": T(prob.t2v_sims)}
+        # get_recall treats a matrix holding an exact 0 as "not computed" (training_utils.py:174-175); the synthetic first-stage
+        # scores are sums of integers and hit 0.0 about once per 10^5 entries, real InternVideo2 similarities do not
+        nz = lambda a: np.where(a == 0, np.float32(1e-6), a)
+        args.iv2_scores = {"v2t": T(nz(prob.v2t_sims)), "t2v": T(nz(prob.t2v_sims))}
     else:
         from .checkpoint import load_checkpoint
         from .dataloader import load_data
