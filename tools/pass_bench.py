@@ -81,6 +81,14 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / a.reps * 1e3
             assert all(torch.isfinite(o).all() for o in outs)
+            model.engine.timing_enable(True)
+            for p in plans:
+                scorer.run(p)
+            rep = model.engine.timing_report()
+            model.engine.timing_enable(False)
+            tot_cls = sum(v["ms"] for v in rep.values())
+            shares = {k: round(100 * v["ms"] / tot_cls, 1) for k, v in rep.items() if v["ms"] > 0.005 * tot_cls}
+            print(f"[{shape}] {name}: kernel-class shares % {shares}", file=sys.stderr, flush=True)
             n_tok = sum(p.n_tokens for p in plans)
             n_rows = sum(p.n_rows for p in plans) if kind == "vtg" else 0
             flops = LAYERS * FLOP_TOKEN_LAYER * n_tok + FLOP_HEAD_ROW * n_rows
