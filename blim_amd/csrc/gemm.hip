@@ -139,6 +139,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K * ES / (BK * 2);   // K-steps of 128 bytes per row
+    // fp8: this thread's dequantisation scale (threads 0-255: the tile's rows, 256-511: its columns), requested before the K loop
+    // so that its latency is not exposed in front of the epilogue
+    float f8_scale = 0.f;
+    if constexpr (DT == DT_F8) f8_scale = tid < 256 ? p.row_scale[min(row0 + tid, p.M - 1)] : p.col_scale[min(col0 + tid - 256, p.N - 1)];
     stamp(1);
     {
         const int grp = wave >> 2;  // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     if constexpr (DT == DT_F8) {
         // dequantise: acc[row][col] *= row_scale[row] * col_scale[col].  The tile's 256 + 256 scales go through LDS (free now).
         float* sc = (float*)smem;
-        sc[tid] = tid < 256 ? p.row_scale[min(row0 + tid, p.M - 1)] : p.col_scale[min(col0 + tid - 256, p.N - 1)];
+        sc[tid] = f8_scale;
         __syncthreads();
         float cs[4];
 #pragma unroll
