@@ -23,35 +23,6 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-// 4x4 transpose inside each quad of lanes: in: lane c holds v[j] = X[row j][col c];
-// out: lane c holds v[j] = X[row c][col j].  Two butterfly stages of DPP quad_perm moves (no LDS traffic).
-__device__ __forceinline__ float quad_xor1(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ float quad_xor2(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-}
-__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int lane) {
-    const bool odd = lane & 1;
-    float s0 = odd ? v0 : v1, s1 = odd ? v2 : v3;
-    float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
-    if (odd) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
-    const bool hi = lane & 2;
-    s0 = hi ? v0 : v2; s1 = hi ? v1 : v3;
-    r0 = quad_xor2(s0); r1 = quad_xor2(s1);
-    if (hi) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
-}
-
-// all-reduce over the 16 lanes of a DPP row (lanes sharing lane>>4) by rotations 8,4,2,1: no LDS crossbar traffic
-template <int N> __device__ __forceinline__ float row_ror(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); return fmaxf(v, row_ror<1>(v));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); return v + row_ror<1>(v);
-}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
@@ -172,6 +143,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 }
             }
         };
+        // The W fragment is passed as the MFMA's first operand, so a 16x16 accumulator fragment holds C TRANSPOSED in the hardware
+        // layout: lane l owns C row (l & 15) and the four consecutive C columns 4 (l >> 4) + {0..3} of fragment (mi, ni).  The
+        // epilogues can then pack and stage 8 / 16 contiguous bytes per lane without any cross-lane transpose.
         auto compute = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_s_setprio(1);
             if constexpr (DT == DT_F8) {
@@ -179,7 +153,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)   // e4m3 x e4m3, MX block scales 2^0 (0x7f): 32 MFMAs of 128-deep K per step
-                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa8[mi], fb8[ni], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni], fa8[mi], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -187,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
-                            acc[mi][ni] = mfma16<DT>(fa[ks][mi], fb[ks][ni], acc[mi][ni]);
+                            acc[mi][ni] = mfma16<DT>(fb[ks][ni], fa[ks][mi], acc[mi][ni]);
             }
             __builtin_amdgcn_s_setprio(0);
         };
@@ -332,49 +306,51 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         float* sc = (float*)smem;
         sc[tid] = f8_scale;
         __syncthreads();
-        float cs[4];
+        float4 cs[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) cs[ni] = sc[256 + 64 * wn + 16 * ni + (lane & 15)];
+        for (int ni = 0; ni < 4; ++ni) cs[ni] = *(const float4*)(sc + 256 + 64 * wn + 16 * ni + 4 * (lane >> 4));
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
-            const float4 rs = *(const float4*)(sc + 128 * wm + 16 * mi + 4 * (lane >> 4));
+            const float rs = sc[128 * wm + 16 * mi + (lane & 15)];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                acc[mi][ni][0] *= rs.x * cs[ni]; acc[mi][ni][1] *= rs.y * cs[ni]; acc[mi][ni][2] *= rs.z * cs[ni]; acc[mi][ni][3] *= rs.w * cs[ni];
+                acc[mi][ni][0] *= rs * cs[ni].x; acc[mi][ni][1] *= rs * cs[ni].y; acc[mi][ni][2] *= rs * cs[ni].z; acc[mi][ni][3] *= rs * cs[ni].w;
             }
         }
         __syncthreads();
     }
 
     if constexpr (EPI == EPI_LSE) {
-        // accumulators as the MFMA leaves them: lane holds col (lane&15) of frag ni, rows 4*(lane>>4)+j of frag mi.
+        // lane (r = lane & 15, q = lane >> 4) holds row 16 mi + r of the wave's tile and its columns 16 ni + 4 q + {0..3}: sixteen
+        // logits of one row per mi; the row's other 48 columns of this wave sit in lanes r + 16, r + 32, r + 48.
         float2* red = (float2*)smem;  // [4 wn][256 rows]
         const int q4 = lane >> 4;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
+            const int rl = 128 * wm + 16 * mi + fr;          // row inside the tile
+            const int row = row0 + rl;
+            const int lab = (row < p.M) ? p.labels[row] : -1;
+            float v[4][4];
+            float mx = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rl = 128 * wm + 16 * mi + 4 * q4 + j;  // row inside the tile
-                const int row = row0 + rl;
-                const int lab = (row < p.M) ? p.labels[row] : -1;
-                float v[4];
-                float mx = -INFINITY;
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int col = wcol0 + 16 * ni + fr;
-                    v[ni] = (col < p.N) ? acc[mi][ni][j] : -INFINITY;
-                    if (col == lab) p.label_logit[row] = v[ni];
-                    mx = fmaxf(mx, v[ni]);
+                for (int j = 0; j < 4; ++j) {
+                    const int col = wcol0 + 16 * ni + 4 * q4 + j;
+                    v[ni][j] = (col < p.N) ? acc[mi][ni][j] : -INFINITY;
+                    if (col == lab) p.label_logit[row] = v[ni][j];
+                    mx = fmaxf(mx, v[ni][j]);
                 }
-                mx = row16_max(mx);
-                float sm = 0.f;
-                if (mx > -INFINITY) {
+            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sm = 0.f;
+            if (mx > -INFINITY) {
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) sm += __expf(v[ni] - mx);
-                }
-                sm = row16_sum(sm);
-                if (fr == 0) red[wn * 256 + rl] = make_float2(mx, sm);
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sm += __expf(v[ni][j] - mx);
             }
+            sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+            if (q4 == 0) red[wn * 256 + rl] = make_float2(mx, sm);
         }
         __syncthreads();
         if (tid < 256) {
@@ -395,23 +371,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     } else {
         // ---- C tile staged through LDS so that global stores are whole rows (512 B / 1 KiB per row), 16 B per lane.
         // (Direct stores from the MFMA layout touch 32-B row segments: measured 10-13 us per tile, 12 % of a K=3584 tile.)
-        const int tq = (lane & 15) >> 2;        // which 4-col group of the fragment this lane owns after the transpose
-        const int rsub = 4 * (lane >> 4) + (lane & 3);
+        const int tq = lane >> 4;               // which 4-col group of a fragment this lane owns
+        const int rsub = lane & 15;             // which of its 16 rows
         __syncthreads();                        // every wave is out of the main loop: LDS is reusable
         if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV || EPI == EPI_SWIGLU) {
             constexpr int NC = (EPI == EPI_SWIGLU) ? 128 : 256;   // output columns of this tile
-            constexpr int RS = NC * 2 + 32;                       // LDS row stride (bytes), = 32 mod 128: conflict-free ds_write_b64
+            constexpr int RS = NC * 2 + 16;                       // LDS row stride (bytes), = 16 mod 256: the 16 rows x 2 column groups of a
+                                                                  // half-wave's ds_write_b64 cover all 64 banks once
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int rl = 128 * wm + 16 * mi + rsub;         // row inside the tile
                 const int row = min(row0 + rl, p.M - 1);
                 float t[4][4];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
-                    quad_transpose(v0, v1, v2, v3, lane);
-                    t[ni][0] = v0; t[ni][1] = v1; t[ni][2] = v2; t[ni][3] = v3;
-                }
+                for (int ni = 0; ni < 4; ++ni) { t[ni][0] = acc[mi][ni][0]; t[ni][1] = acc[mi][ni][1]; t[ni][2] = acc[mi][ni][2]; t[ni][3] = acc[mi][ni][3]; }
                 char* lrow = smem + rl * RS;
                 if constexpr (EPI == EPI_BF16) {
                     if (p.bias == nullptr && p.act == 0) {         // wave-uniform fast path: convert and stage
@@ -499,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }
             stamp(5);
         } else {  // EPI_RESID / EPI_F32: f32 tile, two passes of 128 rows
-            constexpr int RS = 1024 + 32;
+            constexpr int RS = 1024 + 16;                         // = 16 mod 256: 16 rows of a ds_write_b128 lane group on distinct banks
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {
                 if (wm == h) {
@@ -508,9 +481,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         char* lrow = smem + (16 * mi + rsub) * RS;
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
-                            float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
-                            quad_transpose(v0, v1, v2, v3, lane);
-                            *(float4*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 4) = make_float4(v0, v1, v2, v3);
+                            *(float4*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 4) = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
                         }
                     }
                 }
