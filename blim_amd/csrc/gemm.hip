@@ -458,8 +458,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             const int oc0 = (EPI == EPI_SWIGLU) ? col0 / 2 : col0;
             const int seg = tid % LPR;
             const int oc = oc0 + 8 * seg;
-#pragma unroll 4
-            for (int rl = tid / LPR; rl < 256; rl += NTHREADS / LPR) {
+            constexpr int RPP = NTHREADS / LPR;                   // rows per pass of the workgroup
+            if (row0 + 256 <= p.M && oc0 + NC <= n_out && (p.ldc & 7) == 0) {   // interior tile: all LDS reads, then all stores, no branches
+                uint4 v[256 / RPP];
+                const char* lsrc = smem + (tid / LPR) * RS + seg * 16;
+#pragma unroll
+                for (int i = 0; i < 256 / RPP; ++i) v[i] = *(const uint4*)(lsrc + i * RPP * RS);
+                bf16_t* out = (bf16_t*)p.C + (int64_t)(row0 + tid / LPR) * p.ldc + oc;
+#pragma unroll
+                for (int i = 0; i < 256 / RPP; ++i) *(uint4*)(out + (int64_t)i * RPP * p.ldc) = v[i];
+            } else
+#pragma unroll 1
+            for (int rl = tid / LPR; rl < 256; rl += RPP) {
                 const int row = row0 + rl;
                 if (row >= p.M || oc >= n_out) continue;
                 const uint4 v = *(const uint4*)(smem + rl * RS + seg * 16);
