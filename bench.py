@@ -42,8 +42,11 @@ def measured_traffic(kernel_class, dtype):
         return None
     name = f"void gemm_kernel<{epi}, {dict(bf16=0, f16=1, f8=2)[dtype]}>(GemmParams)"
     try:
-        d = json.load(open(files[-1]))
-        return d[name]["hbm_bytes_per_launch"] if name in d else None
+        for f in reversed(files):                                   # newest summary that profiled this kernel
+            d = json.load(open(f))
+            if name in d:
+                return d[name]["hbm_bytes_per_launch"]
+        return None
     except Exception:
         return None
 
