@@ -84,3 +84,30 @@ def merge_row_blocks(S, block: Tuple[int, int], world: int, compat_offset: bool 
         # all_reduce(SUM) of W matrices that hold -100 wherever the rank did not compute (retrieval_utils.py:252-262)
         out = torch.where(out == -100.0, out * world, out - 100.0 * (world - 1))
     return out
+
+
+def merge_row_blocks_many(mats, blocks, world: int, compat_offset: bool = False):
+    """Same as merge_row_blocks for several matrices at once: ONE all-gather of the concatenated row blocks (the <= 6 score
+    matrices of an evaluation travel together).  mats[i]: [N_i, M_i]; blocks[i]: this rank's row range."""
+    import torch
+    d = _dist()
+    if world == 1 or not is_dist_avail_and_initialized() or not mats:
+        return list(mats)
+    parts, shapes = [], []
+    for S, (s, e) in zip(mats, blocks):
+        N, M = S.shape
+        step = N // world + 1
+        mine = torch.full((step, M), -100.0, dtype=torch.float32, device=S.device)
+        if e > s:
+            mine[: e - s] = S[s:e]
+        parts.append(mine.reshape(-1)); shapes.append((N, M, step))
+    flat = torch.cat(parts)
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    d.all_gather(gathered, flat)
+    outs, off = [], 0
+    for (N, M, step) in shapes:
+        out = torch.cat([g[off: off + step * M].reshape(step, M) for g in gathered], dim=0)[:N].contiguous()
+        if compat_offset:
+            out = torch.where(out == -100.0, out * world, out - 100.0 * (world - 1))
+        outs.append(out); off += step * M
+    return outs

@@ -505,9 +505,10 @@ def evaluation(model, data_loader, device, tokenizer, args):
 
     if W > 1:                                                                                    # :252-262
         compat = bool(getattr(args, "compat_allreduce_offset", False))
-        for d, blk in ((v2t, v_block), (t2v, t_block)):
-            for k in list(d):
-                d[k] = dist_utils.merge_row_blocks(d[k], blk, W, compat_offset=compat)
+        keys = [(d, k, blk) for d, blk in ((v2t, v_block), (t2v, t_block)) for k in list(d)]
+        merged = dist_utils.merge_row_blocks_many([d[k] for d, k, _ in keys], [blk for _, _, blk in keys], W, compat_offset=compat)
+        for (d, k, _), m in zip(keys, merged):                                                   # one RCCL all-gather for all matrices
+            d[k] = m
     t2v_dict = {k: v.cpu().numpy() for k, v in t2v.items()}                                      # :264-276
     v2t_dict = {k: v.cpu().numpy() for k, v in v2t.items()}
     t2v_dict["internvideo2"] = t2v_iv2.cpu().numpy()

@@ -26,7 +26,15 @@ def _worker(rank, world, port, n, m, out_q):
     compat = D.merge_row_blocks(mine.clone(), (s, e), world, compat_offset=True)
     ref = mine.clone()
     dist.all_reduce(ref, op=dist.ReduceOp.SUM)          # what the reference does
-    out_q.put((rank, torch.equal(merged, full), torch.allclose(compat, ref, atol=1e-4), D.get_world_size(), D.get_rank()))
+    # several matrices of different shapes in ONE all-gather
+    full2 = torch.from_numpy(np.random.RandomState(1).randn(m, n + 2).astype(np.float32) - 5.0)
+    s2, e2 = D.row_block(m, world, rank)
+    mine2 = torch.full((m, n + 2), -100.0); mine2[s2:e2] = full2[s2:e2]
+    many = D.merge_row_blocks_many([mine.clone(), mine2.clone()], [(s, e), (s2, e2)], world)
+    many_c = D.merge_row_blocks_many([mine.clone(), mine2.clone()], [(s, e), (s2, e2)], world, compat_offset=True)
+    ref2 = mine2.clone(); dist.all_reduce(ref2, op=dist.ReduceOp.SUM)
+    ok_many = torch.equal(many[0], full) and torch.equal(many[1], full2) and torch.allclose(many_c[0], ref, atol=1e-4) and torch.allclose(many_c[1], ref2, atol=1e-4)
+    out_q.put((rank, torch.equal(merged, full) and ok_many, torch.allclose(compat, ref, atol=1e-4), D.get_world_size(), D.get_rank()))
     dist.barrier()
     dist.destroy_process_group()
 
