@@ -461,3 +461,29 @@ def test_fp8_mode_full_size_7b_vs_fp16(capsys):
     # 28 random-weight layers amplify the per-GEMM 1e-2 quantisation noise (tools/f8_ablation.py: every GEMM contributes alike);
     # the bound only guards against a broken path (a wrong scale or layout gives O(1) errors)
     assert all(np.isfinite(x).all() for x in res["f8"]) and max(dev) < 0.15
+
+
+def test_c_abi_error_behaviour():
+    """Every entry point returns a negative code + message instead of throwing or faulting (include/blim.h conventions)."""
+    lib = eng.load_library()
+    import ctypes as C
+    # bad configuration: head_dim != 128
+    cfg = eng.Config(1000, 192, 256, 1, 2, 1, 64, 4, 128, 1, 1e-6, 1e6)
+    h = C.c_void_p()
+    assert lib.blim_create(C.byref(cfg), C.byref(h)) == -1 and b"head_dim" in lib.blim_last_error()
+    # scoring before the weights are loaded, unknown weight names, wrong sizes
+    dims = synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=1, num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+    e = eng.Engine(dims, max_positions=64, dtype="f16")
+    batch = eng.PackedBatch(np.arange(4, dtype=np.int32), np.ones(4, np.uint8), np.array([0], np.int32), np.array([4], np.int32))
+    emb = torch.zeros((4, 256), dtype=torch.float16, device="cuda")
+    with pytest.raises(eng.BlimError, match="not loaded"):
+        e.decode(batch, emb)
+    z = np.zeros((4, 4), np.float32)
+    assert lib.blim_load_weight(e.h, b"layers.0.nonsense", z.ctypes.data, 0, 0) == -1 and b"unknown weight" in lib.blim_last_error()
+    with pytest.raises(eng.BlimError, match="RoPE table"):
+        e.decode(eng.PackedBatch(np.arange(70, dtype=np.int32), np.ones(70, np.uint8), np.array([0], np.int32), np.array([70], np.int32)), torch.zeros((70, 256), dtype=torch.float16, device="cuda"))
+    e.close()
+    # plain GEMM: K must be a whole number of 128-byte steps
+    a = torch.zeros((8, 72), dtype=torch.float16, device="cuda"); w = torch.zeros((8, 72), dtype=torch.float16, device="cuda")
+    with pytest.raises(eng.BlimError, match="bad argument"):
+        eng.gemm_bf16(a, w)
