@@ -88,20 +88,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     // ---- per-lane LDS-DMA sources (see the main loop: each wave stages 8 blocks of ONE operand)
     // 32-bit byte offsets from the (wave-uniform, scalar) operand bases: the K-step advance is a scalar add on the
     // base and the LDS-DMA uses the saddr + voffset form (no per-step vector address arithmetic).
-    const int sq = lane >> 4, sr = (lane >> 1) & 7, sc = 2 * sq + (lane & 1);  // LDS slot lane -> (row sr, 16-B chunk sc)
+    // LDS image of a 1-KiB block = 8 rows x 128 B in natural row order, the eight 16-B chunks of row r stored at slot
+    // c ^ g(r), g(r) = (r >> 1) & 7 with r the row's index inside its 16-row fragment group: (a) the eight consecutive lanes that
+    // fill a row read one whole 128-B line (in permuted order) -- with lane PAIRS reading 32 B of a row each, as in the first
+    // layout, the same bytes moved 25-30 % slower (tools/dma_bench.hip: 68 -> 90 GB/s per CU); (b) the 16 lanes of every
+    // ds_read_b128 hardware lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) hit 16 different 4-bank groups.
+    const int sr = lane >> 3;                                    // DMA lane -> row of the block; its chunk slot is lane & 7
     const char* baseA = (const char*)p.A;
     const char* baseW = (const char*)p.W;
 
     // ---- fragment read offsets (bytes) inside an operand tile
-    // 16-bit: lane (row fr, k-chunk fc of 8 elements) reads 16 B per 32-deep MFMA step ks (quarter 2 ks + fc/2, half fc&1).
-    // fp8: lane (row fr, k-block fc of 32 elements) owns the whole 32-B quarter fc: two 16-B reads feed one 128-deep MFMA.
+    // lane (row fr, fc): its two 16-B reads per K-step are the row's chunks fc and fc + 4 -- the two 32-deep MFMA steps of the
+    // 16-bit forms (k = 8 fc .. and 32 + 8 fc ..), or the 32 e4m3 of one 128-deep fp8 MFMA (any k assignment works as long as the
+    // A and W lanes use the same one).  Chunk c of row r sits at slot c ^ g(r): the second read is the first XOR 64 bytes.
     constexpr int ES = (DT == DT_F8) ? 1 : 2;            // operand element size
-    constexpr int KS_OFF = (DT == DT_F8) ? 16 : 512;     // byte distance of a fragment's second 16-B read
     constexpr int ODT = out16<DT>::value;                // dtype of 16-bit outputs
     const int fr = lane & 15, fc = lane >> 4;
-    const int frag_off = (fr >> 3) * 1024 + (fr & 7) * 32 + (DT == DT_F8 ? fc * 256 : (fc >> 1) * 256 + (fc & 1) * 16);
-    const int a_off = (16 * wm) * 1024 + frag_off;   // + mi*2048 + ks*KS_OFF
-    const int b_off = (8 * wn) * 1024 + frag_off;    // + ni*2048 + ks*KS_OFF
+    const int fg = (fr >> 1) & 7;
+    const int frag_off = (fr >> 3) * 1024 + (fr & 7) * 128 + 16 * ((fc ^ (fg & 3)) + 4 * (fg >> 2));
+    const int a_off = (16 * wm) * 1024 + frag_off;   // + mi*2048; second read: ^ 64
+    const int b_off = (8 * wn) * 1024 + frag_off;    // + ni*2048
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -122,24 +128,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         bf16x8 fa[2][8], fb[2][4];        // 16-bit fragments: [32-deep step][16-row block]
         i32x8 fa8[8], fb8[4];             // fp8 fragments: 32 e4m3 per lane (the two 16-B reads land in the halves of one tuple)
         auto load_frags = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
-            const char* ba = smem + offA_tile + a_off;
-            const char* bb = smem + offB_tile + b_off;
+            const char* ba[2] = {smem + (offA_tile + a_off), smem + ((offA_tile + a_off) ^ 64)};
+            const char* bb[2] = {smem + (offB_tile + b_off), smem + ((offB_tile + b_off) ^ 64)};
             if constexpr (DT == DT_F8) {
-                auto rd = [](const char* q) __attribute__((always_inline)) {
-                    const i32x4 l = *(const i32x4*)q, h = *(const i32x4*)(q + 16);
+                auto rd = [](const char* q0, const char* q1) __attribute__((always_inline)) {
+                    const i32x4 l = *(const i32x4*)q0, h = *(const i32x4*)q1;
                     return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
                 };
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) fb8[ni] = rd(bb + ni * 2048);
+                for (int ni = 0; ni < 4; ++ni) fb8[ni] = rd(bb[0] + ni * 2048, bb[1] + ni * 2048);
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) fa8[mi] = rd(ba + mi * 2048);
+                for (int mi = 0; mi < 8; ++mi) fa8[mi] = rd(ba[0] + mi * 2048, ba[1] + mi * 2048);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) fb[ks][ni] = *(const bf16x8*)(bb + ni * 2048 + ks * KS_OFF);
+                    for (int ni = 0; ni < 4; ++ni) fb[ks][ni] = *(const bf16x8*)(bb[ks] + ni * 2048);
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) fa[ks][mi] = *(const bf16x8*)(ba + mi * 2048 + ks * KS_OFF);
+                    for (int mi = 0; mi < 8; ++mi) fa[ks][mi] = *(const bf16x8*)(ba[ks] + mi * 2048);
                 }
             }
         };
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         constexpr int RING = 5 * TILE_BYTES;
         auto adv = [](int s, int j) { const int x = s + j * TILE_BYTES; return x >= RING ? x - RING : x; };
         const int wg = wave & 3;
+        const int sc = (lane & 7) ^ (4 * (wg & 1) + (sr >> 1));     // source chunk of this lane's slot: blocks wg + 4 i share (block & 1) = wg & 1
         uint32_t off8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

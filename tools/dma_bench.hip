@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512) void dma32_kernel(const uint16_t* A, const uin
 
 // half-step granularity: one operand tile (32 KB = 4 LDS-DMA per wave) per issue, D operand tiles in flight
 template <int D>
-__global__ __launch_bounds__(512) void dmah_kernel(const uint16_t* A, const uint16_t* W, int M, int N, int K, float* sink, int same = 0) {
+__global__ __launch_bounds__(512) void dmah_kernel(const uint16_t* A, const uint16_t* W, int M, int N, int K, float* sink, int same = 0, int nat = 0) {
     __shared__ __attribute__((aligned(16))) char smem[5 * 32768];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(512) void dmah_kernel(const uint16_t* A, const uint
     const int gsz = min(ntm - first_m, GROUP_M);
     const int tm = first_m + (pid % width) % gsz, tn = (pid % width) / gsz;
     const int row0 = same ? 0 : tm * BM, col0 = same ? 0 : tn * BN;   // same: every workgroup streams one L2-resident panel pair
-    const int sq = lane >> 4, sr = (lane >> 1) & 7, sc = 2 * sq + (lane & 1);
+    // nat = 1: 8 consecutive lanes read one whole 128-B line (row = lane / 8, XOR-swizzled chunk order inside the line);
+    // nat = 0: the product kernel's [k-quarter][row][32 B] image, where a lane PAIR reads 32 B of a row
+    const int sq = lane >> 4, sr = nat ? (lane >> 3) : ((lane >> 1) & 7), sc = nat ? ((lane & 7) ^ ((lane >> 4) & 7)) : (2 * sq + (lane & 1));
     uint32_t offA[4], offB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -264,12 +266,12 @@ static void runreg(const char* name, const uint16_t* A, const uint16_t* W, int M
 }
 // the half-step LDS-DMA kernel on only `nwg` workgroups (one per CU on nwg CUs): per-CU limit or chip-wide limit?
 template <int D>
-static void runh_few(const char* name, const uint16_t* A, const uint16_t* W, int M, int N, int K, float* sink, int nwg, int same = 0) {
+static void runh_few(const char* name, const uint16_t* A, const uint16_t* W, int M, int N, int K, float* sink, int nwg, int same = 0, int nat = 0) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((dmah_kernel<D>), dim3(nwg), dim3(512), 0, 0, A, W, M, N, K, sink, same);
+    hipLaunchKernelGGL((dmah_kernel<D>), dim3(nwg), dim3(512), 0, 0, A, W, M, N, K, sink, same, nat);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((dmah_kernel<D>), dim3(nwg), dim3(512), 0, 0, A, W, M, N, K, sink, same);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((dmah_kernel<D>), dim3(nwg), dim3(512), 0, 0, A, W, M, N, K, sink, same, nat);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
     const double bytes = (double)nwg * (K / 64) * 65536.0;
@@ -435,6 +437,11 @@ int main() {
     }
     runreg<1>("register path depth1", A, W, M, N, K, sink);
     runreg<2>("register path depth2", A, W, M, N, K, sink);
+    for (int nat : {0, 1, 0, 1}) {
+        runh_few<4>(nat ? "GEMM map, whole-line lanes, 18944 WGs" : "GEMM map, 32-B lane pairs, 18944 WGs", A, W, M, N, K, sink, 18944, 0, nat);
+        runh_few<4>(nat ? "GEMM map, whole-line lanes, 256 WGs" : "GEMM map, 32-B lane pairs, 256 WGs", A, W, M, N, K, sink, 256, 0, nat);
+        runh_few<2>(nat ? "GEMM map, whole-line lanes, 256 WGs D2" : "GEMM map, 32-B lane pairs, 256 WGs D2", A, W, M, N, K, sink, 256, 0, nat);
+    }
     for (int nwg : {8, 64, 256}) runh_few<4>("half-step D4, few CUs", A, W, M, N, K, sink, nwg);
     for (int nwg : {8, 64, 256, 2048}) runh_few<4>("half-step D4, one L2-resident panel pair", A, W, M, N, K, sink, nwg, 1);
     for (int nwg : {8, 256, 2048}) runh_few<2>("half-step D2, one L2-resident panel pair", A, W, M, N, K, sink, nwg, 1);
