@@ -206,6 +206,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         }
         const char* gbase = grp == 1 ? baseA : baseW;
         auto stage8 = [&](int dst, int kt) __attribute__((always_inline)) {   // one operand tile share: 8 LDS-DMA per wave
+#ifdef GEMM_ABLATE_DMA   // ablation builds only: 1 = stage the first two K-steps only, then compute on stale
+                         // LDS; 2 = keep every LDS-DMA but re-read the first two K-steps (L2-resident, no fabric / HBM traffic)
+            if (GEMM_ABLATE_DMA == 1 && kt >= 2) return;
+            if (GEMM_ABLATE_DMA == 2) kt &= 1;
+#endif
             const char* g = gbase + (int64_t)kt * (BK * 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
