@@ -63,6 +63,8 @@ def load_library(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  -- FIRST: torch ships its own HIP runtime; loaded after ours, the process ends up with two and
+    #                              the second one sees no device (build() followed by smoke() in one process did exactly that)
     if not os.path.exists(path):
         raise BlimError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"(or `make -C blim_amd/csrc`). The BLiM engine has no CPU fallback.")
