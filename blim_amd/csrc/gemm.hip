@@ -1,11 +1,10 @@
-// bf16 MFMA GEMM for gfx950: 256x256x64 tiles, 8 waves (2 M x 4 N), each wave 128x64 of C as
-// 8x4 fragments of v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous ([rows][K]); tiles go
-// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave-instruction) into a
-// double buffer.  LDS image of a 1-KiB block (8 rows x 64 k):  [k-quarter q (32 B)][row 0..7][32 B],
-// i.e. bank-row q holds bytes [32q, 32q+32) of all 8 rows.  A 16-row fragment read (ds_read_b128, lane
-// = (row l&15, 16-B chunk l>>4)) then touches 16 distinct 16-B slots per hardware lane group:
-// conflict-free, with the permutation applied on the per-lane global SOURCE address (the LDS-DMA
-// destination is lane-linear).
+// MFMA GEMM for gfx950 (bf16 / fp16 / fp8-e4m3 operands): 256x256 tiles x 128 bytes of K per step, 8 waves (2 M x 4 N), each
+// wave 128x64 of C as 8x4 fragments of v_mfma_f32_16x16x32_{bf16,f16} (fp8: v_mfma_scale_f32_16x16x128_f8f6f4).  Both operands
+// are K-contiguous ([rows][K]); tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per
+// wave-instruction) into a ring of five 32-KiB slots.  LDS image of a 1-KiB block: natural 128-B rows, chunk c of row r at slot
+// c ^ ((r >> 1) & 7) (r = row inside its 16-row fragment group): eight consecutive DMA lanes read one whole 128-B line, and the
+// 16 lanes of every ds_read_b128 hardware lane group touch 16 different 4-bank groups.  The permutation is applied on the per-lane
+// global SOURCE address (the LDS-DMA destination is lane-linear).
 #include "gemm.hpp"
 
 #define BM 256
