@@ -62,3 +62,23 @@ def test_eval_driver_on_a_synthetic_tree(tmp_path, monkeypatch, capsys):
         assert all(0.0 <= float(x) <= 100.0 for x in flat)
     log = open(tmp_path / "out" / "log.txt").read()
     assert log.count("R@1") >= 3 or log.count("R1") >= 3 or len(log) > 100
+
+
+def test_two_ranks_give_the_single_process_recall_table(tmp_path):
+    """One process per 'GPU' x 2 (both on cuda:0, gloo in place of RCCL so that two ranks can share the device): row-block sharding,
+    text-sharded prior and the fused all-gather with the REAL engine reproduce the single-process recall table exactly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--eval", "--synthetic", "19", "--cpn", "--resume", "x", "--alpha", "0.4", "0.8", "--c", "0.3", "0.6", "0.9", "0.7", "--topk", "5"]
+    env = dict(os.environ, PYTHONPATH=root)
+    r1 = subprocess.run([sys.executable, "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w1")], cwd=root, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    env2 = dict(env, BLIM_DIST_BACKEND="gloo", BLIM_FORCE_DEVICE="0")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29541", "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w2")], cwd=root, env=env2,
+                        capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    t1, t2 = open(tmp_path / "w1" / "log.txt").read(), open(tmp_path / "w2" / "log.txt").read()
+    assert "blim" in t1 and t1 == t2
