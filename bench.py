@@ -74,9 +74,60 @@ def cpu_baseline(seconds_budget=30.0):
     rows = 64
     t0 = time.time(); lg = y.reshape(-1, cfg.hidden_size)[:rows] @ wl.T; O.log_softmax(lg); t_head = (time.time() - t0) * (B * 32 / rows)
     t_batch = LAYERS * t_layer + t_head
-    return {"value": round(B / t_batch, 4), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+    tiny = tiny_config_evaluation()
+    return {"value": round(B / t_batch, 4), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "tiny_config_evaluation": tiny,
             "sample": f"oracle (numpy fp32, BLAS threads = host cores): 1 decoder layer at 7B width on 16 pairs x 128 tokens = {t_layer:.2f}s, "
                       f"lm_head+log-softmax on {rows} rows scaled to 512 = {t_head:.2f}s; x28 layers extrapolated; no prefix sharing"}
+
+
+def tiny_config_evaluation():
+    """One complete v2t + t2v VTG/TVG evaluation of a tiny 2-layer configuration (6 videos x 6 texts, top-4), run by the numpy
+    oracle on the host cores and by the engine on the GPU in this same process; the two score sets are compared (1e-3)."""
+    import types
+    import torch
+    from oracle import blim_oracle as O
+    from blim_amd import retrieval_utils as RU
+    from blim_amd import synth
+    from blim_amd.modeling import BlimModel, DDPLike
+    d = dict(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+    dims = synth.ModelDims(**d)
+    w = synth.synthetic_weights(dims, 3)
+    n, topk = 6, 4
+    prob = synth.make_problem(4, n, dims, tok_per_clip=8, text_len=(3, 9))
+    om = O.OracleModel(O.OracleConfig(**d), w); om.set_tvg_prefix_length(prob.tvg_prefix_length)
+    ov = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+    ot = O.padding_ids(prob.tvg_ids, prob.tvg_labels, prob.tvg_masks, synth.PAD_ID)
+    passes = [(True, "vtg"), (True, "tvg"), (False, "vtg"), (False, "tvg")]
+    t0 = time.time()
+    want = []
+    for qv, ft in passes:
+        ids, lab, msk = ov if ft == "vtg" else ot
+        fn = O.compute_v2t_scores_x if qv else O.compute_t2v_scores_x
+        want.append(fn(np.full((n, n), -100.0, np.float32), prob.v2t_sims if qv else prob.t2v_sims, 0, ids, msk, lab, prob.video, prob.video_vocab,
+                       prob.tvg_video_labels, om, topk, 3, dims.num_clips, ft, False))
+    t_cpu = time.time() - t0
+    model = BlimModel(dims, max_positions=512, dtype="f16")
+    model.engine.load_weights(w)
+    model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    scorer = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video],
+                           torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels), dims.num_clips)
+    worst, t_gpu = 0.0, 0.0
+    for rep in range(2):                                   # second repetition is timed (first one pays allocation / planning warm-up)
+        torch.cuda.synchronize(); t0 = time.time()
+        got = []
+        for qv, ft in passes:
+            pairs = RU._topk_pairs(torch.from_numpy(prob.v2t_sims if qv else prob.t2v_sims), 0, topk, qv)
+            got.append((pairs, scorer.vtg(pairs) if ft == "vtg" else scorer.tvg(pairs)))
+        torch.cuda.synchronize(); t_gpu = time.time() - t0
+    for (qv, ft), W, (pairs, sc) in zip(passes, want, got):
+        r, c = (pairs[:, 0], pairs[:, 1]) if qv else (pairs[:, 1], pairs[:, 0])
+        worst = max(worst, float(np.max(np.abs(sc - W[r, c]) / np.abs(W[r, c]))))
+    model.engine.close()
+    return {"pairs": 4 * n * topk, "oracle_s": round(t_cpu, 3), "engine_s": round(t_gpu, 4), "max_rel_diff": float(f"{worst:.2e}"), "agree_1e-3": worst < 1e-3}
 
 
 def main():
