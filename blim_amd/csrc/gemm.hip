@@ -220,6 +220,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 glds16(g + o, smem + dst + (wg + 4 * i) * 1024);
             }
         };
+        // 16-bit loader: one LDS-DMA after every three fragment reads (instead of 24 reads, then 8 LDS-DMA): the DMA issue, the long
+        // pole of the loading phase, overlaps the LDS reads (+0.4 - 1.3 % per GEMM, +0.9 % on the bench).
+        auto frags_and_dma = [&](int offA_tile, int offB_tile, int dst, int kt, bool on) __attribute__((always_inline)) {
+            const char* ba[2] = {smem + (offA_tile + a_off), smem + ((offA_tile + a_off) ^ 64)};
+            const char* bb[2] = {smem + (offB_tile + b_off), smem + ((offB_tile + b_off) ^ 64)};
+#ifdef GEMM_ABLATE_DMA
+            if (GEMM_ABLATE_DMA == 1 && kt >= 2) on = false;
+            if (GEMM_ABLATE_DMA == 2) kt &= 1;
+#endif
+            const char* g = gbase + (int64_t)kt * (BK * 2);
+            auto dma1 = [&](int q) __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (on) { uint32_t o = off8[q]; asm volatile("" : "+v"(o)); glds16(g + o, smem + dst + (wg + 4 * q) * 1024); }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int j = 3 * q; j < 3 * q + 3; ++j) {
+                        const int ks = j / 12, r = j % 12;
+                        if (r < 4) fb[ks][r] = *(const bf16x8*)(bb[ks] + r * 2048);
+                        else fa[ks][r - 4] = *(const bf16x8*)(ba[ks] + (r - 4) * 2048);
+                    }
+                    dma1(q);
+                }
+            }
+        };
         int sa = 0;
         if (grp == 0) {
             stage8(TILE_BYTES, 0);                                   // W0
@@ -253,8 +281,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_T(2);
                 PHASE_BARRIER();
                 WP_T(3);
-                if (kt + 1 < nk) load_frags(adv(sa, 2), adv(sa, 3));
-                if (kt + 2 < nk) stage8(sa, kt + 2);                 // W(kt+2)
+                if (kt + 1 < nk) frags_and_dma(adv(sa, 2), adv(sa, 3), sa, kt + 2, kt + 2 < nk);   // fragments of kt+1, W(kt+2)
 #ifdef GEMM_WAIT_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -274,8 +301,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             PHASE_BARRIER();
             for (int kt = 0; kt < nk; ++kt) {
                 WP_T(0);
-                load_frags(sa, adv(sa, 1));
-                if (kt + 2 < nk) stage8(adv(sa, 4), kt + 2);
+                if constexpr (DT == DT_F8) {
+                    load_frags(sa, adv(sa, 1));
+                    if (kt + 2 < nk) stage8(adv(sa, 4), kt + 2);
+                } else frags_and_dma(sa, adv(sa, 1), adv(sa, 4), kt + 2, kt + 2 < nk);          // fragments of kt, A(kt+2)
 #ifdef GEMM_WAIT_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
