@@ -45,15 +45,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)stamp_vb * 8 + k] = __builtin_amdgcn_s_memrealtime();
     };
-    // Stagger the XCDs (blocks b, b+8, ... share one) by a few microseconds in the first dispatch round so that their
-    // epilogue write bursts (and LDS-DMA bursts) do not coincide chip-wide: 256 CUs x 128-512 KB written in the same
-    // microsecond is HBM-write-bound (measured epilogue 10-14 us per tile); within an XCD the blocks stay in lock step,
-    // which is what keeps their shared A/W panels L2-resident.
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        const int n = (blockIdx.x & 7) * p.stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-
     // ---- persistent workgroups: grid = one workgroup per CU (a multiple of 8), each walks virtual block ids
     // vb = blockIdx.x, + gridDim.x, ...  (vb % 8 == blockIdx.x % 8: a workgroup keeps its XCD's chunk of the tile order).
     // No relaunch gap between tiles, and the next tile's first LDS-DMA overlaps the previous tile's store drain.
@@ -591,7 +582,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #include <stdlib.h>
 static int g_gemm_persistent = getenv("BLIM_GEMM_PERSISTENT") ? atoi(getenv("BLIM_GEMM_PERSISTENT")) : 1;
 static int g_gemm_tile_map = getenv("BLIM_GEMM_TILE_MAP") ? atoi(getenv("BLIM_GEMM_TILE_MAP")) : -1;   // -1: by shape
-static int g_gemm_stagger = getenv("BLIM_GEMM_STAGGER") ? atoi(getenv("BLIM_GEMM_STAGGER")) : 0;
 static int g_gemm_skip_epi = getenv("BLIM_GEMM_SKIP_EPI") ? atoi(getenv("BLIM_GEMM_SKIP_EPI")) : 0;
 static unsigned long long* g_gemm_stamps = nullptr;
 void gemm_set_debug_stamps(unsigned long long* buf) { g_gemm_stamps = buf; }
@@ -622,7 +612,6 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 int launch_gemm(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
-    p.stagger = g_gemm_stagger;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
     // round-robin map, the wide ones (gate|up 37888, lm_head) lose 4 % -- there the XCDs already walk the same W columns in step
     p.tile_map = g_gemm_tile_map >= 0 ? g_gemm_tile_map : ((p.N + BN - 1) / BN <= 32 ? 1 : 0);

@@ -37,7 +37,6 @@ struct GemmParams {
     const int32_t* labels;   // [M] target column per row (or < 0)
     float2* lse_part;        // [M, ceil(N/256)] (max, sumexp)
     float* label_logit;      // [M]
-    int stagger;             // first-round start delay per XCD index, in units of s_sleep(127) (~4 us); BLIM_GEMM_STAGGER
     int tile_map;            // 1: 32-tile groups round-robin over the XCDs (default), 0: XCD-contiguous chunks (BLIM_GEMM_TILE_MAP)
     int debug_skip_epilogue; // timing aid only (set from BLIM_GEMM_SKIP_EPI)
     unsigned long long* debug_stamps;  // timing aid: [n_workgroups][8] s_memrealtime at {entry, main loop start, main loop end, exit, C staged in LDS, stores issued}
