@@ -1,4 +1,5 @@
 """CPU: host-side mirror (padding, recall, ensemble, sharding, packing plans) and the C-ABI library's symbols."""
+import collections
 import os
 import types
 
@@ -191,3 +192,53 @@ def test_packed_batch_rejects_positions_beyond_the_rope_table():
     b.struct(40)                                         # fits
     with pytest.raises(eng.BlimError, match="RoPE table"):
         b.struct(39)
+
+
+# ----------------------------------------------------------------------------- planner invariants on random inputs (CPU)
+def _check_plan(plan, n_req_seen):
+    b = plan.batch
+    T = plan.n_tokens
+    ss, sl = b.seq_start.numpy(), b.seq_len.numpy()
+    ps, pl = b.pfx_start.numpy(), b.pfx_len.numpy()
+    pos = b.positions.numpy()
+    # sequences tile the packed token range without gaps or overlaps
+    order = np.argsort(ss)
+    assert ss[order][0] == 0 and np.array_equal(ss[order][1:], (ss[order] + sl[order])[:-1]) and ss[order][-1] + sl[order][-1] == T
+    for s in range(b.n_seqs):
+        own = pos[ss[s]: ss[s] + sl[s]]
+        assert np.all(np.diff(own) >= 1)                                      # positions increase inside a sequence
+        if pl[s] > 0:                                                        # a prefix is another sequence's tokens, entirely in front of the own tokens
+            assert 0 <= ps[s] and ps[s] + pl[s] <= T
+            assert pos[ps[s]: ps[s] + pl[s]].max() < own.min()
+    rows = plan.rows.numpy()
+    assert rows.min() >= 0 and rows.max() < T
+    if plan.kind == "vtg":
+        rs = plan.row_start.numpy()
+        assert rs[0] == 0 and rs[-1] == len(rows) == plan.n_rows and np.all(np.diff(rs) >= 1)
+        assert len(plan.labels.numpy()) == plan.n_rows
+    else:
+        assert len(rows) == plan.n_pairs * 4 and len(plan.labels.numpy()) == plan.n_pairs
+    # 32-query blocks cover every sequence
+    bq = collections.Counter(b.blk_seq.numpy().tolist())
+    assert all(bq[s] == (sl[s] + 31) // 32 for s in range(b.n_seqs))
+    for outs in plan.out_index:
+        for o in np.atleast_1d(outs):
+            n_req_seen[int(o)] += 1
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_planner_invariants_on_random_pair_lists(seed):
+    rs = np.random.RandomState(seed)
+    n = int(rs.randint(1, 8))
+    sc, prob = _scorer(n=n, layout=bool(seed % 4))
+    sc.max_tokens = int(rs.choice([90, 200, 700, 4096]))
+    P = int(rs.randint(1, 40))
+    pairs = np.stack([rs.randint(0, n, P), rs.randint(0, n, P)], axis=1)          # duplicates allowed
+    for kind, cpn in (("vtg", False), ("vtg", True), ("tvg", False), ("tvg", True)):
+        if kind == "vtg" and cpn and not (seed % 4):
+            continue                                                              # headline rows: the VTG prior is rejected (tested above)
+        plans = sc.plan_vtg(pairs, cpn) if kind == "vtg" else sc.plan_tvg(pairs, cpn)
+        seen = collections.Counter()
+        for p in plans:
+            _check_plan(p, seen)
+        assert sorted(seen) == list(range(P)) and all(v == 1 for v in seen.values()), (kind, cpn)   # every requested pair answered exactly once
