@@ -99,8 +99,17 @@ def main(args):
         loader = load_data(args, tokenizer=tokenizer, split="test")
     if rank == 0:
         print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")
+    torch.cuda.synchronize()
+    t1 = time.time()
     results = val_one_epoch(DDPLike(model), loader, None, device, 0, None, tokenizer=tokenizer, args=args)
+    torch.cuda.synchronize()
     if rank == 0:
+        n_items = len(loader.dataset)
+        finetuned = bool(args.resume)
+        n_pass = (1 + (1 if args.cpn else 0) + (1 if finetuned else 0)) + (1 + (1 + (1 if args.cpn else 0) if finetuned else 0))
+        n_pairs = n_pass * n_items * min(args.topk, n_items)
+        print(f"evaluation: {n_pass} passes x {n_items} queries x top-{min(args.topk, n_items)} = {n_pairs} pairs in {time.time() - t1:.2f}s "
+              f"({n_pairs / (time.time() - t1):.0f} pairs/s over {world} GPU(s), host planning and loading included)")
         import pandas as pd
         os.makedirs(args.output_dir, exist_ok=True)
         table = pd.DataFrame(results).T                                                    # main.py:170-173
