@@ -82,3 +82,28 @@ def test_two_ranks_give_the_single_process_recall_table(tmp_path):
     assert r2.returncode == 0, r2.stderr[-2000:]
     t1, t2 = open(tmp_path / "w1" / "log.txt").read(), open(tmp_path / "w2" / "log.txt").read()
     assert "blim" in t1 and t1 == t2
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
+    """bench.py's output contract: exactly one JSON line on stdout with the driver's keys, the roofline and (at N = 1) the CPU
+    baseline objects.  Small workload (8 queries) so that the test takes seconds; the numbers themselves are not checked."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "8"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("candidate-pairs/sec") and d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "bf16"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["tiny_config_evaluation"]["agree_1e-3"] is True
+    assert d["value"] > 0 and d["ms_per_step"] > 0
