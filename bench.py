@@ -1,6 +1,6 @@
 """Benchmark of the likelihood-scoring hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one engine pass over one device-resident super-batch of synthetic (query, candidate) pairs of
@@ -130,6 +130,18 @@ def tiny_config_evaluation():
     return {"pairs": 4 * n * topk, "oracle_s": round(t_cpu, 3), "engine_s": round(t_gpu, 4), "max_rel_diff": float(f"{worst:.2e}"), "agree_1e-3": worst < 1e-3}
 
 
+def launcher_command(gpus: int, argv, port: int = 0):
+    """`python bench.py --gpus N` without a launcher around it: the command of the child that runs the ranks
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 -- the reference's env:// init, util/misc.py:199-229)."""
+    if not port:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +156,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # Invoked as plain `python bench.py --gpus N`: start the N ranks as a CHILD process group and exit with its code.  This
+        # parent never touches the GPU (no torch import, no HIP call), so nothing is exec'ed from a GPU-initialised process.
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(launcher_command(a.gpus, sys.argv[1:]), env=env))
+
     import torch
     from blim_amd import distributed as D
     from blim_amd import retrieval_utils as RU
@@ -151,7 +170,7 @@ def main():
     from blim_amd.modeling import BlimModel, DDPLike
 
     rank, world, local = D.init_distributed_mode() if a.gpus > 1 else (0, 1, 0)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

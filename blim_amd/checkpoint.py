@@ -133,10 +133,22 @@ def lora_delta(A: np.ndarray, B: np.ndarray, r: int, alpha: float) -> np.ndarray
 
 # ----------------------------------------------------------------------------- loader
 
+def expected_adapters(dims: ModelDims):
+    """Tensors the reference fine-tunes with LoRA (main.py:98-111): both projector MLPs' Linear 0 / 2, every q/k/v/o_proj, lm_head."""
+    names = [f"{p}.{i}.w" for p in ("mlp", "tvg_mlp") for i in (0, 2)] + ["lm_head"]
+    names += [f"layers.{l}.{q}.w" for l in range(dims.num_layers) for q in ("q_proj", "k_proj", "v_proj", "o_proj")]
+    return names
+
+
 def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Optional[str] = None, lora_r: int = 8, lora_alpha: float = 32.0,
-                    allow_missing_visual_head: bool = True, verbose: bool = False) -> Dict[str, str]:
+                    allow_missing_visual_head: bool = True, verbose: bool = False, strict_resume: bool = True) -> Dict[str, str]:
     """Streams the base checkpoint (+ merged LoRA / visual_head of `resume_path`) into `engine`, one tensor at a time.
-    Returns {canonical name: provenance} for every tensor loaded."""
+    Returns {canonical name: provenance} for every tensor loaded.
+
+    A resume file is checked the way the reference checks it (main.py:127 asserts that the number of checkpoint parameters equals
+    the number of trainable parameters): every key must map onto an engine tensor, every expected adapter (`expected_adapters`) and
+    `visual_head` must be present, and the parameter total must equal the trainable total.  A naming drift therefore raises instead
+    of silently evaluating the base model; strict_resume=False downgrades the checks to warnings (partial adapter files)."""
     import torch
     shapes = weight_shapes(dims)
     keys, get = open_base_checkpoint(base_path)
@@ -150,15 +162,35 @@ def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Option
     if resume_path:
         ck = torch.load(resume_path, map_location="cpu", weights_only=False)
         sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+        unparsed, n_params = [], 0
         for k, v in sd.items():
             parsed = parse_resume_key(k)
-            if parsed is None:
+            if parsed is None or parsed[0] not in shapes:
+                unparsed.append(k)
                 continue
             name, kind = parsed
+            n_params += int(np.prod(v.shape))
             if kind == "full":
                 full[name] = _to_f32(v)
             else:
                 adapters.setdefault(name, {})[kind] = _to_f32(v)
+        problems = []
+        if unparsed:
+            problems.append(f"{len(unparsed)} key(s) map onto no engine tensor, e.g. {unparsed[:3]}")
+        missing = [n for n in expected_adapters(dims) if n not in adapters]
+        if missing:
+            problems.append(f"{len(missing)} expected LoRA adapter(s) absent, e.g. {missing[:3]}")
+        if "visual_head" not in full:
+            problems.append("visual_head absent")
+        want = sum(lora_r * (shapes[n][0] + shapes[n][1]) for n in expected_adapters(dims)) + int(np.prod(shapes["visual_head"]))
+        if not missing and not unparsed and "visual_head" in full and n_params != want:
+            problems.append(f"{n_params} parameters in the file, {want} trainable parameters expected (main.py:127)")
+        if problems:
+            msg = f"resume file {resume_path}: " + "; ".join(problems)
+            if strict_resume:
+                raise ValueError(msg + " -- refusing to evaluate a partially adapted model (strict_resume=False to override)")
+            import warnings
+            warnings.warn(msg)
     report: Dict[str, str] = {}
     for name, shape in shapes.items():
         src = name
@@ -186,7 +218,18 @@ def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Option
         report[name] = prov
         if verbose:
             print(f"{name:32s} {str(tuple(shape)):20s} {prov}")
+    applied = sorted(n for n, p in report.items() if "LoRA" in p)
+    stray = sorted(set(adapters) - set(applied))
+    if stray:
+        raise KeyError(f"LoRA adapters for tensors the engine does not hold: {stray[:3]}")
     return report
+
+
+def summarize_report(report: Dict[str, str]) -> str:
+    """One line for the driver's log: how many tensors came from where."""
+    from collections import Counter
+    c = Counter("base + LoRA" if "+ LoRA" in p else p.split(" (")[0] for p in report.values())
+    return ", ".join(f"{v} {k}" for k, v in sorted(c.items()))
 
 
 def save_hf_checkpoint(weights: Dict[str, np.ndarray], out_dir: str, shards: int = 2, dtype: str = "bf16") -> None:

@@ -20,21 +20,32 @@ import types
 
 def get_args_parser():
     p = argparse.ArgumentParser("BLiM evaluation on the MI355X engine", add_help=True)
-    p.add_argument("--batch_size_eval", default=16, type=int)
-    p.add_argument("--num_workers", default=2, type=int)
+    # the reference's flags with the reference's defaults (main.py:31-75), so that one of its command lines gives the same table
+    p.add_argument("--batch_size_eval", default=64, type=int)
+    p.add_argument("--num_workers", default=4, type=int)
     p.add_argument("--pin_mem", action="store_true")
+    p.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
+    p.set_defaults(pin_mem=True)
     p.add_argument("--model_path", default="./pretrained/VideoChat-Flash-Qwen2-7B_res448", type=str)
-    p.add_argument("--dataset", default="MSRVTT", type=str, choices=["MSRVTT", "DiDeMo", "ActivityNet", "LSMDC"])
-    p.add_argument("--output_dir", default="./output", type=str)
+    p.add_argument("--dataset", default="DiDeMo", type=str, choices=["DiDeMo", "ActivityNet", "LSMDC", "MSRVTT"])
+    p.add_argument("--output_dir", default="./checkpoint", type=str)
     p.add_argument("--resume", default="", type=str, help="fine-tuned LoRA / visual_head checkpoint (empty = zero-shot)")
     p.add_argument("--eval", action="store_true")
-    p.add_argument("--topk", default=16, type=int)
+    p.add_argument("--topk", default=10, type=int)
     p.add_argument("--num_clips", default=4, type=int)
     p.add_argument("--cpn", action="store_true")
-    p.add_argument("--alpha", default=[0.0, 0.0], type=float, nargs=2, help="CPN weights (t2v, v2t)")
-    p.add_argument("--c", default=[0.5, 0.5, 0.5, 0.5], type=float, nargs=4, help="ensemble weights")
+    p.add_argument("--alpha", default=[0.0, 0.0], type=float, nargs="+", help="CPN weights (t2v, v2t)")
+    p.add_argument("--c", default=[0.0, 0.0, 0.0, 0.0], type=float, nargs="+", help="ensemble weights")
     p.add_argument("--lora_r", default=8, type=int)
     p.add_argument("--lora_alpha", default=32, type=int)
+    # flags of the reference that only concern training / its launcher: accepted so that its command lines parse, not used
+    for flag, kw in (("--batch_size", dict(default=64, type=int)), ("--epochs", dict(default=5, type=int)), ("--accum_iter", dict(default=1, type=int)),
+                     ("--weight_decay", dict(default=0.05, type=float)), ("--lr", dict(default=None, type=float)), ("--min_lr", dict(default=0.0, type=float)),
+                     ("--warmup_epochs", dict(default=40, type=int)), ("--device", dict(default="cuda")), ("--seed", dict(default=0, type=int)),
+                     ("--start_epoch", dict(default=0, type=int)), ("--world_size", dict(default=1, type=int)), ("--local_rank", dict(default=-1, type=int)),
+                     ("--dist_on_itp", dict(action="store_true")), ("--dist_url", dict(default="env://")), ("--lora_drop", dict(default=0.05, type=float))):
+        p.add_argument(flag, help="accepted for compatibility with the reference's command lines; unused by the evaluation", **kw)
+    p.add_argument("--allow_partial_resume", action="store_true", help="load a resume file that lacks some of the expected adapters (warn instead of fail)")
     # engine-side options
     p.add_argument("--dtype", default=None, choices=["f16", "bf16", "f8"])
     p.add_argument("--max_tokens", default=32768, type=int, help="packed tokens per engine call")
@@ -45,7 +56,7 @@ def get_args_parser():
     return p
 
 
-def dims_from_config(model_path: str):
+def dims_from_config(model_path: str, num_clips: int = 4):
     from .synth import ModelDims
     c = json.load(open(os.path.join(model_path, "config.json")))
     if c.get("mm_llm_compress", False):
@@ -53,7 +64,7 @@ def dims_from_config(model_path: str):
     return ModelDims(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
                      num_layers=c["num_hidden_layers"], num_heads=c["num_attention_heads"], num_kv_heads=c["num_key_value_heads"],
                      rms_eps=c.get("rms_norm_eps", 1e-6), rope_theta=c.get("rope_theta", 1e6), mm_hidden_size=c.get("mm_hidden_size", 1024),
-                     num_clips=4)
+                     num_clips=num_clips)
 
 
 def load_tokenizer(model_path: str):
@@ -77,8 +88,8 @@ def main(args):
         raise NotImplementedError("only --eval is supported: the training loop is outside the scoring path")
     t0 = time.time()
     if args.synthetic > 0:
-        dims = synth.ModelDims() if args.synthetic_7b else synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2,
-                                                                         num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+        dims = synth.ModelDims(num_clips=args.num_clips) if args.synthetic_7b else synth.ModelDims(
+            vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64, num_clips=args.num_clips)
         model = BlimModel(dims, dtype=args.dtype)
         model.engine.init_synthetic_weights(0)
         prob = synth.make_problem(1, args.synthetic, dims, tok_per_clip=64 if args.synthetic_7b else 8)
@@ -90,12 +101,15 @@ def main(args):
         nz = lambda a: np.where(a == 0, np.float32(1e-6), a)
         args.iv2_scores = {"v2t": T(nz(prob.v2t_sims)), "t2v": T(nz(prob.t2v_sims))}
     else:
-        from .checkpoint import load_checkpoint
+        from .checkpoint import load_checkpoint, summarize_report
         from .dataloader import load_data
         tokenizer = load_tokenizer(args.model_path)
-        dims = dims_from_config(args.model_path)
+        dims = dims_from_config(args.model_path, args.num_clips)
         model = BlimModel(dims, dtype=args.dtype)
-        load_checkpoint(model.engine, dims, args.model_path, args.resume or None, lora_r=args.lora_r, lora_alpha=args.lora_alpha)
+        report = load_checkpoint(model.engine, dims, args.model_path, args.resume or None, lora_r=args.lora_r, lora_alpha=args.lora_alpha,
+                                 strict_resume=not args.allow_partial_resume)
+        if rank == 0:
+            print("weights: " + summarize_report(report))
         loader = load_data(args, tokenizer=tokenizer, split="test")
     if rank == 0:
         print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")

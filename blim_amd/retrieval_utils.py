@@ -190,6 +190,8 @@ class PairScorer:
         self.device = self.m.device
         self.max_tokens = int(max_tokens)
         self.num_clips = int(num_clips)
+        if self.num_clips != int(self.m.dims.num_clips):         # blim_score_tvg reads n_pairs * blim_config.num_clips rows
+            raise ValueError(f"num_clips = {num_clips} but the engine was created with num_clips = {self.m.dims.num_clips}")
         strip = lambda ids, msk, lab: [(np.asarray(ids[i])[np.asarray(msk[i]) != 0], np.asarray(lab[i])[np.asarray(msk[i]) != 0])
                                        for i in range(len(ids))]
         self.vtg_rows = strip(vtg_ids, vtg_masks, vtg_labels)
@@ -233,7 +235,12 @@ class PairScorer:
         pairs = np.asarray(pairs, dtype=np.int64)
         if cpn:
             texts, inv = np.unique(pairs[:, 1], return_inverse=True)
-            nv = int(np.prod(self.video[int(pairs[0, 0])].shape[:2]))
+            # the prior masks the video keys but keeps their positions: every video must contribute the same number of tokens,
+            # else the reference's per-pair cpn forward would differ between queries too
+            nvs = {int(np.prod(self.video[int(j)].shape[-3:-1])) for j in np.unique(pairs[:, 0])}
+            if len(nvs) != 1:
+                raise ValueError(f"VTG candidate prior: the videos of this pass have different token counts {sorted(nvs)}; score them per count")
+            nv = nvs.pop()
             groups: Dict[Tuple, List[int]] = {}
             for ti, i in enumerate(texts):
                 pre, post, _ = self.vtg_split[int(i)]

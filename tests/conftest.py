@@ -16,6 +16,16 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     have_ref = os.path.isdir("/root/reference/videochat_flash")
     skip_ref = pytest.mark.skip(reason="/root/reference not present")
+    have_gpu = None
     for it in items:
         if "needs_reference" in it.keywords and not have_ref:
             it.add_marker(skip_ref)
+        if "gpu" in it.keywords:
+            if have_gpu is None:                     # a plain `pytest tests` on a CPU box skips the GPU tests instead of failing them
+                import torch
+                lib = os.path.join(ROOT, "blim_amd", "libblim_hip.so")
+                have_gpu = (torch.cuda.device_count() > 0, os.path.exists(lib))
+            if not have_gpu[0]:
+                it.add_marker(pytest.mark.skip(reason="no HIP device visible"))
+            elif not have_gpu[1]:
+                pass                                 # on a GPU box a missing library must FAIL loudly, not skip

@@ -73,7 +73,8 @@ def test_load_base_and_merge_lora(tmp_path):
     torch.save(_resume_state(ad, vh), tmp_path / "resume.pth")
 
     rec = RecordingEngine()
-    rep = CK.load_checkpoint(rec, dims, str(tmp_path / "base"), str(tmp_path / "resume.pth"), lora_r=8, lora_alpha=32.0)
+    with pytest.warns(UserWarning, match="expected LoRA adapter"):       # a partial adapter file loads only when asked to
+        rep = CK.load_checkpoint(rec, dims, str(tmp_path / "base"), str(tmp_path / "resume.pth"), lora_r=8, lora_alpha=32.0, strict_resume=False)
     assert set(rec.w) == set(synth.weight_shapes(dims))
     for n in synth.weight_shapes(dims):
         base = w["mlp." + n[len("tvg_mlp."):]] if n.startswith("tvg_mlp.") else w[n]      # tvg_mlp starts as a copy of mlp
@@ -104,8 +105,42 @@ def test_incomplete_adapter_is_an_error(tmp_path):
     st = _resume_state(ad)
     del st["model"]["base_model.model.model.layers.0.self_attn.v_proj.lora_B.default.weight"]
     torch.save(st, tmp_path / "r.pth")
-    with pytest.raises(KeyError):
-        CK.load_checkpoint(RecordingEngine(), dims, str(tmp_path / "base"), str(tmp_path / "r.pth"))
+    with pytest.raises(KeyError), pytest.warns(UserWarning):
+        CK.load_checkpoint(RecordingEngine(), dims, str(tmp_path / "base"), str(tmp_path / "r.pth"), strict_resume=False)
+
+
+def test_resume_file_is_checked_like_the_reference_checks_it(tmp_path):
+    """main.py:127 asserts #parameters(resume file) == #trainable parameters; a file whose keys drift (other adapter name, extra
+    wrapper prefix, missing modules) must not silently evaluate the base model."""
+    dims = synth.ModelDims(**SMALL)
+    w = synth.synthetic_weights(dims, 5)
+    CK.save_hf_checkpoint(w, str(tmp_path / "base"), shards=1)
+    vh = np.random.RandomState(2).randn(*synth.weight_shapes(dims)["visual_head"]).astype(np.float32)
+    full = _adapters(dims, 1, CK.expected_adapters(dims))
+    assert len(full) == 4 + 1 + 4 * dims.num_layers
+    torch.save(_resume_state(full, vh), tmp_path / "ok.pth")
+    rep = CK.load_checkpoint(RecordingEngine(), dims, str(tmp_path / "base"), str(tmp_path / "ok.pth"))
+    assert sum("+ LoRA" in p for p in rep.values()) == len(full) and "LoRA" in CK.summarize_report(rep)
+    # (a) an adapter missing
+    part = dict(full); del part["layers.1.k_proj.w"]
+    torch.save(_resume_state(part, vh), tmp_path / "a.pth")
+    with pytest.raises(ValueError, match="expected LoRA adapter"):
+        CK.load_checkpoint(RecordingEngine(), dims, str(tmp_path / "base"), str(tmp_path / "a.pth"))
+    # (b) naming drift: an extra wrapper level in front of every key -> nothing would be applied
+    st = _resume_state(full, vh)
+    st["model"] = {"module.wrapped." + k: v for k, v in st["model"].items()}
+    torch.save(st, tmp_path / "b.pth")
+    with pytest.raises(ValueError, match="map onto no engine tensor"):
+        CK.load_checkpoint(RecordingEngine(), dims, str(tmp_path / "base"), str(tmp_path / "b.pth"))
+    # (c) visual_head missing
+    torch.save(_resume_state(full), tmp_path / "c.pth")
+    with pytest.raises(ValueError, match="visual_head absent"):
+        CK.load_checkpoint(RecordingEngine(), dims, str(tmp_path / "base"), str(tmp_path / "c.pth"))
+    # (d) wrong rank -> parameter total differs from the trainable total
+    st = _resume_state(_adapters(dims, 1, CK.expected_adapters(dims), r=4), vh)
+    torch.save(st, tmp_path / "d.pth")
+    with pytest.raises(ValueError, match="trainable parameters expected"):
+        CK.load_checkpoint(RecordingEngine(), dims, str(tmp_path / "base"), str(tmp_path / "d.pth"))
 
 
 @pytest.mark.gpu

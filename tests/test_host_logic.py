@@ -242,3 +242,22 @@ def test_planner_invariants_on_random_pair_lists(seed):
         for p in plans:
             _check_plan(p, seen)
         assert sorted(seen) == list(range(P)) and all(v == 1 for v in seen.values()), (kind, cpn)   # every requested pair answered exactly once
+
+
+def test_bench_launcher_command_plumbing():
+    """bench.py --gpus N without a launcher: the child command is torch.distributed.run with one process per GPU, a 127.0.0.1
+    rendezvous and the user's own flags passed through."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+    cmd = bench.launcher_command(8, argv, port=29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == argv
+    port = int(bench.launcher_command(2, [])[bench.launcher_command(2, []).index("--master-port") + 1])
+    assert 1024 < port < 65536

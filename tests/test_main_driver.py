@@ -33,7 +33,7 @@ def _tree(root):
     for name in ("msrvtt.pth", "msrvtt_zeroshot.pth"):
         torch.save({"v2t": torch.from_numpy(sims), "t2v": torch.from_numpy(sims.T.copy())}, os.path.join(root, "scores", name))
     os.makedirs(os.path.join(root, "checkpoint"), exist_ok=True)
-    ad = _adapters(dims, 5, ["layers.0.q_proj.w", "layers.1.o_proj.w", "lm_head", "mlp.0.w", "tvg_mlp.2.w"])
+    ad = _adapters(dims, 5, CK.expected_adapters(dims))
     vh = (np.random.RandomState(7).randn(1024, dims.hidden_size) * 0.02).astype(np.float32)
     torch.save(_resume_state(ad, vh), os.path.join(root, "checkpoint", "msrvtt.pth"))
     return ck
@@ -107,3 +107,23 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "pairs/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["tiny_config_evaluation"]["agree_1e-3"] is True
     assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` exactly as the driver invokes it (no launcher around it): the parent spawns the two ranks, rank 0
+    prints the single JSON line with n_gpus = 2 and the all-gather inside the timed region.  With one visible device both ranks share
+    cuda:0 (gloo stands in for RCCL, which needs one device per rank); with >= 2 devices it is the real RCCL path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env.update(BLIM_DIST_BACKEND="gloo", BLIM_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "8"], cwd=root,
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["pairs_per_step_per_gpu"] == 8 * 16 and "cpu_baseline" not in d

@@ -126,3 +126,29 @@ def test_reference_importable_and_agrees_on_one_layer(tiny):
         np.testing.assert_allclose(e_r.numpy(), emb, atol=1e-6)
         out = ref(inputs_embeds=e_r, attention_mask=m_r)
     np.testing.assert_allclose(m.forward_hidden(emb, mask), out.hidden_states.numpy(), atol=2e-5)
+
+
+def test_oracle_at_depth_28_layers_h1024():
+    """The restatement at DEPTH: 28 layers (H=1024) against tests/golden/deep.npz, which the reference itself produced
+    (oracle/gen_golden.py --case deep): one reference-shaped pass and the headline SYN rows (96 video + 32 text tokens, top-16)."""
+    from oracle.gen_golden import LazyWeights, problem_of
+    g = np.load(os.path.join(GOLD, "deep.npz"))
+    spec = CASES["deep"]
+    dims = synth.ModelDims(**spec["dims"])
+    cfg = O.OracleConfig(**spec["dims"])
+    m = O.OracleModel(cfg, dict(LazyWeights(dims, spec["wseed"]).items()))
+    for prefix, sp, prob, checks in (("S_", spec, problem_of(spec, dims), [("t2v_tvg_cpn", "t2v", "tvg", True, 2)]),
+                                      ("SYN_", spec["syn"], problem_of(spec, dims, spec["syn"]), [("v2t_vtg", "v2t", "vtg", False, 1)])):
+        m.set_tvg_prefix_length(prob.tvg_prefix_length)
+        vtg = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+        tvg = O.padding_ids(prob.tvg_ids, prob.tvg_labels, prob.tvg_masks, synth.PAD_ID)
+        n = sp["n"]
+        for name, direction, ftype, cpn, q in checks:
+            ids, lab, msk = vtg if ftype == "vtg" else tvg
+            fn = O.compute_v2t_scores_x if direction == "v2t" else O.compute_t2v_scores_x
+            sims = (prob.v2t_sims if direction == "v2t" else prob.t2v_sims)[:q]
+            S = fn(np.full((n, n), -100.0, dtype=np.float32), sims, 0, ids, msk, lab, prob.video, prob.video_vocab, prob.tvg_video_labels, m,
+                   sp["topk"], sp["bs"], dims.num_clips, ftype, cpn)
+            G = g[f"{prefix}{name}"]
+            assert np.array_equal(S[:q] == -100.0, G[:q] == -100.0)
+            np.testing.assert_allclose(S[:q], G[:q], rtol=2e-5)
