@@ -580,6 +580,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 }
 
 #include <stdlib.h>
+#include <algorithm>
 static int g_gemm_persistent = getenv("BLIM_GEMM_PERSISTENT") ? atoi(getenv("BLIM_GEMM_PERSISTENT")) : 1;
 static int g_gemm_tile_map = getenv("BLIM_GEMM_TILE_MAP") ? atoi(getenv("BLIM_GEMM_TILE_MAP")) : -1;   // -1: by shape
 static int g_gemm_skip_epi = getenv("BLIM_GEMM_SKIP_EPI") ? atoi(getenv("BLIM_GEMM_SKIP_EPI")) : 0;
@@ -609,7 +610,38 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     return BLIM_OK;
 }
 
-int launch_gemm(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
+static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream);
+
+// The kernel addresses its operands with 32-bit byte offsets from the (scalar) base pointers.  An A operand of 4 GiB or more
+// (e.g. the [T, I] SwiGLU output beyond 113 k tokens at 7B) is processed as consecutive row chunks, each a whole number of
+// 256-row tiles: rows are independent in every epilogue, so the chunks are ordinary launches on shifted bases.
+int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
+    ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0 && p.lda > 0);
+    ARG_CHECK(p.dtype == DT_BF16 || p.dtype == DT_F16 || p.dtype == DT_F8);
+    const int64_t es = p.dtype == DT_F8 ? 1 : 2;
+    const int64_t row_bytes = p.lda * es;
+    if ((int64_t)p.M * row_bytes < (1ll << 32)) return launch_one(epi, p, stream);
+    const int64_t chunk = ((1ll << 32) - 1) / row_bytes / BM * BM;
+    ARG_CHECK(chunk >= BM);
+    const int64_t c_es = (epi == EPI_F32 || epi == EPI_RESID) ? 4 : 2;
+    const int ntn = (p.N + BN - 1) / BN;
+    for (int64_t r0 = 0; r0 < p.M; r0 += chunk) {
+        GemmParams q = p;
+        q.M = (int)std::min<int64_t>(chunk, p.M - r0);
+        q.A = (const bf16_t*)((const char*)p.A + r0 * row_bytes);
+        if (p.C) q.C = (char*)p.C + r0 * p.ldc * c_es;
+        if (p.row_scale) q.row_scale = p.row_scale + r0;
+        if (p.pos) q.pos = p.pos + r0;
+        if (p.labels) q.labels = p.labels + r0;
+        if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
+        if (p.label_logit) q.label_logit = p.label_logit + r0;
+        const int rc = launch_one(epi, q, stream);
+        if (rc != BLIM_OK) return rc;
+    }
+    return BLIM_OK;
+}
+
+static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the

@@ -51,6 +51,10 @@ def get_args_parser():
     p.add_argument("--max_tokens", default=32768, type=int, help="packed tokens per engine call")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")
+    p.add_argument("--no_dedup", action="store_false", dest="dedup", help="score the pairs both directions share twice, as the reference does")
+    p.add_argument("--shard", default=None, type=int, nargs=2, metavar=("W", "RANK"),
+                   help="play rank RANK of a W-process job in this single process: the rank's own row blocks, no merge, no recall table "
+                        "(timing of the 8-GPU configurations on one GPU)")
     p.add_argument("--synthetic", default=0, type=int, help="N > 0: dry run on N synthetic videos/texts (tiny model unless --synthetic_7b)")
     p.add_argument("--synthetic_7b", action="store_true")
     return p
@@ -115,15 +119,21 @@ def main(args):
         print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")
     torch.cuda.synchronize()
     t1 = time.time()
+    torch.cuda.reset_peak_memory_stats()
     results = val_one_epoch(DDPLike(model), loader, None, device, 0, None, tokenizer=tokenizer, args=args)
     torch.cuda.synchronize()
     if rank == 0:
-        n_items = len(loader.dataset)
-        finetuned = bool(args.resume)
-        n_pass = (1 + (1 if args.cpn else 0) + (1 if finetuned else 0)) + (1 + (1 + (1 if args.cpn else 0) if finetuned else 0))
-        n_pairs = n_pass * n_items * min(args.topk, n_items)
-        print(f"evaluation: {n_pass} passes x {n_items} queries x top-{min(args.topk, n_items)} = {n_pairs} pairs in {time.time() - t1:.2f}s "
-              f"({n_pairs / (time.time() - t1):.0f} pairs/s over {world} GPU(s), host planning and loading included)")
+        st = getattr(args, "_eval_stats", {})
+        dt = time.time() - t1
+        free_b, total_b = torch.cuda.mem_get_info()
+        print(f"evaluation: {st.get('pairs_requested', 0)} (query, candidate) pairs of this rank's row blocks, {st.get('pairs_scored', 0)} scored by the engine "
+              f"(the rest shared between directions), in {dt:.2f}s = {st.get('pairs_requested', 0) / dt:.0f} pairs/s per process "
+              f"(world {st.get('world', world)}, host planning and loading included); device memory in use {(total_b - free_b) / 2**30:.1f} GiB, "
+              f"torch peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    if args.shard is not None:
+        model.engine.close()
+        return None                                           # one rank's share: the matrices are partial, no recall table
+    if rank == 0:
         import pandas as pd
         os.makedirs(args.output_dir, exist_ok=True)
         table = pd.DataFrame(results).T                                                    # main.py:170-173

@@ -455,13 +455,27 @@ def evaluation(model, data_loader, device, tokenizer, args):
     model.module.set_tvg_prefix_length(data_loader.dataset.tvg_prefix_length)                     # :210
 
     literal = bool(getattr(args, "literal", False))
+    # shard emulation (one process plays rank r of W without a process group: the rank's own share of the work, no merge;
+    # used to time configurations that are quoted on 8 GPUs on a 1-GPU box)
+    emulate = getattr(args, "shard", None)
+    if emulate is not None:
+        W, rank = int(emulate[0]), int(emulate[1])
+    collective = W > 1 and emulate is None
+    # cross-direction de-duplication (fused path): log P(text i | video j) is v2t.candidate_likelihood[j, i] AND
+    # t2v.query_likelihood[i, j]; log P(video j | text i) is v2t.query_likelihood[j, i] AND t2v.candidate_likelihood[i, j]
+    # (SURVEY.md section 3.3).  The t2v passes therefore only score the pairs the (merged) v2t matrices do not already hold; with
+    # dense candidates (topk >= N) the t2v likelihood passes cost nothing.  The literal path keeps the reference's control flow.
+    dedup = (not literal) and bool(getattr(args, "dedup", True)) and not bool(getattr(args, "compat_allreduce_offset", False))
     full = lambda n, m: torch.full((n, m), -100.0, dtype=torch.float32, device=device)
     scorer = getattr(args, "_scorer", None)              # test hook: any object with .vtg(pairs, cpn) / .tvg(pairs, cpn)
     if scorer is None and not literal:
         scorer = PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
                             tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
+    stats = {"pairs_requested": 0, "pairs_scored": 0}
 
-    def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):
+    def run_pass(S, sims_rows, start, query_is_video, ftype, cpn, known=None):
+        """known = (M, mask): M [videos, texts] device matrix of the opposite direction's pass, mask [videos, texts] host bool
+        array of the entries it holds -- those pairs are copied instead of scored."""
         if literal:
             fn = compute_v2t_scores_x if query_is_video else compute_t2v_scores_x
             ids, msk, lab = (vtg_ids, vtg_masks, vtg_labels) if ftype == "vtg" else (tvg_ids, tvg_masks, tvg_labels)
@@ -470,10 +484,29 @@ def evaluation(model, data_loader, device, tokenizer, args):
         if sims_rows.shape[0] == 0:
             return S
         pairs = _topk_pairs(sims_rows, start, args.topk, query_is_video)
-        sc = scorer.vtg(pairs, cpn) if ftype == "vtg" else scorer.tvg(pairs, cpn)
-        r, c = (pairs[:, 0], pairs[:, 1]) if query_is_video else (pairs[:, 1], pairs[:, 0])
-        S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = torch.from_numpy(sc).to(device)
+        stats["pairs_requested"] += len(pairs)
+        if known is not None:
+            M, mask = known
+            have = mask[pairs[:, 0], pairs[:, 1]]
+            hp = pairs[have]
+            if len(hp):
+                vj, ti = torch.from_numpy(hp[:, 0]).to(device), torch.from_numpy(hp[:, 1]).to(device)
+                r, c = (vj, ti) if query_is_video else (ti, vj)
+                S[r, c] = M[vj, ti]
+            pairs = pairs[~have]
+        if len(pairs):
+            stats["pairs_scored"] += len(pairs)
+            sc = scorer.vtg(pairs, cpn) if ftype == "vtg" else scorer.tvg(pairs, cpn)
+            r, c = (pairs[:, 0], pairs[:, 1]) if query_is_video else (pairs[:, 1], pairs[:, 0])
+            S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = torch.from_numpy(sc).to(device)
         return S
+
+    def merge(dicts_blocks):
+        compat = bool(getattr(args, "compat_allreduce_offset", False))
+        keys = [(d, k, blk) for d, blk in dicts_blocks for k in list(d)]
+        merged = dist_utils.merge_row_blocks_many([d[k] for d, k, _ in keys], [blk for _, _, blk in keys], W, compat_offset=compat)
+        for (d, k, _), m in zip(keys, merged):                                                   # one RCCL all-gather for all matrices
+            d[k] = m
 
     v2t, t2v = {}, {}
     start, end = dist_utils.row_block(num_videos, W, rank)                                       # :213-215
@@ -488,12 +521,18 @@ def evaluation(model, data_loader, device, tokenizer, args):
             if t1 > t0:
                 tp = np.stack([np.zeros(t1 - t0, dtype=np.int64), np.arange(t0, t1, dtype=np.int64)], axis=1)
                 mine[: t1 - t0] = torch.from_numpy(np.asarray(scorer.vtg(tp, True), dtype=np.float32)).to(device)
-            parts = [torch.empty_like(mine) for _ in range(W)]
-            torch.distributed.all_gather(parts, mine)
-            prior = torch.cat(parts)[:num_texts]
+                stats["pairs_scored"] += t1 - t0
+            if collective:
+                parts = [torch.empty_like(mine) for _ in range(W)]
+                torch.distributed.all_gather(parts, mine)
+                prior = torch.cat(parts)[:num_texts]
+            else:                                        # shard emulation: only this rank's texts are known
+                prior = torch.full((num_texts,), -100.0, dtype=torch.float32, device=device)
+                prior[t0:t1] = mine[: t1 - t0]
             S = full(num_videos, num_texts)
             if end > start:
                 pairs = _topk_pairs(v2t_iv2[start:end], start, args.topk, True)
+                stats["pairs_requested"] += len(pairs)
                 r_, c_ = torch.from_numpy(pairs[:, 0]).to(device), torch.from_numpy(pairs[:, 1]).to(device)
                 S[r_, c_] = prior[c_]
             v2t["candidate_prior"] = S
@@ -502,20 +541,28 @@ def evaluation(model, data_loader, device, tokenizer, args):
     if finetuned:
         v2t["query_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "tvg", False)
     v_block = (start, end)
+    known_vtg = known_tvg = None
+    if dedup:
+        if collective:
+            merge([(v2t, v_block)])                      # first all-gather: the complete v2t matrices, before the t2v passes read them
+        k = min(num_texts, args.topk)
+        mask = np.zeros((num_videos, num_texts), dtype=bool)
+        rows = slice(0, num_videos) if (W == 1 or collective) else slice(*v_block)
+        idx = v2t_iv2[rows].topk(k=k, dim=1).indices.cpu().numpy()
+        mask[np.repeat(np.arange(rows.start, rows.stop), k), idx.reshape(-1)] = True
+        known_vtg = (v2t["candidate_likelihood"], mask)
+        known_tvg = (v2t["query_likelihood"], mask) if finetuned else None
     start, end = dist_utils.row_block(num_texts, W, rank)                                        # :233-235
-    t2v["query_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "vtg", False)
+    t2v["query_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "vtg", False, known=known_vtg)
     if finetuned:
-        t2v["candidate_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", False)
+        t2v["candidate_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", False, known=known_tvg)
         if args.cpn:
             t2v["candidate_prior"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", True)
     t_block = (start, end)
 
-    if W > 1:                                                                                    # :252-262
-        compat = bool(getattr(args, "compat_allreduce_offset", False))
-        keys = [(d, k, blk) for d, blk in ((v2t, v_block), (t2v, t_block)) for k in list(d)]
-        merged = dist_utils.merge_row_blocks_many([d[k] for d, k, _ in keys], [blk for _, _, blk in keys], W, compat_offset=compat)
-        for (d, k, _), m in zip(keys, merged):                                                   # one RCCL all-gather for all matrices
-            d[k] = m
+    if collective:                                                                               # :252-262
+        merge([(t2v, t_block)] if dedup else [(v2t, v_block), (t2v, t_block)])
+    args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank)
     t2v_dict = {k: v.cpu().numpy() for k, v in t2v.items()}                                      # :264-276
     v2t_dict = {k: v.cpu().numpy() for k, v in v2t.items()}
     t2v_dict["internvideo2"] = t2v_iv2.cpu().numpy()

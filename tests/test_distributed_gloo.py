@@ -139,3 +139,45 @@ def test_evaluation_world2_equals_single_process_and_shards_the_prior_over_texts
         prior_calls = [c for c in calls if c[0] == "vtg" and c[1]]
         assert prior_calls == [("vtg", True, 6 if rank == 0 else 5)]
     assert ("vtg", True, n * 3) in ref_calls                           # single process: all top-k pairs (deduplicated inside the scorer)
+
+
+def _run_eval_with(n, **kw):
+    import types
+    from blim_amd import retrieval_utils as RU
+    scorer = _FakeScorer()
+    args = _eval_args(n, scorer)
+    for k, v in kw.items():
+        setattr(args, k, v)
+    model = types.SimpleNamespace(eval=lambda: None, module=types.SimpleNamespace(set_tvg_prefix_length=lambda k: None))
+    t2v, v2t = RU.evaluation(model, _Loader(n), torch.device("cpu"), types.SimpleNamespace(pad_token_id=0), args)
+    return t2v, v2t, scorer.calls, args._eval_stats
+
+
+def test_cross_direction_dedup_gives_the_same_matrices_with_fewer_scored_pairs():
+    """v2t.candidate_likelihood[j, i] and t2v.query_likelihood[i, j] are the same number (likewise the two TVG matrices): the t2v
+    passes copy what the v2t matrices hold and score only the rest; with dense candidates (topk >= N) they score nothing."""
+    n = 11
+    a, b = _run_eval_with(n), _run_eval_with(n, dedup=False)
+    for x, y in ((a[0], b[0]), (a[1], b[1])):
+        assert set(x) == set(y)
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    assert b[3]["pairs_scored"] == b[3]["pairs_requested"] == 6 * n * 3
+    assert a[3]["pairs_requested"] == 6 * n * 3 and a[3]["pairs_scored"] < b[3]["pairs_scored"]
+    dense = _run_eval_with(n, topk=n)
+    assert [c[:2] for c in dense[2]] == [("vtg", False), ("vtg", True), ("tvg", False), ("tvg", True)]   # no t2v likelihood pass left
+    ref = _run_eval_with(n, topk=n, dedup=False)
+    for k in ref[0]:
+        assert np.array_equal(dense[0][k], ref[0][k]), k
+    # shard emulation: rank 1 of 2 scores its own row blocks only, and its rows equal the full result's rows
+    sh = _run_eval_with(n, shard=(2, 1))
+    s, e = D.row_block(n, 2, 1)
+    for k in a[1]:
+        if k == "candidate_prior":                        # text-sharded: the emulated rank only knows the prior of ITS texts
+            m = sh[1][k][s:e] != -100.0
+            assert m.any() and np.array_equal(sh[1][k][s:e][m], a[1][k][s:e][m]) and not m[:, :s].any()
+        elif k != "internvideo2":
+            assert np.array_equal(sh[1][k][s:e], a[1][k][s:e]) and (sh[1][k][:s] == -100.0).all()
+    for k in a[0]:
+        if k != "internvideo2":
+            assert np.array_equal(sh[0][k][s:e], a[0][k][s:e])

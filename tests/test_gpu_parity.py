@@ -108,6 +108,38 @@ def test_gemm_vs_numpy(M, N, K, dtype):
     assert relmax(got, want) < (6e-3 if dtype == torch.bfloat16 else 1e-3)        # one 16-bit rounding of the output
 
 
+def test_gemm_row_chunking_beyond_4gib():
+    """An A operand of >= 4 GiB (32-bit operand offsets inside the kernel) is processed as row chunks: rows on both sides of the
+    chunk boundary and the last rows agree with a GEMM on just those rows."""
+    M, N, K = 66000, 512, 32768                      # 66000 x 65536 B = 4.03 GiB; chunk boundary at row 65280
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = (torch.randn((M, K), generator=g, device="cuda", dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda", dtype=torch.float32) * 0.05).to(torch.bfloat16)
+    out = eng.gemm_bf16(a, w)
+    for lo, hi in ((0, 256), (65280 - 128, 65280 + 128), (M - 300, M)):
+        part = eng.gemm_bf16(a[lo:hi].contiguous(), w)
+        assert torch.equal(out[lo:hi], part), (lo, hi)
+        ref = a[lo:hi].float() @ w.float().T
+        assert relmax(part.float().cpu().numpy(), ref.cpu().numpy()) < 6e-3
+
+
+def test_engine_batch_beyond_113k_tokens(wide):
+    """--max_tokens above ~113 k (the [T, I] SwiGLU output reaches 4 GiB at 7B width): one packed batch of 120,000 tokens; the
+    sequences that straddle the 4-GiB row boundary give the hidden states they give in a small batch."""
+    t = wide
+    E = t.model.engine
+    Ls, n_seq = 100, 1200
+    T = Ls * n_seq
+    g = torch.Generator(device="cuda").manual_seed(5)
+    emb = (torch.randn((T, t.dims.hidden_size), generator=g, device="cuda") * 0.02).to(E.torch_dtype)
+    mk = lambda n: eng.PackedBatch(np.tile(np.arange(Ls, dtype=np.int32), n), np.ones(Ls * n, np.uint8), np.arange(n, dtype=np.int32) * Ls, np.full(n, Ls, np.int32))
+    big, _ = E.decode(mk(n_seq), emb)
+    for s0 in (0, 1132, 1133, n_seq - 1):             # 4 GiB / (18944 * 2 B) = row 113,359 -> inside sequence 1133
+        small, _ = E.decode(mk(1), emb[s0 * Ls:(s0 + 1) * Ls].contiguous())
+        assert torch.isfinite(small.float()).all()
+        assert torch.equal(big[s0 * Ls:(s0 + 1) * Ls], small), s0
+
+
 def test_layer_stages_against_oracle(tiny1):
     """QKV+bias+RoPE, attention (key mask incl. CPN), SwiGLU and both residual GEMMs, one stage at a time."""
     t = tiny1

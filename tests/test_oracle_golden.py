@@ -152,3 +152,28 @@ def test_oracle_at_depth_28_layers_h1024():
             G = g[f"{prefix}{name}"]
             assert np.array_equal(S[:q] == -100.0, G[:q] == -100.0)
             np.testing.assert_allclose(S[:q], G[:q], rtol=2e-5)
+
+
+def test_torch_port_of_the_layer_agrees_with_the_numpy_oracle(tiny):
+    """oracle/torch_port.py (the threaded CPU statement bench.py times) == oracle/blim_oracle.py on one layer + the LSE head."""
+    import torch
+    from oracle import torch_port as TP
+    m, prob, cfg = tiny["m"], tiny["prob"], tiny["cfg"]
+    ids, lab, msk = tiny["vtg"]
+    sel = [0, 3, 5]
+    mask, cpn, emb, lab2 = m.prepare_inputs_labels_for_multimodal(ids[sel], msk[sel], lab[sel], [prob.video[i] for i in sel])
+    L = emb.shape[1]
+    w = {k: torch.from_numpy(v) for k, v in m.w.items()}
+    cos, sin = O.rope_tables(cfg.head_dim, cfg.rope_theta, L)
+    tc, ts = TP.rope_tables(cfg.head_dim, cfg.rope_theta, L)
+    np.testing.assert_allclose(tc.numpy(), cos, atol=1e-5); np.testing.assert_allclose(ts.numpy(), sin, atol=1e-5)     # f32 angles up to ~60 rad
+    for mm in (mask, cpn):
+        want = m.decoder_layer(0, emb, O.additive_mask(mm, L), cos, sin)
+        got = TP.decoder_layer(torch.from_numpy(emb), w, "layers.0.", TP.additive_mask(torch.from_numpy(mm), L), tc, ts, cfg.num_heads, cfg.num_kv_heads, cfg.rms_eps)
+        valid = mask.astype(bool)
+        np.testing.assert_allclose(got.numpy()[valid], want[valid], atol=2e-5)
+    rows = torch.from_numpy(want[0, :5])
+    labels = torch.tensor([5, 17, 151644, 3, 99])
+    lp = TP.label_logprobs(rows, w["lm_head"], labels).numpy()
+    ref = O.log_softmax(want[0, :5] @ m.w["lm_head"].T)[np.arange(5), labels.numpy()]
+    np.testing.assert_allclose(lp, ref, rtol=1e-5)
