@@ -18,10 +18,10 @@
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <bool USE_TR, int MAXC, int DT>
+template <bool USE_TR, int MAXC, int DT, bool SPLIT = false>
 __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t k_lds[KT * HD];
-    __shared__ __attribute__((aligned(16))) bf16_t v_lds[KT * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t v_lds[(SPLIT ? 2 : 1) * KT * HD];   // SPLIT: V_hi tile, then V_lo tile
     __shared__ uint32_t vis_lds[KT / 4];  // 32 visibility bytes
 
     const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -62,8 +62,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     float m_run = NEG, l_run = 0.f;
     const float c_log2 = p.scale * 1.4426950408889634f;
 
-    // staging: 1024 16-B chunks per tile (512 K + 512 V) spread over the workgroup's threads
-    // (MAXC * nthreads >= 1024: launch_attention picks MAXC from the group size)
+    // staging: 1024 16-B chunks per tile (512 K + 512 V; SPLIT: + 512 V_lo = 1536) spread over the workgroup's threads
+    // (MAXC * nthreads >= 1024 / 1536: launch_attention picks MAXC from the group size)
+    constexpr int NCHUNK = SPLIT ? 1536 : 1024;
     uint4 st[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) st[i] = make_uint4(0, 0, 0, 0);
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int idx = tid + i * nthreads;
-            if (idx < 1024) {
-                const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;
+            if (idx < NCHUNK) {
+                const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;   // isv: 0 K, 1 V (hi), 2 V_lo
                 const int kk = min(k0 + row, seg_len - 1);
-                st[i] = *(const uint4*)(p.qkv + (int64_t)(base_tok + kk) * p.ldq + (isv ? voff : koff) + 8 * ch);
+                st[i] = *(const uint4*)(p.qkv + (int64_t)(base_tok + kk) * p.ldq + (isv == 0 ? koff : isv == 1 ? voff : voff + p.v_lo_off) + 8 * ch);
             }
         }
     };
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int idx = tid + i * nthreads;
-            if (idx < 1024) {
+            if (idx < NCHUNK) {
                 const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;
-                if (isv) *(uint4*)(v_lds + row * HD + 8 * (ch ^ ((row & 3) << 2))) = st[i];
+                if (isv) *(uint4*)(v_lds + (isv - 1) * KT * HD + row * HD + 8 * (ch ^ ((row & 3) << 2))) = st[i];
                 else *(uint4*)(k_lds + row * HD + 8 * (ch ^ (row & 15))) = st[i];
             }
         }
@@ -171,6 +172,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         }
         // ---- O^T += V^T . P^T : A = V^T fragment (lane: d = 32db + (lane&31); keys 16s+4hf+{0..3} and +8)
 #pragma unroll
+        for (int vp = 0; vp < (SPLIT ? 2 : 1); ++vp) {
+        const bf16_t* vt = v_lds + vp * KT * HD;
+#pragma unroll
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -182,20 +186,21 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
                     const int kr0 = 16 * s2 + 4 * hf + (i16 >> 2);
                     const int kr1 = kr0 + 8;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(v_lds + kr0 * HD + 8 * (ch ^ ((kr0 & 3) << 2)) + within));
+                        (__attribute__((address_space(3))) s16x4*)(vt + kr0 * HD + 8 * (ch ^ ((kr0 & 3) << 2)) + within));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(v_lds + kr1 * HD + 8 * (ch ^ ((kr1 & 3) << 2)) + within));
+                        (__attribute__((address_space(3))) s16x4*)(vt + kr1 * HD + 8 * (ch ^ ((kr1 & 3) << 2)) + within));
                     vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 } else {
                     const int d = 32 * db + (lane & 31);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int kr = 16 * s2 + 8 * (j >> 2) + 4 * hf + (j & 3);
-                        vf[j] = (short)v_lds[kr * HD + 8 * ((d >> 3) ^ ((kr & 3) << 2)) + (d & 7)];
+                        vf[j] = (short)vt[kr * HD + 8 * ((d >> 3) ^ ((kr & 3) << 2)) + (d & 7)];
                     }
                 }
                 o[db] = mfma32<DT>(vf, pf[s2], o[db]);
             }
+        }
         }
     }
 
@@ -208,8 +213,11 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = 32 * db + 8 * g + 4 * hf;
-                *(uint2*)(orow + d) = make_uint2(pack2<DT>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                                                 pack2<DT>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+                const float x0 = o[db][4 * g] * inv, x1 = o[db][4 * g + 1] * inv, x2 = o[db][4 * g + 2] * inv, x3 = o[db][4 * g + 3] * inv;
+                *(uint2*)(orow + d) = make_uint2(pack2<DT>(x0, x1), pack2<DT>(x2, x3));
+                if constexpr (SPLIT)
+                    *(uint2*)(orow + p.out_lo_off + d) = make_uint2(pack2<DT>(x0 - from16<DT>(to16<DT>(x0)), x1 - from16<DT>(to16<DT>(x1))),
+                                                                    pack2<DT>(x2 - from16<DT>(to16<DT>(x2)), x3 - from16<DT>(to16<DT>(x3))));
             }
     }
 }
@@ -221,6 +229,15 @@ int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
     const int G = p.num_heads / p.num_kv_heads;
     if (G > 8) { blim_set_error("attention: %d query heads per kv head > 8 unsupported", G); return BLIM_ERR_ARG; }
     const dim3 grid(p.n_blocks, p.num_kv_heads), block(64 * G);
+    if (p.v_lo_off != 0 || p.out_lo_off != 0) {   // compensated mode (fp16 engines): transposed-read path only
+        ARG_CHECK(p.dtype == DT_F16 && p.v_lo_off > 0 && p.out_lo_off > 0 && p.v_lo_off % 8 == 0 && p.out_lo_off % 4 == 0);
+        if (G >= 4) hipLaunchKernelGGL((attn_kernel<true, 6, DT_F16, true>), grid, block, 0, stream, p);
+        else if (G >= 2) hipLaunchKernelGGL((attn_kernel<true, 12, DT_F16, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_kernel<true, 24, DT_F16, true>), grid, block, 0, stream, p);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { blim_set_error("attention launch failed: %s", hipGetErrorString(e2)); return BLIM_ERR_HIP; }
+        return BLIM_OK;
+    }
 #define ATTN_LAUNCH(TR, MC)                                                                             \
     do {                                                                                            \
         if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<TR, MC, DT_F16>), grid, block, 0, stream, p); \

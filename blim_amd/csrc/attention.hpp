@@ -23,6 +23,10 @@ struct AttnParams {
     bf16_t* out;  // [T, num_heads*128]
     int64_t ldo;
     float scale;  // 1/sqrt(head_dim)
+    // compensated ("precise") mode, fp16: V = V_hi + V_lo with the lo parts v_lo_off columns after the hi parts in `qkv`
+    // (O += V_lo^T.P^T as a second MFMA pass), and the output written as hi at `out`, lo = f16(o - f32(hi)) at out + out_lo_off.
+    // 0 / 0 = plain.
+    int64_t v_lo_off, out_lo_off;
 };
 
 int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream);

@@ -75,6 +75,11 @@ struct blim_engine {
     DevBuf x8, a8, act8, hsel8, rscale;   // fp8 mode: quantised GEMM inputs and their per-row scales
     // options / timing
     int attn_tr = 1;
+    // compensated ("precise") mode, option "precise" (fp16 engines): every 16-bit activation that feeds a GEMM or the attention's
+    // P.V product travels as hi + lo (lo = f16(x - f32(hi))), the GEMMs walk K twice ([hi | lo] against the same weights).  About
+    // 21 significant bits of the activations reach the f32 accumulators; costs 2x the GEMM flops, so the host turns it on for the
+    // cheap TVG calls only (their scores are ~10x smaller in magnitude than the VTG ones: DESIGN.md section 4).
+    bool precise = false;
     bool timing = false;
     std::vector<TimedSpan> spans;
 };
@@ -390,14 +395,14 @@ static int finalize_f8(blim_engine* e) {
 // ---------------------------------------------------------------------------- workspaces
 static int reserve_tokens(blim_engine* e, int64_t T) {
     const blim_config& c = e->c;
-    const int64_t Tp = round_up(T, 256);
+    const int64_t Tp = round_up(T, 256) * (e->precise ? 2 : 1);      // precise mode: [hi | lo] rows of twice the width
     if (e->f8) {
         TRY(ensure(e->x8, (size_t)Tp * c.hidden_size));
         TRY(ensure(e->a8, (size_t)Tp * c.hidden_size));
         TRY(ensure(e->act8, (size_t)Tp * c.intermediate_size));
         TRY(ensure(e->rscale, (size_t)Tp * 4 * 4));      // [x | attn | act | label rows] scales
     }
-    TRY(ensure(e->resid, (size_t)Tp * c.hidden_size * 4));
+    TRY(ensure(e->resid, (size_t)round_up(T, 256) * c.hidden_size * 4));
     TRY(ensure(e->xn, (size_t)Tp * c.hidden_size * 2));
     TRY(ensure(e->qkv, (size_t)Tp * e->qkv_n * 2));
     TRY(ensure(e->attn, (size_t)Tp * c.hidden_size * 2));
@@ -408,7 +413,7 @@ static int reserve_rows(blim_engine* e, int64_t R) {
     const blim_config& c = e->c;
     const int64_t Rp = round_up(R, 256);
     const int ntn = (c.vocab_size + 255) / 256;
-    TRY(ensure(e->hsel, (size_t)Rp * c.hidden_size * 2));
+    TRY(ensure(e->hsel, (size_t)Rp * c.hidden_size * 2 * (e->precise ? 2 : 1)));
     if (e->f8) TRY(ensure(e->hsel8, (size_t)Rp * c.hidden_size + (size_t)Rp * 4));   // e4m3 rows, then their scales
     TRY(ensure(e->lse_part, (size_t)Rp * ntn * sizeof(float2)));
     TRY(ensure(e->lab_logit, (size_t)Rp * 4));
@@ -428,6 +433,14 @@ static GemmParams gp(int dt, const void* A, int64_t lda, const void* W, int64_t 
     memset(&p, 0, sizeof(p));
     p.dtype = dt;
     p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.M = (int)M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.scale = 1.0f;
+    return p;
+}
+
+// compensated mode: A = [hi | lo] (K counts both halves, W is walked twice); 16-bit outputs as hi at C and lo at C + lo_off
+static GemmParams gp2(const blim_engine* e, const void* A, int64_t K1, const void* W, int64_t M, int N, void* C, int64_t ldc1, int64_t n_out1) {
+    const int pf = e->precise ? 2 : 1;
+    GemmParams p = gp(e->c.compute_dtype, A, pf * K1, W, M, N, (int)(pf * K1), C, pf * ldc1);
+    if (e->precise) { p.w_wrap_k = (int)K1; p.lo_off = n_out1; }
     return p;
 }
 
@@ -480,16 +493,18 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s)); }
     const double tok = (double)T;
     const bool q8 = e->f8 && (e->f8_mask & 1), o8 = e->f8 && (e->f8_mask & 2), g8 = e->f8 && (e->f8_mask & 4), d8 = e->f8 && (e->f8_mask & 8);
+    const int pf = e->precise ? 2 : 1;
+    if (e->precise && (e->f8 || c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_STATE; }
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * H, e->precise ? xn + H : nullptr));
         }
         {
-            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n);
-            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp(c.compute_dtype, xn, H, l.wqkv, T, e->qkv_n, H, qkv, e->qkv_n);
+            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * pf);
+            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n);
             p.bias = l.bqkv; p.pos = b->positions; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
             p.rope_cols = (c.num_heads + c.num_kv_heads) * 128;
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -498,31 +513,34 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             SpanGuard g(e, s, TC_ATTN, 0);
             AttnParams a;
             a.dtype = c.compute_dtype;
-            a.qkv = qkv; a.ldq = e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
+            a.qkv = qkv; a.ldq = (int64_t)pf * e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
-            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = H; a.scale = 0.08838834764831845f;
+            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * H; a.scale = 0.08838834764831845f;
+            a.v_lo_off = e->precise ? e->qkv_n : 0; a.out_lo_off = e->precise ? H : 0;
             TRY(launch_attention(a, e->attn_tr, s));
         }
         if (o8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
         {
-            SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H);
-            GemmParams p = o8 ? gp8(a8, H, sa, l.wo8, l.so, T, H, H, resid, H) : gp(c.compute_dtype, attn, H, l.wo, T, H, H, resid, H);
+            SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H * pf);
+            GemmParams p = o8 ? gp8(a8, H, sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0);
+            p.ldc = H; p.lo_off = 0;
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (g8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * H, e->precise ? xn + H : nullptr));
         }
         {
-            SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I);
-            GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp(c.compute_dtype, xn, H, l.wgu, T, 2 * I, H, act, I);
+            SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I * pf);
+            GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I);
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
         if (d8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
         {
-            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I);
-            GemmParams p = d8 ? gp8(act8, I, sact, l.wd8, l.sd, T, H, I, resid, H) : gp(c.compute_dtype, act, I, l.wd, T, H, I, resid, H);
+            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * pf);
+            GemmParams p = d8 ? gp8(act8, I, sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0);
+            p.ldc = H; p.lo_off = 0;
             TRY(launch_gemm(EPI_RESID, p, s));
         }
     }
@@ -535,8 +553,9 @@ static int check_batch(const blim_batch* b) {
     return BLIM_OK;
 }
 
-extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
-                           void* out_hidden_bf16, float* out_hidden_f32, void* stream) {
+// final-norm hidden states of the selected rows; `split` (precise mode): out16 rows are [hi | lo] of width 2H
+static int decode_impl(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
+                       void* out_hidden_bf16, bool split, float* out_hidden_f32, void* stream) {
     ARG_CHECK(e && embeds && (out_hidden_bf16 || out_hidden_f32));
     TRY(check_batch(b));
     TRY(blim_weights_ready(e));
@@ -545,11 +564,20 @@ extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embe
     const int64_t n = out_rows ? n_out : b->n_tokens;
     ARG_CHECK(n > 0);
     SpanGuard g(e, s, TC_NORM, 0);
-    return launch_rmsnorm((const float*)e->resid.p, e->c.hidden_size, out_rows, n, e->c.hidden_size, e->final_norm, e->c.rms_eps,
-                          (bf16_t*)out_hidden_bf16, e->c.compute_dtype, out_hidden_f32, s, b->n_tokens);
+    const int H = e->c.hidden_size;
+    return launch_rmsnorm((const float*)e->resid.p, H, out_rows, n, H, e->final_norm, e->c.rms_eps, (bf16_t*)out_hidden_bf16, e->c.compute_dtype,
+                          out_hidden_f32, s, b->n_tokens, split ? 2 * H : H, split ? (bf16_t*)out_hidden_bf16 + H : nullptr);
+}
+extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
+                           void* out_hidden_bf16, float* out_hidden_f32, void* stream) {
+    return decode_impl(e, b, embeds, out_rows, n_out, out_hidden_bf16, false, out_hidden_f32, stream);
 }
 
+static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split, const int32_t* labels, int64_t n_rows, float* logprob, void* stream);
 extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
+    return vtg_logprobs_impl(e, hidden_bf16, false, labels, n_rows, logprob, stream);
+}
+static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
     ARG_CHECK(e && hidden_bf16 && labels && logprob && n_rows > 0);
     TRY(blim_weights_ready(e));
     hipStream_t s = (hipStream_t)stream;
@@ -566,8 +594,9 @@ extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const 
         TRY(launch_quant_rows((const bf16_t*)hidden_bf16, H, n_rows, H, e->c.compute_dtype, h8, hs, s));
     }
     {
-        SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)H * V);
+        SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)H * V * (split ? 2 : 1));
         GemmParams p = l8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0) : gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
+        if (split) { ARG_CHECK(!l8); p.lda = 2 * H; p.K = 2 * H; p.w_wrap_k = H; }
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
     }
@@ -580,13 +609,17 @@ extern "C" int blim_segment_mean(blim_engine* e, const float* logprob, const int
     return launch_segment_mean(logprob, row_start, n_pairs, mode, score, (hipStream_t)stream);
 }
 
-extern "C" int blim_lm_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, float* logits, void* stream) {
+static int lm_head_impl(blim_engine* e, const void* hidden_bf16, bool split, int64_t n_rows, float* logits, void* stream) {
     ARG_CHECK(e && hidden_bf16 && logits && n_rows > 0);
     TRY(blim_weights_ready(e));
     const int H = e->c.hidden_size, V = e->c.vocab_size;
     SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * V);
     GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, logits, V);
+    if (split) { p.lda = 2 * H; p.K = 2 * H; p.w_wrap_k = H; }
     return launch_gemm(EPI_F32, p, (hipStream_t)stream);
+}
+extern "C" int blim_lm_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, float* logits, void* stream) {
+    return lm_head_impl(e, hidden_bf16, false, n_rows, logits, stream);
 }
 
 extern "C" int blim_ce_rows(blim_engine* e, const float* logits, int64_t ld, int32_t n_cols, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
@@ -594,39 +627,53 @@ extern "C" int blim_ce_rows(blim_engine* e, const float* logits, int64_t ld, int
     return launch_ce_rows(logits, ld, n_cols, labels, n_rows, logprob, (hipStream_t)stream);
 }
 
-extern "C" int blim_visual_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, void* out_bf16, void* stream) {
+// split (precise mode): hidden rows are [hi | lo] of width 2H and the output rows [hi | lo] of width 2M
+static int visual_head_impl(blim_engine* e, const void* hidden_bf16, bool split, int64_t n_rows, void* out_bf16, void* stream) {
     ARG_CHECK(e && hidden_bf16 && out_bf16 && n_rows > 0);
     TRY(blim_weights_ready(e));
     const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
     SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * M);
     GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->visual_head, n_rows, M, H, out_bf16, M);
+    if (split) { p.lda = 2 * H; p.K = 2 * H; p.w_wrap_k = H; p.ldc = 2 * M; p.lo_off = M; }
     return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
 }
+extern "C" int blim_visual_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, void* out_bf16, void* stream) {
+    return visual_head_impl(e, hidden_bf16, false, n_rows, out_bf16, stream);
+}
 
-extern "C" int blim_tvg_logits(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream) {
+static int tvg_logits_impl(blim_engine* e, const void* vh_bf16, bool split, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream) {
     ARG_CHECK(e && vh_bf16 && vocab_bf16 && logits && n_vocab > 0 && n_pairs > 0);
     hipStream_t s = (hipStream_t)stream;
     const int M = e->c.mm_hidden_size, C = e->c.num_clips;
+    const int pf = split ? 2 : 1;
     SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_pairs * C * (double)M * n_vocab);
     for (int c = 0; c < C; ++c) {
-        GemmParams p = gp(e->c.compute_dtype, (const bf16_t*)vh_bf16 + (int64_t)c * M, (int64_t)C * M, (const bf16_t*)vocab_bf16 + (int64_t)c * n_vocab * M, n_pairs, n_vocab, M,
-                          logits + (int64_t)c * n_vocab, (int64_t)C * n_vocab);
+        GemmParams p = gp(e->c.compute_dtype, (const bf16_t*)vh_bf16 + (int64_t)c * pf * M, (int64_t)C * pf * M, (const bf16_t*)vocab_bf16 + (int64_t)c * n_vocab * M, n_pairs, n_vocab,
+                          pf * M, logits + (int64_t)c * n_vocab, (int64_t)C * n_vocab);
+        if (split) p.w_wrap_k = M;
         p.scale = 1.0f / sqrtf((float)M);
         TRY(launch_gemm(EPI_F32, p, s));
     }
     return BLIM_OK;
 }
+extern "C" int blim_tvg_logits(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream) {
+    return tvg_logits_impl(e, vh_bf16, false, vocab_bf16, n_vocab, n_pairs, logits, stream);
+}
 
-extern "C" int blim_tvg_scores(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, const int32_t* labels,
-                               int32_t n_pairs, float* score, void* stream) {
+static int tvg_scores_impl(blim_engine* e, const void* vh_bf16, bool split, const void* vocab_bf16, int32_t n_vocab, const int32_t* labels,
+                           int32_t n_pairs, float* score, void* stream) {
     ARG_CHECK(e && labels && score && n_vocab > 0 && n_pairs > 0);
     hipStream_t s = (hipStream_t)stream;
     const int C = e->c.num_clips;
     TRY(ensure(e->tvg_logits, (size_t)n_pairs * C * n_vocab * 4));
     float* lg = (float*)e->tvg_logits.p;
-    TRY(blim_tvg_logits(e, vh_bf16, vocab_bf16, n_vocab, n_pairs, lg, stream));
+    TRY(tvg_logits_impl(e, vh_bf16, split, vocab_bf16, n_vocab, n_pairs, lg, stream));
     SpanGuard g(e, s, TC_MISC, 0);
     return launch_tvg_score(lg, n_vocab, n_vocab, labels, n_pairs, C, score, s);
+}
+extern "C" int blim_tvg_scores(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, const int32_t* labels,
+                               int32_t n_pairs, float* score, void* stream) {
+    return tvg_scores_impl(e, vh_bf16, false, vocab_bf16, n_vocab, labels, n_pairs, score, stream);
 }
 
 // ---------------------------------------------------------------------------- fused scoring
@@ -634,8 +681,8 @@ extern "C" int blim_score_vtg(blim_engine* e, const blim_batch* b, const void* e
                               int64_t n_rows, const int32_t* row_start, int32_t n_pairs, float* score, void* stream) {
     ARG_CHECK(e && rows && labels && row_start && score && n_rows > 0 && n_pairs > 0);
     TRY(reserve_rows(e, n_rows));
-    TRY(blim_decode(e, b, embeds, rows, n_rows, e->hsel.p, nullptr, stream));
-    TRY(blim_vtg_logprobs(e, e->hsel.p, labels, n_rows, (float*)e->logprob.p, stream));
+    TRY(decode_impl(e, b, embeds, rows, n_rows, e->hsel.p, e->precise, nullptr, stream));
+    TRY(vtg_logprobs_impl(e, e->hsel.p, e->precise, labels, n_rows, (float*)e->logprob.p, stream));
     return blim_segment_mean(e, (const float*)e->logprob.p, row_start, n_pairs, 0, score, stream);
 }
 
@@ -644,10 +691,10 @@ extern "C" int blim_score_tvg(blim_engine* e, const blim_batch* b, const void* e
     ARG_CHECK(e && rows && vocab_bf16 && labels && score && n_pairs > 0);
     const int64_t n_rows = (int64_t)n_pairs * e->c.num_clips;
     TRY(reserve_rows(e, n_rows));
-    TRY(ensure(e->vh, (size_t)round_up(n_rows, 256) * e->c.mm_hidden_size * 2));
-    TRY(blim_decode(e, b, embeds, rows, n_rows, e->hsel.p, nullptr, stream));
-    TRY(blim_visual_head(e, e->hsel.p, n_rows, e->vh.p, stream));
-    return blim_tvg_scores(e, e->vh.p, vocab_bf16, n_vocab, labels, n_pairs, score, stream);
+    TRY(ensure(e->vh, (size_t)round_up(n_rows, 256) * e->c.mm_hidden_size * 2 * (e->precise ? 2 : 1)));
+    TRY(decode_impl(e, b, embeds, rows, n_rows, e->hsel.p, e->precise, nullptr, stream));
+    TRY(visual_head_impl(e, e->hsel.p, e->precise, n_rows, e->vh.p, stream));
+    return tvg_scores_impl(e, e->vh.p, e->precise, vocab_bf16, n_vocab, labels, n_pairs, score, stream);
 }
 
 // ---------------------------------------------------------------------------- literal forward
@@ -669,8 +716,8 @@ extern "C" int blim_forward(blim_engine* e, const void* embeds, const uint8_t* m
     b.n_tokens = T; b.n_seqs = B; b.n_blocks = B * nbs; b.positions = pos; b.key_visible = mask; b.seq_start = seq_start; b.seq_len = seq_len;
     b.pfx_start = pfx; b.pfx_len = pfx; b.blk_seq = blk_seq; b.blk_q0 = blk_q0;
     TRY(reserve_rows(e, T));
-    TRY(blim_decode(e, &b, embeds, nullptr, 0, e->hsel.p, hidden, stream));
-    if (logits) TRY(blim_lm_head(e, e->hsel.p, T, logits, stream));
+    TRY(decode_impl(e, &b, embeds, nullptr, 0, e->hsel.p, e->precise, hidden, stream));
+    if (logits) TRY(lm_head_impl(e, e->hsel.p, e->precise, T, logits, stream));
     return BLIM_OK;
 }
 
@@ -742,6 +789,11 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     ARG_CHECK(e && key);
     if (!strcmp(key, "attn_tr_read")) { e->attn_tr = value; return BLIM_OK; }
     if (!strcmp(key, "f8_mask")) { e->f8_mask = value & 31; return BLIM_OK; }
+    if (!strcmp(key, "precise")) {
+        if (value && (e->f8 || e->c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_ARG; }
+        e->precise = value != 0;
+        return BLIM_OK;
+    }
     blim_set_error("unknown option '%s'", key);
     return BLIM_ERR_ARG;
 }

@@ -33,7 +33,7 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 //    44 GB/s per CU, the same bytes as alternating 32-KB tiles 62 GB/s: tools/dma_bench.hip);
 //  * only the fragment-READING group issues LDS-DMA (group 1 every A tile, group 0 every W tile, after its LDS reads):
 //    the computing group issues nothing but MFMAs.
-template <int EPI, int DT>
+template <int EPI, int DT, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[5 * TILE_BYTES];  // 160 KiB ring / 136 KiB (two stages, or the staged C tile)
 
@@ -192,16 +192,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < 8; ++i) {
             const int b = wg + 4 * i;   // 1-KiB block (8 rows) of the operand tile
             if (grp == 1) off8[i] = (uint32_t)((int64_t)min(row0 + 8 * b + sr, p.M - 1) * p.lda * ES + 16 * sc);
-            else off8[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr, p.N - 1) * p.K * ES + 16 * sc);
+            else off8[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr, p.N - 1) * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * ES + 16 * sc);   // W row stride
         }
         const char* gbase = grp == 1 ? baseA : baseW;
+        // compensated mode: A is [hi | lo] along K and W is used twice -- the W group's K-step index wraps (scalar select)
+        const int wrap = (grp == 0 && p.w_wrap_k > 0) ? p.w_wrap_k * ES / (BK * 2) : 0x7fffffff;
         auto stage8 = [&](int dst, int kt) __attribute__((always_inline)) {   // one operand tile share: 8 LDS-DMA per wave
 #ifdef GEMM_ABLATE_DMA   // ablation builds only: 1 = stage the first two K-steps only, then compute on stale
                          // LDS; 2 = keep every LDS-DMA but re-read the first two K-steps (L2-resident, no fabric / HBM traffic)
             if (GEMM_ABLATE_DMA == 1 && kt >= 2) return;
             if (GEMM_ABLATE_DMA == 2) kt &= 1;
 #endif
-            const char* g = gbase + (int64_t)kt * (BK * 2);
+            const char* g = gbase + (int64_t)(kt >= wrap ? kt - wrap : kt) * (BK * 2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 // keep the lane offset a 32-bit VGPR at the point of use: the zero-extension then folds into the LDS-DMA's
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             if (GEMM_ABLATE_DMA == 1 && kt >= 2) on = false;
             if (GEMM_ABLATE_DMA == 2) kt &= 1;
 #endif
-            const char* g = gbase + (int64_t)kt * (BK * 2);
+            const char* g = gbase + (int64_t)(kt >= wrap ? kt - wrap : kt) * (BK * 2);
             auto dma1 = [&](int q) __attribute__((always_inline)) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (on) { uint32_t o = off8[q]; asm volatile("" : "+v"(o)); glds16(g + o, smem + dst + (wg + 4 * q) * 1024); }
@@ -409,6 +411,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             constexpr int NC = (EPI == EPI_SWIGLU) ? 128 : 256;   // output columns of this tile
             constexpr int RS = NC * 2 + 16;                       // LDS row stride (bytes), = 16 mod 256: the 16 rows x 2 column groups of a
                                                                   // half-wave's ds_write_b64 cover all 64 banks once
+#pragma unroll 1
+            for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {
+            // compensated mode: part 0 stores hi = f16(x), part 1 stores lo = f16(x - f32(hi)) at C + lo_off
+            auto PK = [&](float a_, float b_) __attribute__((always_inline)) {
+                if (SPLIT && part) { a_ -= from16<ODT>(to16<ODT>(a_)); b_ -= from16<ODT>(to16<ODT>(b_)); }
+                return pack2<ODT>(a_, b_);
+            };
+            const int64_t c_part = (SPLIT && part) ? p.lo_off : 0;
+            if (SPLIT && part) __syncthreads();               // part 0's LDS reads are complete
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int rl = 128 * wm + 16 * mi + rsub;         // row inside the tile
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     if (p.bias == nullptr && p.act == 0) {         // wave-uniform fast path: convert and stage
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
-                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(pack2<ODT>(t[ni][0], t[ni][1]), pack2<ODT>(t[ni][2], t[ni][3]));
+                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(PK(t[ni][0], t[ni][1]), PK(t[ni][2], t[ni][3]));
                     } else {
 #pragma unroll 1
                         for (int ni = 0; ni < 4; ++ni) {
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                                 x[j] = t[ni][j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f);
                                 if (p.act == 1) x[j] = gelu_erf(x[j]);
                             }
-                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<ODT>(x[0], x[1]), pack2<ODT>(x[2], x[3]));
+                            *(uint2*)(lrow + cl * 2) = make_uint2(PK(x[0], x[1]), PK(x[2], x[3]));
                         }
                     }
                 } else if constexpr (EPI == EPI_QKV) {
@@ -460,15 +471,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                                 hi[j] = x2 * c4[j] + x1 * s4[j];
                             }
                             char* o = lrow + (hl * 128 + d) * 2;
-                            *(uint2*)o = make_uint2(pack2<ODT>(lo[0], lo[1]), pack2<ODT>(lo[2], lo[3]));
-                            *(uint2*)(o + 128) = make_uint2(pack2<ODT>(hi[0], hi[1]), pack2<ODT>(hi[2], hi[3]));
+                            *(uint2*)o = make_uint2(PK(lo[0], lo[1]), PK(lo[2], lo[3]));
+                            *(uint2*)(o + 128) = make_uint2(PK(hi[0], hi[1]), PK(hi[2], hi[3]));
                         }
                     } else {
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
                             const int cl = 64 * wn + 16 * ni + 4 * tq;
                             const float4 bv = *(const float4*)(p.bias + col0 + cl);
-                            *(uint2*)(lrow + cl * 2) = make_uint2(pack2<ODT>(t[ni][0] + bv.x, t[ni][1] + bv.y), pack2<ODT>(t[ni][2] + bv.z, t[ni][3] + bv.w));
+                            *(uint2*)(lrow + cl * 2) = make_uint2(PK(t[ni][0] + bv.x, t[ni][1] + bv.y), PK(t[ni][2] + bv.z, t[ni][3] + bv.w));
                         }
                     }
                 } else {  // EPI_SWIGLU: fragments (2p, 2p+1) = gate / up of the same 16 intermediate columns
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         float x[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x[j] = silu_f(t[2 * pr][j]) * t[2 * pr + 1][j];
-                        *(uint2*)(lrow + cl * 2) = make_uint2(pack2<ODT>(x[0], x[1]), pack2<ODT>(x[2], x[3]));
+                        *(uint2*)(lrow + cl * 2) = make_uint2(PK(x[0], x[1]), PK(x[2], x[3]));
                     }
                 }
             }
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 const char* lsrc = smem + (tid / LPR) * RS + seg * 16;
 #pragma unroll
                 for (int i = 0; i < 256 / RPP; ++i) v[i] = *(const uint4*)(lsrc + i * RPP * RS);
-                bf16_t* out = (bf16_t*)p.C + (int64_t)(row0 + tid / LPR) * p.ldc + oc;
+                bf16_t* out = (bf16_t*)p.C + c_part + (int64_t)(row0 + tid / LPR) * p.ldc + oc;
 #pragma unroll
                 for (int i = 0; i < 256 / RPP; ++i) *(uint4*)(out + (int64_t)i * RPP * p.ldc) = v[i];
             } else
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 const int row = row0 + rl;
                 if (row >= p.M || oc >= n_out) continue;
                 const uint4 v = *(const uint4*)(smem + rl * RS + seg * 16);
-                bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + oc;
+                bf16_t* out = (bf16_t*)p.C + c_part + (int64_t)row * p.ldc + oc;
                 if (oc + 7 < n_out && (p.ldc & 7) == 0) *(uint4*)out = v;
                 else {
                     const bf16_t* e = (const bf16_t*)&v;
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 }
             }
             stamp(5);
+            }
         } else {  // EPI_RESID / EPI_F32: f32 tile, two passes of 128 rows
             constexpr int RS = 1024 + 16;                         // = 16 mod 256: 16 rows of a ds_write_b128 lane group on distinct banks
 #pragma unroll 1
@@ -599,6 +611,15 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     }
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV || EPI == EPI_SWIGLU) {
+        if (p.lo_off != 0) {   // compensated outputs: fp16 engines only
+            if (p.dtype != DT_F16) { blim_set_error("split (hi|lo) GEMM outputs need an fp16 engine"); return BLIM_ERR_ARG; }
+            hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true>), grid, dim3(NTHREADS), 0, stream, p);
+            hipError_t e2 = hipGetLastError();
+            if (e2 != hipSuccess) { blim_set_error("gemm launch failed: %s", hipGetErrorString(e2)); return BLIM_ERR_HIP; }
+            return BLIM_OK;
+        }
+    }
     if (p.dtype == DT_F8) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F8>), grid, dim3(NTHREADS), 0, stream, p);
     else if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((gemm_kernel<EPI, DT_BF16>), grid, dim3(NTHREADS), 0, stream, p);
@@ -655,7 +676,9 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK((int64_t)p.K * es % 128 == 0);                  // whole 128-byte K-steps
     ARG_CHECK(p.lda * es % 16 == 0);
     ARG_CHECK(p.dtype != DT_F8 || (p.row_scale && p.col_scale));
-    ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * p.K * es < (1ll << 32));  // 32-bit operand offsets
+    ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice
+    ARG_CHECK(p.lo_off == 0 || epi == EPI_BF16 || epi == EPI_QKV || epi == EPI_SWIGLU);
+    ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
         case EPI_BF16: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_BF16>(p, stream);
         case EPI_F32: ARG_CHECK(p.C && p.bias == nullptr); return launch_t<EPI_F32>(p, stream);

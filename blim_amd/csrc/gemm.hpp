@@ -37,6 +37,11 @@ struct GemmParams {
     const int32_t* labels;   // [M] target column per row (or < 0)
     float2* lse_part;        // [M, ceil(N/256)] (max, sumexp)
     float* label_logit;      // [M]
+    // compensated ("precise") mode, fp16 engines: the A operand is [hi | lo] along K (lo = f16(x - f32(hi)): ~21 significant bits of
+    // the activation reach the f32 accumulator) -- K counts both halves and W's K index wraps after w_wrap_k elements;
+    // 16-bit outputs are written as hi at C and lo at C + lo_off elements (0 = plain)
+    int w_wrap_k;
+    int64_t lo_off;
     int tile_map;            // 1: 32-tile groups round-robin over the XCDs (default), 0: XCD-contiguous chunks (BLIM_GEMM_TILE_MAP)
     int debug_skip_epilogue; // timing aid only (set from BLIM_GEMM_SKIP_EPI)
     unsigned long long* debug_stamps;  // timing aid: [n_workgroups][8] s_memrealtime at {entry, main loop start, main loop end, exit, C staged in LDS, stores issued}

@@ -124,7 +124,8 @@ int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s) {
 // One wave per row; the row (H f32) is read once in float4 pieces and kept in registers when H <= 64*4*16.
 template <int MAXV, int DT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H,
-                                                      const float* w, float eps, bf16_t* out_bf16, float* out_f32, int64_t n_src) {
+                                                      const float* w, float eps, bf16_t* out_bf16, float* out_f32, int64_t n_src,
+                                                      int64_t ldo, bf16_t* out_lo) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
     if (src < 0 || src >= n_src) {   // a gather index outside the packed batch: poison the row (NaN score) instead of reading wild memory
         const float qnan = __builtin_nanf("");
         for (int c = lane; c < nv; c += 64) {
-            if (out_bf16) *(uint2*)(out_bf16 + r * H + 4 * c) = make_uint2(pack2<DT>(qnan, qnan), pack2<DT>(qnan, qnan));
+            if (out_bf16) *(uint2*)(out_bf16 + r * ldo + 4 * c) = make_uint2(pack2<DT>(qnan, qnan), pack2<DT>(qnan, qnan));
+            if (out_lo) *(uint2*)(out_lo + r * ldo + 4 * c) = make_uint2(0u, 0u);
             if (out_f32) *(float4*)(out_f32 + r * H + 4 * c) = make_float4(qnan, qnan, qnan, qnan);
         }
         return;
@@ -157,21 +159,26 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
         if (c < nv) {
             const float4 g = *(const float4*)(w + 4 * c);
             const float o0 = g.x * (v[i].x * inv), o1 = g.y * (v[i].y * inv), o2 = g.z * (v[i].z * inv), o3 = g.w * (v[i].w * inv);
-            if (out_bf16) *(uint2*)(out_bf16 + r * H + 4 * c) = make_uint2(pack2<DT>(o0, o1), pack2<DT>(o2, o3));
+            if (out_bf16) *(uint2*)(out_bf16 + r * ldo + 4 * c) = make_uint2(pack2<DT>(o0, o1), pack2<DT>(o2, o3));
+            if (out_lo)      // compensated mode: lo = 16-bit(x - f32(hi)), stored beside hi ([hi | lo] along K of the consuming GEMM)
+                *(uint2*)(out_lo + r * ldo + 4 * c) = make_uint2(pack2<DT>(o0 - from16<DT>(to16<DT>(o0)), o1 - from16<DT>(to16<DT>(o1))),
+                                                                 pack2<DT>(o2 - from16<DT>(to16<DT>(o2)), o3 - from16<DT>(to16<DT>(o3))));
             if (out_f32) *(float4*)(out_f32 + r * H + 4 * c) = make_float4(o0, o1, o2, o3);
         }
     }
 }
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
-                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src) {
+                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src, int64_t ldo, bf16_t* out_lo) {
     if (!rows) n_src = n_rows;
+    if (ldo == 0) ldo = H;
+    ARG_CHECK(ldo % 4 == 0 && (!out_lo || out_h16));
     ARG_CHECK(x && w && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0 && (out_h16 || out_f32));
     const int nv = H / 4;
     const dim3 grid((unsigned)((n_rows + 3) / 4));
 #define RMS_LAUNCH(MV)                                                                                                              \
     do {                                                                                                                            \
-        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src); \
-        else hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src);                \
+        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo); \
+        else hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo);                \
     } while (0)
     if (nv <= 64 * 4) RMS_LAUNCH(4);
     else if (nv <= 64 * 16) RMS_LAUNCH(16);

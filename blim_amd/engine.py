@@ -230,6 +230,19 @@ class Engine:
     def set_option(self, key: str, value: int):
         _check(self.lib.blim_set_option(self.h, key.encode(), value), "blim_set_option")
 
+    @property
+    def can_precise(self) -> bool:
+        return self.dtype == "f16"
+
+    def set_precise(self, on: bool):
+        """Compensated mode for the following calls (fp16 engines; a no-op request on others): every 16-bit activation travels as
+        hi + lo and the GEMMs walk K twice.  The host turns it on for the TVG calls, whose scores are ~10x smaller in magnitude than
+        the VTG ones and need the extra bits to hold 1e-3 at 28 layers; 2x GEMM flops on those calls only."""
+        on = bool(on) and self.can_precise
+        if on != getattr(self, "_precise", False):
+            self.set_option("precise", int(on))
+            self._precise = on
+
     # ---- component ops (torch device tensors in/out)
     def project_video(self, feats, which: int):
         import torch

@@ -32,6 +32,7 @@ class BlimModel:
         self.tokenizer_model_max_length = tokenizer_model_max_length
         self.training = False
         self._proj_cache = {}
+        self._tvg_rows = False          # set by prepare_inputs_labels_for_multimodal(tvg=...): the next forward() is a TVG forward
 
     # ---- nn.Module-ish surface used by the eval loop
     def eval(self):
@@ -88,6 +89,7 @@ class BlimModel:
             raise NotImplementedError("only pre-extracted video features (video_feature=True) are supported")
         if images is None or input_ids.shape[1] == 1:
             raise NotImplementedError("text-only / single-token inputs are outside the scoring path")
+        self._tvg_rows = bool(tvg)
         ids_h = input_ids.detach().cpu().numpy()
         msk_h = (attention_mask.detach().cpu().numpy() != 0) if attention_mask is not None else np.ones_like(ids_h, dtype=bool)
         lab_h = labels.detach().cpu().numpy() if labels is not None else np.full_like(ids_h, IGNORE_INDEX)
@@ -152,7 +154,12 @@ class BlimModel:
             m8 = torch.ones((B, L), dtype=torch.uint8, device=self.device)
         else:
             m8 = (attention_mask != 0).to(torch.uint8).contiguous()
-        logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
+        # a forward over rows prepared with tvg=True runs in the compensated fp16 mode, like the fused TVG calls (engine.set_precise)
+        self.engine.set_precise(self._tvg_rows)
+        try:
+            logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
+        finally:
+            self.engine.set_precise(False)
         return SimpleNamespace(loss=None, logits=logits, past_key_values=None, hidden_states=hidden, attentions=None)
 
     __call__ = forward

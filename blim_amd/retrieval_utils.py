@@ -183,8 +183,9 @@ class PairScorer:
     """Fused scoring of arbitrary (video, text) pairs.  See the module docstring for what is shared."""
 
     def __init__(self, model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video: Sequence, video_vocab,
-                 tvg_video_labels, num_clips: int, max_tokens: int = 24576):
+                 tvg_video_labels, num_clips: int, max_tokens: int = 24576, precise_tvg: bool = True):
         import torch
+        self.precise_tvg = bool(precise_tvg)
         self.m = model.module if hasattr(model, "module") else model
         self.engine = self.m.engine
         self.device = self.m.device
@@ -343,8 +344,13 @@ class PairScorer:
         """One engine call; returns a device f32 tensor [plan.n_pairs]."""
         embeds = self.engine.assemble(plan.src_index, plan.feats)
         if plan.kind == "vtg":
+            self.engine.set_precise(False)
             return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
-        return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)
+        self.engine.set_precise(self.precise_tvg)             # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
+        try:
+            return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)
+        finally:
+            self.engine.set_precise(False)
 
     def score(self, plans, n_requested: int) -> np.ndarray:
         """plans: list or generator of Plan.  Engine calls are asynchronous, so with a generator the host packs plan k+1 while

@@ -84,3 +84,44 @@ def test_random_shapes_fused_and_literal_vs_oracle(models, seed, n, tpc, tl, top
                forward_type=ft, cpn=cpn).cpu().numpy()
         assert np.array_equal(L != -100.0, m), (direction, ft, cpn)
         np.testing.assert_allclose(L[m], want[m], rtol=1e-3, err_msg=f"literal {direction} {ft} cpn={cpn}")
+
+
+@pytest.mark.parametrize("n,topk,bs", [(64, 64, 16), (40, 32, 16)], ids=["dense-64", "top32-of-40"])
+def test_evaluation_dense_and_top32_vs_oracle(models, n, topk, bs):
+    """BASELINE configs 3 / 4 in miniature: evaluation() with dense candidates (k = N = 64) and with top-32 + CPN, all six matrices
+    against the oracle's restatement of the reference loops; with and without the cross-direction de-duplication."""
+    dims, model, om = models
+    prob = synth.make_problem(300 + n, n, dims, tok_per_clip=4, text_len=(2, 12))
+    model.set_tvg_prefix_length(prob.tvg_prefix_length); om.set_tvg_prefix_length(prob.tvg_prefix_length)
+    model.clear_cache()
+    ov = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+    ot = O.padding_ids(prob.tvg_ids, prob.tvg_labels, prob.tvg_masks, synth.PAD_ID)
+    want = {}
+    for direction, ft, cpn in PASSES:
+        qv = direction == "v2t"
+        o_ids, o_lab, o_msk = ov if ft == "vtg" else ot
+        fn_o = O.compute_v2t_scores_x if qv else O.compute_t2v_scores_x
+        want[(direction, ft, cpn)] = fn_o(np.full((n, n), -100.0, np.float32), prob.v2t_sims if qv else prob.t2v_sims, 0, o_ids, o_msk, o_lab, prob.video,
+                                          prob.video_vocab, prob.tvg_video_labels, om, topk, bs, dims.num_clips, ft, cpn)
+    key = {("v2t", "vtg", False): ("v2t", "candidate_likelihood"), ("v2t", "vtg", True): ("v2t", "candidate_prior"), ("v2t", "tvg", False): ("v2t", "query_likelihood"),
+           ("t2v", "vtg", False): ("t2v", "query_likelihood"), ("t2v", "tvg", False): ("t2v", "candidate_likelihood"), ("t2v", "tvg", True): ("t2v", "candidate_prior")}
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    res = {}
+    for dedup in (True, False):
+        args = types.SimpleNamespace(topk=topk, batch_size_eval=bs, num_clips=dims.num_clips, cpn=True, resume="ckpt", eval=True, dataset="SYNTH", dedup=dedup,
+                                     max_tokens=2048, iv2_scores={"v2t": torch.from_numpy(prob.v2t_sims), "t2v": torch.from_numpy(prob.t2v_sims)})
+        t2v, v2t = RU.evaluation(DDPLike(model), synth.ProblemLoader(prob, 16), model.device, tok, args)
+        res[dedup] = (t2v, v2t, args._eval_stats)
+        for k, (d, name) in key.items():
+            S = (v2t if d == "v2t" else t2v)[name]
+            W = want[k]
+            assert np.array_equal(S != -100.0, W != -100.0), (k, dedup)
+            m = W != -100.0
+            np.testing.assert_allclose(S[m], W[m], rtol=1e-3, err_msg=f"{k} dedup={dedup}")
+    assert res[False][2]["pairs_scored"] == res[False][2]["pairs_requested"] == 6 * n * min(topk, n)
+    assert res[True][2]["pairs_scored"] < res[False][2]["pairs_scored"]
+    if topk >= n:                                           # dense: both t2v likelihood passes are free
+        assert res[True][2]["pairs_scored"] == 4 * n * n
+    for a, b in zip(res[True][:2], res[False][:2]):
+        for k in a:
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-5)

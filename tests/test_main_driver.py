@@ -100,7 +100,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"].startswith("candidate-pairs/sec") and d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "bf16"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f16"
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
@@ -126,4 +126,4 @@ def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["pairs_per_step_per_gpu"] == 8 * 16 and "cpu_baseline" not in d
+    assert d["config"]["pairs_per_step_per_gpu"] == 8 * 8 and "cpu_baseline" not in d      # 8 queries x top-min(16, 8 texts)
