@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <bool USE_TR, int MAXC, int DT, bool SPLIT = false>
 __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t k_lds[KT * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t k_lds[(SPLIT ? 2 : 1) * KT * HD];   // SPLIT: K_hi tile, then K_lo tile
     __shared__ __attribute__((aligned(16))) bf16_t v_lds[(SPLIT ? 2 : 1) * KT * HD];   // SPLIT: V_hi tile, then V_lo tile
     __shared__ uint32_t vis_lds[KT / 4];  // 32 visibility bytes
 
@@ -48,6 +48,12 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
     }
+    bf16x8 qf_lo[SPLIT ? 8 : 1];      // compensated mode: Q = Q_hi + Q_lo (lo parts p.v_lo_off columns further)
+    if constexpr (SPLIT) {
+        const bf16_t* qrow = p.qkv + (int64_t)qtok * p.ldq + p.v_lo_off + head * HD + 8 * hf;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf_lo[ks] = *(const bf16x8*)(qrow + 16 * ks);
+    }
 
     const int n_ptiles = (plen + KT - 1) / KT;
     const int own_keys = min(q0 + QB, slen);
@@ -62,9 +68,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     float m_run = NEG, l_run = 0.f;
     const float c_log2 = p.scale * 1.4426950408889634f;
 
-    // staging: 1024 16-B chunks per tile (512 K + 512 V; SPLIT: + 512 V_lo = 1536) spread over the workgroup's threads
-    // (MAXC * nthreads >= 1024 / 1536: launch_attention picks MAXC from the group size)
-    constexpr int NCHUNK = SPLIT ? 1536 : 1024;
+    // staging: 1024 16-B chunks per tile (512 K + 512 V; SPLIT: + 512 V_lo + 512 K_lo = 2048) spread over the workgroup's threads
+    // (MAXC * nthreads >= 1024 / 2048: launch_attention picks MAXC from the group size)
+    constexpr int NCHUNK = SPLIT ? 2048 : 1024;
     uint4 st[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) st[i] = make_uint4(0, 0, 0, 0);
@@ -80,9 +86,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         for (int i = 0; i < MAXC; ++i) {
             const int idx = tid + i * nthreads;
             if (idx < NCHUNK) {
-                const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;   // isv: 0 K, 1 V (hi), 2 V_lo
+                const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;   // isv: 0 K, 1 V (hi), 2 V_lo, 3 K_lo
                 const int kk = min(k0 + row, seg_len - 1);
-                st[i] = *(const uint4*)(p.qkv + (int64_t)(base_tok + kk) * p.ldq + (isv == 0 ? koff : isv == 1 ? voff : voff + p.v_lo_off) + 8 * ch);
+                st[i] = *(const uint4*)(p.qkv + (int64_t)(base_tok + kk) * p.ldq + (isv == 0 ? koff : isv == 1 ? voff : isv == 2 ? voff + p.v_lo_off : koff + p.v_lo_off) + 8 * ch);
             }
         }
     };
@@ -94,8 +100,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             const int idx = tid + i * nthreads;
             if (idx < NCHUNK) {
                 const int isv = idx >> 9, row = (idx >> 4) & 31, ch = idx & 15;
-                if (isv) *(uint4*)(v_lds + (isv - 1) * KT * HD + row * HD + 8 * (ch ^ ((row & 3) << 2))) = st[i];
-                else *(uint4*)(k_lds + row * HD + 8 * (ch ^ (row & 15))) = st[i];
+                if (isv == 1 || isv == 2) *(uint4*)(v_lds + (isv - 1) * KT * HD + row * HD + 8 * (ch ^ ((row & 3) << 2))) = st[i];
+                else *(uint4*)(k_lds + (isv >> 1) * KT * HD + row * HD + 8 * (ch ^ (row & 15))) = st[i];
             }
         }
         if (tid < KT) {
@@ -125,6 +131,11 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             for (int ks = 0; ks < 8; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(k_lds + key * HD + 8 * ((2 * ks + hf) ^ (key & 15)));
                 sacc = mfma32<DT>(kf, qf[ks], sacc);
+                if constexpr (SPLIT) {   // (K_hi + K_lo).(Q_hi + Q_lo) without the lo.lo term
+                    sacc = mfma32<DT>(kf, qf_lo[ks], sacc);
+                    const bf16x8 kl = *(const bf16x8*)(k_lds + KT * HD + key * HD + 8 * ((2 * ks + hf) ^ (key & 15)));
+                    sacc = mfma32<DT>(kl, qf[ks], sacc);
+                }
             }
         }
         // ---- mask + online softmax; this lane's keys: krow(r) = (r&3) + 8*(r>>2) + 4*hf
@@ -162,13 +173,18 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 
         // ---- P^T fragments: registers 8s..8s+7 are k-step s (k order: 16s + 8(j>>2) + 4hf + (j&3))
-        bf16x8 pf[2];
+        bf16x8 pf[2], pf_lo[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            uint32_t w[4];
+            uint32_t w[4], wl[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = pack2<DT>(pv[8 * s2 + 2 * j], pv[8 * s2 + 2 * j + 1]);
+            for (int j = 0; j < 4; ++j) {
+                const float a_ = pv[8 * s2 + 2 * j], b_ = pv[8 * s2 + 2 * j + 1];
+                w[j] = pack2<DT>(a_, b_);
+                if constexpr (SPLIT) wl[j] = pack2<DT>(a_ - from16<DT>(to16<DT>(a_)), b_ - from16<DT>(to16<DT>(b_)));
+            }
             pf[s2] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            if constexpr (SPLIT) pf_lo[s2] = __builtin_bit_cast(bf16x8, make_uint4(wl[0], wl[1], wl[2], wl[3]));
         }
         // ---- O^T += V^T . P^T : A = V^T fragment (lane: d = 32db + (lane&31); keys 16s+4hf+{0..3} and +8)
 #pragma unroll
@@ -199,6 +215,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
                     }
                 }
                 o[db] = mfma32<DT>(vf, pf[s2], o[db]);
+                if constexpr (SPLIT) { if (vp == 0) o[db] = mfma32<DT>(vf, pf_lo[s2], o[db]); }   // V_hi.P_lo (V_lo.P_lo dropped)
             }
         }
         }
@@ -231,9 +248,9 @@ int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
     const dim3 grid(p.n_blocks, p.num_kv_heads), block(64 * G);
     if (p.v_lo_off != 0 || p.out_lo_off != 0) {   // compensated mode (fp16 engines): transposed-read path only
         ARG_CHECK(p.dtype == DT_F16 && p.v_lo_off > 0 && p.out_lo_off > 0 && p.v_lo_off % 8 == 0 && p.out_lo_off % 4 == 0);
-        if (G >= 4) hipLaunchKernelGGL((attn_kernel<true, 6, DT_F16, true>), grid, block, 0, stream, p);
-        else if (G >= 2) hipLaunchKernelGGL((attn_kernel<true, 12, DT_F16, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((attn_kernel<true, 24, DT_F16, true>), grid, block, 0, stream, p);
+        if (G >= 4) hipLaunchKernelGGL((attn_kernel<true, 8, DT_F16, true>), grid, block, 0, stream, p);
+        else if (G >= 2) hipLaunchKernelGGL((attn_kernel<true, 16, DT_F16, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_kernel<true, 32, DT_F16, true>), grid, block, 0, stream, p);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { blim_set_error("attention launch failed: %s", hipGetErrorString(e2)); return BLIM_ERR_HIP; }
         return BLIM_OK;

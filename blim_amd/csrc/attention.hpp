@@ -23,9 +23,9 @@ struct AttnParams {
     bf16_t* out;  // [T, num_heads*128]
     int64_t ldo;
     float scale;  // 1/sqrt(head_dim)
-    // compensated ("precise") mode, fp16: V = V_hi + V_lo with the lo parts v_lo_off columns after the hi parts in `qkv`
-    // (O += V_lo^T.P^T as a second MFMA pass), and the output written as hi at `out`, lo = f16(o - f32(hi)) at out + out_lo_off.
-    // 0 / 0 = plain.
+    // compensated ("precise") mode, fp16: Q, K, V = hi + lo with the lo parts v_lo_off columns after the hi parts in `qkv`; the
+    // products S = K.Q^T and O = V^T.P^T (P = P_hi + P_lo as well) are formed as hi.hi + hi.lo + lo.hi (three MFMA passes), and
+    // the output is written as hi at `out`, lo = f16(o - f32(hi)) at out + out_lo_off.  0 / 0 = plain.
     int64_t v_lo_off, out_lo_off;
 };
 

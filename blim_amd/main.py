@@ -96,7 +96,7 @@ def main(args):
             vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64, num_clips=args.num_clips)
         model = BlimModel(dims, dtype=args.dtype)
         model.engine.init_synthetic_weights(0)
-        prob = synth.make_problem(1, args.synthetic, dims, tok_per_clip=64 if args.synthetic_7b else 8)
+        prob = synth.make_problem(1, args.synthetic, dims, tok_per_clip=64 if args.synthetic_7b else 8, fast_video=args.synthetic > 256)
         T = torch.from_numpy
         loader = synth.ProblemLoader(prob, args.batch_size_eval)
         tokenizer = types.SimpleNamespace(pad_token_id=synth.PAD_ID)

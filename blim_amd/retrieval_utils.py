@@ -553,7 +553,9 @@ def evaluation(model, data_loader, device, tokenizer, args):
             merge([(v2t, v_block)])                      # first all-gather: the complete v2t matrices, before the t2v passes read them
         k = min(num_texts, args.topk)
         mask = np.zeros((num_videos, num_texts), dtype=bool)
-        rows = slice(0, num_videos) if (W == 1 or collective) else slice(*v_block)
+        # shard emulation (timing only): the other ranks' rows count as known too, as they are after the real merge -- their
+        # values are -100 placeholders, which is why an emulated run reports no recall table
+        rows = slice(0, num_videos)
         idx = v2t_iv2[rows].topk(k=k, dim=1).indices.cpu().numpy()
         mask[np.repeat(np.arange(rows.start, rows.stop), k), idx.reshape(-1)] = True
         known_vtg = (v2t["candidate_likelihood"], mask)

@@ -152,7 +152,7 @@ class Problem:
 
 
 def make_problem(seed: int, n: int, dims: ModelDims, tok_per_clip: int = 64, text_len=(8, 48),
-                 reference_layout: bool = True) -> Problem:
+                 reference_layout: bool = True, fast_video: bool = False) -> Problem:
     """reference_layout=True: rows shaped like base_dataset.py:60-105 (system/user headers, instruction ...).
     reference_layout=False: BASELINE.json's headline shape -- VTG row = [<image>][text] only (the row is
     clips*tok_per_clip video tokens + len(text) label tokens), TVG row = [21-id prefix][text][<image>][tail]."""
@@ -167,8 +167,10 @@ def make_problem(seed: int, n: int, dims: ModelDims, tok_per_clip: int = 64, tex
     lo, hi = text_len
     lens = lo + (uniform_ids(seed, "text_len", n, 0, max(1, hi - lo + 1)))
     video, vtg_ids, vtg_labels, tvg_ids, tvg_labels = [], [], [], [], []
-    for i in range(n):
-        video.append(tensor(seed, f"video.{i}", (C, tok_per_clip, M), std=1.0))
+    rng = np.random.default_rng(seed) if fast_video else None   # large dry runs (thousands of videos): numpy's generator instead of the
+    for i in range(n):                                          # counter-based rule (not reproduced on device, not used by any fixture)
+        video.append(bf16_round(rng.standard_normal((C, tok_per_clip, M), dtype=np.float32)) if fast_video
+                     else tensor(seed, f"video.{i}", (C, tok_per_clip, M), std=1.0))
         text = word(f"text.{i}", int(lens[i]))
         resp = np.concatenate([text, [IM_END, NEWLINE]])
         if reference_layout:

@@ -24,6 +24,31 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+def usable_cores() -> int:
+    """Cores this PROCESS may use: physical cores, capped by the scheduler affinity mask and by the cgroup CPU quota (a container
+    on a 256-thread host is often given far fewer; 128 threads on such a quota run slower than 8)."""
+    import os
+    n = physical_cores()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def rms_norm(x, w, eps):
     var = x.pow(2).mean(-1, keepdim=True)
     return w * (x * torch.rsqrt(var + eps))
