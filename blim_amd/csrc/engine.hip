@@ -3,6 +3,7 @@
 // caller's stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -72,6 +73,7 @@ struct blim_engine {
     std::vector<void*> owned;
     // workspaces
     DevBuf resid, xn, qkv, attn, act, hsel, lse_part, lab_logit, logprob, stage, proj_tmp, vh, tvg_logits, dense_idx;
+    DevBuf rope_rows;                     // [T, 128] cos | sin of every token's position (per batch)
     DevBuf x8, a8, act8, hsel8, rscale;   // fp8 mode: quantised GEMM inputs and their per-row scales
     // options / timing
     int attn_tr = 1;
@@ -162,6 +164,16 @@ __global__ void rope_table_kernel(float* cosb, float* sinb, int n_pos, int half,
     cosb[i] = cosf(ang);
     sinb[i] = sinf(ang);
 }
+// rows[t] = cos[pos[t]] (64) | sin[pos[t]] (64): gathered once per batch so that the 28 QKV epilogues read their RoPE factors by row
+__global__ void rope_rows_kernel(float* rows, const int32_t* pos, const float* cosb, const float* sinb, int64_t n_tokens, int n_pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 per thread: 32 per token
+    if (i >= n_tokens * 32) return;
+    const int64_t t = i >> 5;
+    const int c = (int)(i & 31);
+    const int p = min(max(pos[t], 0), n_pos - 1);
+    const float* src = (c < 16 ? cosb : sinb) + (int64_t)p * 64 + 4 * (c & 15);
+    *(float4*)(rows + t * 128 + 4 * c) = *(const float4*)src;
+}
 __global__ void dense_batch_kernel(int32_t* pos, int32_t* seq_start, int32_t* seq_len, int32_t* pfx, int32_t* blk_seq, int32_t* blk_q0,
                                    int B, int L, int nblk_per_seq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,7 +247,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     hipDeviceSynchronize();
     for (void* p : e->owned) hipFree(p);
     DevBuf* bufs[] = {&e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -493,6 +505,14 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s)); }
     const double tok = (double)T;
     const bool q8 = e->f8 && (e->f8_mask & 1), o8 = e->f8 && (e->f8_mask & 2), g8 = e->f8 && (e->f8_mask & 4), d8 = e->f8 && (e->f8_mask & 8);
+    float* rope_rows = nullptr;
+    {
+        SpanGuard g(e, s, TC_MISC, 0);
+        TRY(ensure(e->rope_rows, (size_t)round_up(T, 256) * 128 * 4));
+        rope_rows = (float*)e->rope_rows.p;
+        hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((T * 32 + 255) / 256)), dim3(256), 0, s, rope_rows, b->positions, e->rope_cos, e->rope_sin, T, c.max_positions);
+        HIP_TRY(hipGetLastError());
+    }
     const int pf = e->precise ? 2 : 1;
     if (e->precise && (e->f8 || c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_STATE; }
     for (int li = 0; li < c.num_layers; ++li) {
@@ -505,8 +525,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * pf);
             GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n);
-            p.bias = l.bqkv; p.pos = b->positions; p.rope_cos = e->rope_cos; p.rope_sin = e->rope_sin;
-            p.rope_cols = (c.num_heads + c.num_kv_heads) * 128;
+            p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows;
             TRY(launch_gemm(EPI_QKV, p, s));
         }
         {

@@ -23,7 +23,9 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division (v_div_scale / v_div_fmas / v_div_fixup + Newton
+// steps: ~10 VALU instructions per element, which made the SwiGLU epilogue VALU-bound: 5.4 us of C -> LDS per tile)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // Main loop ("ring" structure; measured ladder in DESIGN.md section 3):
 //  * waves 0-3 / 4-7 (the SIMD partners) ping-pong: while one group issues its 64 MFMAs of K-step k back to back, the other
@@ -68,9 +70,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     }
     stamp_vb = pid;
     stamp(0);
-    const int width = GROUP_M * ntn;
-    const int first_m = (pid / width) * GROUP_M;
-    const int gsz = min(ntm - first_m, GROUP_M);
+    const int width = p.group_m * ntn;
+    const int first_m = (pid / width) * p.group_m;
+    const int gsz = min(ntm - first_m, p.group_m);
     const int tm = first_m + (pid % width) % gsz;
     const int tn = (pid % width) / gsz;
     const int row0 = tm * BM, col0 = tn * BN;
@@ -420,6 +422,64 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             };
             const int64_t c_part = (SPLIT && part) ? p.lo_off : 0;
             if (SPLIT && part) __syncthreads();               // part 0's LDS reads are complete
+            float4 qkv_bias[4];                               // EPI_QKV: this lane's 16 bias values (the same for all eight mi)
+            if constexpr (EPI == EPI_QKV) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) qkv_bias[ni] = *(const float4*)(p.bias + wcol0 + 16 * ni + 4 * tq);
+            }
+            if constexpr (EPI == EPI_QKV) {
+                // fragments (2p, 2p+1) hold RoPE partners d and d+64 for q/k heads; v heads are in natural order.  The wave's 64 columns
+                // are either all rotated or all plain (rope_cols % 64 == 0): one wave-uniform branch OUTSIDE the row loop, and the
+                // cos/sin rows (p.rope_rows: gathered per token once per batch) of row group mi+1 are requested before group mi is
+                // rotated -- as one branchy loop this was a chain of 24 dependent global loads per tile (8.6 us of a 10 us epilogue).
+                if (wcol0 < p.rope_cols) {
+                    const int hl = wn >> 1;                    // head inside the tile
+                    const int gbase = (wn & 1) * 2;            // first 32-group of this wave inside the head
+                    const int d0 = 16 * gbase + 4 * tq;        // natural d of pair 0's lo element; pair 1: + 16
+                    float4 cs[2][2], sn[2][2];                 // [buffer][pair]
+                    auto request = [&](int mi, int buf) __attribute__((always_inline)) {
+                        const int row = min(row0 + 128 * wm + 16 * mi + rsub, p.M - 1);
+                        const float* crow = p.rope_rows + (int64_t)row * 128 + d0;
+                        cs[buf][0] = *(const float4*)crow; cs[buf][1] = *(const float4*)(crow + 16);
+                        sn[buf][0] = *(const float4*)(crow + 64); sn[buf][1] = *(const float4*)(crow + 80);
+                    };
+                    request(0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        if (mi + 1 < 8) request(mi + 1, (mi + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);     // keep the next group's loads in front of this group's arithmetic
+                        char* lrow = smem + (128 * wm + 16 * mi + rsub) * RS;
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const float4 c = cs[mi & 1][pr], sv = sn[mi & 1][pr];
+                            const float c4[4] = {c.x, c.y, c.z, c.w}, s4[4] = {sv.x, sv.y, sv.z, sv.w};
+                            const float4 b0 = qkv_bias[2 * pr], b1 = qkv_bias[2 * pr + 1];
+                            const float bl[4] = {b0.x, b0.y, b0.z, b0.w}, bh[4] = {b1.x, b1.y, b1.z, b1.w};
+                            float lo[4], hi[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float x1 = acc[mi][2 * pr][j] + bl[j];
+                                const float x2 = acc[mi][2 * pr + 1][j] + bh[j];
+                                lo[j] = x1 * c4[j] - x2 * s4[j];
+                                hi[j] = x2 * c4[j] + x1 * s4[j];
+                            }
+                            char* o = lrow + (hl * 128 + d0 + 16 * pr) * 2;
+                            *(uint2*)o = make_uint2(PK(lo[0], lo[1]), PK(lo[2], lo[3]));
+                            *(uint2*)(o + 128) = make_uint2(PK(hi[0], hi[1]), PK(hi[2], hi[3]));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        char* lrow = smem + (128 * wm + 16 * mi + rsub) * RS;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const float4 bv = qkv_bias[ni];
+                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(PK(acc[mi][ni][0] + bv.x, acc[mi][ni][1] + bv.y), PK(acc[mi][ni][2] + bv.z, acc[mi][ni][3] + bv.w));
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int rl = 128 * wm + 16 * mi + rsub;         // row inside the tile
@@ -445,41 +505,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                                 if (p.act == 1) x[j] = gelu_erf(x[j]);
                             }
                             *(uint2*)(lrow + cl * 2) = make_uint2(PK(x[0], x[1]), PK(x[2], x[3]));
-                        }
-                    }
-                } else if constexpr (EPI == EPI_QKV) {
-                    // fragments (2p, 2p+1) hold RoPE partners d and d+64 for q/k heads; v heads are in natural order.
-                    if (wcol0 < p.rope_cols) {
-                        const int pos = p.pos[row];
-                        const int hl = wn >> 1;                    // head inside the tile
-                        const int gbase = (wn & 1) * 2;            // first 32-group of this wave inside the head
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const int cst = wcol0 + 32 * pr + 4 * tq;       // stored col of the lo element
-                            const int d = 16 * (gbase + pr) + 4 * tq;      // natural d of the lo element (0..63)
-                            const float4 cs = *(const float4*)(p.rope_cos + (int64_t)pos * 64 + d);
-                            const float4 sn = *(const float4*)(p.rope_sin + (int64_t)pos * 64 + d);
-                            const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
-                            const float4 b0 = *(const float4*)(p.bias + cst), b1 = *(const float4*)(p.bias + cst + 16);
-                            const float bl[4] = {b0.x, b0.y, b0.z, b0.w}, bh[4] = {b1.x, b1.y, b1.z, b1.w};
-                            float lo[4], hi[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float x1 = t[2 * pr][j] + bl[j];
-                                const float x2 = t[2 * pr + 1][j] + bh[j];
-                                lo[j] = x1 * c4[j] - x2 * s4[j];
-                                hi[j] = x2 * c4[j] + x1 * s4[j];
-                            }
-                            char* o = lrow + (hl * 128 + d) * 2;
-                            *(uint2*)o = make_uint2(PK(lo[0], lo[1]), PK(lo[2], lo[3]));
-                            *(uint2*)(o + 128) = make_uint2(PK(hi[0], hi[1]), PK(hi[2], hi[3]));
-                        }
-                    } else {
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) {
-                            const int cl = 64 * wn + 16 * ni + 4 * tq;
-                            const float4 bv = *(const float4*)(p.bias + col0 + cl);
-                            *(uint2*)(lrow + cl * 2) = make_uint2(PK(t[ni][0] + bv.x, t[ni][1] + bv.y), PK(t[ni][2] + bv.z, t[ni][3] + bv.w));
                         }
                     }
                 } else {  // EPI_SWIGLU: fragments (2p, 2p+1) = gate / up of the same 16 intermediate columns
@@ -595,8 +620,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #include <algorithm>
 static int g_gemm_persistent = getenv("BLIM_GEMM_PERSISTENT") ? atoi(getenv("BLIM_GEMM_PERSISTENT")) : 1;
 static int g_gemm_tile_map = getenv("BLIM_GEMM_TILE_MAP") ? atoi(getenv("BLIM_GEMM_TILE_MAP")) : -1;   // -1: by shape
+static int g_gemm_group_m = getenv("BLIM_GEMM_GROUP_M") ? atoi(getenv("BLIM_GEMM_GROUP_M")) : GROUP_M;   // M-tiles per band of the tile order
 static int g_gemm_skip_epi = getenv("BLIM_GEMM_SKIP_EPI") ? atoi(getenv("BLIM_GEMM_SKIP_EPI")) : 0;
 static unsigned long long* g_gemm_stamps = nullptr;
+static int g_stamp_epi = getenv("BLIM_GEMM_STAMP_EPI") ? atoi(getenv("BLIM_GEMM_STAMP_EPI")) : -1;   // stamp only this epilogue / this K (tools/epi_stamps.py)
+static int g_stamp_k = getenv("BLIM_GEMM_STAMP_K") ? atoi(getenv("BLIM_GEMM_STAMP_K")) : -1;
 void gemm_set_debug_stamps(unsigned long long* buf) { g_gemm_stamps = buf; }
 
 template <int EPI>
@@ -652,7 +680,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         q.A = (const bf16_t*)((const char*)p.A + r0 * row_bytes);
         if (p.C) q.C = (char*)p.C + r0 * p.ldc * c_es;
         if (p.row_scale) q.row_scale = p.row_scale + r0;
-        if (p.pos) q.pos = p.pos + r0;
+        if (p.rope_rows) q.rope_rows = p.rope_rows + r0 * 128;
         if (p.labels) q.labels = p.labels + r0;
         if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
         if (p.label_logit) q.label_logit = p.label_logit + r0;
@@ -665,10 +693,11 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
 static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
+    p.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : GROUP_M;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
     // round-robin map, the wide ones (gate|up 37888, lm_head) lose 4 % -- there the XCDs already walk the same W columns in step
     p.tile_map = g_gemm_tile_map >= 0 ? g_gemm_tile_map : ((p.N + BN - 1) / BN <= 32 ? 1 : 0);
-    p.debug_stamps = g_gemm_stamps;
+    p.debug_stamps = ((g_stamp_epi < 0 || g_stamp_epi == (int)epi) && (g_stamp_k < 0 || g_stamp_k == p.K)) ? g_gemm_stamps : nullptr;
     ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0);
     ARG_CHECK(p.A && p.W);
     ARG_CHECK(p.dtype == DT_BF16 || p.dtype == DT_F16 || p.dtype == DT_F8);
@@ -684,7 +713,7 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
         case EPI_F32: ARG_CHECK(p.C && p.bias == nullptr); return launch_t<EPI_F32>(p, stream);
         case EPI_RESID: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_RESID>(p, stream);
         case EPI_QKV:
-            ARG_CHECK(p.C && p.bias && p.pos && p.rope_cos && p.rope_sin && p.N % 128 == 0 && p.rope_cols % 128 == 0 && p.ldc % 4 == 0);
+            ARG_CHECK(p.C && p.bias && p.rope_rows && p.N % 128 == 0 && p.rope_cols % 128 == 0 && p.ldc % 4 == 0);
             return launch_t<EPI_QKV>(p, stream);
         case EPI_SWIGLU: ARG_CHECK(p.C && p.N % 32 == 0 && p.ldc % 4 == 0); return launch_t<EPI_SWIGLU>(p, stream);
         case EPI_LSE: ARG_CHECK(p.labels && p.lse_part && p.label_logit); return launch_t<EPI_LSE>(p, stream);

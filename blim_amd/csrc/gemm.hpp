@@ -29,10 +29,9 @@ struct GemmParams {
     int act;            // EPI_BF16: 0 none, 1 exact-erf GELU
     float scale;        // EPI_F32
     // EPI_QKV
-    const int32_t* pos;      // [M] RoPE position of every row
-    const float* rope_cos;   // [max_pos, 64]
-    const float* rope_sin;
     int rope_cols;           // (num_heads + num_kv_heads) * 128
+    const float* rope_rows;  // [M, 128]: cos[64] | sin[64] of every ROW's position, gathered once per batch (engine.hip: rope_rows_kernel) -- the
+                             // epilogue needs no dependent position -> table load chain
     // EPI_LSE
     const int32_t* labels;   // [M] target column per row (or < 0)
     float2* lse_part;        // [M, ceil(N/256)] (max, sumexp)
@@ -42,6 +41,7 @@ struct GemmParams {
     // 16-bit outputs are written as hi at C and lo at C + lo_off elements (0 = plain)
     int w_wrap_k;
     int64_t lo_off;
+    int group_m;             // M-tiles per band of the tile order (8; BLIM_GEMM_GROUP_M)
     int tile_map;            // 1: 32-tile groups round-robin over the XCDs (default), 0: XCD-contiguous chunks (BLIM_GEMM_TILE_MAP)
     int debug_skip_epilogue; // timing aid only (set from BLIM_GEMM_SKIP_EPI)
     unsigned long long* debug_stamps;  // timing aid: [n_workgroups][8] s_memrealtime at {entry, main loop start, main loop end, exit, C staged in LDS, stores issued}
