@@ -568,6 +568,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 const bool vec = (col + 3 < p.N) && ((p.ldc & 3) == 0);
                 if constexpr (EPI == EPI_RESID) {
                     if (vec) {   // common case: 16 independent 1-KiB row loads in flight, then add + store
+                        const float4 rb = p.bias ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);   // resid += acc + bias (vision tower's Linear layers)
                         float4 o[16];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             const int rl = wave + 8 * i;
                             const int row = row0 + 128 * h + rl;
                             const float4 v = *(const float4*)(smem + rl * RS + lane * 16);
-                            if (row < p.M) *(float4*)((float*)p.C + (int64_t)row * p.ldc + col) = make_float4(o[i].x + v.x, o[i].y + v.y, o[i].z + v.z, o[i].w + v.w);
+                            if (row < p.M) *(float4*)((float*)p.C + (int64_t)row * p.ldc + col) = make_float4(o[i].x + (v.x + rb.x), o[i].y + (v.y + rb.y), o[i].z + (v.z + rb.z), o[i].w + (v.w + rb.w));
                         }
                     } else {
 #pragma unroll 1
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             const float4 v = *(const float4*)(smem + rl * RS + lane * 16);
                             const float x[4] = {v.x, v.y, v.z, v.w};
                             float* out = (float*)p.C + (int64_t)row * p.ldc + col;
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j];
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j] + (p.bias ? p.bias[col + j] : 0.f);
                         }
                     }
                 } else {

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 3
+#define BLIM_ABI_VERSION 4
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -178,6 +178,41 @@ int blim_debug_gemm_stamps(void* device_buf);
 /* tuning switches: "attn_tr_read" (0/1); "f8_mask" (BLIM_COMPUTE_F8 engines: which GEMMs take fp8 operands, bit 0 qkv, 1 o_proj,
  * 2 gate|up, 3 down, 4 lm_head; default 31 = all; the others run in fp16 from the retained 16-bit weights) */
 int blim_set_option(blim_engine* e, const char* key, int32_t value);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Offline feature extraction: the UMT-L vision encoder + ToMe token merging that produce the
+ * ./data/<DS>/features/<vid>.pth files the scoring path reads.  Replaces model.encode_video_image(video, ...,
+ * return_video_feature=True) as extract.py:104 calls it (modeling_videochat_flash.py:126-181 -> UMTVisionTower.forward,
+ * vision_tower_builder.py:558-571 -> ToMe16_mlp_hd64.forward(compress=True, local_num_frames=4, return_video_feature=True),
+ * mm_projector_builder.py:134-154).  A separate handle: extraction needs no language-model weights. */
+typedef struct blim_vision blim_vision;
+typedef struct blim_vision_config {
+    int32_t image_size;    /* 448 ("umt-hd", vision_tower_builder.py:613-614) */
+    int32_t patch_size;    /* 16 */
+    int32_t num_frames;    /* frames per clip = mm_local_num_frames (4) */
+    int32_t hidden_size;   /* 1024 */
+    int32_t num_heads;     /* 16 (head_dim must be 64) */
+    int32_t mlp_hidden;    /* 4096 */
+    int32_t depth;         /* blocks actually run: encoder_depth 24 + mm_vision_select_layer (-2) + 1 = 23 (vision_tower_builder.py:293) */
+    int32_t tome_tokens;   /* tokens per clip after merging: 16 * num_frames = 64 (mm_projector_builder.py:147) */
+    int32_t compute_dtype; /* BLIM_COMPUTE_F16 / BLIM_COMPUTE_BF16: format of the GEMM / attention operands (residual stream, LayerNorm and ToMe are f32) */
+} blim_vision_config;
+int blim_vision_create(const blim_vision_config* cfg, blim_vision** out);
+void blim_vision_destroy(blim_vision* v);
+/* names: vit.patch.{w,b}, vit.blocks.N.{norm1,norm2}.{w,b}, .q_bias, .v_bias, .qkv.w, .proj.{w,b}, .fc1.{w,b}, .fc2.{w,b}, vit.norm.{w,b}
+ * (blim_amd/vision.py:vision_weight_shapes); natural [out, in] layout, f32 or bf16, host or device. */
+int blim_vision_load_weight(blim_vision* v, const char* name, const void* data, int32_t dtype, int32_t on_device);
+int blim_vision_init_synthetic_weights(blim_vision* v, uint64_t seed);
+/* HOST f32 [num_frames * (image_size/patch_size)^2, hidden]: the sinusoidal position table (vision_tower_builder.py:222-269),
+ * computed by the host (blim_amd/vision.py:pos_embed). */
+int blim_vision_set_pos_embed(blim_vision* v, const float* table_host);
+int blim_vision_ready(const blim_vision* v);
+/* frames: device 16-bit (compute dtype) [n_clips, num_frames, 3, S, S], normalised pixels.  out_feat (may be NULL): f32
+ * [n_clips, L, hidden] encoder output, L = num_frames * (S/patch)^2; out_tome (may be NULL): f32 [n_clips, tome_tokens, hidden]. */
+int blim_vision_encode(blim_vision* v, const void* frames, int32_t n_clips, float* out_feat, float* out_tome, void* stream);
+/* ToMe alone: x f32 [b, p, c] (c = heads * 64) -> out f32 [b, target, c]; bipartite soft matching + size-weighted merge,
+ * mm_projector_builder.py:6-130. */
+int blim_tome_merge(blim_vision* v, const float* x, int32_t b, int32_t p, int32_t c, int32_t heads, int32_t target, float* out, void* stream);
 
 #ifdef __cplusplus
 }
