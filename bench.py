@@ -40,12 +40,14 @@ def measured_traffic(kernel_class, dtype):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if epi is None or not files:
         return None
-    name = f"void gemm_kernel<{epi}, {dict(bf16=0, f16=1, f8=2)[dtype]}>(GemmParams)"
+    dt = dict(bf16=0, f16=1, f8=2)[dtype]
+    names = (f"void gemm_kernel<{epi}, {dt}, false>(GemmParams)", f"void gemm_kernel<{epi}, {dt}>(GemmParams)")
     try:
         for f in reversed(files):                                   # newest summary that profiled this kernel
             d = json.load(open(f))
-            if name in d:
-                return d[name]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+            for name in names:
+                if name in d:
+                    return d[name]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
         return None
     except Exception:
         return None
