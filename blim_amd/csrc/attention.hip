@@ -138,39 +138,49 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
                 }
             }
         }
-        // ---- mask + online softmax; this lane's keys: krow(r) = (r&3) + 8*(r>>2) + 4*hf
+        // ---- mask + online softmax; this lane's keys: krow(r) = (r&3) + 8*(r>>2) + 4*hf.  Bookkeeping in RAW score units (the
+        // scale * log2(e) factor rides in the exponent's fma); the masks are applied only where a tile needs them (a tile that reaches the
+        // causal diagonal or the segment end, or holds an invisible key -- a wave-uniform test), and the accumulators are rescaled only
+        // when some lane's running maximum grew: this VALU work, not the MFMAs, is what bounds the kernel.
         float pv[16];
-        float tmax = NEG;
+        const bool vis_all = (vis_lds[0] & vis_lds[1] & vis_lds[2] & vis_lds[3] & vis_lds[4] & vis_lds[5] & vis_lds[6] & vis_lds[7]) == 0x01010101u;
+        if (!vis_all || (causal && k0 + KT - 1 > q0)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint32_t vb = vis_lds[2 * g + hf];  // bytes for keys 8g + 4hf + 0..3
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t vb = vis_lds[2 * g + hf];  // bytes for keys 8g + 4hf + 0..3
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g + j;
-                const int kk = k0 + 8 * g + 4 * hf + j;
-                const bool ok = ((vb >> (8 * j)) & 0xFF) && (!causal || kk <= q0 + qi);
-                const float sv = ok ? sacc[r] * c_log2 : NEG;
-                pv[r] = sv;
-                tmax = fmaxf(tmax, sv);
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const int kk = k0 + 8 * g + 4 * hf + j;
+                    const bool ok = ((vb >> (8 * j)) & 0xFF) && (!causal || kk <= q0 + qi);
+                    if (!ok) sacc[r] = NEG;
+                }
             }
         }
+        float tmax = NEG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
+        const float mc = m_new * c_log2;
         float rsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = (pv[r] > 0.5f * NEG) ? exp2f(pv[r] - m_new) : 0.f;
+            const float e = (sacc[r] > 0.5f * NEG) ? exp2f(fmaf(sacc[r], c_log2, -mc)) : 0.f;   // a fully masked row keeps m = NEG: no exp2(0) = 1
             pv[r] = e;
             rsum += e;
         }
         rsum += __shfl_xor(rsum, 32);
-        l_run = l_run * alpha + rsum;
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = exp2f((m_run - m_new) * c_log2);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        l_run += rsum;
         m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 
         // ---- P^T fragments: registers 8s..8s+7 are k-step s (k order: 16s + 8(j>>2) + 4hf + (j&3))
         bf16x8 pf[2], pf_lo[2];

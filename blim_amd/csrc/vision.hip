@@ -178,35 +178,40 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* qkv, int64_
                 sacc = mfma32<DT>(kf, qf[ks], sacc);
             }
         }
+        // softmax bookkeeping in RAW score units (the scale * log2(e) factor is folded into the exponent's fma): at head_dim 64 this
+        // VALU work, not the 8 MFMAs, bounds the kernel, so: key-bound masking only in the last tile, one fma + v_exp per score, and
+        // the accumulators are rescaled only when some lane's running maximum actually grew
         float pv[16];
         float tmax = NEG;
+        if (k0 + VKT > L) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g + j;
-                const int kk = k0 + 8 * g + 4 * hf + j;
-                const float sv = kk < L ? sacc[r] * c_log2 : NEG;
-                pv[r] = sv;
-                tmax = fmaxf(tmax, sv);
-            }
+                for (int j = 0; j < 4; ++j) { const int r = 4 * g + j; if (k0 + 8 * g + 4 * hf + j >= L) sacc[r] = NEG; }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
+        const float mc = m_new * c_log2;
         float rsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = (pv[r] > 0.5f * NEG) ? exp2f(pv[r] - m_new) : 0.f;
+            const float e = exp2f(fmaf(sacc[r], c_log2, -mc));      // masked scores: exp2(-huge) = 0
             pv[r] = e;
             rsum += e;
         }
         rsum += __shfl_xor(rsum, 32);
-        l_run = l_run * alpha + rsum;
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = exp2f((m_run - m_new) * c_log2);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        l_run += rsum;
         m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
         bf16x8 pf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {

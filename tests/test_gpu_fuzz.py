@@ -86,12 +86,13 @@ def test_random_shapes_fused_and_literal_vs_oracle(models, seed, n, tpc, tl, top
         np.testing.assert_allclose(L[m], want[m], rtol=1e-3, err_msg=f"literal {direction} {ft} cpn={cpn}")
 
 
-@pytest.mark.parametrize("n,topk,bs", [(64, 64, 16), (40, 32, 16)], ids=["dense-64", "top32-of-40"])
+@pytest.mark.parametrize("n,topk,bs", [(48, 48, 16), (36, 32, 16)], ids=["dense-48", "top32-of-36"])
 def test_evaluation_dense_and_top32_vs_oracle(models, n, topk, bs):
-    """BASELINE configs 3 / 4 in miniature: evaluation() with dense candidates (k = N = 64) and with top-32 + CPN, all six matrices
-    against the oracle's restatement of the reference loops; with and without the cross-direction de-duplication."""
+    """BASELINE configs 3 / 4 in miniature: evaluation() with dense candidates (k = N = 48) and with top-32 + CPN, all six matrices
+    against the oracle's restatement of the reference loops; with and without the cross-direction de-duplication.  (The oracle is the
+    slow side: 151,700-wide lm_head per label row in numpy; short captions keep the test under a minute.)"""
     dims, model, om = models
-    prob = synth.make_problem(300 + n, n, dims, tok_per_clip=4, text_len=(2, 12))
+    prob = synth.make_problem(300 + n, n, dims, tok_per_clip=4, text_len=(1, 4))
     model.set_tvg_prefix_length(prob.tvg_prefix_length); om.set_tvg_prefix_length(prob.tvg_prefix_length)
     model.clear_cache()
     ov = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
@@ -99,6 +100,11 @@ def test_evaluation_dense_and_top32_vs_oracle(models, n, topk, bs):
     want = {}
     for direction, ft, cpn in PASSES:
         qv = direction == "v2t"
+        if topk >= n and not qv and not cpn:
+            # dense: the reference's own fixtures hold bit-identical numbers in v2t[j, i] and t2v[i, j] (tests/golden/full7b.npz:
+            # S_v2t_vtg[0, 0] == S_t2v_vtg[0, 0]); the oracle's transposed matrix stands for the second loop
+            want[(direction, ft, cpn)] = want[("v2t", ft, False)].T.copy()
+            continue
         o_ids, o_lab, o_msk = ov if ft == "vtg" else ot
         fn_o = O.compute_v2t_scores_x if qv else O.compute_t2v_scores_x
         want[(direction, ft, cpn)] = fn_o(np.full((n, n), -100.0, np.float32), prob.v2t_sims if qv else prob.t2v_sims, 0, o_ids, o_msk, o_lab, prob.video,

@@ -365,7 +365,10 @@ def test_full_size_properties_7b(dtype):
                                                    [torch.from_numpy(prob.video[j]).to(dev)], ["video"], video_feature=True, cpn=True)
     out = ddp(inputs_embeds=r[4], attention_mask=r[2][0])
     lit = RU.vtg_criterion(out.logits, r[5]).cpu().numpy()[0]
-    np.testing.assert_allclose(full[j * 6 + i], lit, rtol=SCORE_RTOL)
+    # (not bitwise: the literal row is one causal segment, the fused one a prefix + own segment, so the 32-key softmax tiles fall differently)
+    np.testing.assert_allclose(full[j * 6 + i], lit, rtol=score_rtol(dtype, "vtg"))
+    alone_all = np.array([sc.vtg(pairs[k:k + 1])[0] for k in range(len(pairs))])
+    assert np.array_equal(alone_all, full)                                        # batch composition: bitwise
     model.engine.close()
 
 
