@@ -363,11 +363,34 @@ class PairScorer:
                 out[outs] = sc[k]
         return out
 
+    def score_device(self, plans, n_requested: int):
+        """As score(), but the result stays on the device (f32 [n_requested], NaN where nothing was scored) and nothing
+        synchronises: evaluation() scatters it into the score matrix on the device, so the host goes straight on to plan the next
+        pass while the device is still running this one."""
+        import torch
+        out = torch.full((n_requested,), float("nan"), dtype=torch.float32, device=self.device)
+        res, src, dst, base = [], [], [], 0
+        for p in plans:                                           # every engine call of the pass is queued first ...
+            res.append(self.run(p))
+            src.append(base + np.repeat(np.arange(len(p.out_index)), [len(o) for o in p.out_index]))
+            dst.append(np.concatenate(p.out_index) if len(p.out_index) else np.zeros(0, np.int64))
+            base += p.n_pairs
+        if res:                                                   # ... then one index upload and one device-side scatter
+            idx = torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64)).to(self.device)
+            out[idx[1]] = torch.cat(res).float()[idx[0]]
+        return out
+
     def vtg(self, pairs, cpn=False) -> np.ndarray:
         return self.score(self.iter_vtg(pairs, cpn), len(pairs))
 
     def tvg(self, pairs, cpn=False) -> np.ndarray:
         return self.score(self.iter_tvg(pairs, cpn), len(pairs))
+
+    def vtg_device(self, pairs, cpn=False):
+        return self.score_device(self.iter_vtg(pairs, cpn), len(pairs))
+
+    def tvg_device(self, pairs, cpn=False):
+        return self.score_device(self.iter_tvg(pairs, cpn), len(pairs))
 
 
 class _PackState:
@@ -502,9 +525,13 @@ def evaluation(model, data_loader, device, tokenizer, args):
             pairs = pairs[~have]
         if len(pairs):
             stats["pairs_scored"] += len(pairs)
-            sc = scorer.vtg(pairs, cpn) if ftype == "vtg" else scorer.tvg(pairs, cpn)
             r, c = (pairs[:, 0], pairs[:, 1]) if query_is_video else (pairs[:, 1], pairs[:, 0])
-            S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = torch.from_numpy(sc).to(device)
+            if hasattr(scorer, "vtg_device"):                    # no host round trip: the pass's scores go device -> device
+                sc = scorer.vtg_device(pairs, cpn) if ftype == "vtg" else scorer.tvg_device(pairs, cpn)
+                S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = sc
+            else:
+                sc = scorer.vtg(pairs, cpn) if ftype == "vtg" else scorer.tvg(pairs, cpn)
+                S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = torch.from_numpy(sc).to(device)
         return S
 
     def merge(dicts_blocks):
@@ -526,7 +553,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
             mine = torch.full((num_texts // W + 1,), -100.0, dtype=torch.float32, device=device)
             if t1 > t0:
                 tp = np.stack([np.zeros(t1 - t0, dtype=np.int64), np.arange(t0, t1, dtype=np.int64)], axis=1)
-                mine[: t1 - t0] = torch.from_numpy(np.asarray(scorer.vtg(tp, True), dtype=np.float32)).to(device)
+                mine[: t1 - t0] = scorer.vtg_device(tp, True) if hasattr(scorer, "vtg_device") else \
+                    torch.from_numpy(np.asarray(scorer.vtg(tp, True), dtype=np.float32)).to(device)
                 stats["pairs_scored"] += t1 - t0
             if collective:
                 parts = [torch.empty_like(mine) for _ in range(W)]
