@@ -75,6 +75,8 @@ struct blim_engine {
     DevBuf resid, xn, qkv, attn, act, hsel, lse_part, lab_logit, logprob, stage, proj_tmp, vh, tvg_logits, dense_idx;
     DevBuf rope_rows;                     // [T, 128] cos | sin of every token's position (per batch)
     DevBuf x8, a8, act8, hsel8, rscale;   // fp8 mode: quantised GEMM inputs and their per-row scales
+    DevBuf act_mx;                        // fp8 mode: E8M0 scale per (token, 128 SwiGLU outputs), written by the gate|up epilogue (gemm.hpp: out_mx)
+    int f8_fuse = 1;                      // option "f8_fuse": quantise the SwiGLU output inside the gate|up epilogue (0: separate quant_rows pass)
     // options / timing
     int attn_tr = 1;
     // compensated ("precise") mode, option "precise" (fp16 engines): every 16-bit activation that feeds a GEMM or the attention's
@@ -204,6 +206,7 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     blim_engine* e = new blim_engine();
     e->c = *cfg;
     if (cfg->compute_dtype == BLIM_COMPUTE_F8) { e->f8 = true; e->c.compute_dtype = BLIM_COMPUTE_F16; }
+    if (getenv("BLIM_F8_FUSE")) e->f8_fuse = atoi(getenv("BLIM_F8_FUSE"));
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -247,7 +250,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     hipDeviceSynchronize();
     for (void* p : e->owned) hipFree(p);
     DevBuf* bufs[] = {&e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -413,6 +416,7 @@ static int reserve_tokens(blim_engine* e, int64_t T) {
         TRY(ensure(e->a8, (size_t)Tp * c.hidden_size));
         TRY(ensure(e->act8, (size_t)Tp * c.intermediate_size));
         TRY(ensure(e->rscale, (size_t)Tp * 4 * 4));      // [x | attn | act | label rows] scales
+        TRY(ensure(e->act_mx, (size_t)Tp * (c.intermediate_size / 128)));
     }
     TRY(ensure(e->resid, (size_t)round_up(T, 256) * c.hidden_size * 4));
     TRY(ensure(e->xn, (size_t)Tp * c.hidden_size * 2));
@@ -550,15 +554,18 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (g8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
             else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * H, e->precise ? xn + H : nullptr));
         }
+        const bool fuse = g8 && d8 && e->f8_fuse;      // fp8: the gate|up epilogue emits e4m3 + one E8M0 scale per (token, 128 outputs) itself
         {
             SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I * pf);
             GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I);
+            if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
-        if (d8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
+        if (d8 && !fuse) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * pf);
-            GemmParams p = d8 ? gp8(act8, I, sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0);
+            GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0);
+            if (fuse) { p.a_mx = (const uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             TRY(launch_gemm(EPI_RESID, p, s));
         }
@@ -796,6 +803,8 @@ extern "C" int blim_debug_read(blim_engine* e, const char* which, void* dst, int
     else if (!strcmp(which, "qkv")) b = &e->qkv;
     else if (!strcmp(which, "attn")) b = &e->attn;
     else if (!strcmp(which, "act")) b = &e->act;
+    else if (!strcmp(which, "act8")) b = &e->act8;
+    else if (!strcmp(which, "act_mx")) b = &e->act_mx;
     if (!b || !b->p || (size_t)bytes > b->bytes) { blim_set_error("debug_read: no buffer '%s' of %lld bytes", which, (long long)bytes); return BLIM_ERR_ARG; }
     HIP_TRY(hipMemcpyAsync(dst, b->p, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BLIM_OK;
@@ -808,6 +817,7 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     ARG_CHECK(e && key);
     if (!strcmp(key, "attn_tr_read")) { e->attn_tr = value; return BLIM_OK; }
     if (!strcmp(key, "f8_mask")) { e->f8_mask = value & 31; return BLIM_OK; }
+    if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise")) {
         if (value && (e->f8 || e->c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_ARG; }
         e->precise = value != 0;

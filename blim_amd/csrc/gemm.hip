@@ -35,7 +35,7 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 //    44 GB/s per CU, the same bytes as alternating 32-KB tiles 62 GB/s: tools/dma_bench.hip);
 //  * only the fragment-READING group issues LDS-DMA (group 1 every A tile, group 0 every W tile, after its LDS reads):
 //    the computing group issues nothing but MFMAs.
-template <int EPI, int DT, bool SPLIT = false>
+template <int EPI, int DT, bool SPLIT = false, bool MXA = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[5 * TILE_BYTES];  // 160 KiB ring / 136 KiB (two stages, or the staged C tile)
 
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     // fp8: this thread's dequantisation scale (threads 0-255: the tile's rows, 256-511: its columns), requested before the K loop
     // so that its latency is not exposed in front of the epilogue
     float f8_scale = 0.f;
-    if constexpr (DT == DT_F8) f8_scale = tid < 256 ? p.row_scale[min(row0 + tid, p.M - 1)] : p.col_scale[min(col0 + tid - 256, p.N - 1)];
+    if constexpr (DT == DT_F8) f8_scale = tid < 256 ? (p.row_scale ? p.row_scale[min(row0 + tid, p.M - 1)] : 1.0f) : p.col_scale[min(col0 + tid - 256, p.N - 1)];
     stamp(1);
     {
         const int grp = wave >> 2;  // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
@@ -144,14 +144,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         // The W fragment is passed as the MFMA's first operand, so a 16x16 accumulator fragment holds C TRANSPOSED in the hardware
         // layout: lane l owns C row (l & 15) and the four consecutive C columns 4 (l >> 4) + {0..3} of fragment (mi, ni).  The
         // epilogues can then pack and stage 8 / 16 contiguous bytes per lane without any cross-lane transpose.
+        // MXA: this lane's eight A-side E8M0 bytes of the current K-step (one per 16-row fragment) and of the next one
+        uint2 mx_cur = make_uint2(0x7f7f7f7fu, 0x7f7f7f7fu), mx_nxt = mx_cur;
+        const uint8_t* mx_base = nullptr;
+        if constexpr (MXA) mx_base = p.a_mx + (int64_t)tm * 256 + (wm * 16 + fr) * 8;
+        auto mx_request = [&](int kt) __attribute__((always_inline)) {
+            if constexpr (MXA) mx_nxt = *(const uint2*)(mx_base + (int64_t)min(kt, nk - 1) * p.mx_stride);
+        };
         auto compute = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_s_setprio(1);
             if constexpr (DT == DT_F8) {
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)   // e4m3 x e4m3, MX block scales 2^0 (0x7f): 32 MFMAs of 128-deep K per step
-                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni], fa8[mi], acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                // e4m3 x e4m3 on the block-scaled MFMA: 32 MFMAs of 128-deep K per step.  W side: unit MX scales (0x7f; per-row f32 scales
+                // in the epilogue).  A side: unit, or (MXA) byte mi & 3 of the lane's scale dword mi >> 2 -- opsel must be an immediate
+#define F8_ROW(MI)                                                                                                                                  \
+                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                                                    \
+                    acc[MI][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni], fa8[MI], acc[MI][ni], 0, 0, 0, 0x7f7f7f7f, (MXA ? (MI & 3) : 0), \
+                                                                                  (int)(MXA ? ((MI) < 4 ? mx_cur.x : mx_cur.y) : 0x7f7f7f7fu));
+                F8_ROW(0) F8_ROW(1) F8_ROW(2) F8_ROW(3) F8_ROW(4) F8_ROW(5) F8_ROW(6) F8_ROW(7)
+#undef F8_ROW
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -244,23 +254,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }
         };
         int sa = 0;
+        mx_request(0);
         if (grp == 0) {
             stage8(TILE_BYTES, 0);                                   // W0
             if (nk > 1) stage8(3 * TILE_BYTES, 1);                   // W1
             if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();                                         // A0 W0 landed (every wave waited for its own DMA)
+            if constexpr (MXA) mx_cur = mx_nxt;                      // requested at tile entry, in front of every LDS-DMA
             if constexpr (DT == DT_F8) {
                 // same barrier sequence, loop rotated so that a step's fragments are read and consumed inside one iteration:
                 // the fp8 fragments are 8-register tuples assembled from two 16-B reads, and carried across the back edge the
                 // register allocator keeps a second copy of all twelve (spilling ~200 VGPRs)
                 int sp = 0;                                          // slot of A(k-1)
                 for (int k = 0; k < nk; ++k) {
+                    mx_request(k + 1);                               // (MXA) next step's A scales: in front of the LDS-DMA in the vmcnt order
                     load_frags(sa, adv(sa, 1));
                     if (k >= 1 && k + 1 < nk) stage8(sp, k + 1);     // W(k+1) into the slot A(k-1) left
                     PHASE_BARRIER();
                     compute();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of W(k+1) landed
+                    if constexpr (MXA) mx_cur = mx_nxt;
                     PHASE_BARRIER();
                     sp = sa; sa = adv(sa, 2);
                 }
@@ -293,10 +307,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();
+            if constexpr (MXA) mx_cur = mx_nxt;
             PHASE_BARRIER();
             for (int kt = 0; kt < nk; ++kt) {
                 WP_T(0);
                 if constexpr (DT == DT_F8) {
+                    mx_request(kt + 1);
                     load_frags(sa, adv(sa, 1));
                     if (kt + 2 < nk) stage8(adv(sa, 4), kt + 2);
                 } else frags_and_dma(sa, adv(sa, 1), adv(sa, 4), kt + 2, kt + 2 < nk);          // fragments of kt, A(kt+2)
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 PHASE_BARRIER();
                 WP_T(3);
                 compute();
+                if constexpr (MXA) mx_cur = mx_nxt;                  // older than this iteration's LDS-DMA: landed by the vmcnt(8) above
                 WP_T(4);
                 PHASE_BARRIER();
                 WP_T(5);
@@ -413,6 +430,62 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             constexpr int NC = (EPI == EPI_SWIGLU) ? 128 : 256;   // output columns of this tile
             constexpr int RS = NC * 2 + 16;                       // LDS row stride (bytes), = 16 mod 256: the 16 rows x 2 column groups of a
                                                                   // half-wave's ds_write_b64 cover all 64 banks once
+            if constexpr (EPI == EPI_SWIGLU && DT == DT_F8) {
+                if (p.out_mx != nullptr) {
+                    // fp8 mode, fused quantisation of the SwiGLU output: the tile's 128 output columns are exactly one 128-deep K-step of
+                    // the down GEMM, so each row gets ONE power-of-two (E8M0) scale per tile: 2^e with e minimal such that
+                    // amax * 2^-e <= 448.  x = silu(g) * u replaces the gate accumulators in place; row maxima go lane -> wave (shuffles
+                    // over the four column groups) -> tile (LDS, four waves per row); bytes are staged as rows of 128 B.
+                    float* red = (float*)smem;                              // [4 wn][256 rows]
+                    uint8_t* st8 = (uint8_t*)smem + 4096;                   // [256 rows][144 B]
+                    constexpr int RS8 = 144;
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        float m = 0.f;
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float x = silu_f(acc[mi][2 * pr][j]) * acc[mi][2 * pr + 1][j];
+                                acc[mi][2 * pr][j] = x;
+                                m = fmaxf(m, fabsf(x));
+                            }
+                        m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+                        if (tq == 0) red[wn * 256 + 128 * wm + 16 * mi + rsub] = m;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const int rl = 128 * wm + 16 * mi + rsub;
+                        const float a = fmaxf(fmaxf(red[rl], red[256 + rl]), fmaxf(red[512 + rl], red[768 + rl]));
+                        int e = 0;
+                        if (a > 0.f) {
+                            int ex; const float mant = frexpf(a * (1.0f / FP8_MAX), &ex);
+                            e = (mant == 0.5f) ? ex - 1 : ex;
+                            if (ldexpf(a, -e) > FP8_MAX) e += 1;
+                            e = max(-127, min(127, e));
+                        }
+                        const float inv = ldexpf(1.0f, -e);
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr)
+                            *(uint32_t*)(st8 + rl * RS8 + (2 * wn + pr) * 16 + 4 * tq) =
+                                pack_fp8x4(acc[mi][2 * pr][0] * inv, acc[mi][2 * pr][1] * inv, acc[mi][2 * pr][2] * inv, acc[mi][2 * pr][3] * inv);
+                        if (wn == 0 && tq == 0) p.out_mx[(int64_t)tn * p.mx_stride + (int64_t)tm * 256 + (wm * 16 + rsub) * 8 + mi] = (uint8_t)(e + 127);
+                    }
+                    __syncthreads();
+                    const int64_t ob0 = col0 / 2;                           // first output byte column of the tile
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int chunk = tid + NTHREADS * i, rl = chunk >> 3, seg = chunk & 7;
+                        const int row = row0 + rl;
+                        if (row < p.M && ob0 + seg * 16 + 15 < p.N / 2)
+                            *(uint4*)((uint8_t*)p.C + (int64_t)row * p.ldc + ob0 + seg * 16) = *(const uint4*)(st8 + rl * RS8 + seg * 16);
+                    }
+                    stamp(3);
+                    __syncthreads();
+                    continue;
+                }
+            }
 #pragma unroll 1
             for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {
             // compensated mode: part 0 stores hi = f16(x), part 1 stores lo = f16(x - f32(hi)) at C + lo_off
@@ -649,6 +722,14 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
             return BLIM_OK;
         }
     }
+    if constexpr (EPI == EPI_RESID) {
+        if (p.dtype == DT_F8 && p.a_mx) {
+            hipLaunchKernelGGL((gemm_kernel<EPI, DT_F8, false, true>), grid, dim3(NTHREADS), 0, stream, p);
+            hipError_t e3 = hipGetLastError();
+            if (e3 != hipSuccess) { blim_set_error("gemm launch failed: %s", hipGetErrorString(e3)); return BLIM_ERR_HIP; }
+            return BLIM_OK;
+        }
+    }
     if (p.dtype == DT_F8) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F8>), grid, dim3(NTHREADS), 0, stream, p);
     else if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16>), grid, dim3(NTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((gemm_kernel<EPI, DT_BF16>), grid, dim3(NTHREADS), 0, stream, p);
@@ -682,6 +763,8 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         if (p.C) q.C = (char*)p.C + r0 * p.ldc * c_es;
         if (p.row_scale) q.row_scale = p.row_scale + r0;
         if (p.rope_rows) q.rope_rows = p.rope_rows + r0 * 128;
+        if (p.a_mx) q.a_mx = p.a_mx + r0;                         // r0 is a whole number of 256-row tiles: the table is tile-major inside a K-step
+        if (p.out_mx) q.out_mx = p.out_mx + r0;
         if (p.labels) q.labels = p.labels + r0;
         if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
         if (p.label_logit) q.label_logit = p.label_logit + r0;
@@ -705,7 +788,10 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     const int es = p.dtype == DT_F8 ? 1 : 2;
     ARG_CHECK((int64_t)p.K * es % 128 == 0);                  // whole 128-byte K-steps
     ARG_CHECK(p.lda * es % 16 == 0);
-    ARG_CHECK(p.dtype != DT_F8 || (p.row_scale && p.col_scale));
+    ARG_CHECK(p.dtype != DT_F8 || ((p.row_scale || p.a_mx) && p.col_scale));
+    ARG_CHECK((!p.a_mx && !p.out_mx) || (p.dtype == DT_F8 && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
+    ARG_CHECK(!p.a_mx || epi == EPI_RESID);                      // MX-scaled A operand: instantiated for the down projection
+    ARG_CHECK(!p.out_mx || (epi == EPI_SWIGLU && p.N % 256 == 0 && p.ldc % 16 == 0));
     ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice
     ARG_CHECK(p.lo_off == 0 || epi == EPI_BF16 || epi == EPI_QKV || epi == EPI_SWIGLU);
     ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets

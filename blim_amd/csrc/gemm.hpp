@@ -41,6 +41,14 @@ struct GemmParams {
     // 16-bit outputs are written as hi at C and lo at C + lo_off elements (0 = plain)
     int w_wrap_k;
     int64_t lo_off;
+    // fp8 mode, fused quantisation: EPI_SWIGLU with out8 != nullptr writes its 128 output columns per tile as e4m3
+    // bytes (C = out8, ldc in bytes) plus ONE E8M0 byte per (row, tile column) = per (row, 128-deep K-step of the consuming GEMM) into
+    // out_mx; a DT_F8 GEMM with a_mx != nullptr feeds that byte to the block-scaled MFMA as the A operand's scale (all four 32-blocks of
+    // the K-step share it).  Table layout: [K-step][256-row tile][(wm * 16 + fr) * 8 + mi] with row-in-tile = 128 wm + 16 mi + fr, i.e. the
+    // eight bytes a lane needs for its eight 16-row fragments are one 8-byte load; mx_stride = bytes per K-step = 256 * row tiles.
+    uint8_t* out_mx;
+    const uint8_t* a_mx;
+    int64_t mx_stride;
     int group_m;             // M-tiles per band of the tile order (8; BLIM_GEMM_GROUP_M)
     int tile_map;            // 1: 32-tile groups round-robin over the XCDs (default), 0: XCD-contiguous chunks (BLIM_GEMM_TILE_MAP)
     int debug_skip_epilogue; // timing aid only (set from BLIM_GEMM_SKIP_EPI)
