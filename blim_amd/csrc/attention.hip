@@ -232,6 +232,39 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     }
 
     // ---- normalise and store: o[db][r] is O[q = lane&31][d = 32db + (r&3) + 8(r>>2) + 4hf]
+    if (p.out8 != nullptr) {
+        // fp8 mode: this wave's 128 outputs of a token are one K-step of the o_proj GEMM -> e4m3 with one power-of-two scale (E8M0):
+        // the query's maximum is in two lanes (hf = 0, 1)
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[db][r] *= inv; a = fmaxf(a, fabsf(o[db][r])); }
+        a = fmaxf(a, __shfl_xor(a, 32));
+        int e = 0;
+        if (a > 0.f) {
+            int ex; const float mant = frexpf(a * (1.0f / FP8_MAX), &ex);
+            e = (mant == 0.5f) ? ex - 1 : ex;
+            if (ldexpf(a, -e) > FP8_MAX) e += 1;
+            e = max(-127, min(127, e));
+        }
+        const float qs = ldexpf(1.0f, -e);
+        if (q0 + qi < slen) {
+            const int64_t tok = sstart + q0 + qi;
+            uint8_t* orow = p.out8 + tok * p.ldo8 + head * HD;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(uint32_t*)(orow + 32 * db + 8 * g + 4 * hf) = pack_fp8x4(o[db][4 * g] * qs, o[db][4 * g + 1] * qs, o[db][4 * g + 2] * qs, o[db][4 * g + 3] * qs);
+            if (hf == 0) {
+                const int rl = (int)(tok & 255);
+                p.out_mx[(int64_t)head * p.mx_stride + (tok >> 8) * 256 + ((rl >> 7) * 16 + (rl & 15)) * 8 + ((rl >> 4) & 7)] = (uint8_t)(e + 127);
+            }
+        }
+        return;
+    }
     if (q0 + qi < slen) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16_t* orow = p.out + (int64_t)(sstart + q0 + qi) * p.ldo + head * HD;

@@ -27,6 +27,12 @@ struct AttnParams {
     // products S = K.Q^T and O = V^T.P^T (P = P_hi + P_lo as well) are formed as hi.hi + hi.lo + lo.hi (three MFMA passes), and
     // the output is written as hi at `out`, lo = f16(o - f32(hi)) at out + out_lo_off.  0 / 0 = plain.
     int64_t v_lo_off, out_lo_off;
+    // fp8 mode, fused quantisation: when out8 != nullptr the output is written as e4m3 bytes [T, ldo8] instead of 16-bit, one E8M0 scale per
+    // (token, head) = per 128-deep K-step of the o_proj GEMM, into out_mx (layout: gemm.hpp `a_mx`; mx_stride = bytes per K-step)
+    uint8_t* out8;
+    int64_t ldo8;
+    uint8_t* out_mx;
+    int64_t mx_stride;
 };
 
 int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream);

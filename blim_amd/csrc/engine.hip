@@ -75,6 +75,7 @@ struct blim_engine {
     DevBuf resid, xn, qkv, attn, act, hsel, lse_part, lab_logit, logprob, stage, proj_tmp, vh, tvg_logits, dense_idx;
     DevBuf rope_rows;                     // [T, 128] cos | sin of every token's position (per batch)
     DevBuf x8, a8, act8, hsel8, rscale;   // fp8 mode: quantised GEMM inputs and their per-row scales
+    DevBuf attn_mx;                       // fp8 mode: E8M0 scale per (token, head), written by the attention kernel (attention.hpp: out_mx)
     DevBuf act_mx;                        // fp8 mode: E8M0 scale per (token, 128 SwiGLU outputs), written by the gate|up epilogue (gemm.hpp: out_mx)
     int f8_fuse = 1;                      // option "f8_fuse": quantise the SwiGLU output inside the gate|up epilogue (0: separate quant_rows pass)
     // options / timing
@@ -250,7 +251,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     hipDeviceSynchronize();
     for (void* p : e->owned) hipFree(p);
     DevBuf* bufs[] = {&e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -417,6 +418,7 @@ static int reserve_tokens(blim_engine* e, int64_t T) {
         TRY(ensure(e->act8, (size_t)Tp * c.intermediate_size));
         TRY(ensure(e->rscale, (size_t)Tp * 4 * 4));      // [x | attn | act | label rows] scales
         TRY(ensure(e->act_mx, (size_t)Tp * (c.intermediate_size / 128)));
+        TRY(ensure(e->attn_mx, (size_t)Tp * c.num_heads));
     }
     TRY(ensure(e->resid, (size_t)round_up(T, 256) * c.hidden_size * 4));
     TRY(ensure(e->xn, (size_t)Tp * c.hidden_size * 2));
@@ -540,12 +542,16 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
             a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * H; a.scale = 0.08838834764831845f;
             a.v_lo_off = e->precise ? e->qkv_n : 0; a.out_lo_off = e->precise ? H : 0;
+            a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0;
+            if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
         }
-        if (o8) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
+        const bool fuse_o = o8 && e->f8_fuse;
+        if (o8 && !fuse_o) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H * pf);
-            GemmParams p = o8 ? gp8(a8, H, sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0);
+            GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0);
+            if (fuse_o) { p.a_mx = (const uint8_t*)e->attn_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             TRY(launch_gemm(EPI_RESID, p, s));
         }

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     // amax * 2^-e <= 448.  x = silu(g) * u replaces the gate accumulators in place; row maxima go lane -> wave (shuffles
                     // over the four column groups) -> tile (LDS, four waves per row); bytes are staged as rows of 128 B.
                     float* red = (float*)smem;                              // [4 wn][256 rows]
-                    uint8_t* st8 = (uint8_t*)smem + 4096;                   // [256 rows][144 B]
+                    uint8_t* st8 = (uint8_t*)smem + 8192;                   // [256 rows][144 B]
                     constexpr int RS8 = 144;
 #pragma unroll
                     for (int mi = 0; mi < 8; ++mi) {
@@ -454,10 +454,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         if (tq == 0) red[wn * 256 + 128 * wm + 16 * mi + rsub] = m;
                     }
                     __syncthreads();
-#pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) {
-                        const int rl = 128 * wm + 16 * mi + rsub;
-                        const float a = fmaxf(fmaxf(red[rl], red[256 + rl]), fmaxf(red[512 + rl], red[768 + rl]));
+                    float* qinv = (float*)(smem + 4096);                    // [256 rows] 2^-e
+                    if (tid < 256) {                                        // one thread per row: the scale, once
+                        const float a = fmaxf(fmaxf(red[tid], red[256 + tid]), fmaxf(red[512 + tid], red[768 + tid]));
                         int e = 0;
                         if (a > 0.f) {
                             int ex; const float mant = frexpf(a * (1.0f / FP8_MAX), &ex);
@@ -465,12 +464,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             if (ldexpf(a, -e) > FP8_MAX) e += 1;
                             e = max(-127, min(127, e));
                         }
-                        const float inv = ldexpf(1.0f, -e);
+                        qinv[tid] = ldexpf(1.0f, -e);
+                        p.out_mx[(int64_t)tn * p.mx_stride + (int64_t)tm * 256 + ((tid >> 7) * 16 + (tid & 15)) * 8 + ((tid >> 4) & 7)] = (uint8_t)(e + 127);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const int rl = 128 * wm + 16 * mi + rsub;
+                        const float inv = qinv[rl];
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr)
                             *(uint32_t*)(st8 + rl * RS8 + (2 * wn + pr) * 16 + 4 * tq) =
                                 pack_fp8x4(acc[mi][2 * pr][0] * inv, acc[mi][2 * pr][1] * inv, acc[mi][2 * pr][2] * inv, acc[mi][2 * pr][3] * inv);
-                        if (wn == 0 && tq == 0) p.out_mx[(int64_t)tn * p.mx_stride + (int64_t)tm * 256 + (wm * 16 + rsub) * 8 + mi] = (uint8_t)(e + 127);
                     }
                     __syncthreads();
                     const int64_t ob0 = col0 / 2;                           // first output byte column of the tile

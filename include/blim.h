@@ -36,7 +36,8 @@ extern "C" {
 #define BLIM_COMPUTE_F16 1
 /* fp8 mode (BASELINE.json config 5, "fp8 weights on CDNA4 fp8 MFMA"): q/k/v, o, gate|up, down and
  * lm_head weights are quantised at load to OCP e4m3 with one f32 scale per output row, their input activations per token
- * (scale = absmax / 448), and multiplied on the block-scaled fp8 MFMA (unit MX block scales, the two f32 scales applied to
+ * (scale = absmax / 448; the attention and SwiGLU outputs: one power-of-two E8M0 scale per token and 128 values, written by their
+ * producers and fed to the MFMA as its A-side block scale), and multiplied on the block-scaled fp8 MFMA (the f32 scales applied to
  * the f32 accumulator).  Everything else -- attention, RoPE, residual stream, norms, projector, visual head, criteria -- and
  * every 16-bit buffer crossing the ABI is fp16 as with BLIM_COMPUTE_F16.  Scores differ from the fp32 reference at the 1e-2
  * level (reported, not asserted to 1e-3). */
@@ -175,7 +176,9 @@ int blim_debug_read(blim_engine* e, const char* which, void* dst, int64_t bytes,
  * C staged in LDS, stores issued} to device_buf[workgroup*8 ..] (u64, 100 MHz); NULL turns it off. */
 int blim_debug_gemm_stamps(void* device_buf);
 
-/* tuning switches: "attn_tr_read" (0/1); "f8_mask" (BLIM_COMPUTE_F8 engines: which GEMMs take fp8 operands, bit 0 qkv, 1 o_proj,
+/* "precise" (0/1, fp16 engines): compensated arithmetic for the following calls (activations as hi + lo, GEMMs walk K twice);
+ * "f8_fuse" (0/1, fp8 engines): quantise the attention / SwiGLU outputs inside their producers (default 1);
+ * tuning switches: "attn_tr_read" (0/1); "f8_mask" (BLIM_COMPUTE_F8 engines: which GEMMs take fp8 operands, bit 0 qkv, 1 o_proj,
  * 2 gate|up, 3 down, 4 lm_head; default 31 = all; the others run in fp16 from the retained 16-bit weights) */
 int blim_set_option(blim_engine* e, const char* key, int32_t value);
 
