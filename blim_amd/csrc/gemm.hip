@@ -22,7 +22,16 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU() default, mm_projector_builder.py:89 / vision_tower_builder.py:47) with erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute, one v_rcp + one v_exp + five fmas; libm's erff is ~40 instructions with branches and made the bias + GELU
+// epilogue of the K = 1024 vision GEMMs as long as their main loop).  The result is rounded to 16 bits (2^-11 relative) right after.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division (v_div_scale / v_div_fmas / v_div_fixup + Newton
 // steps: ~10 VALU instructions per element, which made the SwiGLU epilogue VALU-bound: 5.4 us of C -> LDS per tile)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -505,6 +514,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) qkv_bias[ni] = *(const float4*)(p.bias + wcol0 + 16 * ni + 4 * tq);
             }
+            float4 bf16_bias[4];                              // EPI_BF16: likewise (zeros without a bias / beyond N)
+            if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int col = wcol0 + 16 * ni + 4 * tq;
+                    bf16_bias[ni] = (p.bias && col + 3 < p.N) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias && col < p.N && col + 3 >= p.N) {   // ragged last columns
+                        float* bb = (float*)&bf16_bias[ni];
+                        for (int j = 0; j < 4 && col + j < p.N; ++j) bb[j] = p.bias[col + j];
+                    }
+                }
+            }
             if constexpr (EPI == EPI_QKV) {
                 // fragments (2p, 2p+1) hold RoPE partners d and d+64 for q/k heads; v heads are in natural order.  The wave's 64 columns
                 // are either all rotated or all plain (rope_cols % 64 == 0): one wave-uniform branch OUTSIDE the row loop, and the
@@ -571,18 +592,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
                             *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(PK(t[ni][0], t[ni][1]), PK(t[ni][2], t[ni][3]));
-                    } else {
-#pragma unroll 1
-                        for (int ni = 0; ni < 4; ++ni) {
-                            const int cl = 64 * wn + 16 * ni + 4 * tq;
-                            const int col = col0 + cl;
-                            float x[4];
+                    } else if (p.act == 1) {                       // bias (hoisted: bf16_bias) + GELU, wave-uniform branch, unrolled
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                x[j] = t[ni][j] + ((p.bias && col + j < p.N) ? p.bias[col + j] : 0.f);
-                                if (p.act == 1) x[j] = gelu_erf(x[j]);
-                            }
-                            *(uint2*)(lrow + cl * 2) = make_uint2(PK(x[0], x[1]), PK(x[2], x[3]));
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const float4 b = bf16_bias[ni];
+                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) =
+                                make_uint2(PK(gelu_erf(t[ni][0] + b.x), gelu_erf(t[ni][1] + b.y)), PK(gelu_erf(t[ni][2] + b.z), gelu_erf(t[ni][3] + b.w)));
+                        }
+                    } else {
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const float4 b = bf16_bias[ni];
+                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(PK(t[ni][0] + b.x, t[ni][1] + b.y), PK(t[ni][2] + b.z, t[ni][3] + b.w));
                         }
                     }
                 } else {  // EPI_SWIGLU: fragments (2p, 2p+1) = gate / up of the same 16 intermediate columns
