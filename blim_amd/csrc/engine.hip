@@ -85,6 +85,9 @@ struct blim_engine {
     // 21 significant bits of the activations reach the f32 accumulators; costs 2x the GEMM flops, so the host turns it on for the
     // cheap TVG calls only (their scores are ~10x smaller in magnitude than the VTG ones: DESIGN.md section 4).
     bool precise = false;
+    bool precise_embeds = false;   // option "precise_embeds": in precise mode the INPUT embeddings (blim_assemble output, blim_decode / blim_score_* input) and
+                                   // the projector outputs feeding them are [hi | lo] rows of width 2H too (the fused TVG path; the literal
+                                   // forward() keeps the reference's [B, L, H] embeddings)
     bool timing = false;
     std::vector<TimedSpan> spans;
 };
@@ -467,27 +470,30 @@ extern "C" int blim_project_video(blim_engine* e, const void* feats, int64_t n_r
     TRY(blim_weights_ready(e));
     hipStream_t s = (hipStream_t)stream;
     const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
-    TRY(ensure(e->proj_tmp, (size_t)round_up(n_rows, 256) * H * 2));
+    const int pf = e->precise ? 2 : 1;            // compensated mode: the hidden layer and the output travel as [hi | lo] rows of width 2H
+    TRY(ensure(e->proj_tmp, (size_t)round_up(n_rows, 256) * H * 2 * pf));
     SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_rows * ((double)M * H + (double)H * H));
-    GemmParams p1 = gp(e->c.compute_dtype, feats, M, e->mlp_w0[which], n_rows, H, M, e->proj_tmp.p, H);
+    GemmParams p1 = gp(e->c.compute_dtype, feats, M, e->mlp_w0[which], n_rows, H, M, e->proj_tmp.p, (int64_t)pf * H);
     p1.bias = e->mlp_b0[which]; p1.act = 1;
+    if (e->precise) p1.lo_off = H;
     TRY(launch_gemm(EPI_BF16, p1, s));
-    GemmParams p2 = gp(e->c.compute_dtype, e->proj_tmp.p, H, e->mlp_w2[which], n_rows, H, H, out, H);
+    GemmParams p2 = gp(e->c.compute_dtype, e->proj_tmp.p, (int64_t)pf * H, e->mlp_w2[which], n_rows, H, pf * H, out, (int64_t)pf * H);
     p2.bias = e->mlp_b2[which];
+    if (e->precise) { p2.w_wrap_k = H; p2.lo_off = H; }
     TRY(launch_gemm(EPI_BF16, p2, s));
     return BLIM_OK;
 }
 
 extern "C" int blim_group_mean(blim_engine* e, const void* in, int64_t n_out, int32_t group, void* out, void* stream) {
     ARG_CHECK(e && in && out);
-    return launch_group_mean((bf16_t*)out, (const bf16_t*)in, n_out, group, e->c.hidden_size, e->c.compute_dtype, (hipStream_t)stream);
+    return launch_group_mean((bf16_t*)out, (const bf16_t*)in, n_out, group, e->c.hidden_size, e->c.compute_dtype, (hipStream_t)stream, e->precise);
 }
 
 extern "C" int blim_assemble(blim_engine* e, const int32_t* src_index, int64_t n_tokens, const void* feats, void* out_embeds, void* stream) {
     ARG_CHECK(e && src_index && out_embeds && n_tokens > 0);
     TRY(blim_weights_ready(e));
     SpanGuard g(e, (hipStream_t)stream, TC_MISC, 0);
-    return launch_assemble((bf16_t*)out_embeds, src_index, n_tokens, e->c.hidden_size, e->embed, (const bf16_t*)feats, (hipStream_t)stream);
+    return launch_assemble((bf16_t*)out_embeds, src_index, n_tokens, e->c.hidden_size, e->embed, (const bf16_t*)feats, (hipStream_t)stream, e->precise && e->precise_embeds);
 }
 
 static GemmParams gp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, const float* w_scale, int64_t M, int N, int K, void* C, int64_t ldc) {
@@ -508,7 +514,11 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const int64_t Tp = round_up(T, 256);
     uint8_t* x8 = (uint8_t*)e->x8.p; uint8_t* a8 = (uint8_t*)e->a8.p; uint8_t* act8 = (uint8_t*)e->act8.p;
     float* sx = (float*)e->rscale.p; float* sa = sx ? sx + Tp : nullptr; float* sact = sx ? sx + 2 * Tp : nullptr;
-    { SpanGuard g(e, s, TC_MISC, 0); TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s)); }
+    {
+        SpanGuard g(e, s, TC_MISC, 0);
+        if (e->precise && e->precise_embeds) TRY(launch_hilo_to_f32(resid, (const bf16_t*)embeds, T, H, s));     // embeds are [hi | lo] rows
+        else TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s));
+    }
     const double tok = (double)T;
     const bool q8 = e->f8 && (e->f8_mask & 1), o8 = e->f8 && (e->f8_mask & 2), g8 = e->f8 && (e->f8_mask & 4), d8 = e->f8 && (e->f8_mask & 8);
     float* rope_rows = nullptr;
@@ -824,6 +834,7 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "attn_tr_read")) { e->attn_tr = value; return BLIM_OK; }
     if (!strcmp(key, "f8_mask")) { e->f8_mask = value & 31; return BLIM_OK; }
     if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
+    if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise")) {
         if (value && (e->f8 || e->c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_ARG; }
         e->precise = value != 0;

@@ -74,8 +74,28 @@ __global__ void assemble_kernel(bf16_t* out, const int32_t* src, int64_t n_token
         *(uint4*)(out + t * H + 8 * c) = *(const uint4*)(row + 8 * c);
     }
 }
-int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats, hipStream_t s) {
+// compensated mode: rows are [hi | lo] of width 2H -- embedding-table rows are exact in 16 bits (lo = 0), feature rows carry both halves
+__global__ void assemble_split_kernel(bf16_t* out, const int32_t* src, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats) {
+    const int chunks = H / 4;  // 16-B chunks per [hi | lo] row of 2H
+    const int64_t total = n_tokens * chunks;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t t = i / chunks;
+        const int c = (int)(i - t * chunks);
+        const int32_t sidx = src[t];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (sidx >= 0) { if (8 * c < H) v = *(const uint4*)(table + (int64_t)sidx * H + 8 * c); }
+        else v = *(const uint4*)(feats + (int64_t)(-(sidx + 1)) * 2 * H + 8 * c);
+        *(uint4*)(out + t * 2 * H + 8 * c) = v;
+    }
+}
+int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats, hipStream_t s, bool split) {
     ARG_CHECK(out && src_index && n_tokens > 0 && H % 8 == 0 && table);
+    if (split) {
+        hipLaunchKernelGGL(assemble_split_kernel, dim3(grid_for(n_tokens * (H / 4), 256)), dim3(256), 0, s, out, src_index, n_tokens, H, table, feats);
+        LAUNCH_CHECK("assemble");
+        return BLIM_OK;
+    }
     hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(n_tokens * (H / 8), 256)), dim3(256), 0, s, out, src_index, n_tokens, H, table, feats);
     LAUNCH_CHECK("assemble");
     return BLIM_OK;
@@ -105,6 +125,22 @@ __global__ void f32_to_bf16_kernel(bf16_t* out, const float* in, int64_t n) {
             for (int64_t j = i; j < n; ++j) out[j] = f32_to_bf16(in[j]);
         }
     }
+}
+// resid[t, c] = f32(hi[t, c]) + f32(lo[t, c]) for [hi | lo] rows of width 2H (compensated mode, fp16)
+__global__ void hilo_to_f32_kernel(float* out, const bf16_t* in, int64_t n_rows, int H) {
+    const int64_t total = n_rows * H;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t t = i / H;
+        const int c = (int)(i - t * H);
+        out[i] = from16<DT_F16>(in[t * 2 * H + c]) + from16<DT_F16>(in[t * 2 * H + H + c]);
+    }
+}
+int launch_hilo_to_f32(float* out, const bf16_t* in, int64_t n_rows, int H, hipStream_t s) {
+    ARG_CHECK(out && in && n_rows > 0 && H > 0);
+    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3(grid_for(n_rows * H, 256)), dim3(256), 0, s, out, in, n_rows, H);
+    LAUNCH_CHECK("hilo_to_f32");
+    return BLIM_OK;
 }
 int launch_h16_to_f32(float* out, const bf16_t* in, int64_t n, int dtype, hipStream_t s) {
     ARG_CHECK(out && in && n > 0);
@@ -210,8 +246,29 @@ __global__ void group_mean_kernel(bf16_t* out, const bf16_t* in, int64_t n_out, 
         *(uint2*)(out + o * H + 4 * c) = make_uint2(pack2<DT>(a0 * inv, a1 * inv), pack2<DT>(a2 * inv, a3 * inv));
     }
 }
-int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s) {
+// compensated mode (fp16): in [n_out * group, 2H] rows of [hi | lo] -> out [n_out, 2H]: the f32 mean of hi + lo, split again
+__global__ void group_mean_split_kernel(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H) {
+    const int64_t total = n_out * H;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t o = i / H;
+        const int c = (int)(i - o * H);
+        float a = 0.f;
+        for (int j = 0; j < group; ++j) { const bf16_t* r = in + (o * group + j) * 2 * H; a += from16<DT_F16>(r[c]) + from16<DT_F16>(r[H + c]); }
+        a *= 1.0f / (float)group;
+        const uint16_t hi = to16<DT_F16>(a);
+        out[o * 2 * H + c] = hi;
+        out[o * 2 * H + H + c] = to16<DT_F16>(a - from16<DT_F16>(hi));
+    }
+}
+int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s, bool split) {
     ARG_CHECK(out && in && n_out > 0 && group > 0 && H % 4 == 0);
+    if (split) {
+        ARG_CHECK(dtype == DT_F16);
+        hipLaunchKernelGGL(group_mean_split_kernel, dim3(grid_for(n_out * H, 256)), dim3(256), 0, s, out, in, n_out, group, H);
+        LAUNCH_CHECK("group_mean");
+        return BLIM_OK;
+    }
     if (dtype == DT_F16) hipLaunchKernelGGL(group_mean_kernel<DT_F16>, dim3(grid_for(n_out * (H / 4), 256)), dim3(256), 0, s, out, in, n_out, group, H);
     else hipLaunchKernelGGL(group_mean_kernel<DT_BF16>, dim3(grid_for(n_out * (H / 4), 256)), dim3(256), 0, s, out, in, n_out, group, H);
     LAUNCH_CHECK("group_mean");

@@ -8,10 +8,12 @@ int launch_fill_bell_bf16(bf16_t* out, int64_t n, uint64_t seed, uint64_t tensor
 int launch_fill_bell_f32(float* out, int64_t n, uint64_t seed, uint64_t tensor_id, float scale, float mean, int round_bf16, hipStream_t s);
 
 // out[t, :] = src_index[t] >= 0 ? table[src_index[t], :] : feats[-(src_index[t]+1), :]      (bf16 rows of width H)
-int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats, hipStream_t s);
+int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int H, const bf16_t* table, const bf16_t* feats, hipStream_t s,
+                    bool split = false);   // split (compensated mode): out / feats rows are [hi | lo] of width 2H
 
 // resid[t, :] = f32(embeds[t, :])   (16-bit input of the engine's compute dtype)
 int launch_h16_to_f32(float* out, const bf16_t* in, int64_t n, int dtype, hipStream_t s);
+int launch_hilo_to_f32(float* out, const bf16_t* in, int64_t n_rows, int H, hipStream_t s);   // [hi | lo] fp16 rows of width 2H -> f32 [n_rows, H]
 int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s);
 
 // out[i, :] = bf16( w * x[rows ? rows[i] : i, :] * rsqrt(mean(x^2) + eps) ); optionally also f32 copy.
@@ -20,7 +22,7 @@ int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_r
                    int64_t ldo = 0, bf16_t* out_lo = nullptr);   // ldo: row stride of out_h16 / out_lo (0 = H); out_lo: compensated mode, lo = 16-bit(x - f32(hi))
 
 // mean over groups of `group` consecutive rows: out[i,:] = mean_j in[i*group + j, :]   (16-bit in/out, f32 accumulate)
-int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s);
+int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s, bool split = false);
 
 // logprob[r] = labels[r] < 0 ? 0 : label_logit[r] - logsumexp over the n_tiles (max, sumexp) partials of row r
 int launch_lse_combine(const float2* part, int n_tiles, const float* label_logit, const int32_t* labels, int64_t n_rows, float* logprob, hipStream_t s);

@@ -234,20 +234,26 @@ class Engine:
     def can_precise(self) -> bool:
         return self.dtype == "f16"
 
-    def set_precise(self, on: bool):
+    def set_precise(self, on: bool, embeds: bool = False):
         """Compensated mode for the following calls (fp16 engines; a no-op request on others): every 16-bit activation travels as
         hi + lo and the GEMMs walk K twice.  The host turns it on for the TVG calls, whose scores are ~10x smaller in magnitude than
-        the VTG ones and need the extra bits to hold 1e-3 at 28 layers; 2x GEMM flops on those calls only."""
+        the VTG ones and need the extra bits to hold 1e-3 at 28 layers; 2x GEMM flops on those calls only.
+        embeds=True: the input embeddings (assemble -> decode / score_*) are [hi | lo] rows of width 2H as well -- the fused path,
+        whose projected video features are produced in this mode; the literal forward() keeps [B, L, H] embeddings."""
         on = bool(on) and self.can_precise
+        embeds = bool(embeds) and on
         if on != getattr(self, "_precise", False):
             self.set_option("precise", int(on))
             self._precise = on
+        if embeds != getattr(self, "_precise_embeds", False):
+            self.set_option("precise_embeds", int(embeds))
+            self._precise_embeds = embeds
 
     # ---- component ops (torch device tensors in/out)
     def project_video(self, feats, which: int):
         import torch
         n = feats.shape[0]
-        out = torch.empty((n, self.dims.hidden_size), dtype=self.torch_dtype, device=self.device)
+        out = torch.empty((n, self.dims.hidden_size * (2 if getattr(self, "_precise", False) else 1)), dtype=self.torch_dtype, device=self.device)
         _check(self.lib.blim_project_video(self.h, _ptr(feats), n, which, _ptr(out), _stream()), "blim_project_video")
         return out
 
@@ -261,7 +267,7 @@ class Engine:
     def assemble(self, src_index, feats=None):
         import torch
         n = src_index.shape[0]
-        out = torch.empty((n, self.dims.hidden_size), dtype=self.torch_dtype, device=self.device)
+        out = torch.empty((n, self.dims.hidden_size * (2 if getattr(self, "_precise_embeds", False) else 1)), dtype=self.torch_dtype, device=self.device)
         _check(self.lib.blim_assemble(self.h, _ptr(src_index), n, _ptr(feats), _ptr(out), _stream()), "blim_assemble")
         return out
 

@@ -186,6 +186,8 @@ class PairScorer:
                  tvg_video_labels, num_clips: int, max_tokens: int = 24576, precise_tvg: bool = True):
         import torch
         self.precise_tvg = bool(precise_tvg)
+        eng_ = getattr(model.module if hasattr(model, "module") else model, "engine", None)
+        self.split_tvg = self.precise_tvg and eng_ is not None and bool(getattr(eng_, "can_precise", False))   # TVG rows as [hi | lo]
         self.m = model.module if hasattr(model, "module") else model
         self.engine = self.m.engine
         self.device = self.m.device
@@ -216,10 +218,20 @@ class PairScorer:
 
     # ---- projected video features, cached on device (K1 once per video instead of once per pair)
     def video_feat(self, j: int, tvg: bool):
+        """Projected feature rows of video j, cached on device.  TVG rows (clip means) are produced in the compensated mode when the TVG
+        calls run in it: [clips, 2H] rows of hi | lo -- at 7B depth the 16-bit rounding of the projector output was the largest remaining
+        error of the TVG scores."""
         key = (int(j), bool(tvg))
         f = self._vfeat.get(key)
         if f is None:
-            f = self.m.project(self.video[j].to(self.device), tvg, cache=False)
+            split = bool(tvg) and self.split_tvg
+            if split:
+                self.engine.set_precise(True, embeds=True)
+            try:
+                f = self.m.project(self.video[j].to(self.device), tvg, cache=False)
+            finally:
+                if split:
+                    self.engine.set_precise(False)
             self._vfeat[key] = f
         return f
 
@@ -342,12 +354,13 @@ class PairScorer:
     # ---- execution (device) ---------------------------------------------------------------------
     def run(self, plan: Plan):
         """One engine call; returns a device f32 tensor [plan.n_pairs]."""
-        embeds = self.engine.assemble(plan.src_index, plan.feats)
         if plan.kind == "vtg":
             self.engine.set_precise(False)
+            embeds = self.engine.assemble(plan.src_index, plan.feats)
             return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
-        self.engine.set_precise(self.precise_tvg)             # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
+        self.engine.set_precise(self.split_tvg, embeds=self.split_tvg)       # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
         try:
+            embeds = self.engine.assemble(plan.src_index, plan.feats)
             return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)
         finally:
             self.engine.set_precise(False)
@@ -435,7 +448,8 @@ class _PackState:
         batch = PackedBatch(np.concatenate(self.pos), np.concatenate(self.vis), np.array(self.seq_start), np.array(self.seq_len),
                             np.array(self.pfx_start), np.array(self.pfx_len), device=dev)
         H = self.s.m.dims.hidden_size
-        feats = torch.cat(self.feats, dim=0) if self.feats else torch.zeros((1, H), dtype=self.s.m.dtype, device=dev)
+        wide = self.kind == "tvg" and self.s.split_tvg                                       # TVG feature rows are [hi | lo]
+        feats = torch.cat(self.feats, dim=0) if self.feats else torch.zeros((1, H * (2 if wide else 1)), dtype=self.s.m.dtype, device=dev)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         labels = np.concatenate(self.labels)
         return Plan(kind=self.kind, batch=batch, src_index=t(src), feats=feats, rows=t(np.array(self.rows)), labels=t(labels),
