@@ -41,7 +41,7 @@ def measured_traffic(kernel_class, dtype):
     if epi is None or not files:
         return None
     dt = dict(bf16=0, f16=1, f8=2)[dtype]
-    names = (f"void gemm_kernel<{epi}, {dt}, false>(GemmParams)", f"void gemm_kernel<{epi}, {dt}>(GemmParams)")
+    names = (f"void gemm_kernel<{epi}, {dt}, false, false>(GemmParams)", f"void gemm_kernel<{epi}, {dt}, false>(GemmParams)", f"void gemm_kernel<{epi}, {dt}>(GemmParams)")
     try:
         for f in reversed(files):                                   # newest summary that profiled this kernel
             d = json.load(open(f))
