@@ -32,6 +32,7 @@ def get_args_parser():
     p.add_argument("--clear", action="store_true", help="clear the feature folder")
     p.add_argument("--frames_dir", default=None, help="directory of pre-decoded <vid>.npy frame stacks (used when decord is unavailable)")
     p.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    p.add_argument("--num_workers", type=int, default=4, help="host threads decoding + preprocessing ahead of the GPU (the reference's DataLoader uses 4 workers)")
     p.add_argument("--synthetic", default=None, type=int, help="seed of synthetic tower weights (dry run)")
     return p
 
@@ -106,15 +107,34 @@ def main(args):
         enc.load_checkpoint(args.model_path)
     t0, n_done = time.time(), 0
     clips = args.num_frames // dims.num_frames
+
+    def load_one(item):                                                   # host side: decode + resize + normalise (PIL releases the GIL)
+        vid, path = item
+        try:
+            return vid, preprocess(read_frames(path, is_video, args.dataset, args.num_frames), dims.image_size)
+        except Exception as e:                                            # extract.py:73-75 skips unreadable videos
+            print(f"Error loading video {path}: {e}")
+            return vid, None
+
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max(1, args.num_workers))
+    ahead = 2 * max(1, args.num_workers) + args.batch_size               # bounded look-ahead: a preprocessed video is 19 MB
+    pending, nxt = collections.deque(), 0
+
+    def refill():
+        nonlocal nxt
+        while nxt < len(sources) and len(pending) < ahead:
+            pending.append(pool.submit(load_one, sources[nxt])); nxt += 1
+
+    refill()
     for lo in range(0, len(sources), args.batch_size):
-        batch = sources[lo: lo + args.batch_size]
         frames, vids = [], []
-        for vid, path in batch:
-            try:
-                frames.append(preprocess(read_frames(path, is_video, args.dataset, args.num_frames), dims.image_size))
-                vids.append(vid)
-            except Exception as e:                                        # extract.py:73-75 skips unreadable videos
-                print(f"Error loading video {path}: {e}")
+        for _ in range(min(args.batch_size, len(sources) - lo)):
+            vid, fr = pending.popleft().result()
+            refill()
+            if fr is not None:
+                frames.append(fr); vids.append(vid)
         if not vids:
             continue
         tome, _ = enc.encode(torch.cat(frames, dim=0))
@@ -125,6 +145,7 @@ def main(args):
     torch.cuda.synchronize()
     dt = time.time() - t0
     print(f"{n_done} videos in {dt:.1f}s ({n_done / max(dt, 1e-9):.1f} videos/s, decoding and preprocessing included)")
+    pool.shutdown()
     enc.close()
     return n_done
 
