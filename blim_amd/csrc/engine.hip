@@ -85,6 +85,7 @@ struct blim_engine {
     // 21 significant bits of the activations reach the f32 accumulators; costs 2x the GEMM flops, so the host turns it on for the
     // cheap TVG calls only (their scores are ~10x smaller in magnitude than the VTG ones: DESIGN.md section 4).
     bool precise = false;
+    bool precise_mlp = true;       // option "precise_mlp": compensate the MLP branch too (87 % of the flops, ~20 % of the error variance)
     bool precise_embeds = false;   // option "precise_embeds": in precise mode the INPUT embeddings (blim_assemble output, blim_decode / blim_score_* input) and
                                    // the projector outputs feeding them are [hi | lo] rows of width 2H too (the fused TVG path; the literal
                                    // forward() keeps the reference's [B, L, H] embeddings)
@@ -211,6 +212,7 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     e->c = *cfg;
     if (cfg->compute_dtype == BLIM_COMPUTE_F8) { e->f8 = true; e->c.compute_dtype = BLIM_COMPUTE_F16; }
     if (getenv("BLIM_F8_FUSE")) e->f8_fuse = atoi(getenv("BLIM_F8_FUSE"));
+    if (getenv("BLIM_PRECISE_MLP")) e->precise_mlp = atoi(getenv("BLIM_PRECISE_MLP")) != 0;
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -458,10 +460,10 @@ static GemmParams gp(int dt, const void* A, int64_t lda, const void* W, int64_t 
 }
 
 // compensated mode: A = [hi | lo] (K counts both halves, W is walked twice); 16-bit outputs as hi at C and lo at C + lo_off
-static GemmParams gp2(const blim_engine* e, const void* A, int64_t K1, const void* W, int64_t M, int N, void* C, int64_t ldc1, int64_t n_out1) {
-    const int pf = e->precise ? 2 : 1;
+static GemmParams gp2(const blim_engine* e, const void* A, int64_t K1, const void* W, int64_t M, int N, void* C, int64_t ldc1, int64_t n_out1, bool split) {
+    const int pf = split ? 2 : 1;
     GemmParams p = gp(e->c.compute_dtype, A, pf * K1, W, M, N, (int)(pf * K1), C, pf * ldc1);
-    if (e->precise) { p.w_wrap_k = (int)K1; p.lo_off = n_out1; }
+    if (split) { p.w_wrap_k = (int)K1; p.lo_off = n_out1; }
     return p;
 }
 
@@ -529,7 +531,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((T * 32 + 255) / 256)), dim3(256), 0, s, rope_rows, b->positions, e->rope_cos, e->rope_sin, T, c.max_positions);
         HIP_TRY(hipGetLastError());
     }
-    const int pf = e->precise ? 2 : 1;
+    const int pf = e->precise ? 2 : 1;                              // attention branch
+    const bool pm = e->precise && e->precise_mlp;                   // MLP branch (option "precise_mlp")
+    const int pfm = pm ? 2 : 1;
     if (e->precise && (e->f8 || c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_STATE; }
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
@@ -540,7 +544,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         }
         {
             SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * pf);
-            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n);
+            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise);
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows;
             TRY(launch_gemm(EPI_QKV, p, s));
         }
@@ -560,7 +564,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         if (o8 && !fuse_o) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H * pf);
-            GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0);
+            GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0, e->precise);
             if (fuse_o) { p.a_mx = (const uint8_t*)e->attn_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             TRY(launch_gemm(EPI_RESID, p, s));
@@ -568,19 +572,19 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (g8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * H, e->precise ? xn + H : nullptr));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr));
         }
         const bool fuse = g8 && d8 && e->f8_fuse;      // fp8: the gate|up epilogue emits e4m3 + one E8M0 scale per (token, 128 outputs) itself
         {
-            SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I * pf);
-            GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I);
+            SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I * pfm);
+            GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I, pm);
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
         if (d8 && !fuse) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
         {
-            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * pf);
-            GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0);
+            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * pfm);
+            GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0, pm);
             if (fuse) { p.a_mx = (const uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             TRY(launch_gemm(EPI_RESID, p, s));
@@ -835,6 +839,7 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "f8_mask")) { e->f8_mask = value & 31; return BLIM_OK; }
     if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
+    if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise")) {
         if (value && (e->f8 || e->c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_ARG; }
         e->precise = value != 0;
