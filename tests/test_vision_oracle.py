@@ -108,3 +108,21 @@ def test_extract_driver_host_logic(tmp_path):
     assert X.video_id("./data/LSMDC/videos/a/0001_American_Beauty_00.00.51.926-00.00.54.129.avi", "LSMDC") == "0001_American_Beauty_00.00.51.926-00.00.54.129"
     a = X.get_args_parser().parse_args(["--num_chunk", "2", "--chunk_idx", "1"])
     assert a.dataset == "DiDeMo" and a.num_frames == 16 and a.batch_size == 1 and a.model_path.endswith("VideoChat-Flash-Qwen2-7B_res448")
+
+
+@pytest.mark.needs_reference
+def test_preprocess_matches_the_reference_image_processor():
+    """Build container only: blim_amd.vision.preprocess against the reference's own UMTImageProcessor (vision_tower_builder.py:441-475) on
+    random uint8 frames, with and without a resize."""
+    import torch
+    from oracle import ref_harness
+    ref_harness.load()
+    from videochat_flash.vision_tower_builder import UMTImageProcessor
+    rs = np.random.RandomState(5)
+    for shape, S in (((3, 48, 64, 3), 32), ((2, 32, 32, 3), 32), ((2, 100, 75, 3), 64)):
+        frames = rs.randint(0, 256, size=shape, dtype=np.uint8)
+        want = UMTImageProcessor(size=(S, S)).preprocess(frames, return_tensors="pt")["pixel_values"].half()
+        got = V.preprocess(frames, image_size=S)
+        assert got.shape == want.shape
+        # one fp16 ulp at most (the reference rescales and normalises in a different operation order)
+        assert float((got.float() - want.float()).abs().max()) <= 2e-3
