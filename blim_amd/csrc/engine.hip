@@ -171,15 +171,17 @@ __global__ void rope_table_kernel(float* cosb, float* sinb, int n_pos, int half,
     cosb[i] = cosf(ang);
     sinb[i] = sinf(ang);
 }
-// rows[t] = cos[pos[t]] (64) | sin[pos[t]] (64): gathered once per batch so that the 28 QKV epilogues read their RoPE factors by row
-__global__ void rope_rows_kernel(float* rows, const int32_t* pos, const float* cosb, const float* sinb, int64_t n_tokens, int n_pos) {
+// table[chunk q][t][16] with q = {cos, sin} x 4 groups of 16 dims: cos / sin of every token's position, gathered once per batch so that the 28 QKV
+// epilogues read their RoPE factors by row; chunk-major so that the 16 consecutive rows of an MFMA fragment are contiguous (gemm.hpp)
+__global__ void rope_rows_kernel(float* rows, const int32_t* pos, const float* cosb, const float* sinb, int64_t n_tokens, int64_t stride, int n_pos) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 per thread: 32 per token
     if (i >= n_tokens * 32) return;
     const int64_t t = i >> 5;
-    const int c = (int)(i & 31);
+    const int c = (int)(i & 31);                                            // float4 index inside cos[64] | sin[64]
     const int p = min(max(pos[t], 0), n_pos - 1);
     const float* src = (c < 16 ? cosb : sinb) + (int64_t)p * 64 + 4 * (c & 15);
-    *(float4*)(rows + t * 128 + 4 * c) = *(const float4*)src;
+    const int q = (c >> 4) * 4 + ((c & 15) >> 2);                           // chunk: {cos, sin} x (d / 16)
+    *(float4*)(rows + ((int64_t)q * stride + t) * 16 + 4 * (c & 3)) = *(const float4*)src;
 }
 __global__ void dense_batch_kernel(int32_t* pos, int32_t* seq_start, int32_t* seq_len, int32_t* pfx, int32_t* blk_seq, int32_t* blk_q0,
                                    int B, int L, int nblk_per_seq) {
@@ -528,7 +530,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         SpanGuard g(e, s, TC_MISC, 0);
         TRY(ensure(e->rope_rows, (size_t)round_up(T, 256) * 128 * 4));
         rope_rows = (float*)e->rope_rows.p;
-        hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((T * 32 + 255) / 256)), dim3(256), 0, s, rope_rows, b->positions, e->rope_cos, e->rope_sin, T, c.max_positions);
+        hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((T * 32 + 255) / 256)), dim3(256), 0, s, rope_rows, b->positions, e->rope_cos, e->rope_sin, T, round_up(T, 256), c.max_positions);
         HIP_TRY(hipGetLastError());
     }
     const int pf = e->precise ? 2 : 1;                              // attention branch
@@ -545,7 +547,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * pf);
             GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise);
-            p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows;
+            p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
         }
         {

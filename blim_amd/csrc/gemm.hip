@@ -536,11 +536,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     const int gbase = (wn & 1) * 2;            // first 32-group of this wave inside the head
                     const int d0 = 16 * gbase + 4 * tq;        // natural d of pair 0's lo element; pair 1: + 16
                     float4 cs[2][2], sn[2][2];                 // [buffer][pair]
+                    // table layout (engine.hip rope_rows_kernel): [8 chunks = {cos, sin} x 4 groups of 16 dims][rope_stride rows][16 floats] -- the 16
+                    // consecutive rows of a fragment are 1 KB contiguous per chunk, so a wave's load touches 8 full lines (row-major [row][128]
+                    // it touched 16 half-used lines per instruction: 4,096 line requests per tile, the whole 8 us of this epilogue)
+                    const int64_t cstride = p.rope_stride * 16;            // floats per chunk
                     auto request = [&](int mi, int buf) __attribute__((always_inline)) {
                         const int row = min(row0 + 128 * wm + 16 * mi + rsub, p.M - 1);
-                        const float* crow = p.rope_rows + (int64_t)row * 128 + d0;
-                        cs[buf][0] = *(const float4*)crow; cs[buf][1] = *(const float4*)(crow + 16);
-                        sn[buf][0] = *(const float4*)(crow + 64); sn[buf][1] = *(const float4*)(crow + 80);
+                        const float* base = p.rope_rows + (int64_t)row * 16 + 4 * tq;
+                        cs[buf][0] = *(const float4*)(base + (gbase + 0) * cstride); cs[buf][1] = *(const float4*)(base + (gbase + 1) * cstride);
+                        sn[buf][0] = *(const float4*)(base + (4 + gbase + 0) * cstride); sn[buf][1] = *(const float4*)(base + (4 + gbase + 1) * cstride);
                     };
                     request(0, 0);
 #pragma unroll
@@ -788,7 +792,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         q.A = (const bf16_t*)((const char*)p.A + r0 * row_bytes);
         if (p.C) q.C = (char*)p.C + r0 * p.ldc * c_es;
         if (p.row_scale) q.row_scale = p.row_scale + r0;
-        if (p.rope_rows) q.rope_rows = p.rope_rows + r0 * 128;
+        if (p.rope_rows) q.rope_rows = p.rope_rows + r0 * 16;        // chunk-major table: the row offset inside every chunk (rope_stride unchanged)
         if (p.a_mx) q.a_mx = p.a_mx + r0;                         // r0 is a whole number of 256-row tiles: the table is tile-major inside a K-step
         if (p.out_mx) q.out_mx = p.out_mx + r0;
         if (p.labels) q.labels = p.labels + r0;
@@ -826,7 +830,7 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
         case EPI_F32: ARG_CHECK(p.C && p.bias == nullptr); return launch_t<EPI_F32>(p, stream);
         case EPI_RESID: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_RESID>(p, stream);
         case EPI_QKV:
-            ARG_CHECK(p.C && p.bias && p.rope_rows && p.N % 128 == 0 && p.rope_cols % 128 == 0 && p.ldc % 4 == 0);
+            ARG_CHECK(p.C && p.bias && p.rope_rows && p.rope_stride >= p.M && p.N % 128 == 0 && p.rope_cols % 128 == 0 && p.ldc % 4 == 0);
             return launch_t<EPI_QKV>(p, stream);
         case EPI_SWIGLU: ARG_CHECK(p.C && p.N % 32 == 0 && p.ldc % 4 == 0); return launch_t<EPI_SWIGLU>(p, stream);
         case EPI_LSE: ARG_CHECK(p.labels && p.lse_part && p.label_logit); return launch_t<EPI_LSE>(p, stream);

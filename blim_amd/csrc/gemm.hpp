@@ -30,8 +30,9 @@ struct GemmParams {
     float scale;        // EPI_F32
     // EPI_QKV
     int rope_cols;           // (num_heads + num_kv_heads) * 128
-    const float* rope_rows;  // [M, 128]: cos[64] | sin[64] of every ROW's position, gathered once per batch (engine.hip: rope_rows_kernel) -- the
-                             // epilogue needs no dependent position -> table load chain
+    const float* rope_rows;  // cos / sin of every ROW's position, gathered once per batch (engine.hip: rope_rows_kernel), chunk-major:
+                             // [8 = {cos, sin} x 4 groups of 16 dims][rope_stride rows][16]: a fragment's 16 consecutive rows are 1 KB contiguous
+    int64_t rope_stride;     // rows per chunk of that table (>= M)
     // EPI_LSE
     const int32_t* labels;   // [M] target column per row (or < 0)
     float2* lse_part;        // [M, ceil(N/256)] (max, sumexp)
