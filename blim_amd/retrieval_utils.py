@@ -556,62 +556,150 @@ def evaluation(model, data_loader, device, tokenizer, args):
             d[k] = m
 
     v2t, t2v = {}, {}
-    start, end = dist_utils.row_block(num_videos, W, rank)                                       # :213-215
-    v2t["candidate_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", False)
-    if args.cpn:
-        if W > 1 and not literal:
-            # the v2t prior log P(text | masked video) does not depend on the query video: every rank scores its block of
-            # TEXTS once (N/W forwards instead of rows*k/W), the [N] vector is all-gathered and scattered into the rank's top-k
-            # entries
-            t0, t1 = dist_utils.row_block(num_texts, W, rank)
-            mine = torch.full((num_texts // W + 1,), -100.0, dtype=torch.float32, device=device)
-            if t1 > t0:
-                tp = np.stack([np.zeros(t1 - t0, dtype=np.int64), np.arange(t0, t1, dtype=np.int64)], axis=1)
-                mine[: t1 - t0] = scorer.vtg_device(tp, True) if hasattr(scorer, "vtg_device") else \
+    if dedup:
+        # ---- pair ownership (fused path).  Every likelihood is a function of the (video, text) pair, and what is expensive is shared per
+        # VIDEO for VTG (the header + 256 video tokens + instruction prefix) and per TEXT for TVG (the caption prompt).  So the pairs of both
+        # directions are pooled -- P = {(j, i): i in top-k of video j} U {(j, i): j in top-k of text i} -- each scored ONCE, and VTG pairs
+        # are owned by the rank that owns video j, TVG pairs by the rank that owns text i (the reference's row blocks, :213-215 / :233-235):
+        # a prefix is computed once per video / text over both directions.  (Sharding the t2v pass by text rows, as the reference's loop
+        # order suggests, leaves ~2 candidates per video prefix at W = 8: 3x the tokens of the v2t pass.)  The owner fills a row block of
+        # the (video, text) matrix for VTG and a column block for TVG; two all-gathers (+ the priors) assemble all matrices on every rank.
+        Nv, Nt = num_videos, num_texts
+        kt, kv = min(Nt, args.topk), min(Nv, args.topk)
+        m_v2t = np.zeros((Nv, Nt), dtype=bool)
+        m_v2t[np.repeat(np.arange(Nv), kt), v2t_iv2.topk(k=kt, dim=1).indices.cpu().numpy().reshape(-1)] = True
+        m_t2v = np.zeros((Nv, Nt), dtype=bool)                                                 # (video, text) layout of the t2v requests
+        m_t2v[t2v_iv2.topk(k=kv, dim=1).indices.cpu().numpy().reshape(-1), np.repeat(np.arange(Nt), kv)] = True
+        need = m_v2t | m_t2v
+        vs, ve = dist_utils.row_block(Nv, W, rank)
+        ts, te = dist_utils.row_block(Nt, W, rank)
+        n_v2t = 1 + (1 if args.cpn else 0) + (1 if finetuned else 0)
+        n_t2v = 1 + ((1 + (1 if args.cpn else 0)) if finetuned else 0)
+        stats["pairs_requested"] = int(m_v2t[vs:ve].sum()) * n_v2t + int(m_t2v[:, ts:te].sum()) * n_t2v
+        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+        def score_owned(ftype, own):
+            jj, ii = np.nonzero(own)
+            M = full(Nv, Nt)
+            if len(jj):
+                pairs = np.stack([jj, ii], axis=1)
+                stats["pairs_scored"] += len(pairs)
+                fn = getattr(scorer, f"{ftype}_device", None)
+                sc = fn(pairs, False) if fn is not None else torch.from_numpy(np.asarray(getattr(scorer, ftype)(pairs, False), dtype=np.float32)).to(device)
+                M[to_dev(jj), to_dev(ii)] = sc
+            return M
+
+        own_v = need.copy(); own_v[:vs] = False; own_v[ve:] = False                            # VTG: rows of my videos
+        M_vtg = score_owned("vtg", own_v)
+        M_tvg_T = None
+        if finetuned:
+            own_t = need.copy(); own_t[:, :ts] = False; own_t[:, te:] = False                  # TVG: columns of my texts
+            M_tvg_T = score_owned("tvg", own_t).T.contiguous()                                # text-major: a row block
+        prior_t = None
+        if args.cpn:
+            # the v2t prior log P(text | masked video) does not depend on the query video: every rank scores its block of TEXTS once
+            mine = torch.full((Nt // W + 1,), -100.0, dtype=torch.float32, device=device)
+            if te > ts:
+                tp = np.stack([np.zeros(te - ts, dtype=np.int64), np.arange(ts, te, dtype=np.int64)], axis=1)
+                mine[: te - ts] = scorer.vtg_device(tp, True) if hasattr(scorer, "vtg_device") else \
                     torch.from_numpy(np.asarray(scorer.vtg(tp, True), dtype=np.float32)).to(device)
-                stats["pairs_scored"] += t1 - t0
+                stats["pairs_scored"] += te - ts
             if collective:
                 parts = [torch.empty_like(mine) for _ in range(W)]
                 torch.distributed.all_gather(parts, mine)
-                prior = torch.cat(parts)[:num_texts]
-            else:                                        # shard emulation: only this rank's texts are known
-                prior = torch.full((num_texts,), -100.0, dtype=torch.float32, device=device)
-                prior[t0:t1] = mine[: t1 - t0]
-            S = full(num_videos, num_texts)
-            if end > start:
-                pairs = _topk_pairs(v2t_iv2[start:end], start, args.topk, True)
-                stats["pairs_requested"] += len(pairs)
-                r_, c_ = torch.from_numpy(pairs[:, 0]).to(device), torch.from_numpy(pairs[:, 1]).to(device)
-                S[r_, c_] = prior[c_]
-            v2t["candidate_prior"] = S
-        else:
-            v2t["candidate_prior"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", True)
-    if finetuned:
-        v2t["query_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "tvg", False)
-    v_block = (start, end)
-    known_vtg = known_tvg = None
-    if dedup:
-        if collective:
-            merge([(v2t, v_block)])                      # first all-gather: the complete v2t matrices, before the t2v passes read them
-        k = min(num_texts, args.topk)
-        mask = np.zeros((num_videos, num_texts), dtype=bool)
-        # shard emulation (timing only): the other ranks' rows count as known too, as they are after the real merge -- their
-        # values are -100 placeholders, which is why an emulated run reports no recall table
-        rows = slice(0, num_videos)
-        idx = v2t_iv2[rows].topk(k=k, dim=1).indices.cpu().numpy()
-        mask[np.repeat(np.arange(rows.start, rows.stop), k), idx.reshape(-1)] = True
-        known_vtg = (v2t["candidate_likelihood"], mask)
-        known_tvg = (v2t["query_likelihood"], mask) if finetuned else None
-    start, end = dist_utils.row_block(num_texts, W, rank)                                        # :233-235
-    t2v["query_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "vtg", False, known=known_vtg)
-    if finetuned:
-        t2v["candidate_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", False, known=known_tvg)
+                prior_t = torch.cat([parts[r_][: dist_utils.row_block(Nt, W, r_)[1] - dist_utils.row_block(Nt, W, r_)[0]] for r_ in range(W)])
+            else:
+                prior_t = torch.full((Nt,), -100.0, dtype=torch.float32, device=device)
+                prior_t[ts:te] = mine[: te - ts]
+        S_t2v_prior = None
+        if finetuned and args.cpn:                                                             # t2v TVG prior: keyed on (prompt, video); rows of my texts
+            S_t2v_prior = full(Nt, Nv)
+            if te > ts:
+                pairs = _topk_pairs(t2v_iv2[ts:te], ts, args.topk, False)
+                stats["pairs_scored"] += len(pairs)
+                sc = scorer.tvg_device(pairs, True) if hasattr(scorer, "tvg_device") else torch.from_numpy(np.asarray(scorer.tvg(pairs, True), dtype=np.float32)).to(device)
+                S_t2v_prior[to_dev(pairs[:, 1]), to_dev(pairs[:, 0])] = sc
+        if collective:                                                                         # one all-gather for the row blocks of all three
+            mats, blocks = [M_vtg], [(vs, ve)]
+            if M_tvg_T is not None:
+                mats.append(M_tvg_T); blocks.append((ts, te))
+            if S_t2v_prior is not None:
+                mats.append(S_t2v_prior); blocks.append((ts, te))
+            merged = dist_utils.merge_row_blocks_many(mats, blocks, W)
+            M_vtg = merged[0]
+            if M_tvg_T is not None:
+                M_tvg_T = merged[1]
+            if S_t2v_prior is not None:
+                S_t2v_prior = merged[-1]
+        mv, mt = to_dev(m_v2t), to_dev(m_t2v)
+        neg = torch.tensor(-100.0, dtype=torch.float32, device=device)
+        v2t["candidate_likelihood"] = torch.where(mv, M_vtg, neg)
         if args.cpn:
-            t2v["candidate_prior"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", True)
-    t_block = (start, end)
+            v2t["candidate_prior"] = torch.where(mv, prior_t[None, :].expand(Nv, Nt), neg)
+        if finetuned:
+            v2t["query_likelihood"] = torch.where(mv, M_tvg_T.T, neg)
+        t2v["query_likelihood"] = torch.where(mt, M_vtg, neg).T.contiguous()
+        if finetuned:
+            t2v["candidate_likelihood"] = torch.where(mt.T, M_tvg_T, neg).contiguous()
+            if args.cpn:
+                t2v["candidate_prior"] = S_t2v_prior
+    else:
+        start, end = dist_utils.row_block(num_videos, W, rank)                                       # :213-215
+        v2t["candidate_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", False)
+        if args.cpn:
+            if W > 1 and not literal:
+                # the v2t prior log P(text | masked video) does not depend on the query video: every rank scores its block of
+                # TEXTS once (N/W forwards instead of rows*k/W), the [N] vector is all-gathered and scattered into the rank's top-k
+                # entries
+                t0, t1 = dist_utils.row_block(num_texts, W, rank)
+                mine = torch.full((num_texts // W + 1,), -100.0, dtype=torch.float32, device=device)
+                if t1 > t0:
+                    tp = np.stack([np.zeros(t1 - t0, dtype=np.int64), np.arange(t0, t1, dtype=np.int64)], axis=1)
+                    mine[: t1 - t0] = scorer.vtg_device(tp, True) if hasattr(scorer, "vtg_device") else \
+                        torch.from_numpy(np.asarray(scorer.vtg(tp, True), dtype=np.float32)).to(device)
+                    stats["pairs_scored"] += t1 - t0
+                if collective:
+                    parts = [torch.empty_like(mine) for _ in range(W)]
+                    torch.distributed.all_gather(parts, mine)
+                    prior = torch.cat(parts)[:num_texts]
+                else:                                        # shard emulation: only this rank's texts are known
+                    prior = torch.full((num_texts,), -100.0, dtype=torch.float32, device=device)
+                    prior[t0:t1] = mine[: t1 - t0]
+                S = full(num_videos, num_texts)
+                if end > start:
+                    pairs = _topk_pairs(v2t_iv2[start:end], start, args.topk, True)
+                    stats["pairs_requested"] += len(pairs)
+                    r_, c_ = torch.from_numpy(pairs[:, 0]).to(device), torch.from_numpy(pairs[:, 1]).to(device)
+                    S[r_, c_] = prior[c_]
+                v2t["candidate_prior"] = S
+            else:
+                v2t["candidate_prior"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "vtg", True)
+        if finetuned:
+            v2t["query_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "tvg", False)
+        v_block = (start, end)
+        known_vtg = known_tvg = None
+        if dedup:
+            if collective:
+                merge([(v2t, v_block)])                      # first all-gather: the complete v2t matrices, before the t2v passes read them
+            k = min(num_texts, args.topk)
+            mask = np.zeros((num_videos, num_texts), dtype=bool)
+            # shard emulation (timing only): the other ranks' rows count as known too, as they are after the real merge -- their
+            # values are -100 placeholders, which is why an emulated run reports no recall table
+            rows = slice(0, num_videos)
+            idx = v2t_iv2[rows].topk(k=k, dim=1).indices.cpu().numpy()
+            mask[np.repeat(np.arange(rows.start, rows.stop), k), idx.reshape(-1)] = True
+            known_vtg = (v2t["candidate_likelihood"], mask)
+            known_tvg = (v2t["query_likelihood"], mask) if finetuned else None
+        start, end = dist_utils.row_block(num_texts, W, rank)                                        # :233-235
+        t2v["query_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "vtg", False, known=known_vtg)
+        if finetuned:
+            t2v["candidate_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", False, known=known_tvg)
+            if args.cpn:
+                t2v["candidate_prior"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", True)
+        t_block = (start, end)
 
-    if collective:                                                                               # :252-262
-        merge([(t2v, t_block)] if dedup else [(v2t, v_block), (t2v, t_block)])
+        if collective:                                                                               # :252-262
+            merge([(t2v, t_block)] if dedup else [(v2t, v_block), (t2v, t_block)])
     args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank)
     t2v_dict = {k: v.cpu().numpy() for k, v in t2v.items()}                                      # :264-276
     v2t_dict = {k: v.cpu().numpy() for k, v in v2t.items()}

@@ -138,7 +138,9 @@ def test_evaluation_world2_equals_single_process_and_shards_the_prior_over_texts
         # the v2t prior pass scored this rank's TEXT block once (6 and 5 texts), not rows x topk pairs
         prior_calls = [c for c in calls if c[0] == "vtg" and c[1]]
         assert prior_calls == [("vtg", True, 6 if rank == 0 else 5)]
-    assert ("vtg", True, n * 3) in ref_calls                           # single process: all top-k pairs (deduplicated inside the scorer)
+    assert ("vtg", True, n) in ref_calls                               # single process: the prior of every text, once
+    # pooled pairs: one VTG call and one TVG call over the union of both directions' pairs (41 of 2 x 33 requests here)
+    assert [c[:2] for c in ref_calls] == [("vtg", False), ("tvg", False), ("vtg", True), ("tvg", True)] and ref_calls[0][2] == ref_calls[1][2] < 2 * n * 3
 
 
 def _run_eval_with(n, **kw):
@@ -165,20 +167,18 @@ def test_cross_direction_dedup_gives_the_same_matrices_with_fewer_scored_pairs()
     assert b[3]["pairs_scored"] == b[3]["pairs_requested"] == 6 * n * 3
     assert a[3]["pairs_requested"] == 6 * n * 3 and a[3]["pairs_scored"] < b[3]["pairs_scored"]
     dense = _run_eval_with(n, topk=n)
-    assert [c[:2] for c in dense[2]] == [("vtg", False), ("vtg", True), ("tvg", False), ("tvg", True)]   # no t2v likelihood pass left
+    assert [c for c in dense[2]] == [("vtg", False, n * n), ("tvg", False, n * n), ("vtg", True, n), ("tvg", True, n * n)]   # every pair once
     ref = _run_eval_with(n, topk=n, dedup=False)
     for k in ref[0]:
         assert np.array_equal(dense[0][k], ref[0][k]), k
-    # shard emulation: rank 1 of 2 scores its own row blocks only, and its rows equal the full result's rows
+    # shard emulation: rank 1 of 2 scores only the pairs it owns (VTG: its videos, TVG: its texts); whatever it holds equals the full result,
+    # and the VTG matrix of its video rows is complete
     sh = _run_eval_with(n, shard=(2, 1))
     s, e = D.row_block(n, 2, 1)
-    for k in a[1]:
-        if k == "candidate_prior":                        # text-sharded: the emulated rank only knows the prior of ITS texts
-            m = sh[1][k][s:e] != -100.0
-            assert m.any() and np.array_equal(sh[1][k][s:e][m], a[1][k][s:e][m]) and not m[:, :s].any()
-        elif k != "internvideo2":
-            assert np.array_equal(sh[1][k][s:e], a[1][k][s:e]) and (sh[1][k][:s] == -100.0).all()
-    for k in a[0]:                                        # t2v: what another rank's v2t rows would provide stays a -100 placeholder
-        if k != "internvideo2":
-            m = sh[0][k][s:e] != -100.0
-            assert m.any() and np.array_equal(sh[0][k][s:e][m], a[0][k][s:e][m])
+    for full_d, part_d in ((a[0], sh[0]), (a[1], sh[1])):
+        for k in full_d:
+            if k != "internvideo2":
+                m = part_d[k] != -100.0
+                assert m.any() and np.array_equal(part_d[k][m], full_d[k][m]), k
+    assert np.array_equal(sh[1]["candidate_likelihood"][s:e], a[1]["candidate_likelihood"][s:e])
+    assert sh[3]["pairs_scored"] < a[3]["pairs_scored"]

@@ -126,8 +126,8 @@ def test_evaluation_dense_and_top32_vs_oracle(models, n, topk, bs):
             np.testing.assert_allclose(S[m], W[m], rtol=1e-3, err_msg=f"{k} dedup={dedup}")
     assert res[False][2]["pairs_scored"] == res[False][2]["pairs_requested"] == 6 * n * min(topk, n)
     assert res[True][2]["pairs_scored"] < res[False][2]["pairs_scored"]
-    if topk >= n:                                           # dense: both t2v likelihood passes are free
-        assert res[True][2]["pairs_scored"] == 4 * n * n
+    if topk >= n:                                           # dense: every (video, text) pair once for VTG, once for TVG, n priors + the t2v prior
+        assert res[True][2]["pairs_scored"] == 3 * n * n + n
     for a, b in zip(res[True][:2], res[False][:2]):
         for k in a:
             np.testing.assert_allclose(a[k], b[k], rtol=1e-5)
