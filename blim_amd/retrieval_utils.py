@@ -504,10 +504,9 @@ def evaluation(model, data_loader, device, tokenizer, args):
     if emulate is not None:
         W, rank = int(emulate[0]), int(emulate[1])
     collective = W > 1 and emulate is None
-    # cross-direction de-duplication (fused path): log P(text i | video j) is v2t.candidate_likelihood[j, i] AND
-    # t2v.query_likelihood[i, j]; log P(video j | text i) is v2t.query_likelihood[j, i] AND t2v.candidate_likelihood[i, j]
-    # (SURVEY.md section 3.3).  The t2v passes therefore only score the pairs the (merged) v2t matrices do not already hold; with
-    # dense candidates (topk >= N) the t2v likelihood passes cost nothing.  The literal path keeps the reference's control flow.
+    # pair pooling / ownership (fused path; below): log P(text i | video j) is v2t.candidate_likelihood[j, i] AND t2v.query_likelihood[i, j];
+    # log P(video j | text i) is v2t.query_likelihood[j, i] AND t2v.candidate_likelihood[i, j].  args.dedup = False
+    # (--no_dedup), compat_allreduce_offset and the literal path keep the reference's six row-sharded passes.
     dedup = (not literal) and bool(getattr(args, "dedup", True)) and not bool(getattr(args, "compat_allreduce_offset", False))
     full = lambda n, m: torch.full((n, m), -100.0, dtype=torch.float32, device=device)
     scorer = getattr(args, "_scorer", None)              # test hook: any object with .vtg(pairs, cpn) / .tvg(pairs, cpn)
@@ -516,9 +515,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
                             tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
     stats = {"pairs_requested": 0, "pairs_scored": 0}
 
-    def run_pass(S, sims_rows, start, query_is_video, ftype, cpn, known=None):
-        """known = (M, mask): M [videos, texts] device matrix of the opposite direction's pass, mask [videos, texts] host bool
-        array of the entries it holds -- those pairs are copied instead of scored."""
+    def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):
+        """One of the reference's six passes over this rank's query rows (literal: its own loops; fused: the PairScorer)."""
         if literal:
             fn = compute_v2t_scores_x if query_is_video else compute_t2v_scores_x
             ids, msk, lab = (vtg_ids, vtg_masks, vtg_labels) if ftype == "vtg" else (tvg_ids, tvg_masks, tvg_labels)
@@ -528,24 +526,14 @@ def evaluation(model, data_loader, device, tokenizer, args):
             return S
         pairs = _topk_pairs(sims_rows, start, args.topk, query_is_video)
         stats["pairs_requested"] += len(pairs)
-        if known is not None:
-            M, mask = known
-            have = mask[pairs[:, 0], pairs[:, 1]]
-            hp = pairs[have]
-            if len(hp):
-                vj, ti = torch.from_numpy(hp[:, 0]).to(device), torch.from_numpy(hp[:, 1]).to(device)
-                r, c = (vj, ti) if query_is_video else (ti, vj)
-                S[r, c] = M[vj, ti]
-            pairs = pairs[~have]
-        if len(pairs):
-            stats["pairs_scored"] += len(pairs)
-            r, c = (pairs[:, 0], pairs[:, 1]) if query_is_video else (pairs[:, 1], pairs[:, 0])
-            if hasattr(scorer, "vtg_device"):                    # no host round trip: the pass's scores go device -> device
-                sc = scorer.vtg_device(pairs, cpn) if ftype == "vtg" else scorer.tvg_device(pairs, cpn)
-                S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = sc
-            else:
-                sc = scorer.vtg(pairs, cpn) if ftype == "vtg" else scorer.tvg(pairs, cpn)
-                S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = torch.from_numpy(sc).to(device)
+        stats["pairs_scored"] += len(pairs)
+        r, c = (pairs[:, 0], pairs[:, 1]) if query_is_video else (pairs[:, 1], pairs[:, 0])
+        if hasattr(scorer, "vtg_device"):                    # no host round trip: the pass's scores go device -> device
+            sc = scorer.vtg_device(pairs, cpn) if ftype == "vtg" else scorer.tvg_device(pairs, cpn)
+            S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = sc
+        else:
+            sc = scorer.vtg(pairs, cpn) if ftype == "vtg" else scorer.tvg(pairs, cpn)
+            S[torch.from_numpy(r).to(device), torch.from_numpy(c).to(device)] = torch.from_numpy(sc).to(device)
         return S
 
     def merge(dicts_blocks):
@@ -677,29 +665,16 @@ def evaluation(model, data_loader, device, tokenizer, args):
         if finetuned:
             v2t["query_likelihood"] = run_pass(full(num_videos, num_texts), v2t_iv2[start:end], start, True, "tvg", False)
         v_block = (start, end)
-        known_vtg = known_tvg = None
-        if dedup:
-            if collective:
-                merge([(v2t, v_block)])                      # first all-gather: the complete v2t matrices, before the t2v passes read them
-            k = min(num_texts, args.topk)
-            mask = np.zeros((num_videos, num_texts), dtype=bool)
-            # shard emulation (timing only): the other ranks' rows count as known too, as they are after the real merge -- their
-            # values are -100 placeholders, which is why an emulated run reports no recall table
-            rows = slice(0, num_videos)
-            idx = v2t_iv2[rows].topk(k=k, dim=1).indices.cpu().numpy()
-            mask[np.repeat(np.arange(rows.start, rows.stop), k), idx.reshape(-1)] = True
-            known_vtg = (v2t["candidate_likelihood"], mask)
-            known_tvg = (v2t["query_likelihood"], mask) if finetuned else None
         start, end = dist_utils.row_block(num_texts, W, rank)                                        # :233-235
-        t2v["query_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "vtg", False, known=known_vtg)
+        t2v["query_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "vtg", False)
         if finetuned:
-            t2v["candidate_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", False, known=known_tvg)
+            t2v["candidate_likelihood"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", False)
             if args.cpn:
                 t2v["candidate_prior"] = run_pass(full(num_texts, num_videos), t2v_iv2[start:end], start, False, "tvg", True)
         t_block = (start, end)
 
         if collective:                                                                               # :252-262
-            merge([(t2v, t_block)] if dedup else [(v2t, v_block), (t2v, t_block)])
+            merge([(v2t, v_block), (t2v, t_block)])
     args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank)
     t2v_dict = {k: v.cpu().numpy() for k, v in t2v.items()}                                      # :264-276
     v2t_dict = {k: v.cpu().numpy() for k, v in v2t.items()}
