@@ -182,3 +182,34 @@ def test_cross_direction_dedup_gives_the_same_matrices_with_fewer_scored_pairs()
                 assert m.any() and np.array_equal(part_d[k][m], full_d[k][m]), k
     assert np.array_equal(sh[1]["candidate_likelihood"][s:e], a[1]["candidate_likelihood"][s:e])
     assert sh[3]["pairs_scored"] < a[3]["pairs_scored"]
+
+
+def test_pair_ownership_with_unequal_numbers_of_videos_and_texts():
+    """Nv != Nt (DiDeMo / ActivityNet style): pooled pair ownership and the reference's six row-sharded passes give the same matrices, also for
+    an emulated rank whose blocks are cut differently on the two axes."""
+    import types
+    from blim_amd import retrieval_utils as RU
+    nv, nt = 9, 13
+    rs = np.random.RandomState(11)
+    sims = rs.randn(nv, nt).astype(np.float32)
+
+    def run(**kw):
+        scorer = _FakeScorer()
+        args = types.SimpleNamespace(topk=4, batch_size_eval=4, num_clips=4, cpn=True, resume="ckpt", eval=True, dataset="MSRVTT",
+                                     iv2_scores={"v2t": torch.from_numpy(sims), "t2v": torch.from_numpy(sims.T.copy())}, _scorer=scorer, **kw)
+        model = types.SimpleNamespace(eval=lambda: None, module=types.SimpleNamespace(set_tvg_prefix_length=lambda k: None))
+        t2v, v2t = RU.evaluation(model, _Loader(max(nv, nt)), torch.device("cpu"), types.SimpleNamespace(pad_token_id=0), args)
+        return t2v, v2t, args._eval_stats
+
+    a, b = run(), run(dedup=False)
+    for x, y in ((a[0], b[0]), (a[1], b[1])):
+        for k in x:
+            assert x[k].shape == y[k].shape and np.array_equal(x[k], y[k]), k
+    assert a[1]["candidate_likelihood"].shape == (nv, nt) and a[0]["query_likelihood"].shape == (nt, nv)
+    assert a[2]["pairs_scored"] < b[2]["pairs_scored"]
+    sh = run(shard=(3, 2))
+    for full_d, part_d in ((a[0], sh[0]), (a[1], sh[1])):
+        for k in full_d:
+            if k != "internvideo2":
+                m = part_d[k] != -100.0
+                assert np.array_equal(part_d[k][m], full_d[k][m]), k
