@@ -549,7 +549,7 @@ static int tome_merge_tokens(blim_vision* v, const float* x, int b, int p, int c
     int which = 0, tmp = p;
     while (tmp != target) {                                               // merge_tokens' schedule (:108-115)
         const int r = (tmp - target <= tmp / 2) ? tmp - target : tmp / 2;
-        ARG_CHECK(tmp % 2 == 0 || r <= tmp / 2);
+        if (tmp % 2 != 0) { blim_set_error("ToMe: %d tokens in a round -- odd counts (an unpaired even token) are not implemented; 4 x (S/16)^2 -> 64 never produces one", tmp); return BLIM_ERR_ARG; }
         const int t1 = tmp / 2;
         const int64_t n_tok = (int64_t)b * tmp;
         hipLaunchKernelGGL(tome_metric_kernel, dim3((unsigned)((n_tok + 3) / 4)), dim3(256), 0, s, cur, n_tok, heads, (float*)v->metric.p);
