@@ -96,7 +96,7 @@ def main(args):
     sources, is_video = list_sources(args)
     print(f"Number of videos: {len(sources)}")
     sources = chunk_of(sources, args.num_chunk, args.chunk_idx)
-    print(f"num_chunk: {args.num_chunk}\\nchunk_size: {len(sources):,}\\nUsing Batch size: {args.batch_size}")
+    print(f"num_chunk: {args.num_chunk}\nchunk_size: {len(sources):,}\nUsing Batch size: {args.batch_size}")
     dims = VisionDims()
     if args.num_frames % dims.num_frames:
         raise ValueError(f"--num_frames must be a multiple of {dims.num_frames} (clips of mm_local_num_frames frames)")
