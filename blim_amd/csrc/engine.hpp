@@ -1,0 +1,96 @@
+// Engine state shared by engine.hip (scoring path) and train.hip (fine-tuning step).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/blim.h"
+#include "attention.hpp"
+#include "common.hpp"
+#include "gemm.hpp"
+#include "kernels.hpp"
+
+#define TRY(expr)                 \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != BLIM_OK) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------------------- timing classes
+enum TimeClass { TC_GEMM_QKV = 0, TC_ATTN, TC_GEMM_O, TC_GEMM_GATEUP, TC_GEMM_DOWN, TC_NORM, TC_LMHEAD_LSE, TC_GEMM_OTHER, TC_MISC, TC_QUANT, TC_COUNT };
+struct TimedSpan { hipEvent_t a, b; int cls; double flops; };
+
+// ---------------------------------------------------------------------------- engine
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct LayerW {
+    float* norm1 = nullptr; float* norm2 = nullptr;
+    bf16_t* wqkv = nullptr; float* bqkv = nullptr;
+    bf16_t* wo = nullptr; bf16_t* wgu = nullptr; bf16_t* wd = nullptr;
+    // fp8 mode: e4m3 copies of the four matrices (same stored row order) + one f32 scale per stored row
+    uint8_t* wqkv8 = nullptr; uint8_t* wo8 = nullptr; uint8_t* wgu8 = nullptr; uint8_t* wd8 = nullptr;
+    float* sqkv = nullptr; float* so = nullptr; float* sgu = nullptr; float* sd = nullptr;
+};
+
+struct blim_engine {
+    blim_config c;
+    int hd = 128;
+    int qkv_n = 0;
+    std::vector<LayerW> L;
+    bf16_t* embed = nullptr; bf16_t* lm_head = nullptr; bf16_t* visual_head = nullptr;
+    float* final_norm = nullptr;
+    bf16_t* mlp_w0[2] = {nullptr, nullptr}; float* mlp_b0[2] = {nullptr, nullptr};
+    bf16_t* mlp_w2[2] = {nullptr, nullptr}; float* mlp_b2[2] = {nullptr, nullptr};
+    float* rope_cos = nullptr; float* rope_sin = nullptr;
+    bool f8 = false;              // BLIM_COMPUTE_F8: c.compute_dtype is then F16 (the 16-bit side of the mode)
+    bool f8_ready = false;        // fp8 copies are current
+    int f8_mask = 31;             // which GEMMs run in fp8 (option "f8_mask"): 1 qkv, 2 o_proj, 4 gate|up, 8 down, 16 lm_head
+    uint8_t* lm_head8 = nullptr; float* s_lm = nullptr;
+    std::map<std::string, bool> loaded;
+    std::vector<void*> owned;
+    // workspaces
+    DevBuf resid, xn, qkv, attn, act, hsel, lse_part, lab_logit, logprob, stage, proj_tmp, vh, tvg_logits, dense_idx;
+    DevBuf rope_rows;                     // [T, 128] cos | sin of every token's position (per batch)
+    DevBuf x8, a8, act8, hsel8, rscale;   // fp8 mode: quantised GEMM inputs and their per-row scales
+    DevBuf attn_mx;                       // fp8 mode: E8M0 scale per (token, head), written by the attention kernel (attention.hpp: out_mx)
+    DevBuf act_mx;                        // fp8 mode: E8M0 scale per (token, 128 SwiGLU outputs), written by the gate|up epilogue (gemm.hpp: out_mx)
+    int f8_fuse = 1;                      // option "f8_fuse": quantise the SwiGLU output inside the gate|up epilogue (0: separate quant_rows pass)
+    // options / timing
+    int attn_tr = 1;
+    // compensated ("precise") mode, option "precise" (fp16 engines): every 16-bit activation that feeds a GEMM or the attention's
+    // P.V product travels as hi + lo (lo = f16(x - f32(hi))), the GEMMs walk K twice ([hi | lo] against the same weights).  About
+    // 21 significant bits of the activations reach the f32 accumulators; costs 2x the GEMM flops, so the host turns it on for the
+    // cheap TVG calls only (their scores are ~10x smaller in magnitude than the VTG ones: DESIGN.md section 4).
+    bool precise = false;
+    bool precise_mlp = true;       // option "precise_mlp": compensate the MLP branch too (87 % of the flops, ~20 % of the error variance)
+    bool precise_embeds = false;   // option "precise_embeds": in precise mode the INPUT embeddings (blim_assemble output, blim_decode / blim_score_* input) and
+                                   // the projector outputs feeding them are [hi | lo] rows of width 2H too (the fused TVG path; the literal
+                                   // forward() keeps the reference's [B, L, H] embeddings)
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+};
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct SpanGuard {
+    blim_engine* e; hipStream_t s; int idx = -1;
+    SpanGuard(blim_engine* e_, hipStream_t s_, int cls, double flops) : e(e_), s(s_) {
+        if (!e->timing) return;
+        TimedSpan t; t.cls = cls; t.flops = flops;
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+        hipEventRecord(t.a, s);
+        e->spans.push_back(t);
+        idx = (int)e->spans.size() - 1;
+    }
+    ~SpanGuard() { if (idx >= 0) hipEventRecord(e->spans[idx].b, s); }
+};
+
+
+int dev_alloc(blim_engine* e, void** p, size_t bytes);
+int ensure(DevBuf& b, size_t bytes);   // grow-only workspace
+GemmParams gp(int dt, const void* A, int64_t lda, const void* W, int64_t M, int N, int K, void* C, int64_t ldc);
+int engine_rope_rows(blim_engine* e, const blim_batch* b, hipStream_t s, float** out, int64_t* stride);
+int check_batch(const blim_batch* b);

@@ -1,0 +1,669 @@
+// Kernels of the fine-tuning step (train.hpp).  gfx950 only.  Everything here is HBM- or latency-bound helper work around the
+// big GEMMs (which run on gemm.hip's kernel, forward and backward), except the attention backward, whose five batched products
+// run on MFMA 32x32x16 tiles over materialised P / dS (sequences of a training batch are a few hundred tokens long).
+#include "train.hpp"
+
+#define DISPATCH_DT(dtype, CALL)            \
+    do {                                    \
+        if ((dtype) == DT_F16) { constexpr int DT = DT_F16; CALL; } \
+        else { constexpr int DT = DT_BF16; CALL; }                  \
+    } while (0)
+#define LAUNCH_CHECK()                                                                                  \
+    do {                                                                                                \
+        hipError_t _e = hipGetLastError();                                                              \
+        if (_e != hipSuccess) { blim_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); return BLIM_ERR_HIP; } \
+    } while (0)
+
+// ---------------------------------------------------------------------------- dropout (LoRA input, peft: lora_dropout)
+// keep(t, k) of adapter `site` in step `seed`: counter-based, so the backward regenerates the forward's mask.
+__device__ __forceinline__ float drop_mult(uint64_t seed, uint32_t site, uint64_t idx, float p) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+__device__ __forceinline__ int nat_row_of_stored(int r) {   // gemm.hpp qkv_perm_row, head offset kept
+    const int h = r >> 7, c = r & 127;
+    return (h << 7) + 16 * (c >> 5) + (c & 15) + 64 * ((c >> 4) & 1);
+}
+__device__ __forceinline__ int stored_row_of_nat(int n) {
+    const int h = n >> 7, d = n & 127;
+    return (h << 7) + 32 * ((d & 63) >> 4) + 16 * (d >> 6) + (d & 15);
+}
+
+// ---------------------------------------------------------------------------- layout
+__global__ void transpose16_kernel(uint16_t* dst, int64_t ldd, const uint16_t* src, int64_t lds, int64_t n_rows, int n_cols, int mode, int rope_rows) {
+    __shared__ uint16_t tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.y * 32;
+    const int c0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int64_t r = r0 + i; const int c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < n_rows && c < n_cols) ? src[r * lds + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i; const int64_t r = r0 + threadIdx.x;
+        if (c < n_cols && r < n_rows) {
+            const int64_t rn = (mode == 1 && r < rope_rows) ? nat_row_of_stored((int)r) : r;
+            dst[(int64_t)c * ldd + rn] = tile[threadIdx.x][i];
+        }
+    }
+}
+int launch_transpose16(uint16_t* dst, int64_t ldd, const uint16_t* src, int64_t lds, int64_t n_rows, int n_cols, int mode, int rope_rows, hipStream_t s) {
+    dim3 grid((n_cols + 31) / 32, (unsigned)((n_rows + 31) / 32));
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(32, 8), 0, s, dst, ldd, src, lds, n_rows, n_cols, mode, rope_rows);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+template <int DT>
+__global__ void lora_b_to_aug_kernel(uint16_t* w_aug, int64_t ld, int64_t row0, int col0, const float* B, int N, int r, int row_mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * r) return;
+    const int n = i / r, j = i - n * r;
+    const int64_t srow = row0 + (row_mode == 1 ? stored_row_of_nat(n) : n);
+    w_aug[srow * ld + col0 + j] = to16<DT>(B[i]);
+}
+int launch_lora_b_to_aug(uint16_t* w_aug, int64_t ld, int64_t row0, int col0, const float* B, int N, int r, int row_mode, int dtype, hipStream_t s) {
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_b_to_aug_kernel<DT>, dim3((N * r + 255) / 256), dim3(256), 0, s, w_aug, ld, row0, col0, B, N, r, row_mode));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+template <int DT>
+__global__ void lora_merge_kernel(uint16_t* dst, const uint16_t* base_aug, int64_t ld_aug, int64_t row0, const float* B, const float* A, int N, int K, int r, float scale, int row_mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int sr = (int)(i / K), k = (int)(i - (int64_t)sr * K);          // sr: stored row inside this projection's block
+    const int n = row_mode == 1 ? nat_row_of_stored(sr) : sr;
+    float acc = 0.f;
+    for (int j = 0; j < r; ++j) acc += B[n * r + j] * A[(int64_t)j * K + k];
+    dst[(row0 + sr) * K + k] = to16<DT>(from16<DT>(base_aug[(row0 + sr) * ld_aug + k]) + scale * acc);
+}
+int launch_lora_merge(uint16_t* dst, const uint16_t* base_aug, int64_t ld_aug, int64_t row0, const float* B, const float* A, int N, int K, int r, float scale,
+                      int row_mode, int dtype, hipStream_t s) {
+    const int64_t total = (int64_t)N * K;
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_merge_kernel<DT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dst, base_aug, ld_aug, row0, B, A, N, K, r, scale, row_mode));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- LoRA
+#define LORA_MAX_R 16
+__device__ __forceinline__ float block_sum_256(float v, float* red) {   // red: [4] floats of LDS per call site
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site) {
+    __shared__ float red[4];
+    const int64_t t = blockIdx.x;
+    const int seg = blockIdx.y;
+    const float* A = a.A[seg];
+    const uint16_t* x = x16 + t * ldx;
+    float acc[LORA_MAX_R];
+#pragma unroll
+    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
+    for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {
+        const uint4 raw = *(const uint4*)(x + k);
+        const uint16_t* h = (const uint16_t*)&raw;
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xv[e] = from16<DT>(h[e]);
+            if (drop_p > 0.f) xv[e] *= drop_mult(seed, site + seg, (uint64_t)t * K + k + e, drop_p);
+        }
+        for (int j = 0; j < r; ++j) {
+            const float4 a0 = *(const float4*)(A + (int64_t)j * K + k);
+            const float4 a1 = *(const float4*)(A + (int64_t)j * K + k + 4);
+            acc[j] += xv[0] * a0.x + xv[1] * a0.y + xv[2] * a0.z + xv[3] * a0.w + xv[4] * a1.x + xv[5] * a1.y + xv[6] * a1.z + xv[7] * a1.w;
+        }
+    }
+    for (int j = 0; j < r; ++j) {
+        const float v = block_sum_256(acc[j], red);
+        if (threadIdx.x == 0) x16[t * ldx + K + seg * r + j] = to16<DT>(scale * v);
+    }
+}
+int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
+    ARG_CHECK(r > 0 && r <= LORA_MAX_R && K % 8 == 0 && a.n >= 1 && a.n <= 3 && T > 0);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_down_kernel<DT>, dim3((unsigned)T, a.n), dim3(256), 0, s, x16, ldx, K, a, r, scale, drop_p, seed, site));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+#define LORA_TSPLIT 256
+template <int DT>
+__global__ __launch_bounds__(256) void lora_dB_kernel(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.y * LORA_TSPLIT, t1 = min(T, t0 + LORA_TSPLIT);
+    if (n >= N) return;
+    float acc[LORA_MAX_R];
+#pragma unroll
+    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
+    for (int64_t t = t0; t < t1; ++t) {
+        const float d = from16<DT>(dy16[t * ldy + n]);
+        for (int j = 0; j < r; ++j) acc[j] += d * from16<DT>(u16[t * ldu + j]);
+    }
+    for (int j = 0; j < r; ++j) atomicAdd(dB + (int64_t)n * r + j, acc[j]);
+}
+int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, hipStream_t s) {
+    ARG_CHECK(r <= LORA_MAX_R);
+    dim3 grid((N + 255) / 256, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_dB_kernel<DT>, grid, dim3(256), 0, s, dB, dy16, ldy, u16, ldu, T, N, r));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void lora_du_kernel(float* du, const uint16_t* dy16, int64_t ldy, const float* B, int N, int r, float scale) {
+    __shared__ float red[4];
+    const int64_t t = blockIdx.x;
+    float acc[LORA_MAX_R];
+#pragma unroll
+    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float d = from16<DT>(dy16[t * ldy + n]);
+        for (int j = 0; j < r; ++j) acc[j] += d * B[(int64_t)n * r + j];
+    }
+    for (int j = 0; j < r; ++j) {
+        const float v = block_sum_256(acc[j], red);
+        if (threadIdx.x == 0) du[t * r + j] = scale * v;
+    }
+}
+int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const float* B, int64_t T, int N, int r, float scale, int dtype, hipStream_t s) {
+    ARG_CHECK(r <= LORA_MAX_R && T > 0);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_du_kernel<DT>, dim3((unsigned)T), dim3(256), 0, s, du, dy16, ldy, B, N, r, scale));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void lora_dA_kernel(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.y * LORA_TSPLIT, t1 = min(T, t0 + LORA_TSPLIT);
+    if (k >= K) return;
+    float acc[LORA_MAX_R];
+#pragma unroll
+    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
+    for (int64_t t = t0; t < t1; ++t) {
+        float x = from16<DT>(x16[t * ldx + k]);
+        if (drop_p > 0.f) x *= drop_mult(seed, site, (uint64_t)t * K + k, drop_p);
+        for (int j = 0; j < r; ++j) acc[j] += du[t * r + j] * x;
+    }
+    for (int j = 0; j < r; ++j) atomicAdd(dA + (int64_t)j * K + k, acc[j]);
+}
+int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
+    ARG_CHECK(r <= LORA_MAX_R);
+    dim3 grid((K + 255) / 256, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_dA_kernel<DT>, grid, dim3(256), 0, s, dA, du, x16, ldx, T, K, r, drop_p, seed, site));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+__global__ void lora_dx_kernel(float* dx, int64_t ldd, const float* du, const float* A, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * K) return;
+    const int64_t t = i / K; const int k = (int)(i - t * K);
+    float acc = 0.f;
+    for (int j = 0; j < r; ++j) acc += du[t * r + j] * A[(int64_t)j * K + k];
+    if (drop_p > 0.f) acc *= drop_mult(seed, site, (uint64_t)i, drop_p);
+    dx[t * ldd + k] += acc;
+}
+int launch_lora_dx(float* dx, int64_t ldd, const float* du, const float* A, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s) {
+    const int64_t total = T * K;
+    hipLaunchKernelGGL(lora_dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, ldd, du, A, T, K, r, drop_p, seed, site);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- RMSNorm backward
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float* dy, const float* x, const int32_t* rows, int H, const float* w, float eps, int accumulate) {
+    __shared__ float red[4];
+    const int64_t i = blockIdx.x;
+    const int64_t row = rows ? rows[i] : i;
+    const float* xr = x + row * H;
+    const float* dyr = dy + i * H;
+    float ss = 0.f, dot = 0.f;
+    for (int k = threadIdx.x; k < H; k += 256) { const float xv = xr[k]; ss += xv * xv; dot += w[k] * dyr[k] * xv; }
+    ss = block_sum_256(ss, red);
+    dot = block_sum_256(dot, red);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    const float c = rs * rs * rs * dot / (float)H;
+    float* o = dx + row * H;
+    for (int k = threadIdx.x; k < H; k += 256) {
+        const float g = rs * w[k] * dyr[k] - xr[k] * c;
+        o[k] = accumulate ? o[k] + g : g;
+    }
+}
+int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, hipStream_t s) {
+    ARG_CHECK(n_rows > 0);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- SwiGLU
+template <int DT, bool BWD>
+__global__ void swiglu_kernel(uint16_t* act16, uint16_t* gu16, const uint16_t* dact16, int64_t T, int I) {
+    const int chunks = I / 8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * chunks) return;
+    const int64_t t = i / chunks;
+    const int i0 = (int)(i - t * chunks) * 8;
+    const int gcol = 32 * (i0 >> 4) + (i0 & 15);
+    uint16_t* gp = gu16 + t * 2 * I + gcol;
+    const uint4 graw = *(const uint4*)gp, uraw = *(const uint4*)(gp + 16);
+    const uint16_t* gh = (const uint16_t*)&graw; const uint16_t* uh = (const uint16_t*)&uraw;
+    uint4 o0, o1;
+    uint16_t* p0 = (uint16_t*)&o0; uint16_t* p1 = (uint16_t*)&o1;
+    if (!BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = from16<DT>(gh[e]), u = from16<DT>(uh[e]);
+            p0[e] = to16<DT>(g / (1.0f + __expf(-g)) * u);
+        }
+        *(uint4*)(act16 + t * I + i0) = o0;
+    } else {
+        const uint4 draw = *(const uint4*)(dact16 + t * I + i0);
+        const uint16_t* dh = (const uint16_t*)&draw;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = from16<DT>(gh[e]), u = from16<DT>(uh[e]), d = from16<DT>(dh[e]);
+            const float sg = 1.0f / (1.0f + __expf(-g));
+            p0[e] = to16<DT>(d * u * sg * (1.0f + g * (1.0f - sg)));
+            p1[e] = to16<DT>(d * g * sg);
+        }
+        *(uint4*)gp = o0;
+        *(uint4*)(gp + 16) = o1;
+    }
+}
+int launch_swiglu_fwd(uint16_t* act16, const uint16_t* gu16, int64_t T, int I, int dtype, hipStream_t s) {
+    ARG_CHECK(I % 16 == 0);
+    const int64_t total = T * (I / 8);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((swiglu_kernel<DT, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, act16, (uint16_t*)gu16, nullptr, T, I));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+int launch_swiglu_bwd(uint16_t* gu16, const uint16_t* dact16, int64_t T, int I, int dtype, hipStream_t s) {
+    ARG_CHECK(I % 16 == 0);
+    const int64_t total = T * (I / 8);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((swiglu_kernel<DT, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, nullptr, gu16, dact16, T, I));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- casts / GELU
+template <int DT>
+__global__ void f32_to_16_kernel(uint16_t* out, int64_t ldo, const float* in, int64_t ldi, int64_t rows, int cols, float scale) {
+    const int c4 = cols / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * c4) return;
+    const int64_t r = i / c4; const int c = (int)(i - r * c4) * 4;
+    const float4 v = *(const float4*)(in + r * ldi + c);
+    *(uint2*)(out + r * ldo + c) = make_uint2(pack2<DT>(v.x * scale, v.y * scale), pack2<DT>(v.z * scale, v.w * scale));
+}
+int launch_f32_to_16(uint16_t* out, int64_t ldo, const float* in, int64_t ldi, int64_t rows, int cols, float scale, int dtype, hipStream_t s) {
+    ARG_CHECK(cols % 4 == 0 && ldo % 4 == 0 && ldi % 4 == 0 && rows > 0);
+    const int64_t total = rows * (cols / 4);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(f32_to_16_kernel<DT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, ldo, in, ldi, rows, cols, scale));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+template <int DT, bool BWD>
+__global__ void gelu_kernel(uint16_t* out, int64_t ldo, const uint16_t* pre16, const float* dh, int64_t rows, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * H) return;
+    const int64_t r = i / H; const int k = (int)(i - r * H);
+    const float x = from16<DT>(pre16[i]);
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    if (!BWD) out[r * ldo + k] = to16<DT>(x * cdf);
+    else out[r * ldo + k] = to16<DT>(dh[i] * (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x)));
+}
+int launch_gelu_fwd(uint16_t* h16, int64_t ldo, const uint16_t* pre16, int64_t rows, int H, int dtype, hipStream_t s) {
+    const int64_t total = rows * H;
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((gelu_kernel<DT, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h16, ldo, pre16, nullptr, rows, H));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+int launch_gelu_bwd(uint16_t* dpre16, const float* dh, const uint16_t* pre16, int64_t rows, int H, int dtype, hipStream_t s) {
+    const int64_t total = rows * H;
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((gelu_kernel<DT, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpre16, (int64_t)H, pre16, dh, rows, H));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- cross-entropy forward + backward
+template <int DT>
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* logits, int64_t ldl, int V, const int32_t* labels, int label_div, float coef, uint16_t* dl16, float* dl32,
+                                                         int64_t ldd, float* loss) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const float* lg = logits + r * ldl;
+    const int lab = labels[r / label_div];
+    float m = -3.0e38f;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, lg[v]);
+    m = wave_max(m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) sum += __expf(lg[v] - m);
+    sum = block_sum_256(sum, red);
+    const float inv = 1.0f / sum;
+    if (threadIdx.x == 0 && lab >= 0 && lab < V) atomicAdd(loss, -(lg[lab] - m - __logf(sum)));
+    const float c = (lab >= 0 && lab < V) ? coef : 0.f;
+    for (int v = threadIdx.x; v < (int)ldd; v += 256) {
+        const float d = v < V ? c * (__expf(lg[v] - m) * inv - (v == lab ? 1.0f : 0.0f)) : 0.f;
+        if (dl16) dl16[r * ldd + v] = to16<DT>(d);
+        else dl32[r * ldd + v] = d;
+    }
+}
+int launch_ce_fwd_bwd(const float* logits, int64_t ldl, int V, const int32_t* labels, int label_div, int64_t n_rows, float coef, uint16_t* dl16, float* dl32, int64_t ldd,
+                      float* loss, int dtype, hipStream_t s) {
+    ARG_CHECK(n_rows > 0 && ldd >= V && label_div >= 1 && (dl16 || dl32));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<DT>, dim3((unsigned)n_rows), dim3(256), 0, s, logits, ldl, V, labels, label_div, coef, dl16, dl32, ldd, loss));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- TVG head
+template <int DT>
+__global__ void tvg_dvh_kernel(float* dvh, const float* dl, const uint16_t* vocab16, int C, int N, int M, float scale) {
+    const int bc = blockIdx.x;
+    const int m = blockIdx.y * 256 + threadIdx.x;
+    if (m >= M) return;
+    const uint16_t* voc = vocab16 + (int64_t)(bc % C) * N * M;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += dl[(int64_t)bc * N + n] * from16<DT>(voc[(int64_t)n * M + m]);
+    dvh[(int64_t)bc * M + m] = scale * acc;
+}
+int launch_tvg_dvh(float* dvh, const float* dl, const uint16_t* vocab16, int n_rows, int C, int N, int M, float scale, int dtype, hipStream_t s) {
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(tvg_dvh_kernel<DT>, dim3(n_rows, (M + 255) / 256), dim3(256), 0, s, dvh, dl, vocab16, C, N, M, scale));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+template <int DT>
+__global__ void outer_acc_kernel(float* dW, const float* dvh, const uint16_t* h16, int64_t ldh, int n_rows, int M, int H) {
+    const int m = blockIdx.x;
+    const int h = blockIdx.y * 256 + threadIdx.x;
+    if (h >= H) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_rows; ++b) acc += dvh[(int64_t)b * M + m] * from16<DT>(h16[(int64_t)b * ldh + h]);
+    dW[(int64_t)m * H + h] += acc;
+}
+int launch_outer_acc(float* dW, const float* dvh, const uint16_t* h16, int64_t ldh, int n_rows, int M, int H, int dtype, hipStream_t s) {
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(outer_acc_kernel<DT>, dim3(M, (H + 255) / 256), dim3(256), 0, s, dW, dvh, h16, ldh, n_rows, M, H));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+__global__ void rows_matmul_kernel(float* out, const float* dvh, const float* W, int M, int H) {
+    const int b = blockIdx.x;
+    const int h = blockIdx.y * 256 + threadIdx.x;
+    if (h >= H) return;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc += dvh[(int64_t)b * M + m] * W[(int64_t)m * H + h];
+    out[(int64_t)b * H + h] = acc;
+}
+int launch_rows_matmul(float* out, const float* dvh, const float* W, int n_rows, int M, int H, hipStream_t s) {
+    hipLaunchKernelGGL(rows_matmul_kernel, dim3(n_rows, (H + 255) / 256), dim3(256), 0, s, out, dvh, W, M, H);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+template <int DT>
+__global__ void feat_grad_kernel(uint16_t* dout16, const float* dres, const int32_t* src_index, int H, int group) {
+    const int64_t t = blockIdx.x;
+    const int src = src_index[t];
+    if (src >= 0) return;
+    const int64_t f = -(int64_t)src - 1;
+    const float inv = 1.0f / (float)group;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        const uint16_t v = to16<DT>(dres[t * H + k] * inv);
+        for (int g = 0; g < group; ++g) dout16[(f * group + g) * H + k] = v;
+    }
+}
+int launch_feat_grad(uint16_t* dout16, const float* dres, const int32_t* src_index, int64_t T, int H, int group, int dtype, hipStream_t s) {
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(feat_grad_kernel<DT>, dim3((unsigned)T), dim3(256), 0, s, dout16, dres, src_index, H, group));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- attention backward
+// P = softmax(scale * Q K^T + mask) is re-materialised per (sequence, head) as an [Lm, Lm] matrix (Lm = round_up(longest row, 64)),
+// then  dV = P^T dO,  dP = dO V^T,  dS = scale * P o (dP - rowsum(P o dP)),  dQ = dS K,  dK = dS^T Q  as five batched products on
+// 64x64 tiles (4 waves x one 32x32x16 MFMA accumulator each).  Training rows are a few hundred tokens: the matrices are a few
+// hundred MB per layer and the products ~0.4 % of the step's flops.
+int64_t attn_bwd_lm(int max_len) { return (max_len + 63) / 64 * 64; }
+
+enum { AB_S = 0, AB_DP = 1, AB_DQ = 2, AB_DV = 3, AB_DK = 4 };
+#define AB_LD 40    // LDS row stride (16-bit elements) of a [64][32] operand tile: 80 B keeps 16-B alignment and spreads banks
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void attn_bgemm_kernel(AttnBwdParams p, int Lm) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[64 * AB_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[64 * AB_LD];
+    const int nh = p.num_heads, nkv = p.num_kv_heads, grp = nh / nkv;
+    const int HB = (MODE == AB_DV || MODE == AB_DK) ? nkv : nh;
+    const int s = blockIdx.z / HB, hb = blockIdx.z % HB;
+    const int L = p.seq_len[s];
+    const int64_t t0 = p.seq_start[s];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    if (m0 >= L) return;
+    if ((MODE == AB_S || MODE == AB_DP) && (n0 >= L || n0 > m0 + 63)) return;      // tiles above the diagonal are never read
+    const int kvh = HB == nh ? hb / grp : hb;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int64_t mat = ((int64_t)s * nh) * (int64_t)Lm * Lm;      // + h * Lm * Lm
+    const int n_hh = (MODE == AB_DV || MODE == AB_DK) ? grp : 1;
+    for (int hh = 0; hh < n_hh; ++hh) {
+        const int h = (MODE == AB_DV || MODE == AB_DK) ? kvh * grp + hh : hb;
+        const uint16_t* PS = (MODE == AB_DV ? p.P16 : p.dS16) + mat + (int64_t)h * Lm * Lm;
+        int k_begin = 0, k_end = 128;
+        if (MODE == AB_DQ) { k_begin = 0; k_end = min((L + 31) / 32 * 32, m0 + 64); }
+        if (MODE == AB_DV || MODE == AB_DK) { k_begin = m0; k_end = (L + 31) / 32 * 32; }
+        for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+            __syncthreads();
+            // ---- A tile: As[m][k]
+            if (MODE == AB_S || MODE == AB_DP || MODE == AB_DQ) {     // k-contiguous source
+                const int row = tid >> 2, kc = (tid & 3) * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int i = m0 + row;
+                if (i < L) {
+                    if (MODE == AB_S) v = *(const uint4*)(p.qkv + (t0 + i) * p.ldq + hb * 128 + k0 + kc);
+                    else if (MODE == AB_DP) v = *(const uint4*)(p.dout + (t0 + i) * p.ldo + hb * 128 + k0 + kc);
+                    else v = *(const uint4*)(PS + (int64_t)i * Lm + k0 + kc);
+                }
+                *(uint4*)(As + row * AB_LD + kc) = v;
+            } else {                                                  // m-contiguous source: A(m = j, k = i) = P/dS[i][j]
+                const int k = tid >> 3, mc = (tid & 7) * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int i = k0 + k;
+                if (i < L) v = *(const uint4*)(PS + (int64_t)i * Lm + m0 + mc);
+                const uint16_t* e = (const uint16_t*)&v;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) As[(mc + q) * AB_LD + k] = e[q];
+            }
+            // ---- B tile: Bs[n][k]
+            if (MODE == AB_S || MODE == AB_DP) {                      // B(n = j, k = d): k-contiguous rows of K / V
+                const int row = tid >> 2, kc = (tid & 3) * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int j = n0 + row;
+                if (j < L) v = *(const uint4*)(p.qkv + (t0 + j) * p.ldq + (MODE == AB_S ? nh + kvh : nh + nkv + kvh) * 128 + k0 + kc);
+                *(uint4*)(Bs + row * AB_LD + kc) = v;
+            } else {                                                  // B(n = d, k = token): n-contiguous rows
+                const int k = tid >> 3, nc = (tid & 7) * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                const int tok = k0 + k;
+                if (tok < L) {
+                    if (MODE == AB_DQ) v = *(const uint4*)(p.qkv + (t0 + tok) * p.ldq + (nh + kvh) * 128 + n0 + nc);
+                    else if (MODE == AB_DV) v = *(const uint4*)(p.dout + (t0 + tok) * p.ldo + h * 128 + n0 + nc);
+                    else v = *(const uint4*)(p.qkv + (t0 + tok) * p.ldq + h * 128 + n0 + nc);
+                }
+                const uint16_t* e = (const uint16_t*)&v;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) Bs[(nc + q) * AB_LD + k] = e[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 a = *(const bf16x8*)(As + (32 * wm + (lane & 31)) * AB_LD + 16 * kk + 8 * (lane >> 5));
+                const bf16x8 b = *(const bf16x8*)(Bs + (32 * wn + (lane & 31)) * AB_LD + 16 * kk + 8 * (lane >> 5));
+                acc = mfma32<DT>(a, b, acc);
+            }
+        }
+    }
+    // ---- store: acc[4g + j] <-> m = 32 wm + 8 g + 4 (lane >> 5) + j, n = 32 wn + (lane & 31)
+    const int n = n0 + 32 * wn + (lane & 31);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 32 * wm + 8 * g + 4 * (lane >> 5) + j;
+            if (m >= L) continue;
+            const float v = acc[4 * g + j];
+            if (MODE == AB_S) p.S32[mat + (int64_t)hb * Lm * Lm + (int64_t)m * Lm + n] = v * p.scale;
+            else if (MODE == AB_DP) p.dP32[mat + (int64_t)hb * Lm * Lm + (int64_t)m * Lm + n] = v;
+            else if (MODE == AB_DQ) p.dqkv[(t0 + m) * p.ldq + hb * 128 + n] = v;
+            else if (MODE == AB_DK) p.dqkv[(t0 + m) * p.ldq + (nh + kvh) * 128 + n] = v;
+            else p.dqkv[(t0 + m) * p.ldq + (nh + nkv + kvh) * 128 + n] = v;
+        }
+}
+
+// one wave per (row i, head, sequence): P16[i][:] = softmax over visible keys j <= i (zeros elsewhere, all Lm columns)
+template <int DT>
+__global__ __launch_bounds__(64) void attn_softmax_rows_kernel(AttnBwdParams p, int Lm) {
+    const int i = blockIdx.x, h = blockIdx.y, s = blockIdx.z;
+    const int L = p.seq_len[s];
+    if (i >= L) return;
+    const int64_t t0 = p.seq_start[s];
+    const int64_t off = (((int64_t)s * p.num_heads + h) * Lm + i) * Lm;
+    const float* S = p.S32 + off;
+    uint16_t* P = p.P16 + off;
+    const int lane = threadIdx.x;
+    float m = -3.0e38f;
+    for (int j = lane; j <= i; j += 64) if (p.key_visible[t0 + j]) m = fmaxf(m, S[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j <= i; j += 64) if (p.key_visible[t0 + j]) sum += __expf(S[j] - m);
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    for (int j = lane; j < Lm; j += 64) {
+        const float v = (j <= i && p.key_visible[t0 + j]) ? __expf(S[j] - m) * inv : 0.f;
+        P[j] = to16<DT>(v);
+    }
+}
+// dS16[i][:] = scale * P o (dP - sum_j P dP)
+template <int DT>
+__global__ __launch_bounds__(64) void attn_ds_rows_kernel(AttnBwdParams p, int Lm) {
+    const int i = blockIdx.x, h = blockIdx.y, s = blockIdx.z;
+    const int L = p.seq_len[s];
+    if (i >= L) return;
+    const int64_t off = (((int64_t)s * p.num_heads + h) * Lm + i) * Lm;
+    const float* dP = p.dP32 + off;
+    const uint16_t* P = p.P16 + off;
+    uint16_t* dS = p.dS16 + off;
+    const int lane = threadIdx.x;
+    float D = 0.f;
+    for (int j = lane; j <= i; j += 64) D += from16<DT>(P[j]) * dP[j];
+    D = wave_sum(D);
+    for (int j = lane; j < Lm; j += 64) {
+        const float v = j <= i ? p.scale * from16<DT>(P[j]) * (dP[j] - D) : 0.f;
+        dS[j] = to16<DT>(v);
+    }
+}
+
+template <int DT>
+static int attention_bwd_t(const AttnBwdParams& p, hipStream_t s) {
+    const int Lm = (int)attn_bwd_lm(p.max_len);
+    const int nt = Lm / 64;
+    const dim3 blk(256);
+    hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_S>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
+    hipLaunchKernelGGL(attn_softmax_rows_kernel<DT>, dim3(p.max_len, p.num_heads, p.n_seqs), dim3(64), 0, s, p, Lm);
+    hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DP>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
+    hipLaunchKernelGGL(attn_ds_rows_kernel<DT>, dim3(p.max_len, p.num_heads, p.n_seqs), dim3(64), 0, s, p, Lm);
+    hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DQ>), dim3(2, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
+    hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DV>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
+    hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DK>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+int launch_attention_bwd(const AttnBwdParams& p, hipStream_t s) {
+    ARG_CHECK(p.n_seqs > 0 && p.max_len > 0 && p.num_heads % p.num_kv_heads == 0 && p.ldq % 8 == 0 && p.ldo % 8 == 0);
+    if (p.dtype == DT_F16) return attention_bwd_t<DT_F16>(p, s);
+    return attention_bwd_t<DT_BF16>(p, s);
+}
+
+// ---------------------------------------------------------------------------- RoPE backward
+template <int DT>
+__global__ void rope_bwd_kernel(uint16_t* out16, const float* dqkv, int64_t T, int qkv_n, int rope_cols, const int32_t* pos, const float* cosb, const float* sinb, int n_pos) {
+    const int half = qkv_n / 2;       // one thread per (token, head, d < 64) pair: qkv_n / 2 pairs per token
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * half) return;
+    const int64_t t = i / half;
+    const int q = (int)(i - t * half);
+    const int head = q >> 6, d = q & 63;
+    const int c1 = head * 128 + d, c2 = c1 + 64;
+    const float y1 = dqkv[t * qkv_n + c1], y2 = dqkv[t * qkv_n + c2];
+    float x1 = y1, x2 = y2;
+    if (c1 < rope_cols) {
+        const int pp = min(max(pos[t], 0), n_pos - 1);
+        const float c = cosb[(int64_t)pp * 64 + d], sn = sinb[(int64_t)pp * 64 + d];
+        x1 = y1 * c + y2 * sn;
+        x2 = y2 * c - y1 * sn;
+    }
+    out16[t * qkv_n + c1] = to16<DT>(x1);
+    out16[t * qkv_n + c2] = to16<DT>(x2);
+}
+int launch_rope_bwd(uint16_t* out16, const float* dqkv, int64_t T, int qkv_n, int rope_cols, const int32_t* pos, const float* cosb, const float* sinb, int n_pos, int dtype, hipStream_t s) {
+    const int64_t total = T * (qkv_n / 2);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(rope_bwd_kernel<DT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out16, dqkv, T, qkv_n, rope_cols, pos, cosb, sinb, n_pos));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// ---------------------------------------------------------------------------- optimizer
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_scale, float c1, float c2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gr = g[i] * inv_scale;
+    float pv = p[i] * (1.0f - lr * wd);
+    const float mv = b1 * m[i] + (1.0f - b1) * gr;
+    const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
+    m[i] = mv; v[i] = vv;
+    pv -= (lr / c1) * mv / (sqrtf(vv) / sqrtf(c2) + eps);
+    p[i] = pv;
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_scale, float c1, float c2, hipStream_t s) {
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, inv_scale, c1, c2);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+__global__ __launch_bounds__(256) void grad_stats_kernel(const float* g, int64_t n, float inv_scale, float* stats) {
+    __shared__ float red[4];
+    float ss = 0.f; int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i] * inv_scale;
+        if (!(fabsf(v) <= 3.0e38f)) bad = 1;
+        ss += v * v;
+    }
+    ss = block_sum_256(ss, red);
+    if (threadIdx.x == 0) atomicAdd(stats, ss);
+    if (bad) stats[1] = 1.0f;
+}
+int launch_grad_stats(const float* g, int64_t n, float inv_scale, float* stats, hipStream_t s) {
+    const int grid = (int)min((int64_t)1024, (n + 255) / 256);
+    hipLaunchKernelGGL(grad_stats_kernel, dim3(grid), dim3(256), 0, s, g, n, inv_scale, stats);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 4
+#define BLIM_ABI_VERSION 5
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -219,6 +219,60 @@ int blim_vision_encode(blim_vision* v, const void* frames, int32_t n_clips, floa
 /* ToMe alone: x f32 [b, p, c] (c = heads * 64) -> out f32 [b, target, c]; bipartite soft matching + size-weighted merge,
  * mm_projector_builder.py:6-130. */
 int blim_tome_merge(blim_vision* v, const float* x, int32_t b, int32_t p, int32_t c, int32_t heads, int32_t target, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fine-tuning step: what training_utils.py:57-95 does per batch -- two decoder forwards (VTG rows, TVG rows),
+ * loss = vtg_loss + tvg_loss, backward into the LoRA adapters of main.py:96-101 (projector mlp / tvg_mlp Linear 0 and 2, every
+ * q/k/v/o_proj, lm_head; y = W x + b + alpha/r * B A dropout(x)) and the fp32 visual_head (main.py:104-107), AdamW (main.py:147).
+ * Base weights stay frozen in the engine.  The trainable tensors live in ONE flat f32 device buffer owned by the caller (so that the
+ * host can all-reduce the matching gradient buffer over RCCL in one call, as DistributedDataParallel does for the reference,
+ * main.py:141-143); tensor order: blim_amd/lora.py:trainable_names, every tensor starting on a 64-element boundary. */
+typedef struct blim_trainer blim_trainer;
+typedef struct blim_train_config {
+    int32_t lora_r;       /* main.py --lora_r (8); <= 16 */
+    float lora_alpha;     /* --lora_alpha (32) */
+    float lora_dropout;   /* --lora_drop (0.05): dropout on the adapters' input, counter-based mask per (step seed, adapter, token, column) */
+} blim_train_config;
+/* number of f32 elements of the flat parameter / gradient / moment buffers */
+int64_t blim_train_flat_size(const blim_engine* e, int32_t lora_r);
+/* name = "<weight>:A" | "<weight>:B" | "visual_head" (weights: mlp.{0,2}.w, tvg_mlp.{0,2}.w, lm_head, layers.N.{q,k,v,o}_proj.w) */
+int blim_train_param_offset(const blim_engine* e, int32_t lora_r, const char* name, int64_t* offset, int64_t* rows, int64_t* cols);
+/* params / grads: device f32 [blim_train_flat_size].  Builds the training copies of the frozen weights (K-augmented copies that
+ * carry the adapters' B matrices as 64 extra K columns, and transposed copies for the input-gradient GEMMs). */
+int blim_train_create(blim_engine* e, const blim_train_config* cfg, float* params, float* grads, blim_trainer** out);
+void blim_train_destroy(blim_trainer* t);
+/* after `params` changed (load, optimizer step): refresh the 16-bit copies the forward reads */
+int blim_train_sync_params(blim_trainer* t, void* stream);
+/* write W + alpha/r * B A (and visual_head) into the ENGINE's scoring weights: evaluation between epochs (main.py:166) sees the
+ * fine-tuned model; always merged from the pristine base, so it can be called repeatedly */
+int blim_train_merge(blim_trainer* t, void* stream);
+typedef struct blim_train_batch {
+    const blim_batch* batch;      /* packed rows, no shared prefixes */
+    const int32_t* src_index;     /* [T] token id >= 0, or -(f + 1): row f of the projected video (VTG: clip-token rows; TVG: clip means) */
+    const void* feats;            /* 16-bit [n_feat_rows, mm_hidden]: raw features of the batch's videos, video-major */
+    int64_t n_feat_rows;
+    int32_t tok_per_clip;         /* TVG: rows averaged per clip (modeling_videochat_flash.py:243) */
+    int32_t max_seq_len;          /* longest row of the batch */
+    const int32_t* rows;          /* VTG: [n_rows] token rows whose next-token label is scored; TVG: [n_samples * num_clips] rows predicting clip c */
+    const int32_t* labels;        /* VTG: [n_rows] target token ids; TVG: [n_samples] index of the sample's video in the vocabulary */
+    int64_t n_rows;
+    const void* vocab;            /* TVG: 16-bit clip-major [num_clips][n_vocab][mm_hidden] */
+    int32_t n_vocab;
+    float grad_scale;             /* upstream gradient of this loss (AMP loss scale / accum_iter) */
+    uint64_t dropout_seed;
+} blim_train_batch;
+/* forward + backward of one loss; gradients ACCUMULATE into `grads` (scaled by grad_scale); loss_sum[0] += the summed negative
+ * log-likelihood over the n_rows scored rows (device f32; the mean loss of training_utils.py:68 / :79 is loss_sum / n_rows) */
+int blim_train_vtg(blim_trainer* t, const blim_train_batch* b, float* loss_sum, void* stream);
+int blim_train_tvg(blim_trainer* t, const blim_train_batch* b, float* loss_sum, void* stream);
+/* stats[0] += sum((g * inv_scale)^2) over the flat gradient buffer, stats[1] = 1 if any element is inf / nan (device f32 [2]) */
+int blim_train_grad_stats(blim_trainer* t, float inv_scale, float* stats, void* stream);
+/* torch.optim.AdamW over the flat buffers (g = grad * inv_scale; decoupled weight decay on every tensor: all are 2-D, timm's
+ * param_groups_weight_decay exempts only 1-D tensors); step counts from 1; calls blim_train_sync_params */
+int blim_train_adamw(blim_trainer* t, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay, float inv_scale,
+                     int32_t step, void* stream);
+/* bring-up aid: copies a saved activation of the last forward ("res<l>" f32 [T,H], "qkv<l>", "attn<l>", "gu<l>", "dres" f32 [T,H]) */
+int blim_train_debug_read(blim_trainer* t, const char* which, void* dst, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }
