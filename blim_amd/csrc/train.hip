@@ -22,7 +22,7 @@
 
 #define AUG 64   // extra K columns of an augmented weight / activation row
 
-struct Adapter { int64_t offA = 0, offB = 0; int n_in = 0, n_out = 0; };
+struct Adapter { int64_t offA = 0, offB = 0; int n_in = 0, n_out = 0; uint16_t* Bt16 = nullptr; int64_t ldb = 0; };   // Bt16: 16-bit B^T [16, ldb] (train.hpp: launch_lora_du)
 
 struct TrainLayerW { uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr; uint16_t* wqkvT = nullptr; uint16_t* woT = nullptr; uint16_t* wguT = nullptr; uint16_t* wdT = nullptr; };
 
@@ -67,6 +67,14 @@ struct blim_trainer {
     DevBuf feats_aug, pre16, h16, proj16, mean16, embeds, dout16, dh32, vh32, vhb16, dl32, dvh;
     int64_t last_T = 0;
 };
+
+static std::vector<Adapter*> all_adapters(blim_trainer* t) {
+    std::vector<Adapter*> v;
+    for (int w = 0; w < 2; ++w) for (int i = 0; i < 2; ++i) v.push_back(&t->lay.mlp[w][i]);
+    v.push_back(&t->lay.lm);
+    for (auto& l : t->lay.layer) for (auto& a : l) v.push_back(&a);
+    return v;
+}
 
 static int talloc(blim_trainer* t, void** p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes));
@@ -134,6 +142,11 @@ extern "C" int blim_train_create(blim_engine* e, const blim_train_config* cfg, f
     t->Vp = (int)round_up(V, 64);
     int rc = BLIM_OK;
 #define T_(expr) do { if (rc == BLIM_OK) rc = (expr); } while (0)
+    for (Adapter* a : all_adapters(t)) {
+        a->ldb = round_up(a->n_out, 64);
+        T_(talloc(t, (void**)&a->Bt16, (size_t)16 * a->ldb * 2));
+        if (rc == BLIM_OK && hipMemset(a->Bt16, 0, (size_t)16 * a->ldb * 2) != hipSuccess) rc = BLIM_ERR_HIP;
+    }
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& w = e->L[l]; TrainLayerW& x = t->L[l];
         T_(make_aug(t, &x.wqkv_aug, w.wqkv, e->qkv_n, H));
@@ -191,6 +204,7 @@ extern "C" int blim_train_sync_params(blim_trainer* t, void* stream) {
         TRY(launch_lora_b_to_aug(t->w0_aug[w], M + AUG, 0, M, P + t->lay.mlp[w][0].offB, H, r, 0, dt, s));
         TRY(launch_lora_b_to_aug(t->w2_aug[w], H + AUG, 0, H, P + t->lay.mlp[w][1].offB, H, r, 0, dt, s));
     }
+    for (Adapter* a : all_adapters(t)) TRY(launch_lora_bt(a->Bt16, a->ldb, P + a->offB, a->n_out, r, dt, s));
     return launch_f32_to_16(t->vh16, H, P + t->lay.off_vh, H, M, H, 1.0f, dt, s);
 }
 
@@ -226,8 +240,12 @@ static int lora_backward(blim_trainer* t, const Adapter& a, const uint16_t* dy16
                          uint64_t seed, uint32_t site, hipStream_t s) {
     const int dt = t->e->c.compute_dtype;
     TRY(launch_lora_dB(t->grads + a.offB, dy16, ldy, x16 + K + col, ldx, n, a.n_out, t->r, dt, s));
-    TRY(launch_lora_du(du, dy16, ldy, t->params + a.offB, n, a.n_out, t->r, t->s, dt, s));
+    TRY(launch_lora_du(du, dy16, ldy, a.Bt16, a.ldb, n, (int)round_up(a.n_out, 16), t->r, t->s, dt, s));     // dy columns beyond n_out (lm_head: up to Vp) are zero
     return launch_lora_dA(t->grads + a.offA, du, x16, ldx, n, K, t->r, t->p_drop, seed, site, dt, s);
+}
+static int lora_dx1(float* dx, int64_t ldd, const float* du, const float* A, int64_t n, int K, int r, float p, uint64_t seed, uint32_t site, hipStream_t s) {
+    LoraDxArgs a; a.n = 1; a.du[0] = du; a.A[0] = A; a.du[1] = a.du[2] = nullptr; a.A[1] = a.A[2] = nullptr;
+    return launch_lora_dx(dx, ldd, a, n, K, r, p, seed, site, s);
 }
 static int zero_aug_cols(uint16_t* x16, int64_t ldx, int K, int64_t n, hipStream_t s) {
     HIP_TRY(hipMemset2DAsync((char*)x16 + (size_t)K * 2, (size_t)ldx * 2, 0, AUG * 2, n, s));
@@ -362,7 +380,7 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         TRY(launch_f32_to_16(dy16, H, dres, H, T, H, 1.0f, dt, s));
         TRY(lora_backward(t, ad[3], dy16, H, attn, Ha, H, 0, T, du, b->dropout_seed, 8 * li + 3, s));
         { GemmParams p = gp(dt, dy16, H, x.woT, T, H, H, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }                    // d attn (base path)
-        TRY(launch_lora_dx(dtmp, H, du, t->params + ad[3].offA, T, H, r, t->p_drop, b->dropout_seed, 8 * li + 3, s));
+        TRY(lora_dx1(dtmp, H, du, t->params + ad[3].offA, T, H, r, t->p_drop, b->dropout_seed, 8 * li + 3, s));
         TRY(launch_f32_to_16(dattn16, H, dtmp, H, T, H, 1.0f, dt, s));
         {
             AttnBwdParams a;
@@ -376,8 +394,11 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         for (int j = 0; j < 3; ++j)
             TRY(lora_backward(t, ad[j], dqkv16 + qcols[j], qn, xn1, Ha, H, j * r, T, du + (int64_t)j * T * r, b->dropout_seed, 8 * li + j, s));
         { GemmParams p = gp(dt, dqkv16, qn, x.wqkvT, T, H, qn, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }              // d n1 (base path)
-        for (int j = 0; j < 3; ++j)
-            TRY(launch_lora_dx(dtmp, H, du + (int64_t)j * T * r, t->params + ad[j].offA, T, H, r, t->p_drop, b->dropout_seed, 8 * li + j, s));
+        {
+            LoraDxArgs a3; a3.n = 3;
+            for (int j = 0; j < 3; ++j) { a3.du[j] = du + (int64_t)j * T * r; a3.A[j] = t->params + ad[j].offA; }
+            TRY(launch_lora_dx(dtmp, H, a3, T, H, r, t->p_drop, b->dropout_seed, 8 * li, s));
+        }
         TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, s));                              // dres = d x_in
     }
     return BLIM_OK;
@@ -396,7 +417,7 @@ static int train_backward_projector(blim_trainer* t, const blim_train_batch* b, 
     const Adapter& a2 = t->lay.mlp[which][1]; const Adapter& a0 = t->lay.mlp[which][0];
     TRY(lora_backward(t, a2, dout, H, (const uint16_t*)t->h16.p, Ha, H, 0, F, du, b->dropout_seed, 1001 + 2 * which, s));
     { GemmParams p = gp(dt, dout, H, t->w2T[which], F, H, H, dh, H); TRY(launch_gemm(EPI_F32, p, s)); }
-    TRY(launch_lora_dx(dh, H, du, t->params + a2.offA, F, H, r, t->p_drop, b->dropout_seed, 1001 + 2 * which, s));
+    TRY(lora_dx1(dh, H, du, t->params + a2.offA, F, H, r, t->p_drop, b->dropout_seed, 1001 + 2 * which, s));
     TRY(launch_gelu_bwd(dout, dh, (const uint16_t*)t->pre16.p, F, H, dt, s));                                           // dout <- d pre-activation
     return lora_backward(t, a0, dout, H, (const uint16_t*)t->feats_aug.p, Ma, M, 0, F, du, b->dropout_seed, 1000 + 2 * which, s);
 }
@@ -430,7 +451,7 @@ extern "C" int blim_train_vtg(blim_trainer* t, const blim_train_batch* b, float*
     // ---- backward
     TRY(lora_backward(t, t->lay.lm, dlog, Vp, hsel, Ha, H, 0, R, du, b->dropout_seed, 2000, s));
     { GemmParams p = gp(dt, dlog, Vp, t->lmT, R, H, Vp, dhsel, H); TRY(launch_gemm(EPI_F32, p, s)); }
-    TRY(launch_lora_dx(dhsel, H, du, t->params + t->lay.lm.offA, R, H, r, t->p_drop, b->dropout_seed, 2000, s));
+    TRY(lora_dx1(dhsel, H, du, t->params + t->lay.lm.offA, R, H, r, t->p_drop, b->dropout_seed, 2000, s));
     HIP_TRY(hipMemsetAsync(t->dres.p, 0, (size_t)T * H * 4, s));
     TRY(launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, R, H, e->final_norm, c.rms_eps, 0, s));
     TRY(train_backward_layers(t, b, s));

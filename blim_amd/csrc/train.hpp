@@ -24,12 +24,19 @@ struct LoraDownArgs {
 int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s);
 // dB[n, j] += sum_t dy[t, n] * u~[t, j]        (dy16 [T, ldy] columns n0.., u16 = x16 + K + seg*r)
 int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, hipStream_t s);
-// du[t, j] = scale * sum_n dy[t, n] * B[n, j]
-int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const float* B, int64_t T, int N, int r, float scale, int dtype, hipStream_t s);
+// Bt16 [16, ldb] 16-bit <- transposed B [N, r] f32 (rows r.. and columns N.. must already be zero)
+int launch_lora_bt(uint16_t* Bt16, int64_t ldb, const float* B, int N, int r, int dtype, hipStream_t s);
+// du[t, j] = scale * sum_n dy[t, n] * B[n, j]   (N % 16 == 0: pad dy / Bt16 with zero columns)
+int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int N, int r, float scale, int dtype, hipStream_t s);
 // dA[j, k] += sum_t du[t, j] * drop(x)[t, k]
 int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s);
-// dx[t, k] += keep(t, k) / (1 - p) * sum_j du[t, j] * A[j, k]      (dx f32 [T, ldd])
-int launch_lora_dx(float* dx, int64_t ldd, const float* du, const float* A, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s);
+struct LoraDxArgs {
+    const float* du[3];  // du_seg [T, r]
+    const float* A[3];   // A_seg [r, K]
+    int n;
+};
+// dx[t, k] += sum_seg keep_seg(t, k) / (1 - p) * sum_j du_seg[t, j] * A_seg[j, k]      (dx f32 [T, ldd]; adapter seg uses dropout site `site + seg`)
+int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s);
 
 // out[rows ? rows[i] : i, :] (+)= d/dx of  y = w * x * rsqrt(mean(x^2) + eps)  applied to dy[i, :]   (x row = rows ? rows[i] : i)
 int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, hipStream_t s);

@@ -3,6 +3,8 @@
 // run on MFMA 32x32x16 tiles over materialised P / dS (sequences of a training batch are a few hundred tokens long).
 #include "train.hpp"
 
+#include <algorithm>
+
 #define DISPATCH_DT(dtype, CALL)            \
     do {                                    \
         if ((dtype) == DT_F16) { constexpr int DT = DT_F16; CALL; } \
@@ -138,87 +140,182 @@ int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDow
     return BLIM_OK;
 }
 
-#define LORA_TSPLIT 256
-template <int DT>
-__global__ __launch_bounds__(256) void lora_dB_kernel(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.y * LORA_TSPLIT, t1 = min(T, t0 + LORA_TSPLIT);
-    if (n >= N) return;
-    float acc[LORA_MAX_R];
+// out[c, j] += sum_t X[t, c] * U[t, j]  (the two rank-r weight gradients: dB with X = dy, U = u~;  dA with X = drop(x), U = du, stored
+// transposed).  One workgroup = 128 columns x 1024 rows: a lane owns two adjacent columns, the 4 waves split the rows in groups of 64;
+// lane l of a wave holds U row (group start + l) in registers and the row loop broadcasts it with v_readlane (one VMEM instruction per
+// row instead of 1 + r), partial sums meet in LDS and leave as 128 * r atomics.
+#define LORA_TSPLIT 1024
+template <int DT, bool U_F32, bool OUT_T, int R>
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(float* out, const uint16_t* X, int64_t ldx, const void* Uv, int64_t ldu, int64_t T, int C, int r,
+                                                         float drop_p, uint64_t seed, uint32_t site, int drop_k) {
+    __shared__ float red[4][2 * R][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 128 + 2 * lane;
+    const bool ok = c < C;                       // C is even: both columns are valid together
+    float acc0[R], acc1[R];
 #pragma unroll
-    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
-    for (int64_t t = t0; t < t1; ++t) {
-        const float d = from16<DT>(dy16[t * ldy + n]);
-        for (int j = 0; j < r; ++j) acc[j] += d * from16<DT>(u16[t * ldu + j]);
+    for (int j = 0; j < R; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+    const int64_t blk0 = (int64_t)blockIdx.y * LORA_TSPLIT;
+    for (int grp = w; grp < LORA_TSPLIT / 64; grp += 4) {
+        const int64_t tb = blk0 + 64 * grp;
+        if (tb >= T) break;
+        float ureg[R];
+        {
+            const int64_t tr = tb + lane;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                float u = 0.f;
+                if (tr < T && j < r) u = U_F32 ? ((const float*)Uv)[tr * ldu + j] : from16<DT>(((const uint16_t*)Uv)[tr * ldu + j]);
+                ureg[j] = u;
+            }
+        }
+        const int nrow = (int)min((int64_t)64, T - tb);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            if (q < nrow) {
+                const int64_t tt = tb + q;
+                float x0 = 0.f, x1 = 0.f;
+                if (ok) {
+                    const uint32_t raw = *(const uint32_t*)(X + tt * ldx + c);
+                    x0 = from16<DT>((uint16_t)(raw & 0xFFFF)); x1 = from16<DT>((uint16_t)(raw >> 16));
+                    if (drop_p > 0.f) { x0 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c, drop_p); x1 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c + 1, drop_p); }
+                }
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ureg[j]), q));
+                    acc0[j] += x0 * u; acc1[j] += x1 * u;
+                }
+            }
+        }
     }
-    for (int j = 0; j < r; ++j) atomicAdd(dB + (int64_t)n * r + j, acc[j]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) { red[w][2 * j][lane] = acc0[j]; red[w][2 * j + 1][lane] = acc1[j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < r * 128; i += 256) {
+        const int j = i >> 7, cl = i & 127;            // column cl of the block = lane cl / 2, element cl & 1
+        const int cc = blockIdx.x * 128 + cl;
+        if (cc >= C) continue;
+        const int row = 2 * j + (cl & 1), l = cl >> 1;
+        const float v = red[0][row][l] + red[1][row][l] + red[2][row][l] + red[3][row][l];
+        atomicAdd(out + (OUT_T ? (int64_t)j * C + cc : (int64_t)cc * r + j), v);
+    }
 }
 int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R);
-    dim3 grid((N + 255) / 256, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_dB_kernel<DT>, grid, dim3(256), 0, s, dB, dy16, ldy, u16, ldu, T, N, r));
+    ARG_CHECK(r <= LORA_MAX_R && N % 2 == 0 && ldy % 2 == 0);
+    dim3 grid((N + 127) / 128, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
+    if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, false, false, 8>), grid, dim3(256), 0, s, dB, dy16, ldy, (const void*)u16, ldu, T, N, r, 0.f, 0ull, 0u, 0));
+    else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, false, false, 16>), grid, dim3(256), 0, s, dB, dy16, ldy, (const void*)u16, ldu, T, N, r, 0.f, 0ull, 0u, 0));
     LAUNCH_CHECK();
     return BLIM_OK;
-}
-
-template <int DT>
-__global__ __launch_bounds__(256) void lora_du_kernel(float* du, const uint16_t* dy16, int64_t ldy, const float* B, int N, int r, float scale) {
-    __shared__ float red[4];
-    const int64_t t = blockIdx.x;
-    float acc[LORA_MAX_R];
-#pragma unroll
-    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
-    for (int n = threadIdx.x; n < N; n += 256) {
-        const float d = from16<DT>(dy16[t * ldy + n]);
-        for (int j = 0; j < r; ++j) acc[j] += d * B[(int64_t)n * r + j];
-    }
-    for (int j = 0; j < r; ++j) {
-        const float v = block_sum_256(acc[j], red);
-        if (threadIdx.x == 0) du[t * r + j] = scale * v;
-    }
-}
-int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const float* B, int64_t T, int N, int r, float scale, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R && T > 0);
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_du_kernel<DT>, dim3((unsigned)T), dim3(256), 0, s, du, dy16, ldy, B, N, r, scale));
-    LAUNCH_CHECK();
-    return BLIM_OK;
-}
-
-template <int DT>
-__global__ __launch_bounds__(256) void lora_dA_kernel(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.y * LORA_TSPLIT, t1 = min(T, t0 + LORA_TSPLIT);
-    if (k >= K) return;
-    float acc[LORA_MAX_R];
-#pragma unroll
-    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
-    for (int64_t t = t0; t < t1; ++t) {
-        float x = from16<DT>(x16[t * ldx + k]);
-        if (drop_p > 0.f) x *= drop_mult(seed, site, (uint64_t)t * K + k, drop_p);
-        for (int j = 0; j < r; ++j) acc[j] += du[t * r + j] * x;
-    }
-    for (int j = 0; j < r; ++j) atomicAdd(dA + (int64_t)j * K + k, acc[j]);
 }
 int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R);
-    dim3 grid((K + 255) / 256, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_dA_kernel<DT>, grid, dim3(256), 0, s, dA, du, x16, ldx, T, K, r, drop_p, seed, site));
+    ARG_CHECK(r <= LORA_MAX_R && K % 2 == 0 && ldx % 2 == 0);
+    dim3 grid((K + 127) / 128, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
+    if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, true, true, 8>), grid, dim3(256), 0, s, dA, x16, ldx, (const void*)du, (int64_t)r, T, K, r, drop_p, seed, site, K));
+    else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, true, true, 16>), grid, dim3(256), 0, s, dA, x16, ldx, (const void*)du, (int64_t)r, T, K, r, drop_p, seed, site, K));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
 
-__global__ void lora_dx_kernel(float* dx, int64_t ldd, const float* du, const float* A, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * K) return;
-    const int64_t t = i / K; const int k = (int)(i - t * K);
-    float acc = 0.f;
-    for (int j = 0; j < r; ++j) acc += du[t * r + j] * A[(int64_t)j * K + k];
-    if (drop_p > 0.f) acc *= drop_mult(seed, site, (uint64_t)i, drop_p);
-    dx[t * ldd + k] += acc;
+// Bt16[j, n] = 16-bit(B[n, j]) (j < r; rows r..15 and columns N.. stay zero): the B operand of the MFMA below
+template <int DT>
+__global__ void lora_bt_kernel(uint16_t* Bt16, int64_t ldb, const float* B, int N, int r) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * r) return;
+    const int n = i / r, j = i - n * r;
+    Bt16[(int64_t)j * ldb + n] = to16<DT>(B[i]);
 }
-int launch_lora_dx(float* dx, int64_t ldd, const float* du, const float* A, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s) {
-    const int64_t total = T * K;
-    hipLaunchKernelGGL(lora_dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, ldd, du, A, T, K, r, drop_p, seed, site);
+int launch_lora_bt(uint16_t* Bt16, int64_t ldb, const float* B, int N, int r, int dtype, hipStream_t s) {
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_bt_kernel<DT>, dim3((N * r + 255) / 256), dim3(256), 0, s, Bt16, ldb, B, N, r));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// du[t, j] += scale * sum_n dy[t, n] * B[n, j] on the matrix cores: one wave = 32 rows x one slice of N, a 32x32x16 MFMA per 16 columns
+// with B^T (16 rows: j < r real, the rest zero) as the second operand -- 3/4 of the tile is padding, but the kernel is bound by
+// reading dy once.  Slices meet by atomics (du is zeroed first).
+template <int DT>
+__global__ __launch_bounds__(256) void lora_du_kernel(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int steps_total, int steps_per_split,
+                                                      int r, float scale) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + w) * 32;
+    if (t0 >= T) return;
+    const int row = lane & 31, kg = lane >> 5;
+    const int s0 = blockIdx.y * steps_per_split, s1 = min(steps_total, s0 + steps_per_split);
+    const bool rv = t0 + row < T, bv = row < 16;
+    const uint16_t* ap = dy16 + (t0 + row) * ldy + 8 * kg;
+    const uint16_t* bp = Bt16 + (int64_t)row * ldb + 8 * kg;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    int st = s0;
+    for (; st + 4 <= s1; st += 4) {          // four loads of each operand in flight per MFMA group
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = rv ? *(const bf16x8*)(ap + 16 * (st + u)) : zero;
+            b[u] = bv ? *(const bf16x8*)(bp + 16 * (st + u)) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mfma32<DT>(a[u], b[u], acc);
+    }
+    for (; st < s1; ++st) {
+        const bf16x8 a = rv ? *(const bf16x8*)(ap + 16 * st) : zero;
+        const bf16x8 b = bv ? *(const bf16x8*)(bp + 16 * st) : zero;
+        acc = mfma32<DT>(a, b, acc);
+    }
+    if (row < r) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int64_t t = t0 + 8 * g + 4 * kg + jj;
+                if (t < T) atomicAdd(du + t * r + row, scale * acc[4 * g + jj]);
+            }
+    }
+}
+int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int N, int r, float scale, int dtype, hipStream_t s) {
+    ARG_CHECK(r <= LORA_MAX_R && T > 0 && ldy % 8 == 0 && ldb % 8 == 0 && N % 16 == 0);
+    HIP_TRY(hipMemsetAsync(du, 0, (size_t)T * r * 4, s));
+    const int row_blocks = (int)((T + 127) / 128), steps_total = N / 16;
+    int n_split = (1024 + row_blocks - 1) / row_blocks;
+    n_split = std::max(1, std::min(n_split, (steps_total + 15) / 16));
+    const int per = (steps_total + n_split - 1) / n_split;
+    dim3 grid(row_blocks, (steps_total + per - 1) / per);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_du_kernel<DT>, grid, dim3(256), 0, s, du, dy16, ldy, Bt16, ldb, T, steps_total, per, r, scale));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// dx[t, k] += sum over the adapters reading x of keep_seg(t, k) / (1 - p) * sum_j du_seg[t, j] * A_seg[j, k]   (one read-modify-write pass)
+__global__ void lora_dx_kernel(float* dx, int64_t ldd, LoraDxArgs a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site) {
+    const int k4 = K / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * k4) return;
+    const int64_t t = i / k4; const int k = (int)(i - t * k4) * 4;
+    float4 o = *(float4*)(dx + t * ldd + k);
+    for (int sg = 0; sg < a.n; ++sg) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < r; ++j) {
+            const float d = a.du[sg][t * r + j];
+            const float4 av = *(const float4*)(a.A[sg] + (int64_t)j * K + k);
+            acc.x += d * av.x; acc.y += d * av.y; acc.z += d * av.z; acc.w += d * av.w;
+        }
+        if (drop_p > 0.f) {
+            const uint64_t b = (uint64_t)t * K + k;
+            acc.x *= drop_mult(seed, site + sg, b, drop_p); acc.y *= drop_mult(seed, site + sg, b + 1, drop_p);
+            acc.z *= drop_mult(seed, site + sg, b + 2, drop_p); acc.w *= drop_mult(seed, site + sg, b + 3, drop_p);
+        }
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    }
+    *(float4*)(dx + t * ldd + k) = o;
+}
+int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s) {
+    ARG_CHECK(K % 4 == 0 && ldd % 4 == 0 && a.n >= 1 && a.n <= 3);
+    const int64_t total = T * (K / 4);
+    hipLaunchKernelGGL(lora_dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, ldd, a, T, K, r, drop_p, seed, site);
     LAUNCH_CHECK();
     return BLIM_OK;
 }
