@@ -6,7 +6,9 @@
 
 Reads ./data/<DS>/..., ./scores/<ds>[_zeroshot].pth exactly as the reference does.  `--synthetic N` replaces checkpoint,
 tokenizer, dataset and first-stage scores by seeded synthetic ones (no downloads): an end-to-end dry run of the same code path.
-Training (`main.py` without --eval) is out of scope.
+Without --eval it fine-tunes as the reference's main.py:155-195 does: per epoch train_one_epoch (blim_amd/training.py: LoRA adapters +
+visual_head on the engine's trainer), save `epoch<N>.pth`, merge the adapters into the scoring weights,
+val_one_epoch, keep `checkpoint_best.pth`, append to <output_dir>/log.txt.
 """
 from __future__ import annotations
 
@@ -38,13 +40,21 @@ def get_args_parser():
     p.add_argument("--c", default=[0.0, 0.0, 0.0, 0.0], type=float, nargs="+", help="ensemble weights")
     p.add_argument("--lora_r", default=8, type=int)
     p.add_argument("--lora_alpha", default=32, type=int)
-    # flags of the reference that only concern training / its launcher: accepted so that its command lines parse, not used
-    for flag, kw in (("--batch_size", dict(default=64, type=int)), ("--epochs", dict(default=5, type=int)), ("--accum_iter", dict(default=1, type=int)),
-                     ("--weight_decay", dict(default=0.05, type=float)), ("--lr", dict(default=None, type=float)), ("--min_lr", dict(default=0.0, type=float)),
-                     ("--warmup_epochs", dict(default=40, type=int)), ("--device", dict(default="cuda")), ("--seed", dict(default=0, type=int)),
-                     ("--start_epoch", dict(default=0, type=int)), ("--world_size", dict(default=1, type=int)), ("--local_rank", dict(default=-1, type=int)),
-                     ("--dist_on_itp", dict(action="store_true")), ("--dist_url", dict(default="env://")), ("--lora_drop", dict(default=0.05, type=float))):
-        p.add_argument(flag, help="accepted for compatibility with the reference's command lines; unused by the evaluation", **kw)
+    # training flags (main.py:33-43, 62-65), used without --eval
+    p.add_argument("--batch_size", default=64, type=int, help="batch size per GPU")
+    p.add_argument("--epochs", default=5, type=int)
+    p.add_argument("--accum_iter", default=1, type=int)
+    p.add_argument("--weight_decay", default=0.05, type=float)
+    p.add_argument("--lr", default=None, type=float, help="absolute learning rate")
+    p.add_argument("--min_lr", default=0.0, type=float)
+    p.add_argument("--warmup_epochs", default=40, type=int)
+    p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--start_epoch", default=0, type=int)
+    p.add_argument("--lora_drop", default=0.05, type=float)
+    # flags of the reference's launcher: accepted so that its command lines parse, not used
+    for flag, kw in (("--device", dict(default="cuda")), ("--world_size", dict(default=1, type=int)), ("--local_rank", dict(default=-1, type=int)),
+                     ("--dist_on_itp", dict(action="store_true")), ("--dist_url", dict(default="env://"))):
+        p.add_argument(flag, help="accepted for compatibility with the reference's command lines; unused", **kw)
     p.add_argument("--allow_partial_resume", action="store_true", help="load a resume file that lacks some of the expected adapters (warn instead of fail)")
     # engine-side options
     p.add_argument("--dtype", default=None, choices=["f16", "bf16", "f8"])
@@ -88,9 +98,12 @@ def main(args):
     rank, world, local = D.init_distributed_mode()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if not args.eval:
-        raise NotImplementedError("only --eval is supported: the training loop is outside the scoring path")
+    if not args.eval and args.lr is None:
+        raise SystemExit("--lr is required for training (main.py:41: absolute learning rate)")
+    if not args.eval and args.dtype == "f8":
+        raise SystemExit("training needs a 16-bit engine (--dtype f16 | bf16)")
     t0 = time.time()
+    train_loader = None
     if args.synthetic > 0:
         dims = synth.ModelDims(num_clips=args.num_clips) if args.synthetic_7b else synth.ModelDims(
             vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64, num_clips=args.num_clips)
@@ -104,19 +117,38 @@ def main(args):
         # scores are sums of integers and hit 0.0 about once per 10^5 entries, real InternVideo2 similarities do not
         nz = lambda a: np.where(a == 0, np.float32(1e-6), a)
         args.iv2_scores = {"v2t": T(nz(prob.v2t_sims)), "t2v": T(nz(prob.t2v_sims))}
+        if args.eval and args.resume:     # fine-tuned adapters of a (synthetic) training run: merged by the trainer's own merge kernel
+            from .training import Trainer
+            tr = Trainer(model.engine, lora_r=args.lora_r, lora_alpha=float(args.lora_alpha), lora_dropout=0.0)
+            tr.load_checkpoint_state(torch.load(args.resume, map_location="cpu", weights_only=False))
+            tr.merge_into_engine()
+            tr.close()
+        if not args.eval:     # synthetic training set: other videos / captions of the same generator, this rank's share
+            tprob = synth.make_problem(2 + rank, max(args.batch_size, args.synthetic), dims, tok_per_clip=64 if args.synthetic_7b else 8, fast_video=args.synthetic > 256)
+            train_loader = synth.ProblemLoader(tprob, args.batch_size)
     else:
         from .checkpoint import load_checkpoint, summarize_report
         from .dataloader import load_data
         tokenizer = load_tokenizer(args.model_path)
         dims = dims_from_config(args.model_path, args.num_clips)
         model = BlimModel(dims, dtype=args.dtype)
-        report = load_checkpoint(model.engine, dims, args.model_path, args.resume or None, lora_r=args.lora_r, lora_alpha=args.lora_alpha,
-                                 strict_resume=not args.allow_partial_resume)
+        # evaluation merges the resume file's adapters at load time; training keeps the base weights pristine (the trainer owns the adapters)
+        report = load_checkpoint(model.engine, dims, args.model_path, (args.resume or None) if args.eval else None, lora_r=args.lora_r,
+                                 lora_alpha=args.lora_alpha, strict_resume=not args.allow_partial_resume)
         if rank == 0:
             print("weights: " + summarize_report(report))
         loader = load_data(args, tokenizer=tokenizer, split="test")
+        if not args.eval:
+            train_loader = load_data(args, tokenizer=tokenizer, split="train")
     if rank == 0:
         print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")
+    if not args.eval:
+        results = train_loop(args, model, train_loader, loader, tokenizer, device, rank, world)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        model.engine.close()
+        return results
     torch.cuda.synchronize()
     t1 = time.time()
     torch.cuda.reset_peak_memory_stats()
@@ -144,6 +176,56 @@ def main(args):
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     model.engine.close()
+    return results
+
+
+def train_loop(args, model, train_loader, val_loader, tokenizer, device, rank: int, world: int):
+    """main.py:118-195: LoRA set-up, optional resume of adapters / optimizer / scaler, then per epoch train -> save -> evaluate."""
+    import datetime
+    import pandas as pd
+    import torch
+    from .modeling import DDPLike
+    from .training import Trainer, save_model, train_one_epoch
+    from .training_utils import val_one_epoch
+    trainer = Trainer(model.engine, lora_r=args.lora_r, lora_alpha=float(args.lora_alpha), lora_dropout=args.lora_drop, seed=args.seed,
+                      weight_decay=args.weight_decay)                                              # seed: same adapters on every rank (DDP broadcasts rank 0's)
+    if args.resume:                                                                                  # util/misc.py:303-316
+        ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
+        trainer.load_checkpoint_state(ckpt)
+        if "epoch" in ckpt:
+            args.start_epoch = int(ckpt["epoch"]) + 1
+    eff = args.batch_size * args.accum_iter * world                                                  # main.py:133-139
+    if rank == 0:
+        n_train = sum(int(__import__("numpy").prod(s)) for _, s in trainer.layout.values())
+        print(f"Trainable params: {n_train:,}")
+        print("base lr: %.2e" % (args.lr * 256 / eff)); print("actual lr: %.2e" % args.lr)
+        print("accumulate grad iterations: %d" % args.accum_iter); print("effective batch size: %d" % eff)
+        print(f"Start training for {args.epochs} epochs")
+    start, best_r1, results = time.time(), 0.0, None
+    for epoch in range(args.start_epoch, args.epochs):
+        sampler = getattr(train_loader, "sampler", None)
+        if world > 1 and hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)                                                                 # main.py:160-161
+        stats = train_one_epoch(trainer, train_loader, epoch, args, world_size=world, log=print if rank == 0 else (lambda *_: None))
+        if rank == 0:
+            save_model(args, epoch, trainer, name=f"epoch{epoch}")                                   # main.py:165
+        trainer.merge_into_engine()
+        model.clear_cache()                                                                          # projector outputs cached under the previous weights
+        results = val_one_epoch(DDPLike(model), val_loader, None, device, epoch, None, tokenizer=tokenizer, args=args)
+        if rank == 0:
+            cur = results["blim"]["t2v_r1"] + results["blim"]["v2t_r1"]                              # main.py:176-181
+            if best_r1 < cur:
+                best_r1 = cur
+                save_model(args, epoch, trainer, name="checkpoint_best")
+            table = pd.DataFrame(results).transpose().to_string()
+            log_stats = {"epoch": epoch, **{f"train_{k}": v for k, v in stats.items()}, **{f"val_{k}": v for k, v in results.items()}}
+            os.makedirs(args.output_dir, exist_ok=True)
+            with open(os.path.join(args.output_dir, "log.txt"), mode="a", encoding="utf-8") as f:
+                f.write(json.dumps(log_stats) + "\n" + table + "\n")
+            print("\n" + table)
+    if rank == 0:
+        print("Training time {}".format(str(datetime.timedelta(seconds=int(time.time() - start)))))
+    trainer.close()
     return results
 
 

@@ -127,3 +127,34 @@ def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["pairs_per_step_per_gpu"] == 8 * 8 and "cpu_baseline" not in d      # 8 queries x top-min(16, 8 texts)
+
+
+def test_training_driver_on_a_synthetic_tree(tmp_path, monkeypatch, capsys):
+    """main.py without --eval (main.py:155-195): two epochs of LoRA fine-tuning on the on-disk tree through the real train dataloader,
+    epoch checkpoints in the reference's format, and `--eval --resume <epoch file>` (adapters merged by blim_amd/checkpoint.py at load)
+    reproducing the in-training validation (adapters merged by the trainer's kernel)."""
+    ck = _tree(str(tmp_path))
+    fname, annos = __import__("dataset_fixture").annotations("MSRVTT")
+    train = [a for i, a in enumerate(annos) if i != 2] * 2                      # the video without a feature file is dropped by the train split anyway
+    json.dump(train, open(os.path.join(str(tmp_path), "data", "MSRVTT", "msrvtt_ret_train.json"), "w"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(driver, "load_tokenizer", lambda path: StubTokenizer())
+    out_dir = str(tmp_path / "ft")
+    common = ["--dataset", "MSRVTT", "--model_path", ck, "--topk", "4", "--batch_size_eval", "3", "--num_workers", "0", "--output_dir", out_dir,
+              "--cpn", "--alpha", "0.4", "0.8", "--c", "0.3", "0.6", "0.9", "0.7"]
+    last = _run(common + ["--lr", "2e-3", "--epochs", "2", "--warmup_epochs", "1", "--batch_size", "4", "--lora_drop", "0.05", "--seed", "1"])
+    out = capsys.readouterr().out
+    assert "Trainable params" in out and "Training time" in out
+    logs = [json.loads(l) for l in open(os.path.join(out_dir, "log.txt")) if l.startswith("{")]
+    assert [l["epoch"] for l in logs] == [0, 1]
+    assert logs[1]["train_loss"] < logs[0]["train_loss"], logs                   # it learns (12 samples, lr 2e-3)
+    for name in ("epoch0.pth", "epoch1.pth", "checkpoint_best.pth"):
+        assert os.path.exists(os.path.join(out_dir, name)), name
+    ckpt = torch.load(os.path.join(out_dir, "epoch1.pth"), map_location="cpu", weights_only=False)
+    keys = list(ckpt["model"])
+    assert "base_model.model.visual_head.weight" in keys
+    assert "base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight" in keys
+    assert "base_model.model.model.mm_projector.tvg_mlp.base_model.model.2.lora_B.default.weight" in keys
+    assert ckpt["epoch"] == 1 and "scaler" in ckpt and ckpt["optimizer"]["step"] == 6
+    again = _run(["--eval", "--resume", os.path.join(out_dir, "epoch1.pth")] + common)
+    assert again == last, (again, last)
