@@ -141,3 +141,39 @@ def test_merge_equals_adapter_forward():
     merged_loss = float(-(score * ntok).sum() / ntok.sum())
     assert abs(merged_loss - lv) <= 2e-3 * abs(lv), (merged_loss, lv)
     t.close(); eng.close()
+
+
+def test_lora_dropout_mask_is_consistent_forward_and_backward():
+    """lora_drop > 0 (main.py --lora_drop 0.05): the oracle applies the engine's counter-based mask (restated in oracle/train_oracle.py:
+    drop_mult) to the adapters' inputs; losses and gradients must agree, i.e. forward and backward use the same mask at every site."""
+    import torch
+    from blim_amd.engine import Engine
+    from blim_amd.training import Trainer
+    from oracle.blim_oracle import OracleConfig
+    from oracle.train_oracle import TrainOracle
+    spec, dims, weights, prob, tr = _case("train_tiny")
+    p, seed, sel = 0.25, 4242, [0, 2, 3]
+    eng = Engine(dims, max_positions=1024, dtype="f16")
+    eng.load_weights(weights)
+    t = Trainer(eng, lora_r=spec["r"], lora_alpha=spec["alpha"], lora_dropout=p, trainable=tr)
+    t.set_video_vocab(torch.from_numpy(prob.video_vocab))
+    lv, lt = t.forward_backward(collate(prob, sel), seed=seed)
+    grads = t.state("grads")
+    orc = TrainOracle(OracleConfig(**spec["dims"]), weights, tr, spec["r"], spec["alpha"], drop_p=p)
+    orc.seed = seed
+    ov, ot, og = orc.step_grads([prob.vtg_ids[i] for i in sel], [prob.vtg_labels[i] for i in sel], [prob.tvg_ids[i] for i in sel], [prob.tvg_labels[i] for i in sel],
+                                [prob.video[i] for i in sel], prob.video_vocab, prob.tvg_video_labels[sel])
+    print(f"[dropout] vtg {lv:.5f} (oracle {ov:.5f})  tvg {lt:.5f} (oracle {ot:.5f})")
+    assert abs(lv - ov) <= 1e-3 * abs(ov) and abs(lt - ot) <= 1e-3 * abs(ot)
+    worst = {}
+    for n in lora.trainable_names(dims):
+        gr = grads[n] / t.scaler.scale
+        worst[n] = float(np.abs(gr - og[n]).max() / max(np.abs(og[n]).max(), 1e-30))
+    print("[dropout] worst gradient deviations: " + ", ".join(f"{n} {v:.2e}" for n, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]))
+    assert max(worst.values()) <= GRAD_RTOL["f16"], worst
+    # and the mask matters: the same batch without dropout gives a different loss
+    t0 = Trainer(eng, lora_r=spec["r"], lora_alpha=spec["alpha"], lora_dropout=0.0, trainable=tr)
+    t0.set_video_vocab(torch.from_numpy(prob.video_vocab))
+    lv0, _ = t0.forward_backward(collate(prob, sel), seed=seed)
+    assert abs(lv0 - lv) > 1e-4
+    t0.close(); t.close(); eng.close()
