@@ -670,13 +670,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 const int col = col0 + 4 * lane;
                 const bool vec = (col + 3 < p.N) && ((p.ldc & 3) == 0);
                 if constexpr (EPI == EPI_RESID) {
+                    const float* rsrc = p.resid_in ? p.resid_in : (const float*)p.C;      // C = resid_in + acc (in place when resid_in is null)
                     if (vec) {   // common case: 16 independent 1-KiB row loads in flight, then add + store
                         const float4 rb = p.bias ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);   // resid += acc + bias (vision tower's Linear layers)
                         float4 o[16];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int row = min(row0 + 128 * h + wave + 8 * i, p.M - 1);
-                            o[i] = *(const float4*)((const float*)p.C + (int64_t)row * p.ldc + col);
+                            o[i] = *(const float4*)(rsrc + (int64_t)row * p.ldc + col);
                         }
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
@@ -694,7 +695,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             const float4 v = *(const float4*)(smem + rl * RS + lane * 16);
                             const float x[4] = {v.x, v.y, v.z, v.w};
                             float* out = (float*)p.C + (int64_t)row * p.ldc + col;
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] += x[j] + (p.bias ? p.bias[col + j] : 0.f);
+                            const float* in = rsrc + (int64_t)row * p.ldc + col;
+                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = in[j] + x[j] + (p.bias ? p.bias[col + j] : 0.f);
                         }
                     }
                 } else {

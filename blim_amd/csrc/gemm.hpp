@@ -8,7 +8,7 @@
 enum GemmEpi : int {
     EPI_BF16 = 0,    // C bf16 [M,ldc] = act(acc + bias)
     EPI_F32 = 1,     // C f32  [M,ldc] = acc * scale
-    EPI_RESID = 2,   // C f32  [M,ldc] += acc                       (residual stream)
+    EPI_RESID = 2,   // C f32  [M,ldc] = (resid_in ? resid_in : C) + acc (+ bias)   (residual stream)
     EPI_QKV = 3,     // C bf16 [M,ldc] = rope(acc + bias) for cols < rope_cols, acc + bias otherwise;
                      //   W rows of every q/k head are stored pair-interleaved (see qkv_perm_row)
     EPI_SWIGLU = 4,  // C bf16 [M, N/2] = silu(gate) * up;  W rows interleaved 16 gate / 16 up
@@ -26,6 +26,7 @@ struct GemmParams {
     void* C;
     int64_t ldc;
     const float* bias;  // [N] (in W's row order) or nullptr
+    const float* resid_in;  // EPI_RESID: C = resid_in + acc (+ bias); nullptr = in place (C += acc).  Same row stride as C.
     int act;            // EPI_BF16: 0 none, 1 exact-erf GELU
     float scale;        // EPI_F32
     // EPI_QKV

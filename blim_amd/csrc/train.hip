@@ -63,7 +63,7 @@ struct blim_trainer {
     std::vector<void*> owned;
     // saved activations of the last forward (per layer, strided by tokens) and workspaces
     DevBuf sv_res, sv_mid, sv_xn1, sv_qkv, sv_attn, sv_gu;
-    DevBuf xn2, act, dres, dy16, dtmp32, dqkv32, dqkv16, du, S32, dP32, P16, dS16, logits, dlog16, hsel, dhsel;
+    DevBuf xn2, act, dres, dy16, dtmp32, dqkv32, dqkv16, du, S32, dP32, P16, dS16, logits, dlog16, hsel, hsel_t, dhsel;
     DevBuf feats_aug, pre16, h16, proj16, mean16, embeds, dout16, dh32, vh32, vhb16, dl32, dvh;
     int64_t last_T = 0;
 };
@@ -178,7 +178,7 @@ extern "C" void blim_train_destroy(blim_trainer* t) {
     hipDeviceSynchronize();
     for (void* p : t->owned) hipFree(p);
     DevBuf* bufs[] = {&t->sv_res, &t->sv_mid, &t->sv_xn1, &t->sv_qkv, &t->sv_attn, &t->sv_gu, &t->xn2, &t->act, &t->dres, &t->dy16, &t->dtmp32, &t->dqkv32, &t->dqkv16,
-                      &t->du, &t->S32, &t->dP32, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->dhsel, &t->feats_aug, &t->pre16, &t->h16, &t->proj16, &t->mean16,
+                      &t->du, &t->S32, &t->dP32, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->hsel_t, &t->dhsel, &t->feats_aug, &t->pre16, &t->h16, &t->proj16, &t->mean16,
                       &t->embeds, &t->dout16, &t->dh32, &t->vh32, &t->vhb16, &t->dl32, &t->dvh};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     delete t;
@@ -247,8 +247,12 @@ static int lora_dx1(float* dx, int64_t ldd, const float* du, const float* A, int
     LoraDxArgs a; a.n = 1; a.du[0] = du; a.A[0] = A; a.du[1] = a.du[2] = nullptr; a.A[1] = a.A[2] = nullptr;
     return launch_lora_dx(dx, ldd, a, n, K, r, p, seed, site, s);
 }
-static int zero_aug_cols(uint16_t* x16, int64_t ldx, int K, int64_t n, hipStream_t s) {
-    HIP_TRY(hipMemset2DAsync((char*)x16 + (size_t)K * 2, (size_t)ldx * 2, 0, AUG * 2, n, s));
+// buffers of augmented rows [.., K + AUG]: the forward writes columns [0, K) and the adapters' u~ columns; the padding columns after
+// them must be zero and nothing ever writes them, so they are cleared when the buffer is (re)allocated, not per step
+static int ensure_z(DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return BLIM_OK;
+    TRY(ensure(b, bytes));
+    HIP_TRY(hipMemset(b.p, 0, b.bytes));
     return BLIM_OK;
 }
 
@@ -263,11 +267,10 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
     const int NL = c.num_layers;
     ARG_CHECK(F > 0 && T > 0 && (which == 0 || (b->tok_per_clip > 0 && F % b->tok_per_clip == 0)));
     // ---- projector
-    TRY(ensure(t->feats_aug, (size_t)F * Ma * 2)); TRY(ensure(t->pre16, (size_t)F * H * 2)); TRY(ensure(t->h16, (size_t)F * Ha * 2));
+    TRY(ensure_z(t->feats_aug, (size_t)F * Ma * 2)); TRY(ensure(t->pre16, (size_t)F * H * 2)); TRY(ensure_z(t->h16, (size_t)F * Ha * 2));
     TRY(ensure(t->proj16, (size_t)F * H * 2)); TRY(ensure(t->embeds, (size_t)T * H * 2));
     uint16_t* fa = (uint16_t*)t->feats_aug.p; uint16_t* pre = (uint16_t*)t->pre16.p; uint16_t* h16 = (uint16_t*)t->h16.p; uint16_t* proj = (uint16_t*)t->proj16.p;
     HIP_TRY(hipMemcpy2DAsync(fa, (size_t)Ma * 2, b->feats, (size_t)M * 2, (size_t)M * 2, F, hipMemcpyDeviceToDevice, s));
-    TRY(zero_aug_cols(fa, Ma, M, F, s));
     LoraDownArgs la; la.n = 1; la.A[1] = la.A[2] = nullptr;
     la.A[0] = t->params + t->lay.mlp[which][0].offA;
     TRY(launch_lora_down(fa, Ma, F, M, la, r, t->s, t->p_drop, b->dropout_seed, 1000 + 2 * which, dt, s));
@@ -277,7 +280,6 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
         TRY(launch_gemm(EPI_BF16, p, s));
     }
     TRY(launch_gelu_fwd(h16, Ha, pre, F, H, dt, s));
-    TRY(zero_aug_cols(h16, Ha, H, F, s));
     la.A[0] = t->params + t->lay.mlp[which][1].offA;
     TRY(launch_lora_down(h16, Ha, F, H, la, r, t->s, t->p_drop, b->dropout_seed, 1001 + 2 * which, dt, s));
     {
@@ -294,7 +296,7 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
     TRY(launch_assemble((bf16_t*)t->embeds.p, b->src_index, T, H, e->embed, (const bf16_t*)vid_rows, s));
     // ---- decoder
     TRY(ensure(t->sv_res, (size_t)(NL + 1) * T * H * 4)); TRY(ensure(t->sv_mid, (size_t)NL * T * H * 4));
-    TRY(ensure(t->sv_xn1, (size_t)NL * T * Ha * 2)); TRY(ensure(t->sv_qkv, (size_t)NL * T * qn * 2)); TRY(ensure(t->sv_attn, (size_t)NL * T * Ha * 2));
+    TRY(ensure_z(t->sv_xn1, (size_t)NL * T * Ha * 2)); TRY(ensure(t->sv_qkv, (size_t)NL * T * qn * 2)); TRY(ensure_z(t->sv_attn, (size_t)NL * T * Ha * 2));
     TRY(ensure(t->sv_gu, (size_t)NL * T * 2 * I * 2));
     TRY(ensure(t->xn2, (size_t)T * H * 2)); TRY(ensure(t->act, (size_t)T * I * 2));
     float* res = (float*)t->sv_res.p; float* mid = (float*)t->sv_mid.p;
@@ -308,7 +310,6 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
         uint16_t* xn1 = (uint16_t*)t->sv_xn1.p + (int64_t)li * T * Ha; uint16_t* qkv = (uint16_t*)t->sv_qkv.p + (int64_t)li * T * qn;
         uint16_t* attn = (uint16_t*)t->sv_attn.p + (int64_t)li * T * Ha; uint16_t* gu = (uint16_t*)t->sv_gu.p + (int64_t)li * T * 2 * I;
         TRY(launch_rmsnorm(x_in, H, nullptr, T, H, l.norm1, c.rms_eps, (bf16_t*)xn1, dt, nullptr, s, 0, Ha, nullptr));
-        TRY(zero_aug_cols(xn1, Ha, H, T, s));
         LoraDownArgs q3; q3.n = 3; for (int j = 0; j < 3; ++j) q3.A[j] = t->params + ad[j].offA;
         TRY(launch_lora_down(xn1, Ha, T, H, q3, r, t->s, t->p_drop, b->dropout_seed, 8 * li, dt, s));
         {
@@ -324,12 +325,11 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
             a.blk_seq = b->batch->blk_seq; a.blk_q0 = b->batch->blk_q0; a.n_blocks = b->batch->n_blocks; a.out = (bf16_t*)attn; a.ldo = Ha; a.scale = 0.08838834764831845f;
             TRY(launch_attention(a, e->attn_tr, s));
         }
-        TRY(zero_aug_cols(attn, Ha, H, T, s));
         LoraDownArgs o1; o1.n = 1; o1.A[0] = t->params + ad[3].offA; o1.A[1] = o1.A[2] = nullptr;
         TRY(launch_lora_down(attn, Ha, T, H, o1, r, t->s, t->p_drop, b->dropout_seed, 8 * li + 3, dt, s));
-        HIP_TRY(hipMemcpyAsync(x_mid, x_in, (size_t)T * H * 4, hipMemcpyDeviceToDevice, s));
         {
             GemmParams p = gp(dt, attn, Ha, x.wo_aug, T, H, Ha, x_mid, H);
+            p.resid_in = x_in;                                             // x_mid = x_in + o_proj(attn): the layer input stays intact for the backward
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         TRY(launch_rmsnorm(x_mid, H, nullptr, T, H, l.norm2, c.rms_eps, (bf16_t*)t->xn2.p, dt, nullptr, s, 0, 0, nullptr));
@@ -338,9 +338,9 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
             TRY(launch_gemm(EPI_BF16, p, s));
         }
         TRY(launch_swiglu_fwd((uint16_t*)t->act.p, gu, T, I, dt, s));
-        HIP_TRY(hipMemcpyAsync(x_out, x_mid, (size_t)T * H * 4, hipMemcpyDeviceToDevice, s));
         {
             GemmParams p = gp(dt, t->act.p, I, l.wd, T, H, I, x_out, H);
+            p.resid_in = x_mid;
             TRY(launch_gemm(EPI_RESID, p, s));
         }
     }
@@ -370,14 +370,13 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         float* x_in = res + (int64_t)li * T * H; float* x_mid = mid + (int64_t)li * T * H;
         uint16_t* xn1 = (uint16_t*)t->sv_xn1.p + (int64_t)li * T * Ha; uint16_t* qkv = (uint16_t*)t->sv_qkv.p + (int64_t)li * T * qn;
         uint16_t* attn = (uint16_t*)t->sv_attn.p + (int64_t)li * T * Ha; uint16_t* gu = (uint16_t*)t->sv_gu.p + (int64_t)li * T * 2 * I;
-        // ---- MLP block: x_out = x_mid + down(silu(gate(n2)) * up(n2)), n2 = rmsnorm(x_mid)
-        TRY(launch_f32_to_16(dy16, H, dres, H, T, H, 1.0f, dt, s));
+        // ---- MLP block: x_out = x_mid + down(silu(gate(n2)) * up(n2)), n2 = rmsnorm(x_mid); dy16 = 16-bit(dres) comes from the previous RMSNorm backward
+        if (li == c.num_layers - 1) TRY(launch_f32_to_16(dy16, H, dres, H, T, H, 1.0f, dt, s));
         { GemmParams p = gp(dt, dy16, H, x.wdT, T, I, H, t->act.p, I); TRY(launch_gemm(EPI_BF16, p, s)); }            // d act = dy . Wd
         TRY(launch_swiglu_bwd(gu, (const uint16_t*)t->act.p, T, I, dt, s));                                              // gu <- [d gate | d up]
         { GemmParams p = gp(dt, gu, 2 * (int64_t)I, x.wguT, T, H, 2 * I, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }    // d n2
-        TRY(launch_rmsnorm_bwd(dres, dtmp, x_mid, nullptr, T, H, l.norm2, c.rms_eps, 1, s));                             // dres = d x_mid
+        TRY(launch_rmsnorm_bwd(dres, dtmp, x_mid, nullptr, T, H, l.norm2, c.rms_eps, 1, dy16, dt, s));                   // dres = d x_mid (+ its 16-bit copy)
         // ---- attention block: x_mid = x_in + o_proj(attn), attn = Attention(rope(qkv(n1))), n1 = rmsnorm(x_in)
-        TRY(launch_f32_to_16(dy16, H, dres, H, T, H, 1.0f, dt, s));
         TRY(lora_backward(t, ad[3], dy16, H, attn, Ha, H, 0, T, du, b->dropout_seed, 8 * li + 3, s));
         { GemmParams p = gp(dt, dy16, H, x.woT, T, H, H, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }                    // d attn (base path)
         TRY(lora_dx1(dtmp, H, du, t->params + ad[3].offA, T, H, r, t->p_drop, b->dropout_seed, 8 * li + 3, s));
@@ -399,7 +398,7 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
             for (int j = 0; j < 3; ++j) { a3.du[j] = du + (int64_t)j * T * r; a3.A[j] = t->params + ad[j].offA; }
             TRY(launch_lora_dx(dtmp, H, a3, T, H, r, t->p_drop, b->dropout_seed, 8 * li, s));
         }
-        TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, s));                              // dres = d x_in
+        TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, li > 0 ? dy16 : nullptr, dt, s));   // dres = d x_in
     }
     return BLIM_OK;
 }
@@ -439,11 +438,10 @@ extern "C" int blim_train_vtg(blim_trainer* t, const blim_train_batch* b, float*
     const int64_t T = t->last_T, R = b->n_rows;
     const float* x_final = (const float*)t->sv_res.p + (int64_t)c.num_layers * T * H;
     // ---- head: final norm at the scored rows, lm_head (+ adapter), cross-entropy (training_utils.py:23-32: mean over the label tokens)
-    TRY(ensure(t->hsel, (size_t)R * Ha * 2)); TRY(ensure(t->logits, (size_t)R * Vp * 4)); TRY(ensure(t->dlog16, (size_t)R * Vp * 2)); TRY(ensure(t->dhsel, (size_t)R * H * 4));
+    TRY(ensure_z(t->hsel, (size_t)R * Ha * 2)); TRY(ensure(t->logits, (size_t)R * Vp * 4)); TRY(ensure(t->dlog16, (size_t)R * Vp * 2)); TRY(ensure(t->dhsel, (size_t)R * H * 4));
     TRY(ensure(t->dres, (size_t)T * H * 4)); TRY(ensure(t->du, (size_t)std::max<int64_t>(R, T) * 3 * 16 * 4));
     uint16_t* hsel = (uint16_t*)t->hsel.p; float* logits = (float*)t->logits.p; uint16_t* dlog = (uint16_t*)t->dlog16.p; float* dhsel = (float*)t->dhsel.p; float* du = (float*)t->du.p;
     TRY(launch_rmsnorm(x_final, H, b->rows, R, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, Ha, nullptr));
-    TRY(zero_aug_cols(hsel, Ha, H, R, s));
     LoraDownArgs la; la.n = 1; la.A[0] = t->params + t->lay.lm.offA; la.A[1] = la.A[2] = nullptr;
     TRY(launch_lora_down(hsel, Ha, R, H, la, r, t->s, t->p_drop, b->dropout_seed, 2000, dt, s));
     { GemmParams p = gp(dt, hsel, Ha, t->lm_aug, R, V, Ha, logits, Vp); TRY(launch_gemm(EPI_F32, p, s)); }
@@ -453,7 +451,7 @@ extern "C" int blim_train_vtg(blim_trainer* t, const blim_train_batch* b, float*
     { GemmParams p = gp(dt, dlog, Vp, t->lmT, R, H, Vp, dhsel, H); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(lora_dx1(dhsel, H, du, t->params + t->lay.lm.offA, R, H, r, t->p_drop, b->dropout_seed, 2000, s));
     HIP_TRY(hipMemsetAsync(t->dres.p, 0, (size_t)T * H * 4, s));
-    TRY(launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, R, H, e->final_norm, c.rms_eps, 0, s));
+    TRY(launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, R, H, e->final_norm, c.rms_eps, 0, nullptr, dt, s));
     TRY(train_backward_layers(t, b, s));
     return train_backward_projector(t, b, 0, s);
 }
@@ -472,9 +470,9 @@ extern "C" int blim_train_tvg(blim_trainer* t, const blim_train_batch* b, float*
     const int64_t T = t->last_T;
     const float* x_final = (const float*)t->sv_res.p + (int64_t)c.num_layers * T * H;
     // ---- head (training_utils.py:71-79): hidden at the 4 positions before <|im_end|> -> visual_head -> . video_vocab / sqrt(M) -> CE over the N videos
-    TRY(ensure(t->hsel, (size_t)BC * (H + AUG) * 2)); TRY(ensure(t->vh32, (size_t)BC * M * 4)); TRY(ensure(t->vhb16, (size_t)BC * M * 2)); TRY(ensure(t->logits, (size_t)BC * N * 4));
+    TRY(ensure(t->hsel_t, (size_t)BC * H * 2)); TRY(ensure(t->vh32, (size_t)BC * M * 4)); TRY(ensure(t->vhb16, (size_t)BC * M * 2)); TRY(ensure(t->logits, (size_t)BC * N * 4));
     TRY(ensure(t->dl32, (size_t)BC * N * 4)); TRY(ensure(t->dvh, (size_t)BC * M * 4)); TRY(ensure(t->dhsel, (size_t)BC * H * 4)); TRY(ensure(t->dres, (size_t)T * H * 4));
-    uint16_t* hsel = (uint16_t*)t->hsel.p; float* vh32 = (float*)t->vh32.p; uint16_t* vhb = (uint16_t*)t->vhb16.p; float* logits = (float*)t->logits.p;
+    uint16_t* hsel = (uint16_t*)t->hsel_t.p; float* vh32 = (float*)t->vh32.p; uint16_t* vhb = (uint16_t*)t->vhb16.p; float* logits = (float*)t->logits.p;
     float* dl = (float*)t->dl32.p; float* dvh = (float*)t->dvh.p; float* dhsel = (float*)t->dhsel.p;
     TRY(launch_rmsnorm(x_final, H, b->rows, BC, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, 0, nullptr));
     { GemmParams p = gp(dt, hsel, H, t->vh16, BC, M, H, vh32, M); TRY(launch_gemm(EPI_F32, p, s)); }
@@ -486,7 +484,7 @@ extern "C" int blim_train_tvg(blim_trainer* t, const blim_train_batch* b, float*
     TRY(launch_outer_acc(t->grads + t->lay.off_vh, dvh, hsel, H, BC, M, H, dt, s));
     TRY(launch_rows_matmul(dhsel, dvh, t->params + t->lay.off_vh, BC, M, H, s));
     HIP_TRY(hipMemsetAsync(t->dres.p, 0, (size_t)T * H * 4, s));
-    TRY(launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, BC, H, e->final_norm, c.rms_eps, 0, s));
+    TRY(launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, BC, H, e->final_norm, c.rms_eps, 0, nullptr, dt, s));
     TRY(train_backward_layers(t, b, s));
     return train_backward_projector(t, b, 1, s);
 }

@@ -39,7 +39,9 @@ struct LoraDxArgs {
 int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s);
 
 // out[rows ? rows[i] : i, :] (+)= d/dx of  y = w * x * rsqrt(mean(x^2) + eps)  applied to dy[i, :]   (x row = rows ? rows[i] : i)
-int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, hipStream_t s);
+// out16 (optional, rows == nullptr only): 16-bit copy of the updated dx rows (the next GEMM's A operand)
+int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, uint16_t* out16, int dtype,
+                       hipStream_t s);
 
 // gu16 [T, 2I] with 16 gate / 16 up columns interleaved (the fused gate|up matrix's stored row order) -> act16 [T, I] = silu(gate) * up
 int launch_swiglu_fwd(uint16_t* act16, const uint16_t* gu16, int64_t T, int I, int dtype, hipStream_t s);

@@ -103,17 +103,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {   // red: 
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// one wave per token (4 tokens per workgroup): lanes stride over K in 16-byte chunks, r wave reductions, no LDS
 template <int DT>
-__global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site) {
-    __shared__ float red[4];
-    const int64_t t = blockIdx.x;
+__global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int64_t T, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site) {
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y;
     const float* A = a.A[seg];
     const uint16_t* x = x16 + t * ldx;
     float acc[LORA_MAX_R];
 #pragma unroll
     for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
-    for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {
+    for (int k = lane * 8; k < K; k += 64 * 8) {
         const uint4 raw = *(const uint4*)(x + k);
         const uint16_t* h = (const uint16_t*)&raw;
         float xv[8];
@@ -122,20 +124,26 @@ __global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t l
             xv[e] = from16<DT>(h[e]);
             if (drop_p > 0.f) xv[e] *= drop_mult(seed, site + seg, (uint64_t)t * K + k + e, drop_p);
         }
-        for (int j = 0; j < r; ++j) {
-            const float4 a0 = *(const float4*)(A + (int64_t)j * K + k);
-            const float4 a1 = *(const float4*)(A + (int64_t)j * K + k + 4);
-            acc[j] += xv[0] * a0.x + xv[1] * a0.y + xv[2] * a0.z + xv[3] * a0.w + xv[4] * a1.x + xv[5] * a1.y + xv[6] * a1.z + xv[7] * a1.w;
+#pragma unroll
+        for (int j = 0; j < LORA_MAX_R; ++j) {
+            if (j < r) {
+                const float4 a0 = *(const float4*)(A + (int64_t)j * K + k);
+                const float4 a1 = *(const float4*)(A + (int64_t)j * K + k + 4);
+                acc[j] += xv[0] * a0.x + xv[1] * a0.y + xv[2] * a0.z + xv[3] * a0.w + xv[4] * a1.x + xv[5] * a1.y + xv[6] * a1.z + xv[7] * a1.w;
+            }
         }
     }
-    for (int j = 0; j < r; ++j) {
-        const float v = block_sum_256(acc[j], red);
-        if (threadIdx.x == 0) x16[t * ldx + K + seg * r + j] = to16<DT>(scale * v);
+#pragma unroll
+    for (int j = 0; j < LORA_MAX_R; ++j) {
+        if (j < r) {
+            const float v = wave_sum(acc[j]);
+            if (lane == 0) x16[t * ldx + K + seg * r + j] = to16<DT>(scale * v);
+        }
     }
 }
 int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
     ARG_CHECK(r > 0 && r <= LORA_MAX_R && K % 8 == 0 && a.n >= 1 && a.n <= 3 && T > 0);
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_down_kernel<DT>, dim3((unsigned)T, a.n), dim3(256), 0, s, x16, ldx, K, a, r, scale, drop_p, seed, site));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_down_kernel<DT>, dim3((unsigned)((T + 3) / 4), a.n), dim3(256), 0, s, x16, ldx, T, K, a, r, scale, drop_p, seed, site));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
@@ -144,7 +152,7 @@ int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDow
 // transposed).  One workgroup = 128 columns x 1024 rows: a lane owns two adjacent columns, the 4 waves split the rows in groups of 64;
 // lane l of a wave holds U row (group start + l) in registers and the row loop broadcasts it with v_readlane (one VMEM instruction per
 // row instead of 1 + r), partial sums meet in LDS and leave as 128 * r atomics.
-#define LORA_TSPLIT 1024
+#define LORA_TSPLIT 512
 template <int DT, bool U_F32, bool OUT_T, int R>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(float* out, const uint16_t* X, int64_t ldx, const void* Uv, int64_t ldu, int64_t T, int C, int r,
                                                          float drop_p, uint64_t seed, uint32_t site, int drop_k) {
@@ -170,21 +178,27 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(float* out, const uint1
                 ureg[j] = u;
             }
         }
-        const int nrow = (int)min((int64_t)64, T - tb);
+        // rows beyond T have u = 0 (ureg above), so their x may be any valid address: clamp instead of branching, 16 row loads in flight
 #pragma unroll
-        for (int q = 0; q < 64; ++q) {
-            if (q < nrow) {
-                const int64_t tt = tb + q;
-                float x0 = 0.f, x1 = 0.f;
-                if (ok) {
-                    const uint32_t raw = *(const uint32_t*)(X + tt * ldx + c);
-                    x0 = from16<DT>((uint16_t)(raw & 0xFFFF)); x1 = from16<DT>((uint16_t)(raw >> 16));
-                    if (drop_p > 0.f) { x0 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c, drop_p); x1 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c + 1, drop_p); }
+        for (int q0 = 0; q0 < 64; q0 += 16) {
+            uint32_t raw[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int64_t tt = min(tb + q0 + u, T - 1);
+                raw[u] = ok ? *(const uint32_t*)(X + tt * ldx + c) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int q = q0 + u;
+                float x0 = from16<DT>((uint16_t)(raw[u] & 0xFFFF)), x1 = from16<DT>((uint16_t)(raw[u] >> 16));
+                if (drop_p > 0.f) {
+                    const int64_t tt = min(tb + q, T - 1);
+                    x0 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c, drop_p); x1 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c + 1, drop_p);
                 }
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ureg[j]), q));
-                    acc0[j] += x0 * u; acc1[j] += x1 * u;
+                    const float uu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ureg[j]), q));
+                    acc0[j] += x0 * uu; acc1[j] += x1 * uu;
                 }
             }
         }
@@ -321,27 +335,36 @@ int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K
 }
 
 // ---------------------------------------------------------------------------- RMSNorm backward
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float* dy, const float* x, const int32_t* rows, int H, const float* w, float eps, int accumulate) {
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float* dy, const float* x, const int32_t* rows, int H, const float* w, float eps, int accumulate, uint16_t* out16) {
     __shared__ float red[4];
     const int64_t i = blockIdx.x;
     const int64_t row = rows ? rows[i] : i;
     const float* xr = x + row * H;
     const float* dyr = dy + i * H;
     float ss = 0.f, dot = 0.f;
-    for (int k = threadIdx.x; k < H; k += 256) { const float xv = xr[k]; ss += xv * xv; dot += w[k] * dyr[k] * xv; }
+    for (int k = threadIdx.x * 4; k < H; k += 1024) {
+        const float4 xv = *(const float4*)(xr + k), dv = *(const float4*)(dyr + k), wv = *(const float4*)(w + k);
+        ss += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+        dot += wv.x * dv.x * xv.x + wv.y * dv.y * xv.y + wv.z * dv.z * xv.z + wv.w * dv.w * xv.w;
+    }
     ss = block_sum_256(ss, red);
     dot = block_sum_256(dot, red);
     const float rs = rsqrtf(ss / (float)H + eps);
     const float c = rs * rs * rs * dot / (float)H;
     float* o = dx + row * H;
-    for (int k = threadIdx.x; k < H; k += 256) {
-        const float g = rs * w[k] * dyr[k] - xr[k] * c;
-        o[k] = accumulate ? o[k] + g : g;
+    for (int k = threadIdx.x * 4; k < H; k += 1024) {
+        const float4 xv = *(const float4*)(xr + k), dv = *(const float4*)(dyr + k), wv = *(const float4*)(w + k);
+        float4 g = make_float4(rs * wv.x * dv.x - xv.x * c, rs * wv.y * dv.y - xv.y * c, rs * wv.z * dv.z - xv.z * c, rs * wv.w * dv.w - xv.w * c);
+        if (accumulate) { const float4 p = *(const float4*)(o + k); g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w; }
+        *(float4*)(o + k) = g;
+        if (out16) *(uint2*)(out16 + row * H + k) = make_uint2(pack2<DT>(g.x, g.y), pack2<DT>(g.z, g.w));
     }
 }
-int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, hipStream_t s) {
-    ARG_CHECK(n_rows > 0);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate);
+int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, uint16_t* out16, int dtype,
+                       hipStream_t s) {
+    ARG_CHECK(n_rows > 0 && H % 4 == 0 && (!out16 || !rows));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(rmsnorm_bwd_kernel<DT>, dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate, out16));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
