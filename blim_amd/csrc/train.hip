@@ -379,8 +379,10 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         // ---- attention block: x_mid = x_in + o_proj(attn), attn = Attention(rope(qkv(n1))), n1 = rmsnorm(x_in)
         TRY(lora_backward(t, ad[3], dy16, H, attn, Ha, H, 0, T, du, b->dropout_seed, 8 * li + 3, s));
         { GemmParams p = gp(dt, dy16, H, x.woT, T, H, H, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }                    // d attn (base path)
-        TRY(lora_dx1(dtmp, H, du, t->params + ad[3].offA, T, H, r, t->p_drop, b->dropout_seed, 8 * li + 3, s));
-        TRY(launch_f32_to_16(dattn16, H, dtmp, H, T, H, 1.0f, dt, s));
+        {   // d attn = base path + the o_proj adapter's input gradient, written straight as the attention backward's 16-bit operand
+            LoraDxArgs a1; a1.n = 1; a1.du[0] = du; a1.A[0] = t->params + ad[3].offA; a1.du[1] = a1.du[2] = nullptr; a1.A[1] = a1.A[2] = nullptr;
+            TRY(launch_lora_dx(dtmp, H, a1, T, H, r, t->p_drop, b->dropout_seed, 8 * li + 3, s, dattn16, H, dt));
+        }
         {
             AttnBwdParams a;
             memset(&a, 0, sizeof(a));
@@ -393,12 +395,11 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         for (int j = 0; j < 3; ++j)
             TRY(lora_backward(t, ad[j], dqkv16 + qcols[j], qn, xn1, Ha, H, j * r, T, du + (int64_t)j * T * r, b->dropout_seed, 8 * li + j, s));
         { GemmParams p = gp(dt, dqkv16, qn, x.wqkvT, T, H, qn, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }              // d n1 (base path)
-        {
+        {   // dres = d x_in; the three adapters' input gradients join dtmp inside the RMSNorm backward
             LoraDxArgs a3; a3.n = 3;
             for (int j = 0; j < 3; ++j) { a3.du[j] = du + (int64_t)j * T * r; a3.A[j] = t->params + ad[j].offA; }
-            TRY(launch_lora_dx(dtmp, H, a3, T, H, r, t->p_drop, b->dropout_seed, 8 * li, s));
+            TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, li > 0 ? dy16 : nullptr, dt, s, &a3, r, t->p_drop, b->dropout_seed, 8 * li));
         }
-        TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, li > 0 ? dy16 : nullptr, dt, s));   // dres = d x_in
     }
     return BLIM_OK;
 }

@@ -36,12 +36,15 @@ struct LoraDxArgs {
     int n;
 };
 // dx[t, k] += sum_seg keep_seg(t, k) / (1 - p) * sum_j du_seg[t, j] * A_seg[j, k]      (dx f32 [T, ldd]; adapter seg uses dropout site `site + seg`)
-int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s);
+// out16 != nullptr: dx is only read and the sum is written as 16-bit rows (stride ldo) instead -- the cast that would follow, folded in
+int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s, uint16_t* out16 = nullptr,
+                   int64_t ldo = 0, int dtype = DT_F16);
 
 // out[rows ? rows[i] : i, :] (+)= d/dx of  y = w * x * rsqrt(mean(x^2) + eps)  applied to dy[i, :]   (x row = rows ? rows[i] : i)
 // out16 (optional, rows == nullptr only): 16-bit copy of the updated dx rows (the next GEMM's A operand)
+// la (optional, rows == nullptr only): dy is taken as dy + the adapters' rank-r term of launch_lora_dx, formed on the fly (saves that pass)
 int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, uint16_t* out16, int dtype,
-                       hipStream_t s);
+                       hipStream_t s, const LoraDxArgs* la = nullptr, int r = 0, float drop_p = 0.f, uint64_t seed = 0, uint32_t site = 0);
 
 // gu16 [T, 2I] with 16 gate / 16 up columns interleaved (the fused gate|up matrix's stored row order) -> act16 [T, I] = silu(gate) * up
 int launch_swiglu_fwd(uint16_t* act16, const uint16_t* gu16, int64_t T, int I, int dtype, hipStream_t s);

@@ -3,6 +3,8 @@
 // run on MFMA 32x32x16 tiles over materialised P / dS (sequences of a training batch are a few hundred tokens long).
 #include "train.hpp"
 
+#include <string.h>
+
 #include <algorithm>
 
 #define DISPATCH_DT(dtype, CALL)            \
@@ -103,47 +105,60 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {   // red: 
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// one wave per token (4 tokens per workgroup): lanes stride over K in 16-byte chunks, r wave reductions, no LDS
-template <int DT>
+// one wave = 4 tokens (16 per workgroup): lanes stride over K in 16-byte chunks and apply every A chunk they load to all four
+// tokens (A is [r, K] f32 = 114 KB at 7B: re-reading it per token was the kernel's whole cost), r x 4 wave reductions, no LDS
+#define DOWN_TPW 4
+template <int DT, int R>
 __global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int64_t T, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site) {
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= T) return;
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * DOWN_TPW;
+    if (t0 >= T) return;
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.y;
     const float* A = a.A[seg];
-    const uint16_t* x = x16 + t * ldx;
-    float acc[LORA_MAX_R];
+    float acc[DOWN_TPW][R];
 #pragma unroll
-    for (int j = 0; j < LORA_MAX_R; ++j) acc[j] = 0.f;
+    for (int q = 0; q < DOWN_TPW; ++q)
+#pragma unroll
+        for (int j = 0; j < R; ++j) acc[q][j] = 0.f;
     for (int k = lane * 8; k < K; k += 64 * 8) {
-        const uint4 raw = *(const uint4*)(x + k);
-        const uint16_t* h = (const uint16_t*)&raw;
-        float xv[8];
+        float xv[DOWN_TPW][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            xv[e] = from16<DT>(h[e]);
-            if (drop_p > 0.f) xv[e] *= drop_mult(seed, site + seg, (uint64_t)t * K + k + e, drop_p);
+        for (int q = 0; q < DOWN_TPW; ++q) {
+            const int64_t t = min(t0 + q, T - 1);
+            const uint4 raw = *(const uint4*)(x16 + t * ldx + k);
+            const uint16_t* h = (const uint16_t*)&raw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xv[q][e] = from16<DT>(h[e]);
+                if (drop_p > 0.f) xv[q][e] *= drop_mult(seed, site + seg, (uint64_t)t * K + k + e, drop_p);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < LORA_MAX_R; ++j) {
+        for (int j = 0; j < R; ++j) {
             if (j < r) {
                 const float4 a0 = *(const float4*)(A + (int64_t)j * K + k);
                 const float4 a1 = *(const float4*)(A + (int64_t)j * K + k + 4);
-                acc[j] += xv[0] * a0.x + xv[1] * a0.y + xv[2] * a0.z + xv[3] * a0.w + xv[4] * a1.x + xv[5] * a1.y + xv[6] * a1.z + xv[7] * a1.w;
+#pragma unroll
+                for (int q = 0; q < DOWN_TPW; ++q)
+                    acc[q][j] += xv[q][0] * a0.x + xv[q][1] * a0.y + xv[q][2] * a0.z + xv[q][3] * a0.w + xv[q][4] * a1.x + xv[q][5] * a1.y + xv[q][6] * a1.z + xv[q][7] * a1.w;
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < LORA_MAX_R; ++j) {
-        if (j < r) {
-            const float v = wave_sum(acc[j]);
-            if (lane == 0) x16[t * ldx + K + seg * r + j] = to16<DT>(scale * v);
+    for (int q = 0; q < DOWN_TPW; ++q)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j < r) {
+                const float v = wave_sum(acc[q][j]);
+                if (lane == 0 && t0 + q < T) x16[(t0 + q) * ldx + K + seg * r + j] = to16<DT>(scale * v);
+            }
         }
-    }
 }
 int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
     ARG_CHECK(r > 0 && r <= LORA_MAX_R && K % 8 == 0 && a.n >= 1 && a.n <= 3 && T > 0);
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_down_kernel<DT>, dim3((unsigned)((T + 3) / 4), a.n), dim3(256), 0, s, x16, ldx, T, K, a, r, scale, drop_p, seed, site));
+    dim3 grid((unsigned)((T + 4 * DOWN_TPW - 1) / (4 * DOWN_TPW)), a.n);
+    if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 8>), grid, dim3(256), 0, s, x16, ldx, T, K, a, r, scale, drop_p, seed, site));
+    else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 16>), grid, dim3(256), 0, s, x16, ldx, T, K, a, r, scale, drop_p, seed, site));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
@@ -303,13 +318,9 @@ int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t*
     return BLIM_OK;
 }
 
-// dx[t, k] += sum over the adapters reading x of keep_seg(t, k) / (1 - p) * sum_j du_seg[t, j] * A_seg[j, k]   (one read-modify-write pass)
-__global__ void lora_dx_kernel(float* dx, int64_t ldd, LoraDxArgs a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site) {
-    const int k4 = K / 4;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * k4) return;
-    const int64_t t = i / k4; const int k = (int)(i - t * k4) * 4;
-    float4 o = *(float4*)(dx + t * ldd + k);
+// sum over the adapters reading x of keep_seg(t, k..k+3) / (1 - p) * sum_j du_seg[t, j] * A_seg[j, k..k+3]
+__device__ __forceinline__ float4 lora_dx4(const LoraDxArgs& a, int64_t t, int k, int K, int r, float drop_p, uint64_t seed, uint32_t site) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int sg = 0; sg < a.n; ++sg) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < r; ++j) {
@@ -324,47 +335,78 @@ __global__ void lora_dx_kernel(float* dx, int64_t ldd, LoraDxArgs a, int64_t T, 
         }
         o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
     }
-    *(float4*)(dx + t * ldd + k) = o;
+    return o;
 }
-int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s) {
+
+// dx[t, k] += the rank-r term (one read-modify-write pass); out16 (optional): 16-bit copy of the result
+template <int DT>
+__global__ void lora_dx_kernel(float* dx, int64_t ldd, LoraDxArgs a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, uint16_t* out16, int64_t ldo) {
+    const int k4 = K / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * k4) return;
+    const int64_t t = i / k4; const int k = (int)(i - t * k4) * 4;
+    float4 o = *(float4*)(dx + t * ldd + k);
+    const float4 l = lora_dx4(a, t, k, K, r, drop_p, seed, site);
+    o.x += l.x; o.y += l.y; o.z += l.z; o.w += l.w;
+    if (out16) *(uint2*)(out16 + t * ldo + k) = make_uint2(pack2<DT>(o.x, o.y), pack2<DT>(o.z, o.w));
+    else *(float4*)(dx + t * ldd + k) = o;
+}
+int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, hipStream_t s, uint16_t* out16, int64_t ldo, int dtype) {
     ARG_CHECK(K % 4 == 0 && ldd % 4 == 0 && a.n >= 1 && a.n <= 3);
     const int64_t total = T * (K / 4);
-    hipLaunchKernelGGL(lora_dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, ldd, a, T, K, r, drop_p, seed, site);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_dx_kernel<DT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, ldd, a, T, K, r, drop_p, seed, site, out16, ldo));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
 
 // ---------------------------------------------------------------------------- RMSNorm backward
-template <int DT>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float* dy, const float* x, const int32_t* rows, int H, const float* w, float eps, int accumulate, uint16_t* out16) {
+// dy_eff = dy + (optional) the adapters' rank-r input gradient, formed on the fly and kept in registers between the two passes
+#define RB_MAXV 8      // float4 per thread: H <= 8192
+template <int DT, bool LORA>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float* dy, const float* x, const int32_t* rows, int H, const float* w, float eps, int accumulate, uint16_t* out16,
+                                                          LoraDxArgs la, int r, float drop_p, uint64_t seed, uint32_t site) {
     __shared__ float red[4];
     const int64_t i = blockIdx.x;
     const int64_t row = rows ? rows[i] : i;
     const float* xr = x + row * H;
     const float* dyr = dy + i * H;
+    float4 dv[RB_MAXV];
     float ss = 0.f, dot = 0.f;
-    for (int k = threadIdx.x * 4; k < H; k += 1024) {
-        const float4 xv = *(const float4*)(xr + k), dv = *(const float4*)(dyr + k), wv = *(const float4*)(w + k);
-        ss += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
-        dot += wv.x * dv.x * xv.x + wv.y * dv.y * xv.y + wv.z * dv.z * xv.z + wv.w * dv.w * xv.w;
+#pragma unroll
+    for (int u = 0; u < RB_MAXV; ++u) {
+        const int k = (threadIdx.x + 256 * u) * 4;
+        if (k < H) {
+            const float4 xv = *(const float4*)(xr + k), wv = *(const float4*)(w + k);
+            float4 d = *(const float4*)(dyr + k);
+            if (LORA) { const float4 l = lora_dx4(la, i, k, H, r, drop_p, seed, site); d.x += l.x; d.y += l.y; d.z += l.z; d.w += l.w; }
+            dv[u] = d;
+            ss += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+            dot += wv.x * d.x * xv.x + wv.y * d.y * xv.y + wv.z * d.z * xv.z + wv.w * d.w * xv.w;
+        }
     }
     ss = block_sum_256(ss, red);
     dot = block_sum_256(dot, red);
     const float rs = rsqrtf(ss / (float)H + eps);
     const float c = rs * rs * rs * dot / (float)H;
     float* o = dx + row * H;
-    for (int k = threadIdx.x * 4; k < H; k += 1024) {
-        const float4 xv = *(const float4*)(xr + k), dv = *(const float4*)(dyr + k), wv = *(const float4*)(w + k);
-        float4 g = make_float4(rs * wv.x * dv.x - xv.x * c, rs * wv.y * dv.y - xv.y * c, rs * wv.z * dv.z - xv.z * c, rs * wv.w * dv.w - xv.w * c);
-        if (accumulate) { const float4 p = *(const float4*)(o + k); g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w; }
-        *(float4*)(o + k) = g;
-        if (out16) *(uint2*)(out16 + row * H + k) = make_uint2(pack2<DT>(g.x, g.y), pack2<DT>(g.z, g.w));
+#pragma unroll
+    for (int u = 0; u < RB_MAXV; ++u) {
+        const int k = (threadIdx.x + 256 * u) * 4;
+        if (k < H) {
+            const float4 xv = *(const float4*)(xr + k), wv = *(const float4*)(w + k), d = dv[u];
+            float4 g = make_float4(rs * wv.x * d.x - xv.x * c, rs * wv.y * d.y - xv.y * c, rs * wv.z * d.z - xv.z * c, rs * wv.w * d.w - xv.w * c);
+            if (accumulate) { const float4 p = *(const float4*)(o + k); g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w; }
+            *(float4*)(o + k) = g;
+            if (out16) *(uint2*)(out16 + row * H + k) = make_uint2(pack2<DT>(g.x, g.y), pack2<DT>(g.z, g.w));
+        }
     }
 }
 int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, uint16_t* out16, int dtype,
-                       hipStream_t s) {
-    ARG_CHECK(n_rows > 0 && H % 4 == 0 && (!out16 || !rows));
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(rmsnorm_bwd_kernel<DT>, dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate, out16));
+                       hipStream_t s, const LoraDxArgs* la, int r, float drop_p, uint64_t seed, uint32_t site) {
+    ARG_CHECK(n_rows > 0 && H % 4 == 0 && H <= 1024 * RB_MAXV && (!out16 || !rows) && (!la || !rows));
+    LoraDxArgs z; memset(&z, 0, sizeof(z));
+    if (la) DISPATCH_DT(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, true>), dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate, out16, *la, r, drop_p, seed, site));
+    else DISPATCH_DT(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, false>), dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate, out16, z, 0, 0.f, 0ull, 0u));
     LAUNCH_CHECK();
     return BLIM_OK;
 }

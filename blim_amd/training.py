@@ -210,6 +210,7 @@ class Trainer:
         self.step_count = 0               # optimizer steps taken (AdamW bias correction)
         self.scaler = LossScaler(enabled=amp and engine.dtype == "f16")      # bf16 has fp32's exponent range: no scaling needed
         self._vocab_key, self._vocab = None, None
+        self._copy_stream = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -253,7 +254,7 @@ class Trainer:
             self._vocab = v.permute(1, 0, 2).contiguous()
             self._vocab_key = key
 
-    def _train_batch(self, rows: PackedRows, feats, tok_per_clip: int, grad_scale: float, seed: int, vocab=None, labels=None):
+    def _train_batch(self, rows: PackedRows, feats, tok_per_clip: int, seed: int, vocab=None, labels=None):
         import torch
         dev = self.engine.device
         seq_len = rows.seq_len
@@ -269,34 +270,59 @@ class Trainer:
         tb.tok_per_clip, tb.max_seq_len = int(tok_per_clip), int(seq_len.max())
         tb.rows, tb.labels, tb.n_rows = keep[2].data_ptr(), keep[3].data_ptr(), len(rows.rows)
         tb.vocab, tb.n_vocab = (vocab.data_ptr(), vocab.shape[1]) if vocab is not None else (None, 0)
-        tb.grad_scale, tb.dropout_seed = float(grad_scale), int(seed) & 0xFFFFFFFFFFFFFFFF
+        tb.dropout_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         return tb, keep + [st]
 
-    def forward_backward(self, data: dict, accum_iter: int = 1, seed: int = 0):
-        """training_utils.py:57-85 for one collated batch: both losses forward + backward, gradients accumulated (scaled by the loss
-        scale / accum_iter).  Returns (vtg_loss, tvg_loss) as floats."""
+    # One batch in three phases, so that the host work of batch i + 1 (row packing, feature stacking, host-to-device copies on a side
+    # stream) runs while the GPU is busy with batch i (train_one_epoch): stage() -> launch() -> finish().
+    def stage(self, data: dict, seed: int = 0) -> dict:
+        """Host side of one collated batch: packed VTG / TVG rows and everything the step reads, resident on the device."""
         import torch
         dims, dev, dt = self.dims, self.engine.device, self.engine.torch_dtype
+        if self._vocab is None:
+            raise BlimError("set_video_vocab() first (training_utils.py:50-51)")
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
         video = [torch.as_tensor(v) for v in data["video"]]
         bs = len(video)
         C_, tok = video[0].shape[0], video[0].shape[1]
         if C_ != dims.num_clips:
             raise ValueError(f"features have {C_} clips, the model expects {dims.num_clips}")
-        feats = torch.stack(video).to(dev, dt).reshape(bs * C_ * tok, dims.mm_hidden_size).contiguous()
         as_rows = lambda x: [np.asarray(r) for r in (x.cpu().numpy() if hasattr(x, "cpu") else x)]
         vtg = pack_vtg_rows(as_rows(data["vtg_ids"]), as_rows(data["vtg_masks"]), as_rows(data["vtg_labels"]), C_ * tok)
         tvg = pack_tvg_rows(as_rows(data["tvg_ids"]), as_rows(data["tvg_masks"]), as_rows(data["tvg_labels"]), C_)
-        if self._vocab is None:
-            raise BlimError("set_video_vocab() first (training_utils.py:50-51)")
-        gs = self.scaler.scale / accum_iter
-        self._loss.zero_()
-        tb, keep1 = self._train_batch(vtg, feats, tok, gs, seed)
-        _check(self.lib.blim_train_vtg(self.h, C.byref(tb), self._loss.data_ptr(), _stream()), "blim_train_vtg")
         vl = np.asarray(data["tvg_video_labels"].cpu().numpy() if hasattr(data["tvg_video_labels"], "cpu") else data["tvg_video_labels"], np.int32)
-        tb2, keep2 = self._train_batch(tvg, feats, tok, gs, seed + 1, vocab=self._vocab, labels=vl)
-        _check(self.lib.blim_train_tvg(self.h, C.byref(tb2), self._loss.data_ptr() + 4, _stream()), "blim_train_tvg")
-        sums = self._loss.cpu().numpy()                      # synchronises: the index tensors above may be released now
-        return float(sums[0]) / len(vtg.rows), float(sums[1]) / len(tvg.rows)
+        host = torch.stack(video)
+        host = host.pin_memory() if not host.is_pinned() else host
+        with torch.cuda.stream(self._copy_stream):
+            feats = host.to(dev, non_blocking=True).to(dt).reshape(bs * C_ * tok, dims.mm_hidden_size).contiguous()
+            tb1, keep1 = self._train_batch(vtg, feats, tok, seed)
+            tb2, keep2 = self._train_batch(tvg, feats, tok, seed + 1, vocab=self._vocab, labels=vl)
+            loss = torch.zeros(2, dtype=torch.float32, device=dev)
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        return {"tb": (tb1, tb2), "keep": (keep1, keep2, host), "loss": loss, "ready": ready, "n": (len(vtg.rows), len(tvg.rows))}
+
+    def launch(self, staged: dict, accum_iter: int = 1) -> None:
+        """training_utils.py:57-85: both losses forward + backward on the current stream; gradients accumulate, scaled by loss scale / accum_iter."""
+        import torch
+        torch.cuda.current_stream().wait_event(staged["ready"])
+        gs = self.scaler.scale / accum_iter
+        tb1, tb2 = staged["tb"]
+        tb1.grad_scale = tb2.grad_scale = float(gs)
+        _check(self.lib.blim_train_vtg(self.h, C.byref(tb1), staged["loss"].data_ptr(), _stream()), "blim_train_vtg")
+        _check(self.lib.blim_train_tvg(self.h, C.byref(tb2), staged["loss"].data_ptr() + 4, _stream()), "blim_train_tvg")
+
+    def finish(self, staged: dict):
+        """(vtg_loss, tvg_loss) of a launched batch; synchronises with the GPU (the reference's loss.item(), training_utils.py:83)."""
+        sums = staged["loss"].cpu().numpy()
+        staged["keep"] = None
+        return float(sums[0]) / staged["n"][0], float(sums[1]) / staged["n"][1]
+
+    def forward_backward(self, data: dict, accum_iter: int = 1, seed: int = 0):
+        st = self.stage(data, seed)
+        self.launch(st, accum_iter)
+        return self.finish(st)
 
     def optimizer_step(self, lr: float, world_size: int = 1) -> Dict[str, float]:
         """loss_scaler(...)'s update branch (util/misc.py:240-249): [all-reduce], unscale, inf check, grad norm, AdamW, scaler update."""
@@ -350,10 +376,16 @@ def train_one_epoch(trainer: Trainer, data_loader, epoch: int, args, world_size:
     print_freq = max(1, int(n_iter / 4))                                              # :46
     sums = {"loss": 0.0, "vtg_loss": 0.0, "tvg_loss": 0.0}
     lr, seen = 0.0, 0
-    for it, data in enumerate(data_loader):
+    seed_of = lambda i: (epoch * n_iter + i) * 2 + 12345
+    batches = iter(data_loader)
+    nxt = trainer.stage(next(batches), seed_of(0)) if n_iter else None
+    for it in range(n_iter):
         if it % accum == 0:
             lr = adjust_learning_rate(it / n_iter + epoch, args)                     # :58-59
-        vtg_loss, tvg_loss = trainer.forward_backward(data, accum_iter=accum, seed=(epoch * n_iter + it) * 2 + 12345)
+        cur = nxt
+        trainer.launch(cur, accum_iter=accum)
+        nxt = trainer.stage(next(batches), seed_of(it + 1)) if it + 1 < n_iter else None      # host work of the next batch under this batch's kernels
+        vtg_loss, tvg_loss = trainer.finish(cur)
         loss = vtg_loss + tvg_loss
         if not math.isfinite(loss):                                                   # :83-85
             raise FloatingPointError(f"Loss is {loss}, stopping training")

@@ -29,11 +29,15 @@ for B in [int(a) for a in sys.argv[1:]] or [16]:
     data = next(iter(loader))
     tok = sum(len(x) + 255 for x in prob.vtg_ids) + sum(len(x) + 3 for x in prob.tvg_ids)
     lab = sum(int((np.asarray(x)[1:] != -100).sum()) for x in prob.vtg_labels)
-    for it in range(steps + 1):
+    nxt = tr.stage(data, 0)
+    for it in range(steps + 1):                        # the loop of blim_amd.training.train_one_epoch: batch i + 1 is staged under batch i's kernels
         if it == 1:
             torch.cuda.synchronize(); t0 = time.time()
         tr.zero_grad()
-        lv, lt = tr.forward_backward(data, seed=it)
+        cur = nxt
+        tr.launch(cur)
+        nxt = tr.stage(data, it + 1) if it < steps else None
+        lv, lt = tr.finish(cur)
         st = tr.optimizer_step(1e-4)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
