@@ -117,7 +117,8 @@ def main(args):
         # scores are sums of integers and hit 0.0 about once per 10^5 entries, real InternVideo2 similarities do not
         nz = lambda a: np.where(a == 0, np.float32(1e-6), a)
         args.iv2_scores = {"v2t": T(nz(prob.v2t_sims)), "t2v": T(nz(prob.t2v_sims))}
-        if args.eval and args.resume:     # fine-tuned adapters of a (synthetic) training run: merged by the trainer's own merge kernel
+        if args.eval and args.resume and os.path.isfile(args.resume):     # adapters of a (synthetic) training run: merged by the trainer's own merge kernel
+            # (any other non-empty --resume only selects the fine-tuned score combination, training_utils.py:150-167)
             from .training import Trainer
             tr = Trainer(model.engine, lora_r=args.lora_r, lora_alpha=float(args.lora_alpha), lora_dropout=0.0)
             tr.load_checkpoint_state(torch.load(args.resume, map_location="cpu", weights_only=False))
