@@ -161,7 +161,12 @@ def average_gradients(flat_grads, world_size: int) -> None:
     bucketed scheme) and a division by the world size."""
     if world_size > 1:
         import torch.distributed as dist
-        dist.all_reduce(flat_grads)
+        if flat_grads.is_cuda and dist.get_backend() == "gloo":      # test set-up only (two ranks sharing one GPU): gloo reduces host tensors
+            host = flat_grads.cpu()
+            dist.all_reduce(host)
+            flat_grads.copy_(host)
+        else:
+            dist.all_reduce(flat_grads)
         flat_grads.div_(world_size)
 
 
@@ -400,7 +405,7 @@ def train_one_epoch(trainer: Trainer, data_loader, epoch: int, args, world_size:
     if world_size > 1:                                                                # metric_logger.synchronize_between_processes (:100)
         import torch
         import torch.distributed as dist
-        t = torch.tensor([out["loss"], out["vtg_loss"], out["tvg_loss"]], dtype=torch.float64, device=trainer.engine.device)
+        t = torch.tensor([out["loss"], out["vtg_loss"], out["tvg_loss"]], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else trainer.engine.device)
         dist.all_reduce(t)
         out["loss"], out["vtg_loss"], out["tvg_loss"] = (t / world_size).tolist()
     log("Averaged stats: " + "  ".join(f"{k}: {v:.6f}" for k, v in out.items()))

@@ -158,3 +158,21 @@ def test_training_driver_on_a_synthetic_tree(tmp_path, monkeypatch, capsys):
     assert ckpt["epoch"] == 1 and "scaler" in ckpt and ckpt["optimizer"]["step"] == 6
     again = _run(["--eval", "--resume", os.path.join(out_dir, "epoch1.pth")] + common)
     assert again == last, (again, last)
+
+
+def test_two_ranks_train_with_averaged_gradients(tmp_path):
+    """Fine-tuning with one process per 'GPU' x 2 (both on cuda:0, gloo in place of RCCL): each rank steps on its own synthetic batches,
+    the flat gradient buffer is averaged with one all-reduce, so both ranks hold the same adapters and print the same validation."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, BLIM_DIST_BACKEND="gloo", BLIM_FORCE_DEVICE="0")
+    out = str(tmp_path / "ft2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+                        "-m", "blim_amd.main", "--synthetic", "8", "--lr", "1e-3", "--epochs", "2", "--warmup_epochs", "1", "--batch_size", "4", "--topk", "4",
+                        "--cpn", "--alpha", "0.4", "0.8", "--c", "0.3", "0.6", "0.9", "0.7", "--output_dir", out], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "effective batch size: 8" in r.stdout and "Training time" in r.stdout
+    logs = [json.loads(l) for l in open(os.path.join(out, "log.txt")) if l.startswith("{")]
+    assert [l["epoch"] for l in logs] == [0, 1] and all(np.isfinite(l["train_loss"]) for l in logs)
+    assert os.path.exists(os.path.join(out, "epoch1.pth"))
