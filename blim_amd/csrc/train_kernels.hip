@@ -702,17 +702,19 @@ __global__ __launch_bounds__(256) void attn_bgemm_kernel(AttnBwdParams p, int Lm
         }
 }
 
-// one wave per (row i, head, sequence): P16[i][:] = softmax over visible keys j <= i (zeros elsewhere, all Lm columns)
+// one wave per (row i, head, sequence), 4 rows per workgroup: P16[i][:] = softmax over visible keys j <= i, zeros up to the end of the
+// diagonal 64-column tile (the products below never read a tile above the diagonal)
 template <int DT>
-__global__ __launch_bounds__(64) void attn_softmax_rows_kernel(AttnBwdParams p, int Lm) {
-    const int i = blockIdx.x, h = blockIdx.y, s = blockIdx.z;
+__global__ __launch_bounds__(256) void attn_softmax_rows_kernel(AttnBwdParams p, int Lm) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, s = blockIdx.z;
     const int L = p.seq_len[s];
     if (i >= L) return;
     const int64_t t0 = p.seq_start[s];
     const int64_t off = (((int64_t)s * p.num_heads + h) * Lm + i) * Lm;
     const float* S = p.S32 + off;
     uint16_t* P = p.P16 + off;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int jend = (i / 64 + 1) * 64;
     float m = -3.0e38f;
     for (int j = lane; j <= i; j += 64) if (p.key_visible[t0 + j]) m = fmaxf(m, S[j]);
     m = wave_max(m);
@@ -720,26 +722,27 @@ __global__ __launch_bounds__(64) void attn_softmax_rows_kernel(AttnBwdParams p, 
     for (int j = lane; j <= i; j += 64) if (p.key_visible[t0 + j]) sum += __expf(S[j] - m);
     sum = wave_sum(sum);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    for (int j = lane; j < Lm; j += 64) {
+    for (int j = lane; j < jend; j += 64) {
         const float v = (j <= i && p.key_visible[t0 + j]) ? __expf(S[j] - m) * inv : 0.f;
         P[j] = to16<DT>(v);
     }
 }
 // dS16[i][:] = scale * P o (dP - sum_j P dP)
 template <int DT>
-__global__ __launch_bounds__(64) void attn_ds_rows_kernel(AttnBwdParams p, int Lm) {
-    const int i = blockIdx.x, h = blockIdx.y, s = blockIdx.z;
+__global__ __launch_bounds__(256) void attn_ds_rows_kernel(AttnBwdParams p, int Lm) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, s = blockIdx.z;
     const int L = p.seq_len[s];
     if (i >= L) return;
     const int64_t off = (((int64_t)s * p.num_heads + h) * Lm + i) * Lm;
     const float* dP = p.dP32 + off;
     const uint16_t* P = p.P16 + off;
     uint16_t* dS = p.dS16 + off;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int jend = (i / 64 + 1) * 64;
     float D = 0.f;
     for (int j = lane; j <= i; j += 64) D += from16<DT>(P[j]) * dP[j];
     D = wave_sum(D);
-    for (int j = lane; j < Lm; j += 64) {
+    for (int j = lane; j < jend; j += 64) {
         const float v = j <= i ? p.scale * from16<DT>(P[j]) * (dP[j] - D) : 0.f;
         dS[j] = to16<DT>(v);
     }
@@ -751,9 +754,9 @@ static int attention_bwd_t(const AttnBwdParams& p, hipStream_t s) {
     const int nt = Lm / 64;
     const dim3 blk(256);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_S>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
-    hipLaunchKernelGGL(attn_softmax_rows_kernel<DT>, dim3(p.max_len, p.num_heads, p.n_seqs), dim3(64), 0, s, p, Lm);
+    hipLaunchKernelGGL(attn_softmax_rows_kernel<DT>, dim3((p.max_len + 3) / 4, p.num_heads, p.n_seqs), dim3(256), 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DP>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
-    hipLaunchKernelGGL(attn_ds_rows_kernel<DT>, dim3(p.max_len, p.num_heads, p.n_seqs), dim3(64), 0, s, p, Lm);
+    hipLaunchKernelGGL(attn_ds_rows_kernel<DT>, dim3((p.max_len + 3) / 4, p.num_heads, p.n_seqs), dim3(256), 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DQ>), dim3(2, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DV>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DK>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);

@@ -71,7 +71,7 @@ def test_training_step_matches_reference_autograd(case, dtype):
         print(f"[{case}/{dtype}] step {step}: vtg {lv:.5f} (ref {rv:.5f})  tvg {lt:.5f} (ref {rt:.5f})")
         # step 1 runs on the parameters the first AdamW step produced; at lr 1e-2 that step is violent (the 7B-width TVG loss jumps from 1.2
         # to 4.7), so the second loss is a sanity check -- the parameters themselves are compared below
-        tol = LOSS_RTOL[dtype] * (1 if step == 0 else 10)
+        tol = LOSS_RTOL[dtype] if step == 0 else 3e-2        # (elements with ~zero gradient take +-lr steps on rounding noise: measured up to 1.1e-2)
         assert abs(lv - rv) <= tol * abs(rv) and abs(lt - rt) <= tol * abs(rt)
         grads = t.state("grads")
         inv = 1.0 / t.scaler.scale
