@@ -42,6 +42,11 @@ CASES = {
     "train_wide": dict(dims=dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_layers=1, num_heads=28, num_kv_heads=4,
                                  mm_hidden_size=1024), wseed=12, pseed=22, aseed=32, n=3, tok_per_clip=6, text_len=(4, 10),
                        batches=((0, 1), (1, 2)), r=8, alpha=32.0, lr=1e-2, wd=0.05),
+    # depth: all 28 layers (H = 1024, 8 q / 2 kv heads, I = 2816, real vocabulary) -- gradients that crossed 28 decoder layers; a gentler
+    # learning rate so that the second step stays comparable
+    "train_deep": dict(dims=dict(vocab_size=152064, hidden_size=1024, intermediate_size=2816, num_layers=28, num_heads=8, num_kv_heads=2,
+                                 mm_hidden_size=256), wseed=13, pseed=23, aseed=33, n=3, tok_per_clip=16, text_len=(4, 24),
+                       batches=((0, 1), (1, 2)), r=8, alpha=32.0, lr=1e-3, wd=0.05, max_store=2048),
 }
 MAX_STORE = 1 << 16
 
@@ -56,12 +61,12 @@ def adapter_values(dims, r: int, seed: int):
     return out
 
 
-def sample_rows(a: np.ndarray) -> np.ndarray:
-    """Strided row sample keeping at most MAX_STORE elements (the tests apply the same rule)."""
+def sample_rows(a: np.ndarray, max_store: int = MAX_STORE) -> np.ndarray:
+    """Strided row sample keeping at most max_store elements (the tests apply the same rule; CASES[..]['max_store'] overrides)."""
     a = np.asarray(a)
-    if a.size <= MAX_STORE:
+    if a.size <= max_store:
         return a
-    stride = int(math.ceil(a.size / MAX_STORE))
+    stride = int(math.ceil(a.size / max_store))
     return a.reshape(a.shape[0], -1)[::stride] if a.shape[0] >= stride else a.reshape(-1)[::stride]
 
 
@@ -168,11 +173,11 @@ def run_case(name: str, out_dir: str) -> None:
             g = params[n].grad.detach().numpy()
             out[f"gnorm_{step}/{n}"] = np.float32(np.linalg.norm(g.astype(np.float64)))
             if step == 0:
-                out[f"grad/{n}"] = sample_rows(g).copy()
+                out[f"grad/{n}"] = sample_rows(g, spec.get("max_store", MAX_STORE)).copy()
         opt.step()
     for n in names:
         p = params[n].detach().numpy()
-        out[f"param/{n}"] = sample_rows(p).copy()
+        out[f"param/{n}"] = sample_rows(p, spec.get("max_store", MAX_STORE)).copy()
         out[f"pnorm/{n}"] = np.float32(np.linalg.norm(p.astype(np.float64)))
     out["meta_case"] = np.array(name)
     path = os.path.join(out_dir, f"{name}.npz")

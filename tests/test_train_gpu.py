@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 # 16-bit operands everywhere (the reference itself trains under autocast(float16)): a gradient tensor is compared relative to its own
 # largest element / its L2 norm against the fp32 autograd reference
-GRAD_RTOL = {"f16": 5e-3, "bf16": 3e-2}        # measured: 1.4e-3 / 9.0e-3 (tiny), 1.9e-3 (7B width)
+GRAD_RTOL = {"f16": 5e-3, "bf16": 3e-2}        # measured: 1.4e-3 / 9.0e-3 (tiny), 2.1e-3 (7B width); 28 layers: see test body
 LOSS_RTOL = {"f16": 1e-3, "bf16": 1e-2}
 
 
@@ -47,12 +47,12 @@ def collate(prob, sel):
             "tvg_video_labels": torch.from_numpy(prob.tvg_video_labels[sel])}
 
 
-def _sample(a):
-    from oracle.gen_golden_train import sample_rows
-    return sample_rows(a)
+def _sample(a, spec=None):
+    from oracle.gen_golden_train import MAX_STORE, sample_rows
+    return sample_rows(a, (spec or {}).get("max_store", MAX_STORE))
 
 
-@pytest.mark.parametrize("case,dtype", [("train_tiny", "f16"), ("train_tiny", "bf16"), ("train_wide", "f16")])
+@pytest.mark.parametrize("case,dtype", [("train_tiny", "f16"), ("train_tiny", "bf16"), ("train_wide", "f16"), ("train_deep", "f16")])
 def test_training_step_matches_reference_autograd(case, dtype):
     import torch
     from blim_amd.engine import Engine
@@ -80,7 +80,7 @@ def test_training_step_matches_reference_autograd(case, dtype):
             ref_norm = float(g[f"gnorm_{step}/{n}"])
             if step == 0:
                 ref = g[f"grad/{n}"]
-                err = float(np.abs(_sample(gr) - ref).max() / max(np.abs(ref).max(), 1e-30))
+                err = float(np.abs(_sample(gr, spec) - ref).max() / max(np.abs(ref).max(), 1e-30))
                 nerr = abs(float(np.linalg.norm(gr.astype(np.float64))) - ref_norm) / max(ref_norm, 1e-30)
                 worst[n] = (err, nerr)
         if step == 0:
@@ -94,7 +94,7 @@ def test_training_step_matches_reference_autograd(case, dtype):
     params = t.state("params")
     for n in lora.trainable_names(dims):
         ref = g[f"param/{n}"]
-        d = np.abs(_sample(params[n]) - ref)
+        d = np.abs(_sample(params[n], spec) - ref)
         med, mx = (0.05, 5.0) if dtype == "f16" else (0.2, 5.0)     # max: an element with ~zero gradient can take opposite-sign steps twice
         assert np.median(d) <= med * spec["lr"] and d.max() <= mx * spec["lr"], (n, float(np.median(d)), float(d.max()))
     t.close(); eng.close()
