@@ -18,6 +18,8 @@ eng.init_synthetic_weights(0)
 tr = Trainer(eng, lora_r=8, lora_alpha=32.0, lora_dropout=0.05, seed=1)
 n_vocab = int(os.environ.get("BLIM_TRAIN_VOCAB", "4096"))
 steps = int(os.environ.get("BLIM_TRAIN_STEPS", "3"))
+trace = os.environ.get("BLIM_TRAIN_TRACE") == "1"          # per-step losses (the same batch every step: the loss must fall)
+lr = float(os.environ.get("BLIM_TRAIN_LR", "1e-4"))
 H, I, L = dims.hidden_size, dims.intermediate_size, dims.num_layers
 flop_tok = L * (2 * H * (H + 2 * dims.num_kv_heads * 128) + 2 * H * H + 6 * H * I)
 for B in [int(a) for a in sys.argv[1:]] or [16]:
@@ -38,7 +40,9 @@ for B in [int(a) for a in sys.argv[1:]] or [16]:
         tr.launch(cur)
         nxt = tr.stage(data, it + 1) if it < steps else None
         lv, lt = tr.finish(cur)
-        st = tr.optimizer_step(1e-4)
+        st = tr.optimizer_step(lr)
+        if trace:
+            print(f"  step {it}: vtg {lv:.4f} tvg {lt:.4f} grad norm {st['grad_norm']:.3g} scale {tr.scaler.scale:g} skipped {int(st['skipped'])}", flush=True)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
     fl = 2 * tok * flop_tok + 2 * lab * 2 * H * dims.vocab_size          # forward + input-gradient GEMMs (frozen weights: no weight-gradient GEMMs)
