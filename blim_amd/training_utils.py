@@ -35,6 +35,31 @@ def get_recall(t2v, v2t, t2v_ids, v2t_ids) -> Dict[str, float]:
     return {k: round(v, 2) for k, v in res.items()}
 
 
+def _grid_search(combine, t2v_ids, v2t_ids):
+    """The reference's coefficient sweep: c in linspace(0, 1, 11); per direction the FIRST c with a strictly better R@1 wins, rounded to 0.1."""
+    best_v2t = best_t2v = 0
+    v2t_c = t2v_c = 0
+    for c in np.linspace(0, 1, 11):
+        t2v, v2t = combine(c, c)
+        res = get_recall(t2v, v2t, t2v_ids, v2t_ids)
+        if best_v2t < res["v2t_r1"]:
+            best_v2t, v2t_c = res["v2t_r1"], round(float(c), 1)
+        if best_t2v < res["t2v_r1"]:
+            best_t2v, t2v_c = res["t2v_r1"], round(float(c), 1)
+    t2v, v2t = combine(t2v_c, v2t_c)
+    return t2v, v2t, t2v_c, v2t_c
+
+
+def calculate_score(t2v_1, v2t_1, t2v_2, v2t_2, t2v_ids, v2t_ids):
+    """training_utils.py:106-122: best linear ensemble c * S_1 + (1 - c) * S_2 per direction (the sweep the paper's `--c` values come from)."""
+    return _grid_search(lambda ct, cv: (ct * t2v_1 + (1 - ct) * t2v_2, cv * v2t_1 + (1 - cv) * v2t_2), t2v_ids, v2t_ids)
+
+
+def calculate_cpn_score(t2v, v2t, t2v_prior, v2t_prior, t2v_ids, v2t_ids):
+    """training_utils.py:124-140: best CPN strength S - c * prior per direction (the sweep behind `--alpha`)."""
+    return _grid_search(lambda ct, cv: (t2v - ct * t2v_prior, v2t - cv * v2t_prior), t2v_ids, v2t_ids)
+
+
 def combine_and_rank(t2v_dict, v2t_dict, args, n: int) -> Dict[str, Dict[str, float]]:
     """training_utils.py:145-169 (rank 0 part of val_one_epoch)."""
     ids = {i: i for i in range(n)}

@@ -261,3 +261,27 @@ def test_bench_launcher_command_plumbing():
     assert cmd[i + 1:] == argv
     port = int(bench.launcher_command(2, [])[bench.launcher_command(2, []).index("--master-port") + 1])
     assert 1024 < port < 65536
+
+
+def test_coefficient_sweeps_match_the_reference_when_present():
+    """calculate_score / calculate_cpn_score (training_utils.py:106-140): brute-force property here; equality with the reference's own
+    functions when /root/reference is importable (build container only)."""
+    from blim_amd import training_utils as TU
+    rs = np.random.RandomState(4)
+    n = 40
+    a, b = rs.randn(n, n).astype(np.float32) + 1.5 * np.eye(n, dtype=np.float32), rs.randn(n, n).astype(np.float32) + 0.5 * np.eye(n, dtype=np.float32)
+    c, d = rs.randn(n, n).astype(np.float32) + 1.0 * np.eye(n, dtype=np.float32), rs.randn(n, n).astype(np.float32)
+    ids = {i: i for i in range(n)}
+    t2v, v2t, ct, cv = TU.calculate_score(a, b, c, d, ids, ids)
+    grid = [round(float(x), 1) for x in np.linspace(0, 1, 11)]
+    r1 = lambda m: TU.get_recall(m, m, ids, ids)["t2v_r1"]
+    assert ct in grid and r1(ct * a + (1 - ct) * c) == max(r1(x * a + (1 - x) * c) for x in np.linspace(0, 1, 11))
+    assert np.allclose(t2v, ct * a + (1 - ct) * c) and np.allclose(v2t, cv * b + (1 - cv) * d)
+    p2t, p2v, pt, pv = TU.calculate_cpn_score(a, b, c, d, ids, ids)
+    assert np.allclose(p2t, a - pt * c) and np.allclose(p2v, b - pv * d)
+    from oracle import ref_harness
+    if ref_harness.available():
+        R = ref_harness.load().TU
+        for mine, ref in ((TU.calculate_score(a, b, c, d, ids, ids), R.calculate_score(a, b, c, d, ids, ids)),
+                          (TU.calculate_cpn_score(a, b, c, d, ids, ids), R.calculate_cpn_score(a, b, c, d, ids, ids))):
+            assert mine[2:] == ref[2:] and np.array_equal(mine[0], ref[0]) and np.array_equal(mine[1], ref[1])
