@@ -268,6 +268,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     if (q0 + qi < slen) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16_t* orow = p.out + (int64_t)(sstart + q0 + qi) * p.ldo + head * HD;
+        if (p.lse_out && hf == 0) p.lse_out[(int64_t)(sstart + q0 + qi) * p.num_heads + head] = l_run > 0.f ? m_run * p.scale + __logf(l_run) : 1.0e30f;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll

@@ -33,6 +33,9 @@ struct AttnParams {
     int64_t ldo8;
     uint8_t* out_mx;
     int64_t mx_stride;
+    // training: when non-null, the log-sum-exp of every (token, head) row, f32 [T, num_heads] in natural-log units of the SCALED scores
+    // (what the backward needs to re-materialise P = exp(scale * q.k - lse)); 1e30 for a row without a visible key
+    float* lse_out;
 };
 
 int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream);

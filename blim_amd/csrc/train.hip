@@ -62,7 +62,7 @@ struct blim_trainer {
     uint16_t* vh16 = nullptr;
     std::vector<void*> owned;
     // saved activations of the last forward (per layer, strided by tokens) and workspaces
-    DevBuf sv_res, sv_mid, sv_xn1, sv_qkv, sv_attn, sv_gu;
+    DevBuf sv_res, sv_mid, sv_xn1, sv_qkv, sv_attn, sv_gu, sv_lse;
     DevBuf xn2, act, dres, dy16, dtmp32, dqkv32, dqkv16, du, S32, dP32, P16, dS16, logits, dlog16, hsel, hsel_t, dhsel;
     DevBuf feats_aug, pre16, h16, proj16, mean16, embeds, dout16, dh32, vh32, vhb16, dl32, dvh;
     int64_t last_T = 0;
@@ -177,7 +177,7 @@ extern "C" void blim_train_destroy(blim_trainer* t) {
     if (!t) return;
     hipDeviceSynchronize();
     for (void* p : t->owned) hipFree(p);
-    DevBuf* bufs[] = {&t->sv_res, &t->sv_mid, &t->sv_xn1, &t->sv_qkv, &t->sv_attn, &t->sv_gu, &t->xn2, &t->act, &t->dres, &t->dy16, &t->dtmp32, &t->dqkv32, &t->dqkv16,
+    DevBuf* bufs[] = {&t->sv_res, &t->sv_mid, &t->sv_xn1, &t->sv_qkv, &t->sv_attn, &t->sv_gu, &t->sv_lse, &t->xn2, &t->act, &t->dres, &t->dy16, &t->dtmp32, &t->dqkv32, &t->dqkv16,
                       &t->du, &t->S32, &t->dP32, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->hsel_t, &t->dhsel, &t->feats_aug, &t->pre16, &t->h16, &t->proj16, &t->mean16,
                       &t->embeds, &t->dout16, &t->dh32, &t->vh32, &t->vhb16, &t->dl32, &t->dvh};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
@@ -298,6 +298,7 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
     TRY(ensure(t->sv_res, (size_t)(NL + 1) * T * H * 4)); TRY(ensure(t->sv_mid, (size_t)NL * T * H * 4));
     TRY(ensure_z(t->sv_xn1, (size_t)NL * T * Ha * 2)); TRY(ensure(t->sv_qkv, (size_t)NL * T * qn * 2)); TRY(ensure_z(t->sv_attn, (size_t)NL * T * Ha * 2));
     TRY(ensure(t->sv_gu, (size_t)NL * T * 2 * I * 2));
+    TRY(ensure(t->sv_lse, (size_t)NL * T * c.num_heads * 4));
     TRY(ensure(t->xn2, (size_t)T * H * 2)); TRY(ensure(t->act, (size_t)T * I * 2));
     float* res = (float*)t->sv_res.p; float* mid = (float*)t->sv_mid.p;
     t->last_T = T;
@@ -323,6 +324,7 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
             a.dtype = dt; a.qkv = (const bf16_t*)qkv; a.ldq = qn; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.key_visible = b->batch->key_visible; a.seq_start = b->batch->seq_start; a.seq_len = b->batch->seq_len; a.pfx_start = b->batch->pfx_start; a.pfx_len = b->batch->pfx_len;
             a.blk_seq = b->batch->blk_seq; a.blk_q0 = b->batch->blk_q0; a.n_blocks = b->batch->n_blocks; a.out = (bf16_t*)attn; a.ldo = Ha; a.scale = 0.08838834764831845f;
+            a.lse_out = (float*)t->sv_lse.p + (int64_t)li * T * c.num_heads;
             TRY(launch_attention(a, e->attn_tr, s));
         }
         LoraDownArgs o1; o1.n = 1; o1.A[0] = t->params + ad[3].offA; o1.A[1] = o1.A[2] = nullptr;
@@ -360,7 +362,7 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
     TRY(ensure(t->du, (size_t)T * 3 * 16 * 4));
     const int64_t Lm = attn_bwd_lm(b->max_seq_len);
     const size_t mats = (size_t)b->batch->n_seqs * c.num_heads * Lm * Lm;
-    TRY(ensure(t->S32, mats * 4)); TRY(ensure(t->dP32, mats * 4)); TRY(ensure(t->P16, mats * 2)); TRY(ensure(t->dS16, mats * 2));
+    TRY(ensure(t->S32, (size_t)T * c.num_heads * 4)); TRY(ensure(t->P16, mats * 2)); TRY(ensure(t->dS16, mats * 2));      // S32: the D = rowsum(dO o O) workspace
     float* dres = (float*)t->dres.p; uint16_t* dy16 = (uint16_t*)t->dy16.p; float* dtmp = (float*)t->dtmp32.p;
     float* dqkv32 = (float*)t->dqkv32.p; uint16_t* dqkv16 = (uint16_t*)t->dqkv16.p; float* du = (float*)t->du.p;
     uint16_t* dattn16 = (uint16_t*)t->xn2.p;      // [T, H] 16-bit scratch (the forward's normalised MLP input is not needed any more)
@@ -386,10 +388,11 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         {
             AttnBwdParams a;
             memset(&a, 0, sizeof(a));
-            a.dtype = dt; a.qkv = qkv; a.ldq = qn; a.dout = dattn16; a.ldo = H; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
+            a.dtype = dt; a.qkv = qkv; a.ldq = qn; a.dout = dattn16; a.ldo = H; a.o16 = attn; a.ldo16 = Ha; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
+            a.lse = (const float*)t->sv_lse.p + (int64_t)li * T * c.num_heads;
             a.key_visible = b->batch->key_visible; a.seq_start = b->batch->seq_start; a.seq_len = b->batch->seq_len; a.n_seqs = b->batch->n_seqs; a.max_len = b->max_seq_len;
-            a.scale = 0.08838834764831845f; a.S32 = (float*)t->S32.p; a.dP32 = (float*)t->dP32.p; a.P16 = (uint16_t*)t->P16.p; a.dS16 = (uint16_t*)t->dS16.p; a.dqkv = dqkv32;
-            TRY(launch_attention_bwd(a, s));
+            a.scale = 0.08838834764831845f; a.D = (float*)t->S32.p; a.P16 = (uint16_t*)t->P16.p; a.dS16 = (uint16_t*)t->dS16.p; a.dqkv = dqkv32;
+            TRY(launch_attention_bwd(a, T, s));
         }
         TRY(launch_rope_bwd(dqkv16, dqkv32, T, qn, (c.num_heads + c.num_kv_heads) * 128, b->batch->positions, e->rope_cos, e->rope_sin, c.max_positions, dt, s));
         for (int j = 0; j < 3; ++j)

@@ -77,16 +77,20 @@ struct AttnBwdParams {
     int64_t ldq;
     const uint16_t* dout;  // [T, ldo] d(attention output), q-head major
     int64_t ldo;
+    const uint16_t* o16;   // [T, ldo16] the forward's attention output
+    int64_t ldo16;
+    const float* lse;      // [T, num_heads] the forward's log-sum-exp per row (attention.hpp: lse_out)
     int num_heads, num_kv_heads;
     const uint8_t* key_visible;
     const int32_t* seq_start; const int32_t* seq_len;
     int n_seqs, max_len;   // max_len = longest sequence of the batch
     float scale;
-    float* S32; float* dP32; uint16_t* P16; uint16_t* dS16;   // [n_seqs][num_heads][Lm][Lm], Lm = round_up(max_len, 64)
+    float* D;              // workspace [T, num_heads]
+    uint16_t* P16; uint16_t* dS16;   // workspaces [n_seqs][num_heads][Lm][Lm], Lm = round_up(max_len, 64)
     float* dqkv;           // out: f32 [T, ldq] gradient w.r.t. the post-RoPE q | k | v
 };
 int64_t attn_bwd_lm(int max_len);
-int launch_attention_bwd(const AttnBwdParams& p, hipStream_t s);
+int launch_attention_bwd(const AttnBwdParams& p, int64_t n_tokens, hipStream_t s);
 
 // dqkv16[t, :] = 16-bit of the gradient w.r.t. the PRE-RoPE q | k | v: inverse rotation of the q/k columns (positions -> cos/sin tables [n_pos, 64])
 int launch_rope_bwd(uint16_t* out16, const float* dqkv, int64_t T, int qkv_n, int rope_cols, const int32_t* pos, const float* cosb, const float* sinb, int n_pos, int dtype, hipStream_t s);

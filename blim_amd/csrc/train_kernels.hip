@@ -600,10 +600,11 @@ int launch_feat_grad(uint16_t* dout16, const float* dres, const int32_t* src_ind
 }
 
 // ---------------------------------------------------------------------------- attention backward
-// P = softmax(scale * Q K^T + mask) is re-materialised per (sequence, head) as an [Lm, Lm] matrix (Lm = round_up(longest row, 64)),
-// then  dV = P^T dO,  dP = dO V^T,  dS = scale * P o (dP - rowsum(P o dP)),  dQ = dS K,  dK = dS^T Q  as five batched products on
-// 64x64 tiles (4 waves x one 32x32x16 MFMA accumulator each).  Training rows are a few hundred tokens: the matrices are a few
-// hundred MB per layer and the products ~0.4 % of the step's flops.
+// P = exp(scale * Q K^T - lse) is re-materialised per (sequence, head) as a 16-bit [Lm, Lm] matrix (Lm = round_up(longest row, 64); lse =
+// the forward kernel's log-sum-exp per row, so no softmax pass), then  dV = P^T dO,  dS = scale * P o (dO V^T - D) with
+// D = rowsum(dO o O) (formed in the product's epilogue),  dQ = dS K,  dK = dS^T Q: five batched products on 64x64 tiles (4 waves x one
+// 32x32x16 MFMA accumulator each).  Training rows are a few hundred tokens: P and dS are a few hundred MB per layer and the products
+// ~0.4 % of the step's flops.
 int64_t attn_bwd_lm(int max_len) { return (max_len + 63) / 64 * 64; }
 
 enum { AB_S = 0, AB_DP = 1, AB_DQ = 2, AB_DV = 3, AB_DK = 4 };
@@ -694,79 +695,53 @@ __global__ __launch_bounds__(256) void attn_bgemm_kernel(AttnBwdParams p, int Lm
             const int m = m0 + 32 * wm + 8 * g + 4 * (lane >> 5) + j;
             if (m >= L) continue;
             const float v = acc[4 * g + j];
-            if (MODE == AB_S) p.S32[mat + (int64_t)hb * Lm * Lm + (int64_t)m * Lm + n] = v * p.scale;
-            else if (MODE == AB_DP) p.dP32[mat + (int64_t)hb * Lm * Lm + (int64_t)m * Lm + n] = v;
-            else if (MODE == AB_DQ) p.dqkv[(t0 + m) * p.ldq + hb * 128 + n] = v;
+            if (MODE == AB_S) {            // P = exp(scale * q.k - lse) on the visible keys j <= i (the forward's softmax, re-materialised)
+                const bool vis = n <= m && n < L && p.key_visible[t0 + n];
+                const float pv = vis ? __expf(v * p.scale - p.lse[(t0 + m) * nh + hb]) : 0.f;
+                p.P16[mat + (int64_t)hb * Lm * Lm + (int64_t)m * Lm + n] = to16<DT>(pv);
+            } else if (MODE == AB_DP) {    // dS = scale * P o (dP - D),  D = rowsum(dO o O) = rowsum(P o dP)
+                const int64_t at = mat + (int64_t)hb * Lm * Lm + (int64_t)m * Lm + n;
+                const float pv = from16<DT>(p.P16[at]);
+                p.dS16[at] = to16<DT>(p.scale * pv * (v - p.D[(t0 + m) * nh + hb]));
+            } else if (MODE == AB_DQ) p.dqkv[(t0 + m) * p.ldq + hb * 128 + n] = v;
             else if (MODE == AB_DK) p.dqkv[(t0 + m) * p.ldq + (nh + kvh) * 128 + n] = v;
             else p.dqkv[(t0 + m) * p.ldq + (nh + nkv + kvh) * 128 + n] = v;
         }
 }
 
-// one wave per (row i, head, sequence), 4 rows per workgroup: P16[i][:] = softmax over visible keys j <= i, zeros up to the end of the
-// diagonal 64-column tile (the products below never read a tile above the diagonal)
+// D[t, h] = sum_d dO[t, h, d] * O[t, h, d]  (= rowsum(P o dP)): one wave per (token, head), 4 per workgroup
 template <int DT>
-__global__ __launch_bounds__(256) void attn_softmax_rows_kernel(AttnBwdParams p, int Lm) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, s = blockIdx.z;
-    const int L = p.seq_len[s];
-    if (i >= L) return;
-    const int64_t t0 = p.seq_start[s];
-    const int64_t off = (((int64_t)s * p.num_heads + h) * Lm + i) * Lm;
-    const float* S = p.S32 + off;
-    uint16_t* P = p.P16 + off;
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(float* D, const uint16_t* dout, int64_t ldo, const uint16_t* o16, int64_t ldo16, int64_t n_pairs, int nh) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_pairs) return;
+    const int64_t t = i / nh; const int h = (int)(i - t * nh);
     const int lane = threadIdx.x & 63;
-    const int jend = (i / 64 + 1) * 64;
-    float m = -3.0e38f;
-    for (int j = lane; j <= i; j += 64) if (p.key_visible[t0 + j]) m = fmaxf(m, S[j]);
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int j = lane; j <= i; j += 64) if (p.key_visible[t0 + j]) sum += __expf(S[j] - m);
-    sum = wave_sum(sum);
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    for (int j = lane; j < jend; j += 64) {
-        const float v = (j <= i && p.key_visible[t0 + j]) ? __expf(S[j] - m) * inv : 0.f;
-        P[j] = to16<DT>(v);
-    }
-}
-// dS16[i][:] = scale * P o (dP - sum_j P dP)
-template <int DT>
-__global__ __launch_bounds__(256) void attn_ds_rows_kernel(AttnBwdParams p, int Lm) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, s = blockIdx.z;
-    const int L = p.seq_len[s];
-    if (i >= L) return;
-    const int64_t off = (((int64_t)s * p.num_heads + h) * Lm + i) * Lm;
-    const float* dP = p.dP32 + off;
-    const uint16_t* P = p.P16 + off;
-    uint16_t* dS = p.dS16 + off;
-    const int lane = threadIdx.x & 63;
-    const int jend = (i / 64 + 1) * 64;
-    float D = 0.f;
-    for (int j = lane; j <= i; j += 64) D += from16<DT>(P[j]) * dP[j];
-    D = wave_sum(D);
-    for (int j = lane; j < jend; j += 64) {
-        const float v = j <= i ? p.scale * from16<DT>(P[j]) * (dP[j] - D) : 0.f;
-        dS[j] = to16<DT>(v);
-    }
+    const uint32_t a = *(const uint32_t*)(dout + t * ldo + h * 128 + 2 * lane), b = *(const uint32_t*)(o16 + t * ldo16 + h * 128 + 2 * lane);
+    float v = from16<DT>((uint16_t)(a & 0xFFFF)) * from16<DT>((uint16_t)(b & 0xFFFF)) + from16<DT>((uint16_t)(a >> 16)) * from16<DT>((uint16_t)(b >> 16));
+    v = wave_sum(v);
+    if (lane == 0) D[i] = v;
 }
 
 template <int DT>
-static int attention_bwd_t(const AttnBwdParams& p, hipStream_t s) {
+static int attention_bwd_t(const AttnBwdParams& p, int64_t n_tokens, hipStream_t s) {
     const int Lm = (int)attn_bwd_lm(p.max_len);
     const int nt = Lm / 64;
     const dim3 blk(256);
+    const int64_t n_pairs = n_tokens * p.num_heads;
+    hipLaunchKernelGGL(attn_rowdot_kernel<DT>, dim3((unsigned)((n_pairs + 3) / 4)), blk, 0, s, p.D, p.dout, p.ldo, p.o16, p.ldo16, n_pairs, p.num_heads);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_S>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
-    hipLaunchKernelGGL(attn_softmax_rows_kernel<DT>, dim3((p.max_len + 3) / 4, p.num_heads, p.n_seqs), dim3(256), 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DP>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
-    hipLaunchKernelGGL(attn_ds_rows_kernel<DT>, dim3((p.max_len + 3) / 4, p.num_heads, p.n_seqs), dim3(256), 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DQ>), dim3(2, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DV>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DK>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
     LAUNCH_CHECK();
     return BLIM_OK;
 }
-int launch_attention_bwd(const AttnBwdParams& p, hipStream_t s) {
-    ARG_CHECK(p.n_seqs > 0 && p.max_len > 0 && p.num_heads % p.num_kv_heads == 0 && p.ldq % 8 == 0 && p.ldo % 8 == 0);
-    if (p.dtype == DT_F16) return attention_bwd_t<DT_F16>(p, s);
-    return attention_bwd_t<DT_BF16>(p, s);
+int launch_attention_bwd(const AttnBwdParams& p, int64_t n_tokens, hipStream_t s) {
+    ARG_CHECK(p.n_seqs > 0 && p.max_len > 0 && p.num_heads % p.num_kv_heads == 0 && p.ldq % 8 == 0 && p.ldo % 8 == 0 && p.ldo16 % 2 == 0);
+    ARG_CHECK(p.lse && p.D && p.o16 && p.P16 && p.dS16 && n_tokens > 0);
+    if (p.dtype == DT_F16) return attention_bwd_t<DT_F16>(p, n_tokens, s);
+    return attention_bwd_t<DT_BF16>(p, n_tokens, s);
 }
 
 // ---------------------------------------------------------------------------- RoPE backward
