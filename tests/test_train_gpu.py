@@ -180,3 +180,58 @@ def test_lora_dropout_mask_is_consistent_forward_and_backward():
     lv0, _ = t0.forward_backward(collate(prob, sel), seed=seed)
     assert abs(lv0 - lv) > 1e-4
     t0.close(); t.close(); eng.close()
+
+
+@pytest.mark.parametrize("r", [4, 16])
+def test_other_ranks_match_the_oracle(r):
+    """--lora_r other than 8 (the kernels have 8- and 16-wide register variants; r = 4 runs in the 8-wide one): against oracle/train_oracle.py."""
+    import torch
+    from blim_amd.engine import Engine
+    from blim_amd.training import Trainer
+    from oracle.blim_oracle import OracleConfig
+    from oracle.gen_golden_train import adapter_values
+    from oracle.train_oracle import TrainOracle
+    spec, dims, weights, prob, _ = _case("train_tiny")
+    tr = adapter_values(dims, r, 77)
+    tr["visual_head"] = weights["visual_head"].copy()
+    tr = {n: tr[n] for n in lora.trainable_names(dims)}
+    sel = [0, 1, 4]
+    eng = Engine(dims, max_positions=1024, dtype="f16")
+    eng.load_weights(weights)
+    t = Trainer(eng, lora_r=r, lora_alpha=16.0, lora_dropout=0.0, trainable=tr)
+    t.set_video_vocab(torch.from_numpy(prob.video_vocab))
+    lv, lt = t.forward_backward(collate(prob, sel))
+    grads = t.state("grads")
+    orc = TrainOracle(OracleConfig(**spec["dims"]), weights, tr, r, 16.0)
+    ov, ot, og = orc.step_grads([prob.vtg_ids[i] for i in sel], [prob.vtg_labels[i] for i in sel], [prob.tvg_ids[i] for i in sel], [prob.tvg_labels[i] for i in sel],
+                                [prob.video[i] for i in sel], prob.video_vocab, prob.tvg_video_labels[sel])
+    assert abs(lv - ov) <= 1e-3 * abs(ov) and abs(lt - ot) <= 1e-3 * abs(ot)
+    worst = max(float(np.abs(grads[n] / t.scaler.scale - og[n]).max() / max(np.abs(og[n]).max(), 1e-30)) for n in lora.trainable_names(dims))
+    print(f"[r={r}] worst gradient deviation {worst:.2e}")
+    assert worst <= GRAD_RTOL["f16"]
+    t.close(); eng.close()
+
+
+def test_gradient_accumulation_equals_the_mean_of_micro_batches():
+    """--accum_iter 2 (training_utils.py:87-91): two micro-batches accumulated with loss / 2 give the mean of their separate gradients."""
+    import torch
+    from blim_amd.engine import Engine
+    from blim_amd.training import Trainer
+    spec, dims, weights, prob, tr = _case("train_tiny")
+    eng = Engine(dims, max_positions=1024, dtype="f16")
+    eng.load_weights(weights)
+    t = Trainer(eng, lora_r=spec["r"], lora_alpha=spec["alpha"], lora_dropout=0.0, trainable=tr)
+    t.set_video_vocab(torch.from_numpy(prob.video_vocab))
+    a, b = collate(prob, [0, 1]), collate(prob, [2, 3, 4])
+    sep = []
+    for d in (a, b):
+        t.zero_grad(); t.forward_backward(d); sep.append({n: g.copy() for n, g in t.state("grads").items()})
+    t.zero_grad()
+    t.forward_backward(a, accum_iter=2); t.forward_backward(b, accum_iter=2)
+    acc = t.state("grads")
+    for n in lora.trainable_names(dims):
+        want = 0.5 * (sep[0][n] + sep[1][n])
+        assert np.abs(acc[n] - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-30), n      # 16-bit gradients at half the scale: rounding only
+    st = t.optimizer_step(1e-3)
+    assert st["skipped"] == 0.0 and np.isfinite(st["grad_norm"])
+    t.close(); eng.close()
