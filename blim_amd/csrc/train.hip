@@ -4,9 +4,10 @@
 // weight, [W | B | 0] with 64 extra K columns, against activations [x | alpha/r * A drop(x) | 0] -- the rank-r update rides in the
 // same MFMA accumulation as the base product, before bias / RoPE, at +1.8 % of the K loop; (2) activations the backward needs are
 // kept per layer (288 GB of HBM: no recomputation): the f32 residual stream before each sub-block, the normalised QKV input with
-// its adapter columns, q|k|v after RoPE, the attention output, and the gate|up pre-activations.
+// its adapter columns, q|k|v after RoPE, the attention output and its rows' log-sum-exp, and the gate|up pre-activations.
 // Backward = input-gradient GEMMs on the same 256x256 MFMA kernel against TRANSPOSED copies of the frozen weights (built once),
-// rank-r gradient kernels for the adapters, and the attention backward of train_kernels.hip.  Gradients w.r.t. 16-bit activations
+// rank-r gradient kernels for the adapters, and the attention backward of train_kernels.hip (P re-materialised from the saved
+// log-sum-exp).  Gradients w.r.t. 16-bit activations
 // travel as the engine's 16-bit type scaled by the AMP loss scale (util/misc.py:232-252 NativeScaler), the residual-stream gradient
 // stays f32 like the forward's residual stream.
 #include <math.h>
@@ -63,7 +64,7 @@ struct blim_trainer {
     std::vector<void*> owned;
     // saved activations of the last forward (per layer, strided by tokens) and workspaces
     DevBuf sv_res, sv_mid, sv_xn1, sv_qkv, sv_attn, sv_gu, sv_lse;
-    DevBuf xn2, act, dres, dy16, dtmp32, dqkv32, dqkv16, du, S32, dP32, P16, dS16, logits, dlog16, hsel, hsel_t, dhsel;
+    DevBuf xn2, act, dres, dy16, dtmp32, dqkv32, dqkv16, du, attn_D, P16, dS16, logits, dlog16, hsel, hsel_t, dhsel;
     DevBuf feats_aug, pre16, h16, proj16, mean16, embeds, dout16, dh32, vh32, vhb16, dl32, dvh;
     int64_t last_T = 0;
 };
@@ -178,7 +179,7 @@ extern "C" void blim_train_destroy(blim_trainer* t) {
     hipDeviceSynchronize();
     for (void* p : t->owned) hipFree(p);
     DevBuf* bufs[] = {&t->sv_res, &t->sv_mid, &t->sv_xn1, &t->sv_qkv, &t->sv_attn, &t->sv_gu, &t->sv_lse, &t->xn2, &t->act, &t->dres, &t->dy16, &t->dtmp32, &t->dqkv32, &t->dqkv16,
-                      &t->du, &t->S32, &t->dP32, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->hsel_t, &t->dhsel, &t->feats_aug, &t->pre16, &t->h16, &t->proj16, &t->mean16,
+                      &t->du, &t->attn_D, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->hsel_t, &t->dhsel, &t->feats_aug, &t->pre16, &t->h16, &t->proj16, &t->mean16,
                       &t->embeds, &t->dout16, &t->dh32, &t->vh32, &t->vhb16, &t->dl32, &t->dvh};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     delete t;
@@ -362,7 +363,7 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
     TRY(ensure(t->du, (size_t)T * 3 * 16 * 4));
     const int64_t Lm = attn_bwd_lm(b->max_seq_len);
     const size_t mats = (size_t)b->batch->n_seqs * c.num_heads * Lm * Lm;
-    TRY(ensure(t->S32, (size_t)T * c.num_heads * 4)); TRY(ensure(t->P16, mats * 2)); TRY(ensure(t->dS16, mats * 2));      // S32: the D = rowsum(dO o O) workspace
+    TRY(ensure(t->attn_D, (size_t)T * c.num_heads * 4)); TRY(ensure(t->P16, mats * 2)); TRY(ensure(t->dS16, mats * 2));
     float* dres = (float*)t->dres.p; uint16_t* dy16 = (uint16_t*)t->dy16.p; float* dtmp = (float*)t->dtmp32.p;
     float* dqkv32 = (float*)t->dqkv32.p; uint16_t* dqkv16 = (uint16_t*)t->dqkv16.p; float* du = (float*)t->du.p;
     uint16_t* dattn16 = (uint16_t*)t->xn2.p;      // [T, H] 16-bit scratch (the forward's normalised MLP input is not needed any more)
@@ -391,7 +392,7 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
             a.dtype = dt; a.qkv = qkv; a.ldq = qn; a.dout = dattn16; a.ldo = H; a.o16 = attn; a.ldo16 = Ha; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.lse = (const float*)t->sv_lse.p + (int64_t)li * T * c.num_heads;
             a.key_visible = b->batch->key_visible; a.seq_start = b->batch->seq_start; a.seq_len = b->batch->seq_len; a.n_seqs = b->batch->n_seqs; a.max_len = b->max_seq_len;
-            a.scale = 0.08838834764831845f; a.D = (float*)t->S32.p; a.P16 = (uint16_t*)t->P16.p; a.dS16 = (uint16_t*)t->dS16.p; a.dqkv = dqkv32;
+            a.scale = 0.08838834764831845f; a.D = (float*)t->attn_D.p; a.P16 = (uint16_t*)t->P16.p; a.dS16 = (uint16_t*)t->dS16.p; a.dqkv = dqkv32;
             TRY(launch_attention_bwd(a, T, s));
         }
         TRY(launch_rope_bwd(dqkv16, dqkv32, T, qn, (c.num_heads + c.num_kv_heads) * 128, b->batch->positions, e->rope_cos, e->rope_sin, c.max_positions, dt, s));
