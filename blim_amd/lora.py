@@ -63,7 +63,8 @@ def resume_key(name: str) -> str:
 
 def init_trainable(dims: ModelDims, r: int, seed: int, visual_head: np.ndarray = None) -> Dict[str, np.ndarray]:
     """peft's LoRA init: A ~ kaiming_uniform(a = sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)), B = 0; tvg_mlp's adapters are copies of mlp's
-    (deepcopy, main.py:98).  visual_head keeps the checkpoint's values (zeros when the checkpoint has none)."""
+    (deepcopy, main.py:98).  visual_head keeps the checkpoint's values; when the checkpoint has none (the public VideoChat-Flash checkpoint
+    predates the head, modeling_videochat_flash.py:584) it is drawn as from_pretrained() initialises a missing nn.Linear: N(0, initializer_range = 0.02)."""
     rng = np.random.default_rng(seed)
     out = {}
     for n, s in trainable_shapes(dims, r).items():
@@ -73,7 +74,7 @@ def init_trainable(dims: ModelDims, r: int, seed: int, visual_head: np.ndarray =
         elif n.endswith(":B"):
             out[n] = np.zeros(s, np.float32)
         else:
-            out[n] = np.zeros(s, np.float32) if visual_head is None else np.asarray(visual_head, np.float32).copy()
+            out[n] = (rng.standard_normal(s) * 0.02).astype(np.float32) if visual_head is None else np.asarray(visual_head, np.float32).copy()
     for i in (0, 2):
         for k in ("A", "B"):
             out[f"tvg_mlp.{i}.w:{k}"] = out[f"mlp.{i}.w:{k}"].copy()

@@ -188,8 +188,13 @@ def train_loop(args, model, train_loader, val_loader, tokenizer, device, rank: i
     from .modeling import DDPLike
     from .training import Trainer, save_model, train_one_epoch
     from .training_utils import val_one_epoch
+    vh = None
+    if not args.synthetic:                                                                           # visual_head of the base checkpoint, when it has one
+        from .checkpoint import open_base_checkpoint
+        keys, get = open_base_checkpoint(args.model_path)
+        vh = get("visual_head.weight") if "visual_head.weight" in keys else None
     trainer = Trainer(model.engine, lora_r=args.lora_r, lora_alpha=float(args.lora_alpha), lora_dropout=args.lora_drop, seed=args.seed,
-                      weight_decay=args.weight_decay)                                              # seed: same adapters on every rank (DDP broadcasts rank 0's)
+                      weight_decay=args.weight_decay, visual_head=vh)                              # seed: same adapters on every rank (DDP broadcasts rank 0's)
     if args.resume:                                                                                  # util/misc.py:303-316
         ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
         trainer.load_checkpoint_state(ckpt)

@@ -235,3 +235,55 @@ def test_gradient_accumulation_equals_the_mean_of_micro_batches():
     st = t.optimizer_step(1e-3)
     assert st["skipped"] == 0.0 and np.isfinite(st["grad_norm"])
     t.close(); eng.close()
+
+
+def test_full_size_training_properties_7b():
+    """The real 7B configuration (28 layers, reference-shaped rows) through size-independent properties: with peft's initialisation
+    (B = 0) the adapter forward is the base model, so (1) the VTG loss equals what the SCORING path gives for the same rows, (2) every
+    dA is exactly zero while every dB is finite and non-zero; (3) AdamW steps on the batch lower both losses; (4) after the merge the
+    scoring path reproduces the trainer's loss."""
+    import torch
+    from blim_amd import retrieval_utils as RU
+    from blim_amd.modeling import BlimModel
+    from blim_amd.training import Trainer
+    dims = synth.ModelDims()
+    model = BlimModel(dims, max_positions=1024, dtype="f16")
+    eng = model.engine
+    eng.init_synthetic_weights(0)
+    prob = synth.make_problem(31, 4, dims, tok_per_clip=64, text_len=(8, 24), fast_video=True)
+    model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    data = collate(prob, [0, 1, 2, 3])
+    dev = eng.device
+
+    def scoring_loss():
+        model.clear_cache()
+        (_, _, (m, _), _, emb, lab) = model.prepare_inputs_labels_for_multimodal(data["vtg_ids"].to(dev), None, data["vtg_masks"].to(dev), None, data["vtg_labels"].to(dev),
+                                                                                 [v.to(dev) for v in data["video"]], ["video"] * 4, image_sizes=None, video_feature=True, cpn=True)
+        score = RU.vtg_criterion(model(inputs_embeds=emb, attention_mask=m).logits, lab).float().cpu().numpy()
+        ntok = (lab[:, 1:] != -100).sum(1).cpu().numpy()
+        return float(-(score * ntok).sum() / ntok.sum())
+
+    base = scoring_loss()
+    t = Trainer(eng, lora_r=8, lora_alpha=32.0, lora_dropout=0.0, seed=5)                  # visual_head ~ N(0, 0.02): no head in the "checkpoint"
+    t.set_video_vocab(torch.from_numpy(prob.video_vocab))
+    lv0, lt0 = t.forward_backward(data)
+    print(f"[7B] vtg loss {lv0:.5f} (scoring path {base:.5f}), tvg loss {lt0:.5f}")
+    assert abs(lv0 - base) <= 1e-3 * abs(base)
+    g = t.state("grads")
+    for n, a in g.items():
+        assert np.isfinite(a).all(), n
+        if n.endswith(":A"):
+            assert not a.any(), n                                   # dA = du^T x with du = s * dy . B = 0
+        elif n.endswith(":B") and not n.startswith("tvg_mlp") and not n.startswith("mlp"):
+            assert np.abs(a).max() > 0, n
+    for _ in range(3):
+        st = t.optimizer_step(2e-4)
+        assert st["skipped"] == 0.0
+        t.zero_grad()
+        lv1, lt1 = t.forward_backward(data)
+    print(f"[7B] after 3 AdamW steps: vtg {lv1:.5f}, tvg {lt1:.5f}")
+    assert lv1 < lv0 and lt1 < lt0
+    t.merge_into_engine()
+    merged = scoring_loss()
+    assert abs(merged - lv1) <= 2e-3 * abs(lv1), (merged, lv1)
+    t.close(); eng.close()

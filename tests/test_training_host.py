@@ -86,6 +86,8 @@ def test_flat_layout_and_init():
     a = init["layers.0.q_proj.w:A"]
     assert a.shape == (8, 256) and np.abs(a).max() <= 1 / math.sqrt(256) and a.std() > 0.5 / math.sqrt(3 * 256)
     assert np.array_equal(init["tvg_mlp.0.w:A"], init["mlp.0.w:A"])                      # deepcopy, main.py:98
+    assert abs(init["visual_head"].std() - 0.02) < 2e-3                                  # no head in the checkpoint: N(0, 0.02) like a missing nn.Linear
+    assert np.array_equal(lora.init_trainable(DIMS, 8, seed=3, visual_head=np.ones((64, 256), np.float32))["visual_head"], np.ones((64, 256), np.float32))
     n_trainable = sum(int(np.prod(s)) for s in lora.trainable_shapes(synth.ModelDims(), 8).values())
     # Qwen2-7B, r = 8: 28 x (q 57,344 + k 32,768 + v 32,768 + o 57,344) + lm_head 1,245,184 + projectors 2 x (36,864 + 57,344) + visual_head 3,670,016
     assert n_trainable == 28 * 180_224 + 1_245_184 + 2 * 94_208 + 3_670_016
