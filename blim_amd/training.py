@@ -381,7 +381,11 @@ def train_one_epoch(trainer: Trainer, data_loader, epoch: int, args, world_size:
     print_freq = max(1, int(n_iter / 4))                                              # :46
     sums = {"loss": 0.0, "vtg_loss": 0.0, "tvg_loss": 0.0}
     lr, seen = 0.0, 0
-    seed_of = lambda i: (epoch * n_iter + i) * 2 + 12345
+    rank = 0
+    if world_size > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank()
+    seed_of = lambda i: ((epoch * n_iter + i) * 2 + 12345) * 1009 + rank          # dropout masks differ per step and per rank (main.py:87: seed + rank)
     batches = iter(data_loader)
     nxt = trainer.stage(next(batches), seed_of(0)) if n_iter else None
     for it in range(n_iter):
