@@ -176,3 +176,25 @@ def test_two_ranks_train_with_averaged_gradients(tmp_path):
     logs = [json.loads(l) for l in open(os.path.join(out, "log.txt")) if l.startswith("{")]
     assert [l["epoch"] for l in logs] == [0, 1] and all(np.isfinite(l["train_loss"]) for l in logs)
     assert os.path.exists(os.path.join(out, "epoch1.pth"))
+
+
+def test_training_resumes_from_an_epoch_checkpoint(tmp_path, monkeypatch):
+    """util/misc.py:303-316 (load_model): adapters, AdamW moments, step count, loss scale and the epoch counter come back from
+    `epoch0.pth`; the resumed second epoch ends where the uninterrupted run ends (up to the order of floating-point atomics)."""
+    ck = _tree(str(tmp_path))
+    fname, annos = __import__("dataset_fixture").annotations("MSRVTT")
+    json.dump([a for i, a in enumerate(annos) if i != 2] * 2, open(os.path.join(str(tmp_path), "data", "MSRVTT", "msrvtt_ret_train.json"), "w"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(driver, "load_tokenizer", lambda path: StubTokenizer())
+    common = ["--dataset", "MSRVTT", "--model_path", ck, "--topk", "4", "--batch_size_eval", "3", "--num_workers", "0", "--lr", "1e-3", "--warmup_epochs", "1",
+              "--batch_size", "4", "--lora_drop", "0.05", "--seed", "1"]
+    _run(common + ["--epochs", "2", "--output_dir", str(tmp_path / "a")])
+    _run(common + ["--epochs", "1", "--output_dir", str(tmp_path / "b")])
+    _run(common + ["--epochs", "2", "--output_dir", str(tmp_path / "b"), "--resume", str(tmp_path / "b" / "epoch0.pth")])
+    A = torch.load(str(tmp_path / "a" / "epoch1.pth"), map_location="cpu", weights_only=False)
+    B = torch.load(str(tmp_path / "b" / "epoch1.pth"), map_location="cpu", weights_only=False)
+    assert A["epoch"] == B["epoch"] == 1 and A["optimizer"]["step"] == B["optimizer"]["step"] == 6
+    for k in A["model"]:
+        a, b = A["model"][k].float(), B["model"][k].float()
+        d = (a - b).abs()
+        assert d.median() <= 1e-6 and d.max() <= 3e-4, (k, d.median().item(), d.max().item())   # Adam normalises: an element with ~zero gradient moves by O(lr) on atomics' rounding order
