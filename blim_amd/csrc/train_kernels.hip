@@ -740,6 +740,7 @@ static int attention_bwd_t(const AttnBwdParams& p, int64_t n_tokens, hipStream_t
 int launch_attention_bwd(const AttnBwdParams& p, int64_t n_tokens, hipStream_t s) {
     ARG_CHECK(p.n_seqs > 0 && p.max_len > 0 && p.num_heads % p.num_kv_heads == 0 && p.ldq % 8 == 0 && p.ldo % 8 == 0 && p.ldo16 % 2 == 0);
     ARG_CHECK(p.lse && p.D && p.o16 && p.P16 && p.dS16 && n_tokens > 0);
+    if ((int64_t)p.n_seqs * p.num_heads > 65535) { blim_set_error("attention backward: %d sequences x %d heads exceed the grid's z range; split the batch", p.n_seqs, p.num_heads); return BLIM_ERR_ARG; }
     if (p.dtype == DT_F16) return attention_bwd_t<DT_F16>(p, n_tokens, s);
     return attention_bwd_t<DT_BF16>(p, n_tokens, s);
 }
