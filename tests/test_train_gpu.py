@@ -287,3 +287,39 @@ def test_full_size_training_properties_7b():
     merged = scoring_loss()
     assert abs(merged - lv1) <= 2e-3 * abs(lv1), (merged, lv1)
     t.close(); eng.close()
+
+
+@pytest.mark.parametrize("heads,kv,layers,tok,text", [(4, 2, 2, 16, (20, 70)), (4, 1, 1, 24, (1, 40)), (8, 8, 1, 8, (30, 100))])
+def test_training_shapes_against_the_oracle(heads, kv, layers, tok, text):
+    """Other head groupings (GQA 2:1, 4:1, MHA) and rows whose lengths straddle the 32 / 64 / 128-token tile edges of the attention
+    kernels (32 - 96 video tokens + 1 - 100 caption tokens), ragged inside one batch: losses and every gradient against
+    oracle/train_oracle.py (itself pinned by the reference's autograd fixtures)."""
+    import torch
+    from blim_amd.engine import Engine
+    from blim_amd.training import Trainer
+    from oracle.blim_oracle import OracleConfig
+    from oracle.gen_golden_train import adapter_values
+    from oracle.train_oracle import TrainOracle
+    d = dict(vocab_size=151700, hidden_size=128 * heads, intermediate_size=256 * heads, num_layers=layers, num_heads=heads, num_kv_heads=kv, mm_hidden_size=64)
+    dims = synth.ModelDims(**d)
+    weights = synth.synthetic_weights(dims, 40 + heads)
+    prob = synth.make_problem(50 + kv, 5, dims, tok_per_clip=tok, text_len=text)
+    tr = adapter_values(dims, 8, 60 + layers)
+    tr["visual_head"] = weights["visual_head"].copy()
+    tr = {n: tr[n] for n in lora.trainable_names(dims)}
+    sel = [0, 1, 2, 3, 4]
+    eng = Engine(dims, max_positions=1024, dtype="f16")
+    eng.load_weights(weights)
+    t = Trainer(eng, lora_r=8, lora_alpha=32.0, lora_dropout=0.0, trainable=tr)
+    t.set_video_vocab(torch.from_numpy(prob.video_vocab))
+    lv, lt = t.forward_backward(collate(prob, sel))
+    grads = t.state("grads")
+    orc = TrainOracle(OracleConfig(**d), weights, tr, 8, 32.0)
+    ov, ot, og = orc.step_grads([prob.vtg_ids[i] for i in sel], [prob.vtg_labels[i] for i in sel], [prob.tvg_ids[i] for i in sel], [prob.tvg_labels[i] for i in sel],
+                                [prob.video[i] for i in sel], prob.video_vocab, prob.tvg_video_labels[sel])
+    lens = sorted(len(prob.vtg_ids[i]) + dims.num_clips * tok - 1 for i in sel)
+    worst = max(float(np.abs(grads[n] / t.scaler.scale - og[n]).max() / max(np.abs(og[n]).max(), 1e-30)) for n in lora.trainable_names(dims))
+    print(f"[heads {heads}/{kv}, {layers} layer(s)] VTG row lengths {lens}: vtg {lv:.5f} ({ov:.5f}) tvg {lt:.5f} ({ot:.5f}), worst gradient deviation {worst:.2e}")
+    assert abs(lv - ov) <= 1e-3 * abs(ov) and abs(lt - ot) <= 1e-3 * abs(ot)
+    assert worst <= GRAD_RTOL["f16"]
+    t.close(); eng.close()
