@@ -396,13 +396,17 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
             TRY(launch_attention_bwd(a, T, s));
         }
         TRY(launch_rope_bwd(dqkv16, dqkv32, T, qn, (c.num_heads + c.num_kv_heads) * 128, b->batch->positions, e->rope_cos, e->rope_sin, c.max_positions, dt, s));
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j)      // (a single pass over x for the three dA was tried: slower, 48 accumulators per lane)
             TRY(lora_backward(t, ad[j], dqkv16 + qcols[j], qn, xn1, Ha, H, j * r, T, du + (int64_t)j * T * r, b->dropout_seed, 8 * li + j, s));
         { GemmParams p = gp(dt, dqkv16, qn, x.wqkvT, T, H, qn, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }              // d n1 (base path)
         {   // dres = d x_in; the three adapters' input gradients join dtmp inside the RMSNorm backward
             LoraDxArgs a3; a3.n = 3;
             for (int j = 0; j < 3; ++j) { a3.du[j] = du + (int64_t)j * T * r; a3.A[j] = t->params + ad[j].offA; }
-            TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, li > 0 ? dy16 : nullptr, dt, s, &a3, r, t->p_drop, b->dropout_seed, 8 * li));
+            if (H <= 4096) TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, li > 0 ? dy16 : nullptr, dt, s, &a3, r, t->p_drop, b->dropout_seed, 8 * li));
+            else {
+                TRY(launch_lora_dx(dtmp, H, a3, T, H, r, t->p_drop, b->dropout_seed, 8 * li, s));
+                TRY(launch_rmsnorm_bwd(dres, dtmp, x_in, nullptr, T, H, l.norm1, c.rms_eps, 1, li > 0 ? dy16 : nullptr, dt, s));
+            }
         }
     }
     return BLIM_OK;

@@ -105,60 +105,72 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {   // red: 
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// one wave = 4 tokens (16 per workgroup): lanes stride over K in 16-byte chunks and apply every A chunk they load to all four
-// tokens (A is [r, K] f32 = 114 KB at 7B: re-reading it per token was the kernel's whole cost), r x 4 wave reductions, no LDS
+// one wave = 4 tokens (16 per workgroup): lanes stride over K in 16-byte chunks and apply every A chunk they load to the four tokens
+// (A is [r, K] f32 = 114 KB at 7B: re-reading it per token was the first version's whole cost), r x 4 wave reductions, no LDS
 #define DOWN_TPW 4
-template <int DT, int R>
-__global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int64_t T, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site) {
+template <int DT, int R, int NSEG>
+__global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int64_t T, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int col0) {
     const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * DOWN_TPW;
     if (t0 >= T) return;
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y;
-    const float* A = a.A[seg];
-    float acc[DOWN_TPW][R];
+    float acc[NSEG][DOWN_TPW][R];
 #pragma unroll
-    for (int q = 0; q < DOWN_TPW; ++q)
+    for (int sg = 0; sg < NSEG; ++sg)
 #pragma unroll
-        for (int j = 0; j < R; ++j) acc[q][j] = 0.f;
+        for (int q = 0; q < DOWN_TPW; ++q)
+#pragma unroll
+            for (int j = 0; j < R; ++j) acc[sg][q][j] = 0.f;
     for (int k = lane * 8; k < K; k += 64 * 8) {
         float xv[DOWN_TPW][8];
+        int64_t tq[DOWN_TPW];
 #pragma unroll
         for (int q = 0; q < DOWN_TPW; ++q) {
-            const int64_t t = min(t0 + q, T - 1);
-            const uint4 raw = *(const uint4*)(x16 + t * ldx + k);
+            tq[q] = min(t0 + q, T - 1);
+            const uint4 raw = *(const uint4*)(x16 + tq[q] * ldx + k);
             const uint16_t* h = (const uint16_t*)&raw;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xv[q][e] = from16<DT>(h[e]);
-                if (drop_p > 0.f) xv[q][e] *= drop_mult(seed, site + seg, (uint64_t)t * K + k + e, drop_p);
-            }
+            for (int e = 0; e < 8; ++e) xv[q][e] = from16<DT>(h[e]);
         }
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            if (j < r) {
-                const float4 a0 = *(const float4*)(A + (int64_t)j * K + k);
-                const float4 a1 = *(const float4*)(A + (int64_t)j * K + k + 4);
+        for (int sg = 0; sg < NSEG; ++sg) {
+            float xm[DOWN_TPW][8];
 #pragma unroll
-                for (int q = 0; q < DOWN_TPW; ++q)
-                    acc[q][j] += xv[q][0] * a0.x + xv[q][1] * a0.y + xv[q][2] * a0.z + xv[q][3] * a0.w + xv[q][4] * a1.x + xv[q][5] * a1.y + xv[q][6] * a1.z + xv[q][7] * a1.w;
+            for (int q = 0; q < DOWN_TPW; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xm[q][e] = drop_p > 0.f ? xv[q][e] * drop_mult(seed, site + sg, (uint64_t)tq[q] * K + k + e, drop_p) : xv[q][e];
+            const float* A = a.A[sg];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (j < r) {
+                    const float4 a0 = *(const float4*)(A + (int64_t)j * K + k);
+                    const float4 a1 = *(const float4*)(A + (int64_t)j * K + k + 4);
+#pragma unroll
+                    for (int q = 0; q < DOWN_TPW; ++q)
+                        acc[sg][q][j] += xm[q][0] * a0.x + xm[q][1] * a0.y + xm[q][2] * a0.z + xm[q][3] * a0.w + xm[q][4] * a1.x + xm[q][5] * a1.y + xm[q][6] * a1.z + xm[q][7] * a1.w;
+                }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < DOWN_TPW; ++q)
+    for (int sg = 0; sg < NSEG; ++sg)
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            if (j < r) {
-                const float v = wave_sum(acc[q][j]);
-                if (lane == 0 && t0 + q < T) x16[(t0 + q) * ldx + K + seg * r + j] = to16<DT>(scale * v);
+        for (int q = 0; q < DOWN_TPW; ++q)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (j < r) {
+                    const float v = wave_sum(acc[sg][q][j]);
+                    if (lane == 0 && t0 + q < T) x16[(t0 + q) * ldx + K + col0 + sg * r + j] = to16<DT>(scale * v);
+                }
             }
-        }
 }
 int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
     ARG_CHECK(r > 0 && r <= LORA_MAX_R && K % 8 == 0 && a.n >= 1 && a.n <= 3 && T > 0);
-    dim3 grid((unsigned)((T + 4 * DOWN_TPW - 1) / (4 * DOWN_TPW)), a.n);
-    if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 8>), grid, dim3(256), 0, s, x16, ldx, T, K, a, r, scale, drop_p, seed, site));
-    else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 16>), grid, dim3(256), 0, s, x16, ldx, T, K, a, r, scale, drop_p, seed, site));
+    dim3 grid((unsigned)((T + 4 * DOWN_TPW - 1) / (4 * DOWN_TPW)));
+    for (int sg = 0; sg < a.n; ++sg) {      // one adapter per launch: a three-adapter variant (x read once) was slower -- 96 accumulators per lane cost more occupancy than the re-read
+        LoraDownArgs one; one.n = 1; one.A[0] = a.A[sg]; one.A[1] = one.A[2] = nullptr;
+        if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 8, 1>), grid, dim3(256), 0, s, x16, ldx, T, K, one, r, scale, drop_p, seed, site + sg, sg * r));
+        else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 16, 1>), grid, dim3(256), 0, s, x16, ldx, T, K, one, r, scale, drop_p, seed, site + sg, sg * r));
+    }
     LAUNCH_CHECK();
     return BLIM_OK;
 }
@@ -360,53 +372,98 @@ int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K
 }
 
 // ---------------------------------------------------------------------------- RMSNorm backward
-// dy_eff = dy + (optional) the adapters' rank-r input gradient, formed on the fly and kept in registers between the two passes
-#define RB_MAXV 8      // float4 per thread: H <= 8192
+// dy_eff = dy + (optional) the adapters' rank-r input gradient, formed on the fly and kept in registers between the two passes.  The
+// adapter variant handles RB rows per workgroup: every A chunk a thread loads (A is [r, K] f32 per adapter, 344 KB for q + k + v at 7B,
+// L2-resident) serves RB rows instead of one.
+#define RB_MAXV 8      // float4 per thread and row: H <= 8192 (plain variant)
+#define RB_ROWS 4      // adapter variant: rows per workgroup, H <= 4096
 template <int DT, bool LORA>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float* dy, const float* x, const int32_t* rows, int H, const float* w, float eps, int accumulate, uint16_t* out16,
-                                                          LoraDxArgs la, int r, float drop_p, uint64_t seed, uint32_t site) {
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate,
+                                                          uint16_t* out16, LoraDxArgs la, int r, float drop_p, uint64_t seed, uint32_t site) {
     __shared__ float red[4];
-    const int64_t i = blockIdx.x;
-    const int64_t row = rows ? rows[i] : i;
-    const float* xr = x + row * H;
-    const float* dyr = dy + i * H;
-    float4 dv[RB_MAXV];
-    float ss = 0.f, dot = 0.f;
+    constexpr int NR = LORA ? RB_ROWS : 1;
+    constexpr int NV = LORA ? 4 : RB_MAXV;
+    const int64_t i0 = (int64_t)blockIdx.x * NR;
+    float4 dv[NR][NV];
+    float ss[NR], dot[NR];
 #pragma unroll
-    for (int u = 0; u < RB_MAXV; ++u) {
+    for (int q = 0; q < NR; ++q) { ss[q] = 0.f; dot[q] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
         const int k = (threadIdx.x + 256 * u) * 4;
         if (k < H) {
-            const float4 xv = *(const float4*)(xr + k), wv = *(const float4*)(w + k);
-            float4 d = *(const float4*)(dyr + k);
-            if (LORA) { const float4 l = lora_dx4(la, i, k, H, r, drop_p, seed, site); d.x += l.x; d.y += l.y; d.z += l.z; d.w += l.w; }
-            dv[u] = d;
-            ss += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
-            dot += wv.x * d.x * xv.x + wv.y * d.y * xv.y + wv.z * d.z * xv.z + wv.w * d.w * xv.w;
+            const float4 wv = *(const float4*)(w + k);
+            float4 l[NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) l[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LORA) {
+                for (int sg = 0; sg < la.n; ++sg) {
+                    float4 acc[NR];
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int j = 0; j < r; ++j) {
+                        const float4 av = *(const float4*)(la.A[sg] + (int64_t)j * H + k);
+#pragma unroll
+                        for (int q = 0; q < NR; ++q) {
+                            const float d = la.du[sg][min(i0 + q, n_rows - 1) * r + j];
+                            acc[q].x += d * av.x; acc[q].y += d * av.y; acc[q].z += d * av.z; acc[q].w += d * av.w;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        if (drop_p > 0.f) {
+                            const uint64_t b = (uint64_t)min(i0 + q, n_rows - 1) * H + k;
+                            acc[q].x *= drop_mult(seed, site + sg, b, drop_p); acc[q].y *= drop_mult(seed, site + sg, b + 1, drop_p);
+                            acc[q].z *= drop_mult(seed, site + sg, b + 2, drop_p); acc[q].w *= drop_mult(seed, site + sg, b + 3, drop_p);
+                        }
+                        l[q].x += acc[q].x; l[q].y += acc[q].y; l[q].z += acc[q].z; l[q].w += acc[q].w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int64_t i = min(i0 + q, n_rows - 1);
+                const int64_t row = rows ? rows[i] : i;
+                const float4 xv = *(const float4*)(x + row * H + k);
+                float4 d = *(const float4*)(dy + i * H + k);
+                d.x += l[q].x; d.y += l[q].y; d.z += l[q].z; d.w += l[q].w;
+                dv[q][u] = d;
+                ss[q] += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+                dot[q] += wv.x * d.x * xv.x + wv.y * d.y * xv.y + wv.z * d.z * xv.z + wv.w * d.w * xv.w;
+            }
         }
     }
-    ss = block_sum_256(ss, red);
-    dot = block_sum_256(dot, red);
-    const float rs = rsqrtf(ss / (float)H + eps);
-    const float c = rs * rs * rs * dot / (float)H;
-    float* o = dx + row * H;
 #pragma unroll
-    for (int u = 0; u < RB_MAXV; ++u) {
-        const int k = (threadIdx.x + 256 * u) * 4;
-        if (k < H) {
-            const float4 xv = *(const float4*)(xr + k), wv = *(const float4*)(w + k), d = dv[u];
-            float4 g = make_float4(rs * wv.x * d.x - xv.x * c, rs * wv.y * d.y - xv.y * c, rs * wv.z * d.z - xv.z * c, rs * wv.w * d.w - xv.w * c);
-            if (accumulate) { const float4 p = *(const float4*)(o + k); g.x += p.x; g.y += p.y; g.z += p.z; g.w += p.w; }
-            *(float4*)(o + k) = g;
-            if (out16) *(uint2*)(out16 + row * H + k) = make_uint2(pack2<DT>(g.x, g.y), pack2<DT>(g.z, g.w));
+    for (int q = 0; q < NR; ++q) {
+        const float s2 = block_sum_256(ss[q], red);
+        const float dt2 = block_sum_256(dot[q], red);
+        const int64_t i = i0 + q;
+        if (i >= n_rows) continue;                       // uniform per workgroup
+        const int64_t row = rows ? rows[i] : i;
+        const float rs = rsqrtf(s2 / (float)H + eps);
+        const float c = rs * rs * rs * dt2 / (float)H;
+        float* o = dx + row * H;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int k = (threadIdx.x + 256 * u) * 4;
+            if (k < H) {
+                const float4 xv = *(const float4*)(x + row * H + k), wv = *(const float4*)(w + k), d = dv[q][u];
+                float4 g = make_float4(rs * wv.x * d.x - xv.x * c, rs * wv.y * d.y - xv.y * c, rs * wv.z * d.z - xv.z * c, rs * wv.w * d.w - xv.w * c);
+                if (accumulate) { const float4 pp = *(const float4*)(o + k); g.x += pp.x; g.y += pp.y; g.z += pp.z; g.w += pp.w; }
+                *(float4*)(o + k) = g;
+                if (out16) *(uint2*)(out16 + row * H + k) = make_uint2(pack2<DT>(g.x, g.y), pack2<DT>(g.z, g.w));
+            }
         }
     }
 }
 int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, uint16_t* out16, int dtype,
                        hipStream_t s, const LoraDxArgs* la, int r, float drop_p, uint64_t seed, uint32_t site) {
-    ARG_CHECK(n_rows > 0 && H % 4 == 0 && H <= 1024 * RB_MAXV && (!out16 || !rows) && (!la || !rows));
+    ARG_CHECK(n_rows > 0 && H % 4 == 0 && H <= 1024 * RB_MAXV && (!out16 || !rows) && (!la || (!rows && H <= 4096)));
     LoraDxArgs z; memset(&z, 0, sizeof(z));
-    if (la) DISPATCH_DT(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, true>), dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate, out16, *la, r, drop_p, seed, site));
-    else DISPATCH_DT(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, false>), dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, H, w, eps, accumulate, out16, z, 0, 0.f, 0ull, 0u));
+    if (la) DISPATCH_DT(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, true>), dim3((unsigned)((n_rows + RB_ROWS - 1) / RB_ROWS)), dim3(256), 0, s, dx, dy, x, rows, n_rows, H, w, eps, accumulate,
+                                                  out16, *la, r, drop_p, seed, site));
+    else DISPATCH_DT(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, false>), dim3((unsigned)n_rows), dim3(256), 0, s, dx, dy, x, rows, n_rows, H, w, eps, accumulate, out16, z, 0, 0.f,
+                                               0ull, 0u));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
