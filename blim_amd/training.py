@@ -204,6 +204,9 @@ class Trainer:
         self._stats = torch.zeros(2, dtype=torch.float32, device=dev)
         self._loss = torch.zeros(2, dtype=torch.float32, device=dev)
         init = trainable if trainable is not None else lora.init_trainable(self.dims, self.r, seed, visual_head)
+        missing = [n for n in self.layout if n not in init]
+        if missing:
+            raise BlimError(f"trainable tensors missing: {missing[:4]}{' ...' if len(missing) > 4 else ''} ({len(missing)} of {len(self.layout)})")
         for name, arr in init.items():
             off, shape = self.layout[name]
             assert tuple(arr.shape) == tuple(shape), (name, arr.shape, shape)
@@ -353,7 +356,9 @@ class Trainer:
                "weight_decay": self.weight_decay, "layout": {n: (o, tuple(s)) for n, (o, s) in self.layout.items()}}
         return {"model": model, "optimizer": opt, "scaler": self.scaler.state_dict()}
 
-    def load_checkpoint_state(self, ckpt: dict) -> None:
+    def load_checkpoint_state(self, ckpt: dict, strict: bool = True) -> None:
+        """`--resume` for training (util/misc.py:303-316).  strict: every trainable tensor must be in the file (the reference asserts the
+        parameter total, main.py:127), so that a naming drift cannot silently continue from fresh adapters."""
         import torch
         from .checkpoint import parse_resume_key
         tensors = {}
@@ -363,6 +368,9 @@ class Trainer:
                 continue
             w, kind = parsed
             tensors["visual_head" if kind == "full" else f"{w}:{kind}"] = v.float().numpy()
+        absent = [n for n in self.layout if n not in tensors]
+        if strict and absent:
+            raise BlimError(f"resume file lacks {len(absent)} of {len(self.layout)} trainable tensors (first: {absent[:3]})")
         self.load_trainable(tensors)
         opt = ckpt.get("optimizer")
         if isinstance(opt, dict) and "exp_avg" in opt:
