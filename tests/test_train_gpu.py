@@ -13,8 +13,9 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 # 16-bit operands everywhere (the reference itself trains under autocast(float16)): a gradient tensor is compared relative to its own
 # largest element / its L2 norm against the fp32 autograd reference
-GRAD_RTOL = {"f16": 1e-2, "bf16": 3e-2}        # worst element; measured 1.4e-3 / 9.0e-3 (tiny), 2.1e-3 (7B width), 5.9e-3 (28 layers: k_proj A)
-GRAD_NORM_RTOL = {"f16": 2e-3, "bf16": 1e-2}   # the tensor's L2 norm; measured <= 1.3e-3 (28 layers), 5.6e-3 bf16
+GRAD_RTOL = {"f16": 1e-2, "bf16": 1e-1}        # worst element; measured 1.4e-3 / 9.0e-3 (tiny), 2.1e-3 (7B width), 5.9e-3 (28 layers: k_proj A)
+GRAD_NORM_RTOL = {"f16": 2e-3, "bf16": 3e-2}   # the tensor's L2 norm; measured <= 1.3e-3 (28 layers); bf16 (a reported, not a parity mode): 5.6e-3 tiny,
+                                               # 5.9e-2 worst element / 1.6e-2 norm through 28 layers (8-bit mantissas in P and the activation gradients)
 LOSS_RTOL = {"f16": 1e-3, "bf16": 1e-2}
 
 
@@ -53,7 +54,7 @@ def _sample(a, spec=None):
     return sample_rows(a, (spec or {}).get("max_store", MAX_STORE))
 
 
-@pytest.mark.parametrize("case,dtype", [("train_tiny", "f16"), ("train_tiny", "bf16"), ("train_wide", "f16"), ("train_deep", "f16")])
+@pytest.mark.parametrize("case,dtype", [("train_tiny", "f16"), ("train_tiny", "bf16"), ("train_wide", "f16"), ("train_deep", "f16"), ("train_deep", "bf16")])
 def test_training_step_matches_reference_autograd(case, dtype):
     import torch
     from blim_amd.engine import Engine
