@@ -95,6 +95,25 @@ int launch_lora_merge(uint16_t* dst, const uint16_t* base_aug, int64_t ld_aug, i
     return BLIM_OK;
 }
 
+// MFMA fragment of a row-major LDS tile [k][STRIDE columns] whose contraction index is the ROW: lane (col32 + lane & 31) gets its 8
+// k values (k = 16 s + 4 hf + {0..3} and + 8) through the transposing LDS load ds_read_b64_tr_b16 -- the scheme of the forward attention
+// kernel's P.V product.  16-byte chunks are XOR-swizzled by the row (STRIDE 128: 16 chunks, STRIDE 32: 4 chunks).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+template <int STRIDE>
+__device__ __forceinline__ int tr_off(int row, int col) {
+    const int ch = col >> 3, sw = STRIDE == 128 ? ((row & 3) << 2) : (row & 3);
+    return row * STRIDE + 8 * (ch ^ sw) + (col & 7);
+}
+template <int STRIDE>
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int col32, int s, int lane) {
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1, hf = lane >> 5;
+    const int col = col32 + 16 * g16 + 4 * (i16 & 3);
+    const int kr0 = 16 * s + 4 * hf + (i16 >> 2), kr1 = kr0 + 8;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + tr_off<STRIDE>(kr0, col)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + tr_off<STRIDE>(kr1, col)));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // ---------------------------------------------------------------------------- LoRA
 #define LORA_MAX_R 16
 __device__ __forceinline__ float block_sum_256(float v, float* red) {   // red: [4] floats of LDS per call site
@@ -176,85 +195,90 @@ int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDow
 }
 
 // out[c, j] += sum_t X[t, c] * U[t, j]  (the two rank-r weight gradients: dB with X = dy, U = u~;  dA with X = drop(x), U = du, stored
-// transposed).  One workgroup = 128 columns x 1024 rows: a lane owns two adjacent columns, the 4 waves split the rows in groups of 64;
-// lane l of a wave holds U row (group start + l) in registers and the row loop broadcasts it with v_readlane (one VMEM instruction per
-// row instead of 1 + r), partial sums meet in LDS and leave as 128 * r atomics.
-#define LORA_TSPLIT 512
-template <int DT, bool U_F32, bool OUT_T, int R>
+// transposed) on the matrix cores.  The contraction index t is the ROW index of both operands, so the tiles are staged row-major
+// (coalesced 16-byte copies of X) and the fragments come from the transposing LDS load (tr_frag).  One workgroup = 128 columns x 1024
+// rows, 64 rows per stage, wave w owns columns 32 w .. 32 w + 31 and one 32x32 accumulator (n = j < r real, the rest zero padding).
+// An f32 U (du carries the loss scale: up to ~1e4 and down to ~1e-3 in one tensor) enters as hi + lo with hi = 16-bit(u / 256),
+// lo = 16-bit(u - 256 hi): two MFMAs, out = 256 acc_hi + acc_lo, exact to ~3e-5 relative over that whole range in fp16.
+#define LORA_TSPLIT 1024
+template <int DT, bool U_F32, bool OUT_T>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(float* out, const uint16_t* X, int64_t ldx, const void* Uv, int64_t ldu, int64_t T, int C, int r,
                                                          float drop_p, uint64_t seed, uint32_t site, int drop_k) {
-    __shared__ float red[4][2 * R][64];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = blockIdx.x * 128 + 2 * lane;
-    const bool ok = c < C;                       // C is even: both columns are valid together
-    float acc0[R], acc1[R];
+    __shared__ __attribute__((aligned(16))) uint16_t x_lds[64 * 128];
+    __shared__ __attribute__((aligned(16))) uint16_t u_hi[64 * 32];
+    __shared__ __attribute__((aligned(16))) uint16_t u_lo[64 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hf = lane >> 5;
+    const int c0 = blockIdx.x * 128;
+    const int64_t tb = (int64_t)blockIdx.y * LORA_TSPLIT, te = min(T, tb + LORA_TSPLIT);
+    for (int i = tid; i < 64 * 32; i += 256) { u_hi[i] = 0; u_lo[i] = 0; }          // columns >= r stay zero
+    f32x16 acc_hi, acc_lo;
 #pragma unroll
-    for (int j = 0; j < R; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
-    const int64_t blk0 = (int64_t)blockIdx.y * LORA_TSPLIT;
-    for (int grp = w; grp < LORA_TSPLIT / 64; grp += 4) {
-        const int64_t tb = blk0 + 64 * grp;
-        if (tb >= T) break;
-        float ureg[R];
-        {
-            const int64_t tr = tb + lane;
+    for (int i = 0; i < 16; ++i) { acc_hi[i] = 0.f; acc_lo[i] = 0.f; }
+    for (int64_t t0 = tb; t0 < te; t0 += 64) {
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                float u = 0.f;
-                if (tr < T && j < r) u = U_F32 ? ((const float*)Uv)[tr * ldu + j] : from16<DT>(((const uint16_t*)Uv)[tr * ldu + j]);
-                ureg[j] = u;
-            }
-        }
-        // rows beyond T have u = 0 (ureg above), so their x may be any valid address: clamp instead of branching, 16 row loads in flight
-#pragma unroll
-        for (int q0 = 0; q0 < 64; q0 += 16) {
-            uint32_t raw[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int64_t tt = min(tb + q0 + u, T - 1);
-                raw[u] = ok ? *(const uint32_t*)(X + tt * ldx + c) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int q = q0 + u;
-                float x0 = from16<DT>((uint16_t)(raw[u] & 0xFFFF)), x1 = from16<DT>((uint16_t)(raw[u] >> 16));
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u;
+            const int row = idx >> 4, ch = idx & 15;
+            const int64_t t = t0 + row;
+            const int col = c0 + 8 * ch;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t < te && col < C) {
+                v = *(const uint4*)(X + t * ldx + col);
                 if (drop_p > 0.f) {
-                    const int64_t tt = min(tb + q, T - 1);
-                    x0 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c, drop_p); x1 *= drop_mult(seed, site, (uint64_t)tt * drop_k + c + 1, drop_p);
-                }
+                    uint16_t* e = (uint16_t*)&v;
 #pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const float uu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ureg[j]), q));
-                    acc0[j] += x0 * uu; acc1[j] += x1 * uu;
+                    for (int q = 0; q < 8; ++q) e[q] = to16<DT>(from16<DT>(e[q]) * drop_mult(seed, site, (uint64_t)t * drop_k + col + q, drop_p));
                 }
             }
+            *(uint4*)(x_lds + tr_off<128>(row, 8 * ch)) = v;
+        }
+        for (int i = tid; i < 64 * r; i += 256) {
+            const int row = i / r, j = i - row * r;
+            const int64_t t = t0 + row;
+            uint16_t h = 0, l = 0;
+            if (t < te) {
+                if (U_F32) {
+                    const float uv = ((const float*)Uv)[t * ldu + j];
+                    h = to16<DT>(uv * (1.0f / 256.0f));
+                    l = to16<DT>(uv - 256.0f * from16<DT>(h));
+                } else h = ((const uint16_t*)Uv)[t * ldu + j];
+            }
+            u_hi[tr_off<32>(row, j)] = h;
+            if (U_F32) u_lo[tr_off<32>(row, j)] = l;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const bf16x8 af = tr_frag<128>(x_lds, 32 * w, s4, lane);
+            acc_hi = mfma32<DT>(af, tr_frag<32>(u_hi, 0, s4, lane), acc_hi);
+            if (U_F32) acc_lo = mfma32<DT>(af, tr_frag<32>(u_lo, 0, s4, lane), acc_lo);
         }
     }
+    const int n = lane & 31;
+    if (n < r) {
 #pragma unroll
-    for (int j = 0; j < R; ++j) { red[w][2 * j][lane] = acc0[j]; red[w][2 * j + 1][lane] = acc1[j]; }
-    __syncthreads();
-    for (int i = threadIdx.x; i < r * 128; i += 256) {
-        const int j = i >> 7, cl = i & 127;            // column cl of the block = lane cl / 2, element cl & 1
-        const int cc = blockIdx.x * 128 + cl;
-        if (cc >= C) continue;
-        const int row = 2 * j + (cl & 1), l = cl >> 1;
-        const float v = red[0][row][l] + red[1][row][l] + red[2][row][l] + red[3][row][l];
-        atomicAdd(out + (OUT_T ? (int64_t)j * C + cc : (int64_t)cc * r + j), v);
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = c0 + 32 * w + 8 * g + 4 * hf + jj;
+                if (m >= C) continue;
+                const float v = U_F32 ? 256.0f * acc_hi[4 * g + jj] + acc_lo[4 * g + jj] : acc_hi[4 * g + jj];
+                atomicAdd(out + (OUT_T ? (int64_t)n * C + m : (int64_t)m * r + n), v);
+            }
     }
 }
 int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R && N % 2 == 0 && ldy % 2 == 0);
+    ARG_CHECK(r <= LORA_MAX_R && ldy % 8 == 0 && ldy >= (N + 7) / 8 * 8);      // the last 16-byte chunk of a row may reach into the row's padding columns
     dim3 grid((N + 127) / 128, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
-    if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, false, false, 8>), grid, dim3(256), 0, s, dB, dy16, ldy, (const void*)u16, ldu, T, N, r, 0.f, 0ull, 0u, 0));
-    else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, false, false, 16>), grid, dim3(256), 0, s, dB, dy16, ldy, (const void*)u16, ldu, T, N, r, 0.f, 0ull, 0u, 0));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, false, false>), grid, dim3(256), 0, s, dB, dy16, ldy, (const void*)u16, ldu, T, N, r, 0.f, 0ull, 0u, 0));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
 int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R && K % 2 == 0 && ldx % 2 == 0);
+    ARG_CHECK(r <= LORA_MAX_R && K % 8 == 0 && ldx % 8 == 0);
     dim3 grid((K + 127) / 128, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
-    if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, true, true, 8>), grid, dim3(256), 0, s, dA, x16, ldx, (const void*)du, (int64_t)r, T, K, r, drop_p, seed, site, K));
-    else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, true, true, 16>), grid, dim3(256), 0, s, dA, x16, ldx, (const void*)du, (int64_t)r, T, K, r, drop_p, seed, site, K));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, true, true>), grid, dim3(256), 0, s, dA, x16, ldx, (const void*)du, (int64_t)r, T, K, r, drop_p, seed, site, K));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
@@ -678,7 +702,26 @@ __global__ __launch_bounds__(256) void attn_bgemm_kernel(AttnBwdParams p, int Lm
     const int64_t t0 = p.seq_start[s];
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     if (m0 >= L) return;
-    if ((MODE == AB_S || MODE == AB_DP) && (n0 >= L || n0 > m0 + 63)) return;      // tiles above the diagonal are never read
+    if ((MODE == AB_S || MODE == AB_DP) && n0 > m0 + 63) {
+        // above the diagonal: never read, except the tile that shares a 128-column block with a diagonal tile (attn_tn_kernel reads
+        // 128-wide column blocks of P / dS): that one is written as zeros
+        if (n0 < (m0 / 128 + 1) * 128) {
+            uint16_t* dst = (MODE == AB_S ? p.P16 : p.dS16) + ((int64_t)s * p.num_heads + hb) * (int64_t)Lm * Lm;
+            for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+                const int r = m0 + (i >> 3), c = n0 + 8 * (i & 7);
+                if (r < L) *(uint4*)(dst + (int64_t)r * Lm + c) = make_uint4(0, 0, 0, 0);
+            }
+        }
+        return;
+    }
+    if ((MODE == AB_S || MODE == AB_DP) && n0 >= L) {      // columns beyond the row's length: zeros (same readers)
+        uint16_t* dst = (MODE == AB_S ? p.P16 : p.dS16) + ((int64_t)s * p.num_heads + hb) * (int64_t)Lm * Lm;
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int r = m0 + (i >> 3), c = n0 + 8 * (i & 7);
+            if (r < L) *(uint4*)(dst + (int64_t)r * Lm + c) = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
     const int kvh = HB == nh ? hb / grp : hb;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     f32x16 acc;
@@ -766,6 +809,68 @@ __global__ __launch_bounds__(256) void attn_bgemm_kernel(AttnBwdParams p, int Lm
         }
 }
 
+// dV = P^T dO and dK = dS^T Q: both operands have the contraction index (the query row i) as their ROW index, so the tiles are staged
+// row-major (coalesced 16-byte copies, XOR-swizzled chunks) and the MFMA fragments are read with the transposing LDS load
+// (ds_read_b64_tr_b16), the scheme of the forward kernel's P.V product.  One workgroup = 128 key rows j x 128 head dims of one
+// (sequence, kv head); wave w owns key rows 32 w .. 32 w + 31; the contraction runs over the group's q heads and the query rows i >= j.
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void attn_tn_kernel(AttnBwdParams p, int Lm) {
+    __shared__ __attribute__((aligned(16))) uint16_t a_lds[32 * 128];
+    __shared__ __attribute__((aligned(16))) uint16_t b_lds[32 * 128];
+    const int nh = p.num_heads, nkv = p.num_kv_heads, grp = nh / nkv;
+    const int s = blockIdx.z / nkv, kvh = blockIdx.z % nkv;
+    const int L = p.seq_len[s];
+    const int64_t t0 = p.seq_start[s];
+    const int m0 = blockIdx.y * 128;
+    if (m0 >= L) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hf = lane >> 5;
+    f32x16 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    const int64_t mat = ((int64_t)s * nh) * (int64_t)Lm * Lm;
+    const int k_end = (L + 31) / 32 * 32;
+    for (int hh = 0; hh < grp; ++hh) {
+        const int h = kvh * grp + hh;
+        const uint16_t* PS = (MODE == AB_DV ? p.P16 : p.dS16) + mat + (int64_t)h * Lm * Lm;
+        for (int i0 = m0; i0 < k_end; i0 += 32) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + 256 * u;
+                const int row = idx >> 4, ch = idx & 15;
+                const int i = i0 + row;
+                uint4 av = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
+                if (i < L) {
+                    if (m0 + 8 * ch + 8 <= Lm) av = *(const uint4*)(PS + (int64_t)i * Lm + m0 + 8 * ch);
+                    bv = MODE == AB_DV ? *(const uint4*)(p.dout + (t0 + i) * p.ldo + h * 128 + 8 * ch) : *(const uint4*)(p.qkv + (t0 + i) * p.ldq + h * 128 + 8 * ch);
+                }
+                const int off = row * 128 + 8 * (ch ^ ((row & 3) << 2));
+                *(uint4*)(a_lds + off) = av;
+                *(uint4*)(b_lds + off) = bv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 af = tr_frag<128>(a_lds, 32 * w, s2, lane);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) o[db] = mfma32<DT>(af, tr_frag<128>(b_lds, 32 * db, s2, lane), o[db]);
+            }
+        }
+    }
+    const int col0 = (MODE == AB_DK ? nh + kvh : nh + nkv + kvh) * 128;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = m0 + 32 * w + 8 * g + 4 * hf + jj;
+                if (m < L) p.dqkv[(t0 + m) * p.ldq + col0 + 32 * db + (lane & 31)] = o[db][4 * g + jj];
+            }
+}
+
 // D[t, h] = sum_d dO[t, h, d] * O[t, h, d]  (= rowsum(P o dP)): one wave per (token, head), 4 per workgroup
 template <int DT>
 __global__ __launch_bounds__(256) void attn_rowdot_kernel(float* D, const uint16_t* dout, int64_t ldo, const uint16_t* o16, int64_t ldo16, int64_t n_pairs, int nh) {
@@ -789,8 +894,8 @@ static int attention_bwd_t(const AttnBwdParams& p, int64_t n_tokens, hipStream_t
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_S>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DP>), dim3(nt, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
     hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DQ>), dim3(2, nt, p.n_seqs * p.num_heads), blk, 0, s, p, Lm);
-    hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DV>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
-    hipLaunchKernelGGL((attn_bgemm_kernel<DT, AB_DK>), dim3(2, nt, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
+    hipLaunchKernelGGL((attn_tn_kernel<DT, AB_DV>), dim3(1, (Lm + 127) / 128, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
+    hipLaunchKernelGGL((attn_tn_kernel<DT, AB_DK>), dim3(1, (Lm + 127) / 128, p.n_seqs * p.num_kv_heads), blk, 0, s, p, Lm);
     LAUNCH_CHECK();
     return BLIM_OK;
 }
