@@ -23,7 +23,7 @@
 
 #define AUG 64   // extra K columns of an augmented weight / activation row
 
-struct Adapter { int64_t offA = 0, offB = 0; int n_in = 0, n_out = 0; uint16_t* Bt16 = nullptr; int64_t ldb = 0; };   // Bt16: 16-bit B^T [16, ldb] (train.hpp: launch_lora_du)
+struct Adapter { int64_t offA = 0, offB = 0; int n_in = 0, n_out = 0; uint16_t* Bt16 = nullptr; int64_t ldb = 0; uint16_t* A16 = nullptr; };   // Bt16: 16-bit B^T [16, ldb] (launch_lora_du); A16: 16-bit A [16, n_in] (launch_lora_down)
 
 struct TrainLayerW { uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr; uint16_t* wqkvT = nullptr; uint16_t* woT = nullptr; uint16_t* wguT = nullptr; uint16_t* wdT = nullptr; };
 
@@ -147,6 +147,8 @@ extern "C" int blim_train_create(blim_engine* e, const blim_train_config* cfg, f
         a->ldb = round_up(a->n_out, 64);
         T_(talloc(t, (void**)&a->Bt16, (size_t)16 * a->ldb * 2));
         if (rc == BLIM_OK && hipMemset(a->Bt16, 0, (size_t)16 * a->ldb * 2) != hipSuccess) rc = BLIM_ERR_HIP;
+        T_(talloc(t, (void**)&a->A16, (size_t)16 * a->n_in * 2));
+        if (rc == BLIM_OK && hipMemset(a->A16, 0, (size_t)16 * a->n_in * 2) != hipSuccess) rc = BLIM_ERR_HIP;
     }
     for (int l = 0; l < c.num_layers; ++l) {
         const LayerW& w = e->L[l]; TrainLayerW& x = t->L[l];
@@ -205,7 +207,10 @@ extern "C" int blim_train_sync_params(blim_trainer* t, void* stream) {
         TRY(launch_lora_b_to_aug(t->w0_aug[w], M + AUG, 0, M, P + t->lay.mlp[w][0].offB, H, r, 0, dt, s));
         TRY(launch_lora_b_to_aug(t->w2_aug[w], H + AUG, 0, H, P + t->lay.mlp[w][1].offB, H, r, 0, dt, s));
     }
-    for (Adapter* a : all_adapters(t)) TRY(launch_lora_bt(a->Bt16, a->ldb, P + a->offB, a->n_out, r, dt, s));
+    for (Adapter* a : all_adapters(t)) {
+        TRY(launch_lora_bt(a->Bt16, a->ldb, P + a->offB, a->n_out, r, dt, s));
+        TRY(launch_lora_a16(a->A16, P + a->offA, a->n_in, r, dt, s));
+    }
     return launch_f32_to_16(t->vh16, H, P + t->lay.off_vh, H, M, H, 1.0f, dt, s);
 }
 
@@ -272,8 +277,8 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
     TRY(ensure(t->proj16, (size_t)F * H * 2)); TRY(ensure(t->embeds, (size_t)T * H * 2));
     uint16_t* fa = (uint16_t*)t->feats_aug.p; uint16_t* pre = (uint16_t*)t->pre16.p; uint16_t* h16 = (uint16_t*)t->h16.p; uint16_t* proj = (uint16_t*)t->proj16.p;
     HIP_TRY(hipMemcpy2DAsync(fa, (size_t)Ma * 2, b->feats, (size_t)M * 2, (size_t)M * 2, F, hipMemcpyDeviceToDevice, s));
-    LoraDownArgs la; la.n = 1; la.A[1] = la.A[2] = nullptr;
-    la.A[0] = t->params + t->lay.mlp[which][0].offA;
+    LoraDownArgs la; la.n = 1; la.A16[1] = la.A16[2] = nullptr;
+    la.A16[0] = t->lay.mlp[which][0].A16;
     TRY(launch_lora_down(fa, Ma, F, M, la, r, t->s, t->p_drop, b->dropout_seed, 1000 + 2 * which, dt, s));
     {
         GemmParams p = gp(dt, fa, Ma, t->w0_aug[which], F, H, Ma, pre, H);
@@ -281,7 +286,7 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
         TRY(launch_gemm(EPI_BF16, p, s));
     }
     TRY(launch_gelu_fwd(h16, Ha, pre, F, H, dt, s));
-    la.A[0] = t->params + t->lay.mlp[which][1].offA;
+    la.A16[0] = t->lay.mlp[which][1].A16;
     TRY(launch_lora_down(h16, Ha, F, H, la, r, t->s, t->p_drop, b->dropout_seed, 1001 + 2 * which, dt, s));
     {
         GemmParams p = gp(dt, h16, Ha, t->w2_aug[which], F, H, Ha, proj, H);
@@ -312,7 +317,7 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
         uint16_t* xn1 = (uint16_t*)t->sv_xn1.p + (int64_t)li * T * Ha; uint16_t* qkv = (uint16_t*)t->sv_qkv.p + (int64_t)li * T * qn;
         uint16_t* attn = (uint16_t*)t->sv_attn.p + (int64_t)li * T * Ha; uint16_t* gu = (uint16_t*)t->sv_gu.p + (int64_t)li * T * 2 * I;
         TRY(launch_rmsnorm(x_in, H, nullptr, T, H, l.norm1, c.rms_eps, (bf16_t*)xn1, dt, nullptr, s, 0, Ha, nullptr));
-        LoraDownArgs q3; q3.n = 3; for (int j = 0; j < 3; ++j) q3.A[j] = t->params + ad[j].offA;
+        LoraDownArgs q3; q3.n = 3; for (int j = 0; j < 3; ++j) q3.A16[j] = ad[j].A16;
         TRY(launch_lora_down(xn1, Ha, T, H, q3, r, t->s, t->p_drop, b->dropout_seed, 8 * li, dt, s));
         {
             GemmParams p = gp(dt, xn1, Ha, x.wqkv_aug, T, qn, Ha, qkv, qn);
@@ -328,7 +333,7 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
             a.lse_out = (float*)t->sv_lse.p + (int64_t)li * T * c.num_heads;
             TRY(launch_attention(a, e->attn_tr, s));
         }
-        LoraDownArgs o1; o1.n = 1; o1.A[0] = t->params + ad[3].offA; o1.A[1] = o1.A[2] = nullptr;
+        LoraDownArgs o1; o1.n = 1; o1.A16[0] = ad[3].A16; o1.A16[1] = o1.A16[2] = nullptr;
         TRY(launch_lora_down(attn, Ha, T, H, o1, r, t->s, t->p_drop, b->dropout_seed, 8 * li + 3, dt, s));
         {
             GemmParams p = gp(dt, attn, Ha, x.wo_aug, T, H, Ha, x_mid, H);
@@ -451,7 +456,7 @@ extern "C" int blim_train_vtg(blim_trainer* t, const blim_train_batch* b, float*
     TRY(ensure(t->dres, (size_t)T * H * 4)); TRY(ensure(t->du, (size_t)std::max<int64_t>(R, T) * 3 * 16 * 4));
     uint16_t* hsel = (uint16_t*)t->hsel.p; float* logits = (float*)t->logits.p; uint16_t* dlog = (uint16_t*)t->dlog16.p; float* dhsel = (float*)t->dhsel.p; float* du = (float*)t->du.p;
     TRY(launch_rmsnorm(x_final, H, b->rows, R, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, Ha, nullptr));
-    LoraDownArgs la; la.n = 1; la.A[0] = t->params + t->lay.lm.offA; la.A[1] = la.A[2] = nullptr;
+    LoraDownArgs la; la.n = 1; la.A16[0] = t->lay.lm.A16; la.A16[1] = la.A16[2] = nullptr;
     TRY(launch_lora_down(hsel, Ha, R, H, la, r, t->s, t->p_drop, b->dropout_seed, 2000, dt, s));
     { GemmParams p = gp(dt, hsel, Ha, t->lm_aug, R, V, Ha, logits, Vp); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(launch_ce_fwd_bwd(logits, Vp, V, b->labels, 1, R, b->grad_scale / (float)R, dlog, nullptr, Vp, loss_sum, dt, s));

@@ -17,9 +17,10 @@ int launch_lora_merge(uint16_t* dst, const uint16_t* base_aug, int64_t ld_aug, i
                       int row_mode, int dtype, hipStream_t s);
 
 struct LoraDownArgs {
-    const float* A[3];   // up to three adapters reading the same x (q, k, v): A_j [r, K] f32
-    int n;               // adapters
+    const uint16_t* A16[3];   // up to three adapters reading the same x (q, k, v): 16-bit copy of A_j, [16, K] with rows >= r zero (launch_lora_a16)
+    int n;                    // adapters
 };
+int launch_lora_a16(uint16_t* A16, const float* A, int K, int r, int dtype, hipStream_t s);
 // u~[t, seg*r + j] = 16-bit( scale * sum_k drop_seg(x)[t, k] * A_seg[j, k] ), written into x16[t, K + seg*r + j]  (columns K.. of the augmented row)
 int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s);
 // dB[n, j] += sum_t dy[t, n] * u~[t, j]        (dy16 [T, ldy] columns n0.., u16 = x16 + K + seg*r)

@@ -19,14 +19,22 @@
     } while (0)
 
 // ---------------------------------------------------------------------------- dropout (LoRA input, peft: lora_dropout)
-// keep(t, k) of adapter `site` in step `seed`: counter-based, so the backward regenerates the forward's mask.
-__device__ __forceinline__ float drop_mult(uint64_t seed, uint32_t site, uint64_t idx, float p) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + idx * 0xD1B54A32D192ED03ull;
+// keep(t, k) of adapter `site` in step `seed`: counter-based, so the backward regenerates the forward's mask.  One 64-bit hash serves
+// the four elements idx & ~3 .. + 3 (16 bits each: the drop probability is floor(65536 p) / 65536) -- hashing every element cost 3 % of
+// the step.  oracle/train_oracle.py:drop_mult restates this rule for the tests.
+__device__ __forceinline__ uint64_t drop_hash(uint64_t seed, uint32_t site, uint64_t grp) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + grp * 0xD1B54A32D192ED03ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-    return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+    return z ^ (z >> 31);
+}
+// multipliers of the four elements idx .. idx + 3 (idx % 4 == 0)
+__device__ __forceinline__ void drop_mult4(uint64_t seed, uint32_t site, uint64_t idx, float p, float* m) {
+    const uint64_t z = drop_hash(seed, site, idx >> 2);
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    const float keep = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = (((uint32_t)(z >> (16 * q))) & 0xFFFFu) >= thr ? keep : 0.0f;
 }
 
 __device__ __forceinline__ int nat_row_of_stored(int r) {   // gemm.hpp qkv_perm_row, head offset kept
@@ -124,72 +132,76 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {   // red: 
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// one wave = 4 tokens (16 per workgroup): lanes stride over K in 16-byte chunks and apply every A chunk they load to the four tokens
-// (A is [r, K] f32 = 114 KB at 7B: re-reading it per token was the first version's whole cost), r x 4 wave reductions, no LDS
-#define DOWN_TPW 4
-template <int DT, int R, int NSEG>
-__global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int64_t T, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int col0) {
-    const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * DOWN_TPW;
-    if (t0 >= T) return;
-    const int lane = threadIdx.x & 63;
-    float acc[NSEG][DOWN_TPW][R];
+// A16[j, k] = 16-bit(A[j, k]) for j < r (rows r..15 stay zero): the B operand of the MFMA below
+template <int DT>
+__global__ void lora_a16_kernel(uint16_t* A16, const float* A, int K, int r) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r * K) A16[i] = to16<DT>(A[i]);
+}
+int launch_lora_a16(uint16_t* A16, const float* A, int K, int r, int dtype, hipStream_t s) {
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_a16_kernel<DT>, dim3((r * K + 255) / 256), dim3(256), 0, s, A16, A, K, r));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+
+// u~ = scale * drop(x) A^T on the matrix cores: one workgroup = 32 tokens, its 4 waves split K; a 32x32x16 MFMA per 16 columns with the
+// 16-row A16 as the second operand (j < r real), both operands K-contiguous straight from memory; the waves' partial sums meet in LDS.
+// The adapters of one call (q, k, v) share the x fragment when there is no dropout, otherwise each masks its own copy.
+template <int DT>
+__global__ __launch_bounds__(256) void lora_down_kernel(uint16_t* x16, int64_t ldx, int64_t T, int K, LoraDownArgs a, int r, float scale, float drop_p, uint64_t seed, uint32_t site) {
+    __shared__ float red[4][3][32][LORA_MAX_R];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * 32;
+    const int row = lane & 31, kg = lane >> 5;
+    const int64_t t = min(t0 + row, T - 1);
+    const int steps = K / 16, per = (steps + 3) / 4;
+    const int s0 = w * per, s1 = min(steps, s0 + per);
+    f32x16 acc[3];
 #pragma unroll
-    for (int sg = 0; sg < NSEG; ++sg)
+    for (int sg = 0; sg < 3; ++sg)
 #pragma unroll
-        for (int q = 0; q < DOWN_TPW; ++q)
+        for (int i = 0; i < 16; ++i) acc[sg][i] = 0.f;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint16_t* xp = x16 + t * ldx + 8 * kg;
+    for (int st = s0; st < s1; ++st) {
+        const bf16x8 xa = *(const bf16x8*)(xp + 16 * st);
 #pragma unroll
-            for (int j = 0; j < R; ++j) acc[sg][q][j] = 0.f;
-    for (int k = lane * 8; k < K; k += 64 * 8) {
-        float xv[DOWN_TPW][8];
-        int64_t tq[DOWN_TPW];
+        for (int sg = 0; sg < 3; ++sg) {
+            if (sg < a.n) {
+                bf16x8 xs = xa;
+                if (drop_p > 0.f) {
+                    float m[8];
+                    const uint64_t b0 = (uint64_t)t * K + 16 * st + 8 * kg;
+                    drop_mult4(seed, site + sg, b0, drop_p, m); drop_mult4(seed, site + sg, b0 + 4, drop_p, m + 4);
 #pragma unroll
-        for (int q = 0; q < DOWN_TPW; ++q) {
-            tq[q] = min(t0 + q, T - 1);
-            const uint4 raw = *(const uint4*)(x16 + tq[q] * ldx + k);
-            const uint16_t* h = (const uint16_t*)&raw;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xv[q][e] = from16<DT>(h[e]);
-        }
-#pragma unroll
-        for (int sg = 0; sg < NSEG; ++sg) {
-            float xm[DOWN_TPW][8];
-#pragma unroll
-            for (int q = 0; q < DOWN_TPW; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xm[q][e] = drop_p > 0.f ? xv[q][e] * drop_mult(seed, site + sg, (uint64_t)tq[q] * K + k + e, drop_p) : xv[q][e];
-            const float* A = a.A[sg];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (j < r) {
-                    const float4 a0 = *(const float4*)(A + (int64_t)j * K + k);
-                    const float4 a1 = *(const float4*)(A + (int64_t)j * K + k + 4);
-#pragma unroll
-                    for (int q = 0; q < DOWN_TPW; ++q)
-                        acc[sg][q][j] += xm[q][0] * a0.x + xm[q][1] * a0.y + xm[q][2] * a0.z + xm[q][3] * a0.w + xm[q][4] * a1.x + xm[q][5] * a1.y + xm[q][6] * a1.z + xm[q][7] * a1.w;
+                    for (int e = 0; e < 8; ++e) xs[e] = (short)to16<DT>(from16<DT>((uint16_t)xa[e]) * m[e]);
                 }
+                const bf16x8 bb = row < 16 ? *(const bf16x8*)(a.A16[sg] + (int64_t)row * K + 16 * st + 8 * kg) : zero;
+                acc[sg] = mfma32<DT>(xs, bb, acc[sg]);
             }
         }
     }
+    // acc[sg][4g + jj] <-> token t0 + 8 g + 4 kg + jj, column j = lane & 31
+    if (row < r) {
 #pragma unroll
-    for (int sg = 0; sg < NSEG; ++sg)
+        for (int sg = 0; sg < 3; ++sg)
+            if (sg < a.n)
 #pragma unroll
-        for (int q = 0; q < DOWN_TPW; ++q)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                if (j < r) {
-                    const float v = wave_sum(acc[sg][q][j]);
-                    if (lane == 0 && t0 + q < T) x16[(t0 + q) * ldx + K + col0 + sg * r + j] = to16<DT>(scale * v);
-                }
-            }
+                    for (int jj = 0; jj < 4; ++jj) red[w][sg][8 * g + 4 * kg + jj][row] = acc[sg][4 * g + jj];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n * 32 * r; i += 256) {
+        const int sg = i / (32 * r), rem = i - sg * 32 * r;
+        const int m = rem / r, j = rem - m * r;
+        if (t0 + m < T) x16[(t0 + m) * ldx + K + sg * r + j] = to16<DT>(scale * (red[0][sg][m][j] + red[1][sg][m][j] + red[2][sg][m][j] + red[3][sg][m][j]));
+    }
 }
 int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
-    ARG_CHECK(r > 0 && r <= LORA_MAX_R && K % 8 == 0 && a.n >= 1 && a.n <= 3 && T > 0);
-    dim3 grid((unsigned)((T + 4 * DOWN_TPW - 1) / (4 * DOWN_TPW)));
-    for (int sg = 0; sg < a.n; ++sg) {      // one adapter per launch: a three-adapter variant (x read once) was slower -- 96 accumulators per lane cost more occupancy than the re-read
-        LoraDownArgs one; one.n = 1; one.A[0] = a.A[sg]; one.A[1] = one.A[2] = nullptr;
-        if (r <= 8) DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 8, 1>), grid, dim3(256), 0, s, x16, ldx, T, K, one, r, scale, drop_p, seed, site + sg, sg * r));
-        else DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_down_kernel<DT, 16, 1>), grid, dim3(256), 0, s, x16, ldx, T, K, one, r, scale, drop_p, seed, site + sg, sg * r));
-    }
+    ARG_CHECK(r > 0 && r <= LORA_MAX_R && K % 16 == 0 && ldx % 8 == 0 && a.n >= 1 && a.n <= 3 && T > 0);
+    for (int sg = 0; sg < a.n; ++sg) ARG_CHECK(a.A16[sg] != nullptr);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_down_kernel<DT>, dim3((unsigned)((T + 31) / 32)), dim3(256), 0, s, x16, ldx, T, K, a, r, scale, drop_p, seed, site));
     LAUNCH_CHECK();
     return BLIM_OK;
 }
@@ -227,8 +239,11 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(float* out, const uint1
                 v = *(const uint4*)(X + t * ldx + col);
                 if (drop_p > 0.f) {
                     uint16_t* e = (uint16_t*)&v;
+                    float m[8];
+                    const uint64_t b0 = (uint64_t)t * drop_k + col;
+                    drop_mult4(seed, site, b0, drop_p, m); drop_mult4(seed, site, b0 + 4, drop_p, m + 4);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) e[q] = to16<DT>(from16<DT>(e[q]) * drop_mult(seed, site, (uint64_t)t * drop_k + col + q, drop_p));
+                    for (int q = 0; q < 8; ++q) e[q] = to16<DT>(from16<DT>(e[q]) * m[q]);
                 }
             }
             *(uint4*)(x_lds + tr_off<128>(row, 8 * ch)) = v;
@@ -366,8 +381,9 @@ __device__ __forceinline__ float4 lora_dx4(const LoraDxArgs& a, int64_t t, int k
         }
         if (drop_p > 0.f) {
             const uint64_t b = (uint64_t)t * K + k;
-            acc.x *= drop_mult(seed, site + sg, b, drop_p); acc.y *= drop_mult(seed, site + sg, b + 1, drop_p);
-            acc.z *= drop_mult(seed, site + sg, b + 2, drop_p); acc.w *= drop_mult(seed, site + sg, b + 3, drop_p);
+            float m[4];
+            drop_mult4(seed, site + sg, b, drop_p, m);
+            acc.x *= m[0]; acc.y *= m[1]; acc.z *= m[2]; acc.w *= m[3];
         }
         o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
     }
@@ -437,8 +453,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(float* dx, const float
                     for (int q = 0; q < NR; ++q) {
                         if (drop_p > 0.f) {
                             const uint64_t b = (uint64_t)min(i0 + q, n_rows - 1) * H + k;
-                            acc[q].x *= drop_mult(seed, site + sg, b, drop_p); acc[q].y *= drop_mult(seed, site + sg, b + 1, drop_p);
-                            acc[q].z *= drop_mult(seed, site + sg, b + 2, drop_p); acc[q].w *= drop_mult(seed, site + sg, b + 3, drop_p);
+                            float m[4];
+                            drop_mult4(seed, site + sg, b, drop_p, m);
+                            acc[q].x *= m[0]; acc[q].y *= m[1]; acc[q].z *= m[2]; acc[q].w *= m[3];
                         }
                         l[q].x += acc[q].x; l[q].y += acc[q].y; l[q].z += acc[q].z; l[q].w += acc[q].w;
                     }

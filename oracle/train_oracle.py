@@ -32,17 +32,19 @@ def _rope(x, cos, sin):
 
 
 def drop_mult(seed: int, site: int, n_rows: int, K: int, row0: int, p: float) -> np.ndarray:
-    """The engine's counter-based LoRA-input dropout mask (csrc/train_kernels.hip: drop_mult), restated: multiplier 1/(1-p) or 0 for
-    element (row0 + i, k) of adapter `site` under step seed `seed`."""
+    """The engine's counter-based LoRA-input dropout mask (csrc/train_kernels.hip: drop_hash / drop_mult4), restated: multiplier 1/(1-p) or 0
+    for element (row0 + i, k) of adapter `site` under step seed `seed`.  One 64-bit hash per group of four consecutive elements, 16 bits each;
+    an element is dropped when its 16 bits are below floor(65536 p)."""
     u64 = np.uint64
     idx = (np.arange(row0, row0 + n_rows, dtype=np.uint64)[:, None] * u64(K) + np.arange(K, dtype=np.uint64)[None, :])
     with np.errstate(over="ignore"):
-        z = u64(seed & 0xFFFFFFFFFFFFFFFF) + u64(0x9E3779B97F4A7C15) * u64(site + 1) + idx * u64(0xD1B54A32D192ED03)
+        z = u64(seed & 0xFFFFFFFFFFFFFFFF) + u64(0x9E3779B97F4A7C15) * u64(site + 1) + (idx >> u64(2)) * u64(0xD1B54A32D192ED03)
         z = (z ^ (z >> u64(30))) * u64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> u64(27))) * u64(0x94D049BB133111EB)
         z = z ^ (z >> u64(31))
-    u = (z >> u64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return np.where(u >= np.float32(p), np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
+    bits = (z >> (u64(16) * (idx & u64(3)))) & u64(0xFFFF)
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    return np.where(bits >= thr, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
 
 
 class TrainOracle:

@@ -15,7 +15,7 @@ dims = synth.ModelDims(num_layers=4) if small else synth.ModelDims()
 dtype = os.environ.get("BLIM_DTYPE", "f16")
 eng = Engine(dims, max_positions=1024, dtype=dtype)
 eng.init_synthetic_weights(0)
-tr = Trainer(eng, lora_r=8, lora_alpha=32.0, lora_dropout=0.05, seed=1)
+tr = Trainer(eng, lora_r=8, lora_alpha=32.0, lora_dropout=float(os.environ.get("BLIM_TRAIN_DROPOUT", "0.05")), seed=1)
 n_vocab = int(os.environ.get("BLIM_TRAIN_VOCAB", "4096"))
 steps = int(os.environ.get("BLIM_TRAIN_STEPS", "3"))
 trace = os.environ.get("BLIM_TRAIN_TRACE") == "1"          # per-step losses (the same batch every step: the loss must fall)
