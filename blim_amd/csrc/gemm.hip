@@ -629,7 +629,37 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             const int seg = tid % LPR;
             const int oc = oc0 + 8 * seg;
             constexpr int RPP = NTHREADS / LPR;                   // rows per pass of the workgroup
-            if (row0 + 256 <= p.M && oc0 + NC <= n_out && (p.ldc & 7) == 0) {   // interior tile: all LDS reads, then all stores, no branches
+            bool fused_done = false;
+            if constexpr (EPI == EPI_BF16) {
+                if (p.swiglu_gu != nullptr) {
+                    // fine-tuning backward (train.hip): this tile is d act = dy . Wd; instead of storing it, turn the saved gate | up
+                    // pre-activations (16 gate / 16 up columns interleaved, the fused matrix's stored row order) into [d gate | d up] in place
+                    constexpr int ODT = out16<DT>::value;
+#pragma unroll 2
+                    for (int rl = tid / LPR; rl < 256; rl += RPP) {
+                        const int row = row0 + rl;
+                        if (row >= p.M || oc >= n_out) continue;
+                        const uint4 dv = *(const uint4*)(smem + rl * RS + seg * 16);
+                        uint16_t* gp = p.swiglu_gu + (int64_t)row * p.swiglu_ld + 32 * (oc >> 4) + (oc & 15);
+                        const uint4 gr = *(const uint4*)gp, ur = *(const uint4*)(gp + 16);
+                        const uint16_t* dh = (const uint16_t*)&dv; const uint16_t* gh = (const uint16_t*)&gr; const uint16_t* uh = (const uint16_t*)&ur;
+                        uint4 og, ou;
+                        uint16_t* pg = (uint16_t*)&og; uint16_t* pu = (uint16_t*)&ou;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float g = from16<ODT>(gh[e]), u = from16<ODT>(uh[e]), d = from16<ODT>(dh[e]);
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+                            pg[e] = to16<ODT>(d * u * sg * (1.0f + g * (1.0f - sg)));
+                            pu[e] = to16<ODT>(d * g * sg);
+                        }
+                        *(uint4*)gp = og;
+                        *(uint4*)(gp + 16) = ou;
+                    }
+                    fused_done = true;
+                }
+            }
+            if (fused_done) {
+            } else if (row0 + 256 <= p.M && oc0 + NC <= n_out && (p.ldc & 7) == 0) {   // interior tile: all LDS reads, then all stores, no branches
                 uint4 v[256 / RPP];
                 const char* lsrc = smem + (tid / LPR) * RS + seg * 16;
 #pragma unroll

@@ -27,6 +27,8 @@ struct GemmParams {
     int64_t ldc;
     const float* bias;  // [N] (in W's row order) or nullptr
     const float* resid_in;  // EPI_RESID: C = resid_in + acc (+ bias); nullptr = in place (C += acc).  Same row stride as C.
+    uint16_t* swiglu_gu;    // EPI_BF16, fine-tuning backward: when non-null the tile (d act, N = I columns) is not stored; the saved gate | up
+    int64_t swiglu_ld;      //   pre-activations [M, swiglu_ld] (16 gate / 16 up columns interleaved) become [d gate | d up] in place
     int act;            // EPI_BF16: 0 none, 1 exact-erf GELU
     float scale;        // EPI_F32
     // EPI_QKV
