@@ -667,6 +667,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 bf16_t* out = (bf16_t*)p.C + c_part + (int64_t)(row0 + tid / LPR) * p.ldc + oc;
 #pragma unroll
                 for (int i = 0; i < 256 / RPP; ++i) *(uint4*)(out + (int64_t)i * RPP * p.ldc) = v[i];
+                if constexpr (EPI == EPI_BF16) {
+                    // fine-tuning forward (train.hip): the tile is the gate | up pre-activations (kept for the backward); the lanes holding a
+                    // gate chunk also form act = silu(gate) * up from the up chunk two 16-byte chunks further in the same LDS row
+                    if (p.swiglu_act != nullptr && (seg & 3) < 2) {
+                        constexpr int ODT = out16<DT>::value;
+                        uint16_t* aout = p.swiglu_act + (int64_t)(row0 + tid / LPR) * p.swiglu_act_ld + oc0 / 2 + 16 * (seg >> 2) + 8 * (seg & 3);
+#pragma unroll
+                        for (int i = 0; i < 256 / RPP; ++i) {
+                            const uint4 ur = *(const uint4*)(lsrc + i * RPP * RS + 32);
+                            const uint16_t* gh = (const uint16_t*)&v[i]; const uint16_t* uh = (const uint16_t*)&ur;
+                            uint4 o; uint16_t* po = (uint16_t*)&o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float g = from16<ODT>(gh[e]); po[e] = to16<ODT>(silu_f(g) * from16<ODT>(uh[e])); }
+                            *(uint4*)(aout + (int64_t)i * RPP * p.swiglu_act_ld) = o;
+                        }
+                    }
+                }
             } else
 #pragma unroll 1
             for (int rl = tid / LPR; rl < 256; rl += RPP) {
@@ -678,6 +695,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 else {
                     const bf16_t* e = (const bf16_t*)&v;
                     for (int j = 0; j < 8 && oc + j < n_out; ++j) out[j] = e[j];
+                }
+                if constexpr (EPI == EPI_BF16) {
+                    if (p.swiglu_act != nullptr && (seg & 3) < 2) {      // edge tiles: same rule as above (N = 2 I is a multiple of 32)
+                        constexpr int ODT = out16<DT>::value;
+                        const uint4 ur = *(const uint4*)(smem + rl * RS + seg * 16 + 32);
+                        const uint16_t* gh = (const uint16_t*)&v; const uint16_t* uh = (const uint16_t*)&ur;
+                        uint4 o; uint16_t* po = (uint16_t*)&o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float g = from16<ODT>(gh[e]); po[e] = to16<ODT>(silu_f(g) * from16<ODT>(uh[e])); }
+                        *(uint4*)(p.swiglu_act + (int64_t)row * p.swiglu_act_ld + oc0 / 2 + 16 * (seg >> 2) + 8 * (seg & 3)) = o;
+                    }
                 }
             }
             stamp(5);

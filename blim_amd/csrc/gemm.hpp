@@ -29,6 +29,8 @@ struct GemmParams {
     const float* resid_in;  // EPI_RESID: C = resid_in + acc (+ bias); nullptr = in place (C += acc).  Same row stride as C.
     uint16_t* swiglu_gu;    // EPI_BF16, fine-tuning backward: when non-null the tile (d act, N = I columns) is not stored; the saved gate | up
     int64_t swiglu_ld;      //   pre-activations [M, swiglu_ld] (16 gate / 16 up columns interleaved) become [d gate | d up] in place
+    uint16_t* swiglu_act;   // EPI_BF16, fine-tuning forward: when non-null the tile is the gate | up pre-activations (stored to C as usual) and
+    int64_t swiglu_act_ld;  //   act = silu(gate) * up [M, N / 2] is written here as well (row stride swiglu_act_ld)
     int act;            // EPI_BF16: 0 none, 1 exact-erf GELU
     float scale;        // EPI_F32
     // EPI_QKV

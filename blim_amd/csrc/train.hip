@@ -341,11 +341,11 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         TRY(launch_rmsnorm(x_mid, H, nullptr, T, H, l.norm2, c.rms_eps, (bf16_t*)t->xn2.p, dt, nullptr, s, 0, 0, nullptr));
-        {
+        {   // gate | up pre-activations kept for the backward; act = silu(gate) * up formed in the same epilogue
             GemmParams p = gp(dt, t->xn2.p, H, l.wgu, T, 2 * I, H, gu, 2 * (int64_t)I);
+            p.swiglu_act = (uint16_t*)t->act.p; p.swiglu_act_ld = I;
             TRY(launch_gemm(EPI_BF16, p, s));
         }
-        TRY(launch_swiglu_fwd((uint16_t*)t->act.p, gu, T, I, dt, s));
         {
             GemmParams p = gp(dt, t->act.p, I, l.wd, T, H, I, x_out, H);
             p.resid_in = x_mid;

@@ -47,11 +47,6 @@ int launch_lora_dx(float* dx, int64_t ldd, const LoraDxArgs& a, int64_t T, int K
 int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps, int accumulate, uint16_t* out16, int dtype,
                        hipStream_t s, const LoraDxArgs* la = nullptr, int r = 0, float drop_p = 0.f, uint64_t seed = 0, uint32_t site = 0);
 
-// gu16 [T, 2I] with 16 gate / 16 up columns interleaved (the fused gate|up matrix's stored row order) -> act16 [T, I] = silu(gate) * up
-int launch_swiglu_fwd(uint16_t* act16, const uint16_t* gu16, int64_t T, int I, int dtype, hipStream_t s);
-// in place: gu16 <- [d gate | d up] (same interleave) from dact16 [T, I]
-int launch_swiglu_bwd(uint16_t* gu16, const uint16_t* dact16, int64_t T, int I, int dtype, hipStream_t s);
-
 int launch_f32_to_16(uint16_t* out, int64_t ldo, const float* in, int64_t ldi, int64_t rows, int cols, float scale, int dtype, hipStream_t s);
 // h16[t, :H] = gelu(pre16[t, :H]) (exact erf)
 int launch_gelu_fwd(uint16_t* h16, int64_t ldo, const uint16_t* pre16, int64_t rows, int H, int dtype, hipStream_t s);

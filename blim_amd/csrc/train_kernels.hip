@@ -509,56 +509,6 @@ int launch_rmsnorm_bwd(float* dx, const float* dy, const float* x, const int32_t
     return BLIM_OK;
 }
 
-// ---------------------------------------------------------------------------- SwiGLU
-template <int DT, bool BWD>
-__global__ void swiglu_kernel(uint16_t* act16, uint16_t* gu16, const uint16_t* dact16, int64_t T, int I) {
-    const int chunks = I / 8;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * chunks) return;
-    const int64_t t = i / chunks;
-    const int i0 = (int)(i - t * chunks) * 8;
-    const int gcol = 32 * (i0 >> 4) + (i0 & 15);
-    uint16_t* gp = gu16 + t * 2 * I + gcol;
-    const uint4 graw = *(const uint4*)gp, uraw = *(const uint4*)(gp + 16);
-    const uint16_t* gh = (const uint16_t*)&graw; const uint16_t* uh = (const uint16_t*)&uraw;
-    uint4 o0, o1;
-    uint16_t* p0 = (uint16_t*)&o0; uint16_t* p1 = (uint16_t*)&o1;
-    if (!BWD) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float g = from16<DT>(gh[e]), u = from16<DT>(uh[e]);
-            p0[e] = to16<DT>(g / (1.0f + __expf(-g)) * u);
-        }
-        *(uint4*)(act16 + t * I + i0) = o0;
-    } else {
-        const uint4 draw = *(const uint4*)(dact16 + t * I + i0);
-        const uint16_t* dh = (const uint16_t*)&draw;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float g = from16<DT>(gh[e]), u = from16<DT>(uh[e]), d = from16<DT>(dh[e]);
-            const float sg = 1.0f / (1.0f + __expf(-g));
-            p0[e] = to16<DT>(d * u * sg * (1.0f + g * (1.0f - sg)));
-            p1[e] = to16<DT>(d * g * sg);
-        }
-        *(uint4*)gp = o0;
-        *(uint4*)(gp + 16) = o1;
-    }
-}
-int launch_swiglu_fwd(uint16_t* act16, const uint16_t* gu16, int64_t T, int I, int dtype, hipStream_t s) {
-    ARG_CHECK(I % 16 == 0);
-    const int64_t total = T * (I / 8);
-    DISPATCH_DT(dtype, hipLaunchKernelGGL((swiglu_kernel<DT, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, act16, (uint16_t*)gu16, nullptr, T, I));
-    LAUNCH_CHECK();
-    return BLIM_OK;
-}
-int launch_swiglu_bwd(uint16_t* gu16, const uint16_t* dact16, int64_t T, int I, int dtype, hipStream_t s) {
-    ARG_CHECK(I % 16 == 0);
-    const int64_t total = T * (I / 8);
-    DISPATCH_DT(dtype, hipLaunchKernelGGL((swiglu_kernel<DT, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, nullptr, gu16, dact16, T, I));
-    LAUNCH_CHECK();
-    return BLIM_OK;
-}
-
 // ---------------------------------------------------------------------------- casts / GELU
 template <int DT>
 __global__ void f32_to_16_kernel(uint16_t* out, int64_t ldo, const float* in, int64_t ldi, int64_t rows, int cols, float scale) {
