@@ -858,6 +858,9 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         if (p.labels) q.labels = p.labels + r0;
         if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
         if (p.label_logit) q.label_logit = p.label_logit + r0;
+        if (p.resid_in) q.resid_in = p.resid_in + r0 * p.ldc;
+        if (p.swiglu_gu) q.swiglu_gu = p.swiglu_gu + r0 * p.swiglu_ld;
+        if (p.swiglu_act) q.swiglu_act = p.swiglu_act + r0 * p.swiglu_act_ld;
         const int rc = launch_one(epi, q, stream);
         if (rc != BLIM_OK) return rc;
     }
@@ -886,7 +889,11 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK(p.lo_off == 0 || epi == EPI_BF16 || epi == EPI_QKV || epi == EPI_SWIGLU);
     ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
-        case EPI_BF16: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_BF16>(p, stream);
+        case EPI_BF16:
+            ARG_CHECK(p.C && p.ldc % 4 == 0);
+            ARG_CHECK(!p.swiglu_gu || (p.N % 16 == 0 && p.swiglu_ld % 8 == 0 && p.swiglu_ld >= 2 * (int64_t)p.N));
+            ARG_CHECK(!p.swiglu_act || (p.N % 32 == 0 && p.swiglu_act_ld % 8 == 0 && p.swiglu_act_ld >= p.N / 2 && !p.swiglu_gu));
+            return launch_t<EPI_BF16>(p, stream);
         case EPI_F32: ARG_CHECK(p.C && p.bias == nullptr); return launch_t<EPI_F32>(p, stream);
         case EPI_RESID: ARG_CHECK(p.C && p.ldc % 4 == 0); return launch_t<EPI_RESID>(p, stream);
         case EPI_QKV:
