@@ -6,10 +6,10 @@
 // kept per layer (288 GB of HBM: no recomputation): the f32 residual stream before each sub-block, the normalised QKV input with
 // its adapter columns, q|k|v after RoPE, the attention output and its rows' log-sum-exp, and the gate|up pre-activations.
 // Backward = input-gradient GEMMs on the same 256x256 MFMA kernel against TRANSPOSED copies of the frozen weights (built once),
-// rank-r gradient kernels for the adapters, and the attention backward of train_kernels.hip (P re-materialised from the saved
-// log-sum-exp).  Gradients w.r.t. 16-bit activations
-// travel as the engine's 16-bit type scaled by the AMP loss scale (util/misc.py:232-252 NativeScaler), the residual-stream gradient
-// stays f32 like the forward's residual stream.
+// rank-r products for the adapters on the matrix cores, and the attention backward of train_kernels.hip (P re-materialised from the
+// saved log-sum-exp).  SwiGLU has no pass of its own: forward and backward sit in the epilogues of the gate|up and d act GEMMs
+// (gemm.hpp: swiglu_act / swiglu_gu).  Gradients w.r.t. 16-bit activations travel as the engine's 16-bit type scaled by the AMP loss
+// scale (util/misc.py:232-252 NativeScaler), the residual-stream gradient stays f32 like the forward's residual stream.
 #include <math.h>
 #include <stdio.h>
 #include <string.h>

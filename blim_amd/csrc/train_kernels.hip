@@ -1,6 +1,7 @@
-// Kernels of the fine-tuning step (train.hpp).  gfx950 only.  Everything here is HBM- or latency-bound helper work around the
-// big GEMMs (which run on gemm.hip's kernel, forward and backward), except the attention backward, whose five batched products
-// run on MFMA 32x32x16 tiles over materialised P / dS (sequences of a training batch are a few hundred tokens long).
+// Kernels of the fine-tuning step (train.hpp).  gfx950 only.  Everything here works around the big GEMMs (which run on gemm.hip's
+// kernel, forward and backward): the rank-r adapter products and the attention backward's batched products run on 32x32x16 MFMA
+// tiles (operands whose contraction index is their row index come through the transposing LDS load, tr_frag); the rest are
+// one-pass HBM-bound kernels (RMSNorm / RoPE / GELU / cross-entropy backward, casts, AdamW).
 #include "train.hpp"
 
 #include <string.h>
