@@ -301,7 +301,8 @@ class Trainer:
         tvg = pack_tvg_rows(as_rows(data["tvg_ids"]), as_rows(data["tvg_masks"]), as_rows(data["tvg_labels"]), C_)
         vl = np.asarray(data["tvg_video_labels"].cpu().numpy() if hasattr(data["tvg_video_labels"], "cpu") else data["tvg_video_labels"], np.int32)
         host = torch.stack(video)
-        host = host.pin_memory() if not host.is_pinned() else host
+        if not host.is_cuda and not host.is_pinned():
+            host = host.pin_memory()                          # features may also arrive on the device already
         with torch.cuda.stream(self._copy_stream):
             feats = host.to(dev, non_blocking=True).to(dt).reshape(bs * C_ * tok, dims.mm_hidden_size).contiguous()
             tb1, keep1 = self._train_batch(vtg, feats, tok, seed)
