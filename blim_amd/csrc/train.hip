@@ -65,7 +65,7 @@ struct blim_trainer {
     // saved activations of the last forward (per layer, strided by tokens) and workspaces
     DevBuf sv_res, sv_mid, sv_xn1, sv_qkv, sv_attn, sv_gu, sv_lse;
     DevBuf xn2, act, dres, dy16, dtmp32, dqkv32, dqkv16, du, attn_D, P16, dS16, logits, dlog16, hsel, hsel_t, dhsel;
-    DevBuf feats_aug, pre16, h16, proj16, mean16, embeds, dout16, dh32, vh32, vhb16, dl32, dvh;
+    DevBuf feats_aug[2], pre16[2], h16[2], vid16, proj16, embeds, dout16[2], dh32, vh32, vhb16, dl32, dvh;      // [2]: projector mlp / tvg_mlp
     int64_t last_T = 0;
 };
 
@@ -181,8 +181,8 @@ extern "C" void blim_train_destroy(blim_trainer* t) {
     hipDeviceSynchronize();
     for (void* p : t->owned) hipFree(p);
     DevBuf* bufs[] = {&t->sv_res, &t->sv_mid, &t->sv_xn1, &t->sv_qkv, &t->sv_attn, &t->sv_gu, &t->sv_lse, &t->xn2, &t->act, &t->dres, &t->dy16, &t->dtmp32, &t->dqkv32, &t->dqkv16,
-                      &t->du, &t->attn_D, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->hsel_t, &t->dhsel, &t->feats_aug, &t->pre16, &t->h16, &t->proj16, &t->mean16,
-                      &t->embeds, &t->dout16, &t->dh32, &t->vh32, &t->vhb16, &t->dl32, &t->dvh};
+                      &t->du, &t->attn_D, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->hsel_t, &t->dhsel, &t->feats_aug[0], &t->feats_aug[1], &t->pre16[0], &t->pre16[1], &t->h16[0], &t->h16[1],
+                      &t->vid16, &t->proj16, &t->embeds, &t->dout16[0], &t->dout16[1], &t->dh32, &t->vh32, &t->vhb16, &t->dl32, &t->dvh};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     delete t;
 }
@@ -263,19 +263,18 @@ static int ensure_z(DevBuf& b, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------- forward
-// projector (mm_projector_builder.py:88-93 with the adapters of main.py:96-98) + sequence assembly + the decoder, keeping activations
-static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, hipStream_t s) {
+// One projector (mm_projector_builder.py:88-93 with the adapters of main.py:96-98): which = 0 `mlp` -> rows [0, F) of vid16 (the VTG rows'
+// video tokens), which = 1 `tvg_mlp` + mean over each clip's tokens (modeling_videochat_flash.py:243) -> rows [F, F + F / tok) (the TVG rows'
+// clip tokens).  Both keep their own saved activations: the two backward passes run after the shared decoder backward.
+static int projector_forward(blim_trainer* t, const blim_train_batch* b, int which, hipStream_t s) {
     blim_engine* e = t->e;
     const blim_config& c = e->c;
-    const int H = c.hidden_size, I = c.intermediate_size, M = c.mm_hidden_size, dt = c.compute_dtype, r = t->r;
-    const int Ha = H + AUG, Ma = M + AUG, qn = e->qkv_n;
-    const int64_t T = b->batch->n_tokens, F = b->n_feat_rows;
-    const int NL = c.num_layers;
-    ARG_CHECK(F > 0 && T > 0 && (which == 0 || (b->tok_per_clip > 0 && F % b->tok_per_clip == 0)));
-    // ---- projector
-    TRY(ensure_z(t->feats_aug, (size_t)F * Ma * 2)); TRY(ensure(t->pre16, (size_t)F * H * 2)); TRY(ensure_z(t->h16, (size_t)F * Ha * 2));
-    TRY(ensure(t->proj16, (size_t)F * H * 2)); TRY(ensure(t->embeds, (size_t)T * H * 2));
-    uint16_t* fa = (uint16_t*)t->feats_aug.p; uint16_t* pre = (uint16_t*)t->pre16.p; uint16_t* h16 = (uint16_t*)t->h16.p; uint16_t* proj = (uint16_t*)t->proj16.p;
+    const int H = c.hidden_size, M = c.mm_hidden_size, dt = c.compute_dtype, r = t->r;
+    const int Ha = H + AUG, Ma = M + AUG;
+    const int64_t F = b->n_feat_rows;
+    TRY(ensure_z(t->feats_aug[which], (size_t)F * Ma * 2)); TRY(ensure(t->pre16[which], (size_t)F * H * 2)); TRY(ensure_z(t->h16[which], (size_t)F * Ha * 2));
+    uint16_t* fa = (uint16_t*)t->feats_aug[which].p; uint16_t* pre = (uint16_t*)t->pre16[which].p; uint16_t* h16 = (uint16_t*)t->h16[which].p;
+    uint16_t* vid = (uint16_t*)t->vid16.p;
     HIP_TRY(hipMemcpy2DAsync(fa, (size_t)Ma * 2, b->feats, (size_t)M * 2, (size_t)M * 2, F, hipMemcpyDeviceToDevice, s));
     LoraDownArgs la; la.n = 1; la.A16[1] = la.A16[2] = nullptr;
     la.A16[0] = t->lay.mlp[which][0].A16;
@@ -288,18 +287,30 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, int which, 
     TRY(launch_gelu_fwd(h16, Ha, pre, F, H, dt, s));
     la.A16[0] = t->lay.mlp[which][1].A16;
     TRY(launch_lora_down(h16, Ha, F, H, la, r, t->s, t->p_drop, b->dropout_seed, 1001 + 2 * which, dt, s));
+    uint16_t* proj = which == 0 ? vid : (uint16_t*)t->proj16.p;
     {
         GemmParams p = gp(dt, h16, Ha, t->w2_aug[which], F, H, Ha, proj, H);
         p.bias = e->mlp_b2[which];
         TRY(launch_gemm(EPI_BF16, p, s));
     }
-    const uint16_t* vid_rows = proj;
-    if (which == 1) {     // TVG: one token per clip = mean over its tokens (modeling_videochat_flash.py:243)
-        TRY(ensure(t->mean16, (size_t)(F / b->tok_per_clip) * H * 2));
-        TRY(launch_group_mean((bf16_t*)t->mean16.p, (const bf16_t*)proj, F / b->tok_per_clip, b->tok_per_clip, H, dt, s));
-        vid_rows = (const uint16_t*)t->mean16.p;
-    }
-    TRY(launch_assemble((bf16_t*)t->embeds.p, b->src_index, T, H, e->embed, (const bf16_t*)vid_rows, s));
+    if (which == 1) TRY(launch_group_mean((bf16_t*)(vid + F * H), (const bf16_t*)proj, F / b->tok_per_clip, b->tok_per_clip, H, dt, s));
+    return BLIM_OK;
+}
+
+// both projectors + sequence assembly + the decoder over ONE packed batch holding the VTG rows and the TVG rows (the TVG rows are a
+// tenth of the tokens: as a pass of their own they ran at a third of the VTG pass's efficiency), keeping activations
+static int train_forward(blim_trainer* t, const blim_train_batch* b, hipStream_t s) {
+    blim_engine* e = t->e;
+    const blim_config& c = e->c;
+    const int H = c.hidden_size, I = c.intermediate_size, dt = c.compute_dtype, r = t->r;
+    const int Ha = H + AUG, qn = e->qkv_n;
+    const int64_t T = b->batch->n_tokens, F = b->n_feat_rows;
+    const int NL = c.num_layers;
+    ARG_CHECK(F > 0 && T > 0 && b->tok_per_clip > 0 && F % b->tok_per_clip == 0);
+    TRY(ensure(t->vid16, (size_t)(F + F / b->tok_per_clip) * H * 2)); TRY(ensure(t->proj16, (size_t)F * H * 2)); TRY(ensure(t->embeds, (size_t)T * H * 2));
+    if (b->n_rows > 0) TRY(projector_forward(t, b, 0, s));
+    if (b->n_tvg_rows > 0) TRY(projector_forward(t, b, 1, s));
+    TRY(launch_assemble((bf16_t*)t->embeds.p, b->src_index, T, H, e->embed, (const bf16_t*)t->vid16.p, s));
     // ---- decoder
     TRY(ensure(t->sv_res, (size_t)(NL + 1) * T * H * 4)); TRY(ensure(t->sv_mid, (size_t)NL * T * H * 4));
     TRY(ensure_z(t->sv_xn1, (size_t)NL * T * Ha * 2)); TRY(ensure(t->sv_qkv, (size_t)NL * T * qn * 2)); TRY(ensure_z(t->sv_attn, (size_t)NL * T * Ha * 2));
@@ -423,84 +434,91 @@ static int train_backward_projector(blim_trainer* t, const blim_train_batch* b, 
     const int H = c.hidden_size, M = c.mm_hidden_size, dt = c.compute_dtype, r = t->r;
     const int Ha = H + AUG, Ma = M + AUG;
     const int64_t T = t->last_T, F = b->n_feat_rows;
-    TRY(ensure(t->dout16, (size_t)F * H * 2)); TRY(ensure(t->dh32, (size_t)F * H * 4)); TRY(ensure(t->du, (size_t)std::max<int64_t>(F, T) * 3 * 16 * 4));
-    uint16_t* dout = (uint16_t*)t->dout16.p; float* dh = (float*)t->dh32.p; float* du = (float*)t->du.p;
-    HIP_TRY(hipMemsetAsync(dout, 0, (size_t)F * H * 2, s));
-    TRY(launch_feat_grad(dout, (const float*)t->dres.p, b->src_index, T, H, which == 1 ? b->tok_per_clip : 1, dt, s));
+    TRY(ensure(t->dh32, (size_t)F * H * 4)); TRY(ensure(t->du, (size_t)std::max<int64_t>(F, T) * 3 * 16 * 4));
+    uint16_t* dout = (uint16_t*)t->dout16[which].p; float* dh = (float*)t->dh32.p; float* du = (float*)t->du.p;
     const Adapter& a2 = t->lay.mlp[which][1]; const Adapter& a0 = t->lay.mlp[which][0];
-    TRY(lora_backward(t, a2, dout, H, (const uint16_t*)t->h16.p, Ha, H, 0, F, du, b->dropout_seed, 1001 + 2 * which, s));
+    TRY(lora_backward(t, a2, dout, H, (const uint16_t*)t->h16[which].p, Ha, H, 0, F, du, b->dropout_seed, 1001 + 2 * which, s));
     { GemmParams p = gp(dt, dout, H, t->w2T[which], F, H, H, dh, H); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(lora_dx1(dh, H, du, t->params + a2.offA, F, H, r, t->p_drop, b->dropout_seed, 1001 + 2 * which, s));
-    TRY(launch_gelu_bwd(dout, dh, (const uint16_t*)t->pre16.p, F, H, dt, s));                                           // dout <- d pre-activation
-    return lora_backward(t, a0, dout, H, (const uint16_t*)t->feats_aug.p, Ma, M, 0, F, du, b->dropout_seed, 1000 + 2 * which, s);
+    TRY(launch_gelu_bwd(dout, dh, (const uint16_t*)t->pre16[which].p, F, H, dt, s));                                    // dout <- d pre-activation
+    return lora_backward(t, a0, dout, H, (const uint16_t*)t->feats_aug[which].p, Ma, M, 0, F, du, b->dropout_seed, 1000 + 2 * which, s);
 }
 
 static int check_train_batch(const blim_trainer* t, const blim_train_batch* b) {
-    ARG_CHECK(t && b && b->batch && b->src_index && b->feats && b->rows && b->labels && b->n_rows > 0 && b->max_seq_len > 0);
+    ARG_CHECK(t && b && b->batch && b->src_index && b->feats && b->max_seq_len > 0 && (b->n_rows > 0 || b->n_tvg_rows > 0));
+    ARG_CHECK(b->n_rows == 0 || (b->rows && b->labels));
+    ARG_CHECK(b->n_tvg_rows == 0 || (b->tvg_rows && b->tvg_labels && b->vocab && b->n_vocab > 0 && b->n_tvg_rows % t->e->c.num_clips == 0));
     TRY(check_batch(b->batch));
     return BLIM_OK;
 }
 
-extern "C" int blim_train_vtg(blim_trainer* t, const blim_train_batch* b, float* loss_sum, void* stream) {
-    ARG_CHECK(loss_sum);
-    TRY(check_train_batch(t, b));
-    hipStream_t s = (hipStream_t)stream;
+// VTG head: final norm at the scored rows, lm_head (+ adapter), cross-entropy (training_utils.py:23-32: mean over the label tokens), and
+// back to the residual-stream gradient of those rows (dres rows are disjoint from the TVG head's)
+static int vtg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum, hipStream_t s) {
     blim_engine* e = t->e;
     const blim_config& c = e->c;
     const int H = c.hidden_size, V = c.vocab_size, dt = c.compute_dtype, r = t->r, Ha = H + AUG, Vp = t->Vp;
-    TRY(train_forward(t, b, 0, s));
     const int64_t T = t->last_T, R = b->n_rows;
     const float* x_final = (const float*)t->sv_res.p + (int64_t)c.num_layers * T * H;
-    // ---- head: final norm at the scored rows, lm_head (+ adapter), cross-entropy (training_utils.py:23-32: mean over the label tokens)
     TRY(ensure_z(t->hsel, (size_t)R * Ha * 2)); TRY(ensure(t->logits, (size_t)R * Vp * 4)); TRY(ensure(t->dlog16, (size_t)R * Vp * 2)); TRY(ensure(t->dhsel, (size_t)R * H * 4));
-    TRY(ensure(t->dres, (size_t)T * H * 4)); TRY(ensure(t->du, (size_t)std::max<int64_t>(R, T) * 3 * 16 * 4));
+    TRY(ensure(t->du, (size_t)std::max<int64_t>(R, T) * 3 * 16 * 4));
     uint16_t* hsel = (uint16_t*)t->hsel.p; float* logits = (float*)t->logits.p; uint16_t* dlog = (uint16_t*)t->dlog16.p; float* dhsel = (float*)t->dhsel.p; float* du = (float*)t->du.p;
     TRY(launch_rmsnorm(x_final, H, b->rows, R, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, Ha, nullptr));
     LoraDownArgs la; la.n = 1; la.A16[0] = t->lay.lm.A16; la.A16[1] = la.A16[2] = nullptr;
     TRY(launch_lora_down(hsel, Ha, R, H, la, r, t->s, t->p_drop, b->dropout_seed, 2000, dt, s));
     { GemmParams p = gp(dt, hsel, Ha, t->lm_aug, R, V, Ha, logits, Vp); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(launch_ce_fwd_bwd(logits, Vp, V, b->labels, 1, R, b->grad_scale / (float)R, dlog, nullptr, Vp, loss_sum, dt, s));
-    // ---- backward
     TRY(lora_backward(t, t->lay.lm, dlog, Vp, hsel, Ha, H, 0, R, du, b->dropout_seed, 2000, s));
     { GemmParams p = gp(dt, dlog, Vp, t->lmT, R, H, Vp, dhsel, H); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(lora_dx1(dhsel, H, du, t->params + t->lay.lm.offA, R, H, r, t->p_drop, b->dropout_seed, 2000, s));
-    HIP_TRY(hipMemsetAsync(t->dres.p, 0, (size_t)T * H * 4, s));
-    TRY(launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, R, H, e->final_norm, c.rms_eps, 0, nullptr, dt, s));
-    TRY(train_backward_layers(t, b, s));
-    return train_backward_projector(t, b, 0, s);
+    return launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, R, H, e->final_norm, c.rms_eps, 0, nullptr, dt, s);
 }
 
-extern "C" int blim_train_tvg(blim_trainer* t, const blim_train_batch* b, float* loss_sum, void* stream) {
-    ARG_CHECK(loss_sum);
-    TRY(check_train_batch(t, b));
-    ARG_CHECK(b->vocab && b->n_vocab > 0);
+// TVG head (training_utils.py:71-79): hidden at the 4 positions before <|im_end|> -> visual_head -> . video_vocab / sqrt(M) -> CE over the N videos
+static int tvg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     blim_engine* e = t->e;
     const blim_config& c = e->c;
     const int H = c.hidden_size, M = c.mm_hidden_size, dt = c.compute_dtype, C = c.num_clips, N = b->n_vocab;
-    ARG_CHECK(b->n_rows % C == 0);
-    const int BC = (int)b->n_rows, B = BC / C;
-    TRY(train_forward(t, b, 1, s));
+    const int BC = (int)b->n_tvg_rows, B = BC / C;
     const int64_t T = t->last_T;
     const float* x_final = (const float*)t->sv_res.p + (int64_t)c.num_layers * T * H;
-    // ---- head (training_utils.py:71-79): hidden at the 4 positions before <|im_end|> -> visual_head -> . video_vocab / sqrt(M) -> CE over the N videos
     TRY(ensure(t->hsel_t, (size_t)BC * H * 2)); TRY(ensure(t->vh32, (size_t)BC * M * 4)); TRY(ensure(t->vhb16, (size_t)BC * M * 2)); TRY(ensure(t->logits, (size_t)BC * N * 4));
-    TRY(ensure(t->dl32, (size_t)BC * N * 4)); TRY(ensure(t->dvh, (size_t)BC * M * 4)); TRY(ensure(t->dhsel, (size_t)BC * H * 4)); TRY(ensure(t->dres, (size_t)T * H * 4));
+    TRY(ensure(t->dl32, (size_t)BC * N * 4)); TRY(ensure(t->dvh, (size_t)BC * M * 4)); TRY(ensure(t->dhsel, (size_t)BC * H * 4));
     uint16_t* hsel = (uint16_t*)t->hsel_t.p; float* vh32 = (float*)t->vh32.p; uint16_t* vhb = (uint16_t*)t->vhb16.p; float* logits = (float*)t->logits.p;
     float* dl = (float*)t->dl32.p; float* dvh = (float*)t->dvh.p; float* dhsel = (float*)t->dhsel.p;
-    TRY(launch_rmsnorm(x_final, H, b->rows, BC, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, 0, nullptr));
+    TRY(launch_rmsnorm(x_final, H, b->tvg_rows, BC, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, 0, nullptr));
     { GemmParams p = gp(dt, hsel, H, t->vh16, BC, M, H, vh32, M); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(launch_f32_to_16(vhb, M, vh32, M, BC, M, 1.0f, dt, s));
     TRY(blim_tvg_logits(e, vhb, b->vocab, N, B, logits, stream));
-    TRY(launch_ce_fwd_bwd(logits, N, N, b->labels, C, BC, b->grad_scale / (float)BC, nullptr, dl, N, loss_sum, dt, s));
-    // ---- backward
+    TRY(launch_ce_fwd_bwd(logits, N, N, b->tvg_labels, C, BC, b->grad_scale / (float)BC, nullptr, dl, N, loss_sum, dt, s));
     TRY(launch_tvg_dvh(dvh, dl, (const uint16_t*)b->vocab, BC, C, N, M, 1.0f / sqrtf((float)M), dt, s));
     TRY(launch_outer_acc(t->grads + t->lay.off_vh, dvh, hsel, H, BC, M, H, dt, s));
     TRY(launch_rows_matmul(dhsel, dvh, t->params + t->lay.off_vh, BC, M, H, s));
+    return launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->tvg_rows, BC, H, e->final_norm, c.rms_eps, 0, nullptr, dt, s);
+}
+
+extern "C" int blim_train_step(blim_trainer* t, const blim_train_batch* b, float* loss_sums, void* stream) {
+    ARG_CHECK(loss_sums);
+    TRY(check_train_batch(t, b));
+    hipStream_t s = (hipStream_t)stream;
+    const blim_config& c = t->e->c;
+    const int H = c.hidden_size, dt = c.compute_dtype;
+    TRY(train_forward(t, b, s));
+    const int64_t T = t->last_T, F = b->n_feat_rows;
+    TRY(ensure(t->dres, (size_t)T * H * 4));
     HIP_TRY(hipMemsetAsync(t->dres.p, 0, (size_t)T * H * 4, s));
-    TRY(launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, BC, H, e->final_norm, c.rms_eps, 0, nullptr, dt, s));
+    if (b->n_rows > 0) TRY(vtg_head(t, b, loss_sums, s));
+    if (b->n_tvg_rows > 0) TRY(tvg_head(t, b, loss_sums + 1, stream));
     TRY(train_backward_layers(t, b, s));
-    return train_backward_projector(t, b, 1, s);
+    // d embeds -> the two projectors' output gradients (VTG video tokens: rows [0, F) of vid16; TVG clip tokens: rows F.. = clip means)
+    TRY(ensure(t->dout16[0], (size_t)F * H * 2)); TRY(ensure(t->dout16[1], (size_t)F * H * 2));
+    if (b->n_rows > 0) HIP_TRY(hipMemsetAsync(t->dout16[0].p, 0, (size_t)F * H * 2, s));
+    if (b->n_tvg_rows > 0) HIP_TRY(hipMemsetAsync(t->dout16[1].p, 0, (size_t)F * H * 2, s));
+    TRY(launch_feat_grad((uint16_t*)t->dout16[0].p, (uint16_t*)t->dout16[1].p, (const float*)t->dres.p, b->src_index, T, H, F, b->tok_per_clip, dt, s));
+    if (b->n_rows > 0) TRY(train_backward_projector(t, b, 0, s));
+    if (b->n_tvg_rows > 0) TRY(train_backward_projector(t, b, 1, s));
+    return BLIM_OK;
 }
 
 extern "C" int blim_train_grad_stats(blim_trainer* t, float inv_scale, float* stats, void* stream) {

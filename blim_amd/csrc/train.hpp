@@ -63,8 +63,9 @@ int launch_tvg_dvh(float* dvh, const float* dl, const uint16_t* vocab16, int n_r
 int launch_outer_acc(float* dW, const float* dvh, const uint16_t* h16, int64_t ldh, int n_rows, int M, int H, int dtype, hipStream_t s);             // dW[m, h] += sum_bc dvh[bc, m] * h16[bc, h]
 int launch_rows_matmul(float* out, const float* dvh, const float* W, int n_rows, int M, int H, hipStream_t s);                                       // out[bc, h] = sum_m dvh[bc, m] * W[m, h]
 
-// d embeds -> d projector output: for tokens with src_index[t] < 0 (feature row f = -src - 1): dout16[f*group + g, :] = 16-bit(dres[t, :] / group), g < group
-int launch_feat_grad(uint16_t* dout16, const float* dres, const int32_t* src_index, int64_t T, int H, int group, int dtype, hipStream_t s);
+// d embeds -> d projector outputs: token t with src_index[t] = -(f + 1): f < F -> dout_a[f, :] = 16-bit(dres[t, :]) (a VTG video token);
+// f >= F -> dout_b[(f - F) * group + g, :] = 16-bit(dres[t, :] / group), g < group (a TVG clip token = the mean of `group` projector rows)
+int launch_feat_grad(uint16_t* dout_a, uint16_t* dout_b, const float* dres, const int32_t* src_index, int64_t T, int H, int64_t F, int group, int dtype, hipStream_t s);
 
 // ---- attention backward over materialised scores.  Sequences have no shared prefix; token of (s, i) = seq_start[s] + i.
 struct AttnBwdParams {

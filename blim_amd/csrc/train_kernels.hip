@@ -630,20 +630,26 @@ int launch_rows_matmul(float* out, const float* dvh, const float* W, int n_rows,
     return BLIM_OK;
 }
 
+// d embeds -> d projector outputs.  Token t with src_index[t] = -(f + 1): f < F is row f of the `mlp` output (a VTG video token):
+// dout_a[f] = dres[t]; f >= F is clip mean f - F of the `tvg_mlp` output: dout_b[(f - F) * group + g] = dres[t] / group, g < group.
 template <int DT>
-__global__ void feat_grad_kernel(uint16_t* dout16, const float* dres, const int32_t* src_index, int H, int group) {
+__global__ void feat_grad_kernel(uint16_t* dout_a, uint16_t* dout_b, const float* dres, const int32_t* src_index, int H, int64_t F, int group) {
     const int64_t t = blockIdx.x;
     const int src = src_index[t];
     if (src >= 0) return;
     const int64_t f = -(int64_t)src - 1;
-    const float inv = 1.0f / (float)group;
-    for (int k = threadIdx.x; k < H; k += blockDim.x) {
-        const uint16_t v = to16<DT>(dres[t * H + k] * inv);
-        for (int g = 0; g < group; ++g) dout16[(f * group + g) * H + k] = v;
+    if (f < F) {
+        for (int k = threadIdx.x; k < H; k += blockDim.x) dout_a[f * H + k] = to16<DT>(dres[t * H + k]);
+    } else {
+        const float inv = 1.0f / (float)group;
+        for (int k = threadIdx.x; k < H; k += blockDim.x) {
+            const uint16_t v = to16<DT>(dres[t * H + k] * inv);
+            for (int g = 0; g < group; ++g) dout_b[((f - F) * group + g) * H + k] = v;
+        }
     }
 }
-int launch_feat_grad(uint16_t* dout16, const float* dres, const int32_t* src_index, int64_t T, int H, int group, int dtype, hipStream_t s) {
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(feat_grad_kernel<DT>, dim3((unsigned)T), dim3(256), 0, s, dout16, dres, src_index, H, group));
+int launch_feat_grad(uint16_t* dout_a, uint16_t* dout_b, const float* dres, const int32_t* src_index, int64_t T, int H, int64_t F, int group, int dtype, hipStream_t s) {
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(feat_grad_kernel<DT>, dim3((unsigned)T), dim3(256), 0, s, dout_a, dout_b, dres, src_index, H, F, group));
     LAUNCH_CHECK();
     return BLIM_OK;
 }

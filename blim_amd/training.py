@@ -37,6 +37,7 @@ class TrainConfig(C.Structure):
 class TrainBatch(C.Structure):
     _fields_ = [("batch", C.POINTER(Batch)), ("src_index", C.c_void_p), ("feats", C.c_void_p), ("n_feat_rows", C.c_int64),
                 ("tok_per_clip", C.c_int32), ("max_seq_len", C.c_int32), ("rows", C.c_void_p), ("labels", C.c_void_p), ("n_rows", C.c_int64),
+                ("tvg_rows", C.c_void_p), ("tvg_labels", C.c_void_p), ("n_tvg_rows", C.c_int64),
                 ("vocab", C.c_void_p), ("n_vocab", C.c_int32), ("grad_scale", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
@@ -55,8 +56,7 @@ def _lib():
             "blim_train_destroy": ([vp], None),
             "blim_train_sync_params": ([vp, vp], C.c_int),
             "blim_train_merge": ([vp, vp], C.c_int),
-            "blim_train_vtg": ([vp, C.POINTER(TrainBatch), vp, vp], C.c_int),
-            "blim_train_tvg": ([vp, C.POINTER(TrainBatch), vp, vp], C.c_int),
+            "blim_train_step": ([vp, C.POINTER(TrainBatch), vp, vp], C.c_int),
             "blim_train_grad_stats": ([vp, f32, vp, vp], C.c_int),
             "blim_train_adamw": ([vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, vp], C.c_int),
             "blim_train_debug_read": ([vp, C.c_char_p, vp, i64, vp], C.c_int),
@@ -262,22 +262,32 @@ class Trainer:
             self._vocab = v.permute(1, 0, 2).contiguous()
             self._vocab_key = key
 
-    def _train_batch(self, rows: PackedRows, feats, tok_per_clip: int, seed: int, vocab=None, labels=None):
+    def _train_batch(self, vtg: PackedRows, tvg: PackedRows, feats, tok_per_clip: int, seed: int, vocab, video_labels):
+        """ONE packed batch: the VTG rows, then the TVG rows (a tenth of the tokens: as a decoder pass of their own they ran at a third of
+        the VTG pass's efficiency).  VTG video tokens point at rows [0, F) of the `mlp` projection, TVG clip tokens at the clip means of the
+        `tvg_mlp` projection, numbered from F."""
         import torch
         dev = self.engine.device
-        seq_len = rows.seq_len
+        F = vtg.n_feat_rows
+        t_src = tvg.src_index.copy()
+        neg = t_src < 0
+        t_src[neg] -= F                                   # -(fm + 1) -> -(F + fm + 1)
+        src = np.concatenate([vtg.src_index, t_src]).astype(np.int32)
+        seq_len = np.concatenate([vtg.seq_len, tvg.seq_len]).astype(np.int32)
         seq_start = np.concatenate([[0], np.cumsum(seq_len)[:-1]]).astype(np.int32)
         positions = np.concatenate([np.arange(n, dtype=np.int32) for n in seq_len])
+        n_vtg_tok = int(vtg.seq_len.sum())
         pb = PackedBatch(positions, np.ones(len(positions), np.uint8), seq_start, seq_len, device=dev)
-        keep = [pb, torch.from_numpy(rows.src_index).to(dev), torch.from_numpy(rows.rows).to(dev),
-                torch.from_numpy(np.asarray(labels if labels is not None else rows.labels, np.int32)).to(dev), feats]
+        keep = [pb, torch.from_numpy(src).to(dev), torch.from_numpy(vtg.rows).to(dev), torch.from_numpy(vtg.labels).to(dev),
+                torch.from_numpy((tvg.rows + n_vtg_tok).astype(np.int32)).to(dev), torch.from_numpy(np.asarray(video_labels, np.int32)).to(dev), feats]
         st = pb.struct(self.engine.max_positions)
         tb = TrainBatch()
         tb.batch = C.pointer(st)
         tb.src_index, tb.feats, tb.n_feat_rows = keep[1].data_ptr(), feats.data_ptr(), feats.shape[0]
         tb.tok_per_clip, tb.max_seq_len = int(tok_per_clip), int(seq_len.max())
-        tb.rows, tb.labels, tb.n_rows = keep[2].data_ptr(), keep[3].data_ptr(), len(rows.rows)
-        tb.vocab, tb.n_vocab = (vocab.data_ptr(), vocab.shape[1]) if vocab is not None else (None, 0)
+        tb.rows, tb.labels, tb.n_rows = keep[2].data_ptr(), keep[3].data_ptr(), len(vtg.rows)
+        tb.tvg_rows, tb.tvg_labels, tb.n_tvg_rows = keep[4].data_ptr(), keep[5].data_ptr(), len(tvg.rows)
+        tb.vocab, tb.n_vocab = vocab.data_ptr(), vocab.shape[1]
         tb.dropout_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         return tb, keep + [st]
 
@@ -305,22 +315,20 @@ class Trainer:
             host = host.pin_memory()                          # features may also arrive on the device already
         with torch.cuda.stream(self._copy_stream):
             feats = host.to(dev, non_blocking=True).to(dt).reshape(bs * C_ * tok, dims.mm_hidden_size).contiguous()
-            tb1, keep1 = self._train_batch(vtg, feats, tok, seed)
-            tb2, keep2 = self._train_batch(tvg, feats, tok, seed + 1, vocab=self._vocab, labels=vl)
+            tb, keep = self._train_batch(vtg, tvg, feats, tok, seed, self._vocab, vl)
             loss = torch.zeros(2, dtype=torch.float32, device=dev)
             ready = torch.cuda.Event()
             ready.record(self._copy_stream)
-        return {"tb": (tb1, tb2), "keep": (keep1, keep2, host), "loss": loss, "ready": ready, "n": (len(vtg.rows), len(tvg.rows))}
+        return {"tb": tb, "keep": (keep, host), "loss": loss, "ready": ready, "n": (len(vtg.rows), len(tvg.rows))}
 
     def launch(self, staged: dict, accum_iter: int = 1) -> None:
-        """training_utils.py:57-85: both losses forward + backward on the current stream; gradients accumulate, scaled by loss scale / accum_iter."""
+        """training_utils.py:57-85: both losses forward + backward on the current stream, the two kinds of rows in one decoder pass;
+        gradients accumulate, scaled by loss scale / accum_iter."""
         import torch
         torch.cuda.current_stream().wait_event(staged["ready"])
-        gs = self.scaler.scale / accum_iter
-        tb1, tb2 = staged["tb"]
-        tb1.grad_scale = tb2.grad_scale = float(gs)
-        _check(self.lib.blim_train_vtg(self.h, C.byref(tb1), staged["loss"].data_ptr(), _stream()), "blim_train_vtg")
-        _check(self.lib.blim_train_tvg(self.h, C.byref(tb2), staged["loss"].data_ptr() + 4, _stream()), "blim_train_tvg")
+        tb = staged["tb"]
+        tb.grad_scale = float(self.scaler.scale / accum_iter)
+        _check(self.lib.blim_train_step(self.h, C.byref(tb), staged["loss"].data_ptr(), _stream()), "blim_train_step")
 
     def finish(self, staged: dict):
         """(vtg_loss, tvg_loss) of a launched batch; synchronises with the GPU (the reference's loss.item(), training_utils.py:83)."""

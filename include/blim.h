@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 5
+#define BLIM_ABI_VERSION 6
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -247,24 +247,28 @@ int blim_train_sync_params(blim_trainer* t, void* stream);
  * fine-tuned model; always merged from the pristine base, so it can be called repeatedly */
 int blim_train_merge(blim_trainer* t, void* stream);
 typedef struct blim_train_batch {
-    const blim_batch* batch;      /* packed rows, no shared prefixes */
-    const int32_t* src_index;     /* [T] token id >= 0, or -(f + 1): row f of the projected video (VTG: clip-token rows; TVG: clip means) */
+    const blim_batch* batch;      /* ONE packed batch holding the VTG rows and the TVG rows (either part may be absent), no shared prefixes */
+    const int32_t* src_index;     /* [T] token id >= 0, or -(f + 1): f < n_feat_rows = row f of the `mlp` projection (a VTG row's video token),
+                                   * f >= n_feat_rows = clip mean f - n_feat_rows of the `tvg_mlp` projection (a TVG row's clip token) */
     const void* feats;            /* 16-bit [n_feat_rows, mm_hidden]: raw features of the batch's videos, video-major */
     int64_t n_feat_rows;
-    int32_t tok_per_clip;         /* TVG: rows averaged per clip (modeling_videochat_flash.py:243) */
+    int32_t tok_per_clip;         /* rows averaged per clip for the TVG tokens (modeling_videochat_flash.py:243) */
     int32_t max_seq_len;          /* longest row of the batch */
-    const int32_t* rows;          /* VTG: [n_rows] token rows whose next-token label is scored; TVG: [n_samples * num_clips] rows predicting clip c */
-    const int32_t* labels;        /* VTG: [n_rows] target token ids; TVG: [n_samples] index of the sample's video in the vocabulary */
+    const int32_t* rows;          /* VTG: [n_rows] token rows whose next-token label is scored */
+    const int32_t* labels;        /* VTG: [n_rows] target token ids */
     int64_t n_rows;
+    const int32_t* tvg_rows;      /* TVG: [n_samples * num_clips] rows predicting clip c (training_utils.py:73) */
+    const int32_t* tvg_labels;    /* TVG: [n_samples] index of the sample's video in the vocabulary */
+    int64_t n_tvg_rows;
     const void* vocab;            /* TVG: 16-bit clip-major [num_clips][n_vocab][mm_hidden] */
     int32_t n_vocab;
-    float grad_scale;             /* upstream gradient of this loss (AMP loss scale / accum_iter) */
+    float grad_scale;             /* upstream gradient of both losses (AMP loss scale / accum_iter) */
     uint64_t dropout_seed;
 } blim_train_batch;
-/* forward + backward of one loss; gradients ACCUMULATE into `grads` (scaled by grad_scale); loss_sum[0] += the summed negative
- * log-likelihood over the n_rows scored rows (device f32; the mean loss of training_utils.py:68 / :79 is loss_sum / n_rows) */
-int blim_train_vtg(blim_trainer* t, const blim_train_batch* b, float* loss_sum, void* stream);
-int blim_train_tvg(blim_trainer* t, const blim_train_batch* b, float* loss_sum, void* stream);
+/* training_utils.py:57-85 for one batch: forward of both kinds of rows through the decoder in one pass, loss = vtg_loss + tvg_loss, backward;
+ * gradients ACCUMULATE into `grads` (scaled by grad_scale); loss_sums[0] += the summed negative log-likelihood over the n_rows VTG label rows,
+ * loss_sums[1] += the same over the n_tvg_rows TVG rows (device f32 [2]; the mean losses of training_utils.py:68 / :79 divide by the row counts) */
+int blim_train_step(blim_trainer* t, const blim_train_batch* b, float* loss_sums, void* stream);
 /* stats[0] += sum((g * inv_scale)^2) over the flat gradient buffer, stats[1] = 1 if any element is inf / nan (device f32 [2]) */
 int blim_train_grad_stats(blim_trainer* t, float inv_scale, float* stats, void* stream);
 /* torch.optim.AdamW over the flat buffers (g = grad * inv_scale; decoupled weight decay on every tensor: all are 2-D, timm's

@@ -119,7 +119,6 @@ class TrainOracle:
         import torch.nn.functional as F
         C = self.cfg.num_clips
         nll, cnt = [], 0
-        seed0 = self.seed                                   # the engine runs the TVG pass under seed + 1 (blim_amd/training.py)
         tok0 = frow0 = 0
         for ids, lab, vid in zip(vtg_ids, vtg_labels, videos):
             x, where, nv = self.embeds_of(np.asarray(ids), vid, False, frow0)
@@ -132,8 +131,7 @@ class TrainOracle:
         vtg_loss = torch.stack(nll).sum() / cnt
         vocab = torch.from_numpy(np.asarray(video_vocab, np.float32))
         rows = []
-        self.seed = seed0 + 1
-        tok0 = frow0 = 0
+        frow0 = 0                                          # one packed batch: the TVG rows' tokens are numbered after the VTG rows' (tok0 continues)
         for ids, lab, vid, vl in zip(tvg_ids, tvg_labels, videos, tvg_video_labels):
             x, where, nv = self.embeds_of(np.asarray(ids), vid, True, frow0)
             lab = np.concatenate([lab[:where], np.full(nv, IGNORE_INDEX, np.int64), lab[where + 1:]])
@@ -144,7 +142,6 @@ class TrainOracle:
             lg = torch.einsum("cm,ncm->cn", hv, vocab) / math.sqrt(vocab.shape[-1])       # training_utils.py:78
             rows.append(F.cross_entropy(lg, torch.full((C,), int(vl)), reduction="sum"))
         tvg_loss = torch.stack(rows).sum() / (C * len(rows))
-        self.seed = seed0
         return vtg_loss, tvg_loss
 
     def step_grads(self, *batch):
