@@ -1,6 +1,7 @@
 // Fine-tuning step behind include/blim.h's blim_train_* (training_utils.py:57-95, main.py:96-150).
 //
-// Forward = the scoring path's kernels with two changes: (1) every LoRA-adapted Linear runs on a K-AUGMENTED copy of its frozen
+// The VTG rows and the TVG rows of a batch go through the decoder as ONE packed batch (forward and backward once; the two heads and the
+// two projectors differ).  Forward = the scoring path's kernels with two changes: (1) every LoRA-adapted Linear runs on a K-AUGMENTED copy of its frozen
 // weight, [W | B | 0] with 64 extra K columns, against activations [x | alpha/r * A drop(x) | 0] -- the rank-r update rides in the
 // same MFMA accumulation as the base product, before bias / RoPE, at +1.8 % of the K loop; (2) activations the backward needs are
 // kept per layer (288 GB of HBM: no recomputation): the f32 residual stream before each sub-block, the normalised QKV input with
