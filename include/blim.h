@@ -221,8 +221,8 @@ int blim_vision_encode(blim_vision* v, const void* frames, int32_t n_clips, floa
 int blim_tome_merge(blim_vision* v, const float* x, int32_t b, int32_t p, int32_t c, int32_t heads, int32_t target, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Fine-tuning step: what training_utils.py:57-95 does per batch -- two decoder forwards (VTG rows, TVG rows),
- * loss = vtg_loss + tvg_loss, backward into the LoRA adapters of main.py:96-101 (projector mlp / tvg_mlp Linear 0 and 2, every
+ * Fine-tuning step: what training_utils.py:57-95 does per batch -- the reference's two decoder forwards (VTG rows, TVG rows;
+ * here one forward over a packed batch holding both), loss = vtg_loss + tvg_loss, backward into the LoRA adapters of main.py:96-101 (projector mlp / tvg_mlp Linear 0 and 2, every
  * q/k/v/o_proj, lm_head; y = W x + b + alpha/r * B A dropout(x)) and the fp32 visual_head (main.py:104-107), AdamW (main.py:147).
  * Base weights stay frozen in the engine.  The trainable tensors live in ONE flat f32 device buffer owned by the caller (so that the
  * host can all-reduce the matching gradient buffer over RCCL in one call, as DistributedDataParallel does for the reference,
