@@ -13,8 +13,8 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 # 16-bit operands everywhere (the reference itself trains under autocast(float16)): a gradient tensor is compared relative to its own
 # largest element / its L2 norm against the fp32 autograd reference
-GRAD_RTOL = {"f16": 1e-2, "bf16": 1e-1}        # worst element; measured 1.4e-3 / 9.0e-3 (tiny), 2.1e-3 (7B width), 5.9e-3 (28 layers: k_proj A)
-GRAD_NORM_RTOL = {"f16": 2e-3, "bf16": 3e-2}   # the tensor's L2 norm; measured <= 1.3e-3 (28 layers); bf16 (a reported, not a parity mode): 5.6e-3 tiny,
+GRAD_RTOL = {"f16": 2e-2, "bf16": 1e-1}        # worst element; measured 1.4e-3 / 9.0e-3 (tiny), 2.1e-3 (7B width), 4.3e-3 - 6.5e-3 over runs at 28 layers (the sums are atomic)
+GRAD_NORM_RTOL = {"f16": 3e-3, "bf16": 3e-2}   # the tensor's L2 norm; measured <= 1.3e-3 (28 layers); bf16 (a reported, not a parity mode): 5.6e-3 tiny,
                                                # 5.9e-2 worst element / 1.6e-2 norm through 28 layers (8-bit mantissas in P and the activation gradients)
 LOSS_RTOL = {"f16": 1e-3, "bf16": 1e-2}
 
