@@ -256,10 +256,11 @@ static int lora_dx1(float* dx, int64_t ldd, const float* du, const float* A, int
 }
 // buffers of augmented rows [.., K + AUG]: the forward writes columns [0, K) and the adapters' u~ columns; the padding columns after
 // them must be zero and nothing ever writes them, so they are cleared when the buffer is (re)allocated, not per step
-static int ensure_z(DevBuf& b, size_t bytes) {
+// (cleared on the step's own stream: a memset on the null stream is not ordered against a non-blocking caller stream)
+static int ensure_z(DevBuf& b, size_t bytes, hipStream_t s) {
     if (b.bytes >= bytes) return BLIM_OK;
     TRY(ensure(b, bytes));
-    HIP_TRY(hipMemset(b.p, 0, b.bytes));
+    HIP_TRY(hipMemsetAsync(b.p, 0, b.bytes, s));
     return BLIM_OK;
 }
 
@@ -273,7 +274,7 @@ static int projector_forward(blim_trainer* t, const blim_train_batch* b, int whi
     const int H = c.hidden_size, M = c.mm_hidden_size, dt = c.compute_dtype, r = t->r;
     const int Ha = H + AUG, Ma = M + AUG;
     const int64_t F = b->n_feat_rows;
-    TRY(ensure_z(t->feats_aug[which], (size_t)F * Ma * 2)); TRY(ensure(t->pre16[which], (size_t)F * H * 2)); TRY(ensure_z(t->h16[which], (size_t)F * Ha * 2));
+    TRY(ensure_z(t->feats_aug[which], (size_t)F * Ma * 2, s)); TRY(ensure(t->pre16[which], (size_t)F * H * 2)); TRY(ensure_z(t->h16[which], (size_t)F * Ha * 2, s));
     uint16_t* fa = (uint16_t*)t->feats_aug[which].p; uint16_t* pre = (uint16_t*)t->pre16[which].p; uint16_t* h16 = (uint16_t*)t->h16[which].p;
     uint16_t* vid = (uint16_t*)t->vid16.p;
     HIP_TRY(hipMemcpy2DAsync(fa, (size_t)Ma * 2, b->feats, (size_t)M * 2, (size_t)M * 2, F, hipMemcpyDeviceToDevice, s));
@@ -314,7 +315,7 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, hipStream_t
     TRY(launch_assemble((bf16_t*)t->embeds.p, b->src_index, T, H, e->embed, (const bf16_t*)t->vid16.p, s));
     // ---- decoder
     TRY(ensure(t->sv_res, (size_t)(NL + 1) * T * H * 4)); TRY(ensure(t->sv_mid, (size_t)NL * T * H * 4));
-    TRY(ensure_z(t->sv_xn1, (size_t)NL * T * Ha * 2)); TRY(ensure(t->sv_qkv, (size_t)NL * T * qn * 2)); TRY(ensure_z(t->sv_attn, (size_t)NL * T * Ha * 2));
+    TRY(ensure_z(t->sv_xn1, (size_t)NL * T * Ha * 2, s)); TRY(ensure(t->sv_qkv, (size_t)NL * T * qn * 2)); TRY(ensure_z(t->sv_attn, (size_t)NL * T * Ha * 2, s));
     TRY(ensure(t->sv_gu, (size_t)NL * T * 2 * I * 2));
     TRY(ensure(t->sv_lse, (size_t)NL * T * c.num_heads * 4));
     TRY(ensure(t->xn2, (size_t)T * H * 2)); TRY(ensure(t->act, (size_t)T * I * 2));
@@ -461,7 +462,7 @@ static int vtg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum,
     const int H = c.hidden_size, V = c.vocab_size, dt = c.compute_dtype, r = t->r, Ha = H + AUG, Vp = t->Vp;
     const int64_t T = t->last_T, R = b->n_rows;
     const float* x_final = (const float*)t->sv_res.p + (int64_t)c.num_layers * T * H;
-    TRY(ensure_z(t->hsel, (size_t)R * Ha * 2)); TRY(ensure(t->logits, (size_t)R * Vp * 4)); TRY(ensure(t->dlog16, (size_t)R * Vp * 2)); TRY(ensure(t->dhsel, (size_t)R * H * 4));
+    TRY(ensure_z(t->hsel, (size_t)R * Ha * 2, s)); TRY(ensure(t->logits, (size_t)R * Vp * 4)); TRY(ensure(t->dlog16, (size_t)R * Vp * 2)); TRY(ensure(t->dhsel, (size_t)R * H * 4));
     TRY(ensure(t->du, (size_t)std::max<int64_t>(R, T) * 3 * 16 * 4));
     uint16_t* hsel = (uint16_t*)t->hsel.p; float* logits = (float*)t->logits.p; uint16_t* dlog = (uint16_t*)t->dlog16.p; float* dhsel = (float*)t->dhsel.p; float* du = (float*)t->du.p;
     TRY(launch_rmsnorm(x_final, H, b->rows, R, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, Ha, nullptr));

@@ -81,7 +81,7 @@ def read_frames(path: str, is_video: bool, dataset: str, num_frames: int) -> np.
     vlen, fps = len(vr), vr.get_avg_fps()
     if vlen / float(fps) > 30 and dataset == "DiDeMo":                    # extract.py:50-52
         vlen = 30 * fps
-    return vr.get_batch(sample_frame_indices(int(vlen), num_frames)).asnumpy()
+    return vr.get_batch(sample_frame_indices(vlen, num_frames)).asnumpy()    # vlen stays a float for cut DiDeMo videos (30 * fps), as extract.py:52-54
 
 
 def main(args):

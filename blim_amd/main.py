@@ -198,8 +198,15 @@ def train_loop(args, model, train_loader, val_loader, tokenizer, device, rank: i
     if args.resume:                                                                                  # util/misc.py:303-316
         ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
         trainer.load_checkpoint_state(ckpt)
-        if "epoch" in ckpt:
+        # The reference's load_model restores the weights only and restarts at --start_epoch (util/misc.py:303-316).  A file written by
+        # THIS trainer also carries its optimizer moments (flat layout): only then is the run continued after the saved epoch.
+        opt = ckpt.get("optimizer")
+        if isinstance(opt, dict) and "exp_avg" in opt and "epoch" in ckpt:
             args.start_epoch = int(ckpt["epoch"]) + 1
+        elif rank == 0:
+            print(f"resume: weights only (no optimizer state in this repo's layout): starting at --start_epoch {args.start_epoch}")
+    if args.start_epoch >= args.epochs and rank == 0:
+        print(f"warning: nothing to train: start epoch {args.start_epoch} >= --epochs {args.epochs}")
     eff = args.batch_size * args.accum_iter * world                                                  # main.py:133-139
     if rank == 0:
         n_train = sum(int(__import__("numpy").prod(s)) for _, s in trainer.layout.values())

@@ -368,15 +368,7 @@ class Trainer:
     def load_checkpoint_state(self, ckpt: dict, strict: bool = True) -> None:
         """`--resume` for training (util/misc.py:303-316).  strict: every trainable tensor must be in the file (the reference asserts the
         parameter total, main.py:127), so that a naming drift cannot silently continue from fresh adapters."""
-        import torch
-        from .checkpoint import parse_resume_key
-        tensors = {}
-        for k, v in ckpt["model"].items():
-            parsed = parse_resume_key(k)
-            if parsed is None:
-                continue
-            w, kind = parsed
-            tensors["visual_head" if kind == "full" else f"{w}:{kind}"] = v.float().numpy()
+        tensors = resume_tensors(ckpt)
         absent = [n for n in self.layout if n not in tensors]
         if strict and absent:
             raise BlimError(f"resume file lacks {len(absent)} of {len(self.layout)} trainable tensors (first: {absent[:3]})")
@@ -387,6 +379,21 @@ class Trainer:
             self.exp_avg.copy_(opt["exp_avg"]); self.exp_avg_sq.copy_(opt["exp_avg_sq"])
         if "scaler" in ckpt:
             self.scaler.load_state_dict(ckpt["scaler"])
+
+
+def resume_tensors(ckpt: dict) -> Dict[str, np.ndarray]:
+    """Trainable tensors of a resume file under the flat layout's names (`<weight>:A`, `<weight>:B`, `visual_head`).  The reference's
+    save_model stores the nn.Parameter objects themselves (requires_grad=True, util/misc.py:282-285) and torch.load hands them back as such:
+    detach before leaving torch."""
+    from .checkpoint import parse_resume_key
+    tensors = {}
+    for k, v in ckpt["model"].items():
+        parsed = parse_resume_key(k)
+        if parsed is None:
+            continue
+        w, kind = parsed
+        tensors["visual_head" if kind == "full" else f"{w}:{kind}"] = v.detach().float().cpu().numpy()
+    return tensors
 
 
 def train_one_epoch(trainer: Trainer, data_loader, epoch: int, args, world_size: int = 1, log=print) -> Dict[str, float]:
@@ -440,6 +447,7 @@ def save_model(args, epoch: int, trainer: Trainer, name: str) -> str:
     path = os.path.join(args.output_dir, f"{name}.pth")
     st = trainer.checkpoint_state()
     st["epoch"] = epoch
-    st["args"] = dict(vars(args))
+    # the reference stores its argparse namespace; ours also carries tensors (iv2_scores: two N x N matrices) and private fields
+    st["args"] = {k: v for k, v in vars(args).items() if not k.startswith("_") and isinstance(v, (int, float, str, bool, list, tuple, type(None)))}
     torch.save(st, path)
     return path

@@ -267,6 +267,6 @@ def preprocess(frames_u8: np.ndarray, image_size: int = 448):
     return torch.from_numpy(out).half()
 
 
-def sample_frame_indices(vlen: int, num_frames: int = 16) -> np.ndarray:
-    """extract.py:54: np.linspace(0, vlen - 2, num_frames, dtype=int)."""
+def sample_frame_indices(vlen, num_frames: int = 16) -> np.ndarray:
+    """extract.py:54: np.linspace(0, vlen - 2, num_frames, dtype=int); vlen may be fractional (30 * fps of a cut DiDeMo video): only linspace truncates."""
     return np.linspace(0, vlen - 2, num_frames, dtype=int)

@@ -119,3 +119,24 @@ def test_gradient_averaging_world2_gloo():
         p.join(timeout=60); assert p.exitcode == 0
     assert all(ok for _, ok in res)
     g = torch.ones(4); average_gradients(g, 1); assert torch.equal(g, torch.ones(4))
+
+
+def test_resume_file_holding_parameters_like_the_reference_writes():
+    """The reference's save_model stores named_parameters() objects with requires_grad=True (util/misc.py:282-285) and torch.load returns
+    them unchanged: the trainer's resume path must detach (`.numpy()` on such a tensor raises)."""
+    import io
+    import torch
+    from blim_amd import lora, synth
+    from blim_amd.training import resume_tensors
+    dims = synth.ModelDims(vocab_size=300, hidden_size=64, intermediate_size=128, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=32)
+    init = lora.init_trainable(dims, 8, seed=3)
+    model = {lora.resume_key(n): torch.nn.Parameter(torch.from_numpy(a.copy()).half(), requires_grad=True) for n, a in init.items()}
+    buf = io.BytesIO()
+    torch.save({"model": model, "optimizer": {"state": {}, "param_groups": []}, "epoch": 4, "args": None}, buf)      # torch-format optimizer, as the reference
+    buf.seek(0)
+    ckpt = torch.load(buf, map_location="cpu", weights_only=False)
+    assert all(v.requires_grad for v in ckpt["model"].values())
+    got = resume_tensors(ckpt)
+    assert set(got) == set(init)
+    for n in init:
+        assert got[n].dtype == np.float32 and np.array_equal(got[n], init[n].astype(np.float16).astype(np.float32)), n

@@ -88,6 +88,9 @@ def test_preprocess_and_frame_sampling():
     same = V.preprocess(rs.randint(0, 256, size=(1, 32, 32, 3), dtype=np.uint8), image_size=32)       # no resize: pure rescale + normalise
     assert np.isfinite(same.float().numpy()).all() and abs(float(same.float().mean())) < 3.0
     assert list(V.sample_frame_indices(100, 16)) == list(np.linspace(0, 98, 16, dtype=int))
+    # a DiDeMo video cut to 30 s at a fractional frame rate: vlen = 30 * fps is a float in the reference (extract.py:50-54)
+    assert list(V.sample_frame_indices(30 * 23.976, 16)) == list(np.linspace(0, 30 * 23.976 - 2, 16, dtype=int))
+    assert list(V.sample_frame_indices(30 * 23.976, 16)) != list(V.sample_frame_indices(int(30 * 23.976), 16))
 
 
 def test_library_exports_the_vision_symbols():
