@@ -158,6 +158,91 @@ def tiny_config_evaluation():
     return {"pairs": 4 * n * topk, "oracle_s": round(t_cpu, 3), "engine_s": round(t_gpu, 4), "max_rel_diff": float(f"{worst:.2e}"), "agree_1e-3": worst < 1e-3}
 
 
+def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8):
+    """The fixed-size job north_star's scaling clause names: ONE complete evaluation of an MSRVTT-1kA-shaped test set (N = 1000 videos and
+    texts, top-16 re-rank, all six passes of the fine-tuned + CPN flow = 96,000 (query, candidate) pairs, reference-shaped rows with
+    4 x 64 = 256 video tokens, the full 7B model) through blim_amd.retrieval_utils.evaluation -- data handling, planning, pair ownership
+    and the RCCL all-gather of the score blocks all INSIDE the timed region (/root/reference/retrieval_utils.py:169-281).  Total work is
+    fixed, so seconds(W = 1) / seconds(W) is the strong-scaling speed-up.  At W = 1 the same process also plays each rank of an
+    `emulate`-process job in turn (`shard`: the rank's own blocks, no merge; the merge is one all-gather of < 1 MB) and the slowest rank's
+    time is the predicted `emulate`-GPU time."""
+    import types
+    import torch
+    from blim_amd import retrieval_utils as RU
+    from blim_amd import synth
+    from blim_amd.modeling import DDPLike
+    dims = model.dims
+    prob = synth.make_problem(1, n, dims, tok_per_clip=64, fast_video=True)
+    loader = synth.ProblemLoader(prob, 64, video_dtype=torch.float16)        # fp16 per-video feature tensors, as the reference's files hold
+    tokenizer = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    nz = lambda a: np.where(a == 0, np.float32(1e-6), a)
+    ddp = DDPLike(model)
+
+    def run(shard):
+        args = types.SimpleNamespace(topk=topk, num_clips=dims.num_clips, cpn=True, resume="x", eval=True, dataset="MSRVTT", batch_size_eval=16,
+                                     iv2_scores={"v2t": torch.from_numpy(nz(prob.v2t_sims)), "t2v": torch.from_numpy(nz(prob.t2v_sims))},
+                                     max_tokens=32768, dedup=True, shard=shard)
+        model.clear_cache()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t2v, v2t = RU.evaluation(ddp, loader, dev, tokenizer, args)          # ends with the matrices on the host: synchronises
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, args._eval_stats, (t2v, v2t)
+
+    run((4 * max(world, emulate), rank))                                      # warm-up: workspaces, allocator, first-call costs (a small share)
+    dt, st, (t2v, v2t) = run(None)
+    ok = all(np.isfinite(m).all() for d in (t2v, v2t) for m in d.values())
+    pairs = 6 * n * min(topk, n)
+    out = {"workload": f"one evaluation, N = {n} videos x {n} texts, top-{topk}, six passes (VTG/TVG likelihoods both directions + both CPN priors) = {pairs} "
+                       "(query, candidate) pairs, reference-shaped rows (256 video tokens), full 7B; host planning, pair ownership and the RCCL "
+                       "all-gather of score blocks inside the timed region",
+           "scaling": "strong", "world": world, "seconds": round(dt, 3), "pairs_per_s": round(pairs / dt, 1), "pairs": pairs,
+           "pairs_scored_rank0": st["pairs_scored"], "finite": bool(ok), "host_marks_rank0": st["host_marks"]}
+    if world == 1 and emulate > 1:
+        per_rank = []
+        for r in range(emulate):
+            d_r, st_r, _ = run((emulate, r))
+            per_rank.append(round(d_r, 3))
+            if r == 0:
+                out["emulated_rank0_host_marks"] = st_r["host_marks"]
+        out.update({"emulated_world": emulate, "emulated_rank_seconds": per_rank, "predicted_seconds": max(per_rank),
+                    "predicted_speedup": round(dt / max(per_rank), 2),
+                    "predicted_note": f"slowest of the {emulate} ranks' own shares run one after another on this GPU; merge (one all-gather of < 1 MB) excluded"})
+    return out
+
+
+def build_step_plans(model, rank, n_plans, Q, K):
+    """The device-resident super-batches the timed steps run: plan `pi` of rank `rank` = the v2t VTG pass over synthetic problem
+    1000 + 17 * rank + pi (Q videos and texts of the headline shape: 96 video + 32 text tokens; top-K texts per video query).
+    Returns [(scorer, plan, problem, pairs)].  tests/test_gpu_parity.py scores plan 0 of rank 0 and compares the query rows that
+    tests/golden/full7b_bench.npz holds (the reference's own loops on the same problem) -- the benched batch itself meets the oracle."""
+    import torch
+    from blim_amd import retrieval_utils as RU
+    from blim_amd import synth
+    from blim_amd.modeling import DDPLike
+    dims = model.dims
+    tok = type("T", (), {"pad_token_id": synth.PAD_ID})()
+    out = []
+    for pi in range(n_plans):
+        prob = synth.make_problem(1000 + 17 * rank + pi, Q, dims, tok_per_clip=24, text_len=(32, 32), reference_layout=False)
+        Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+        vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+        tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+        scorer = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video],
+                               torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels), dims.num_clips, max_tokens=1 << 20)
+        pairs = RU._topk_pairs(torch.from_numpy(prob.v2t_sims), 0, K, True)
+        (plan,) = scorer.plan_vtg(pairs)
+        out.append((scorer, plan, prob, pairs))
+    return out
+
+
 def launcher_command(gpus: int, argv, port: int = 0):
     """`python bench.py --gpus N` without a launcher around it: the command of the child that runs the ranks
     (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 -- the reference's env:// init, util/misc.py:199-229)."""
@@ -183,6 +268,9 @@ def main():
                          "f8 (separate mode, deviations reported)")
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the fixed-size N = 1000 evaluation (strong-scaling leg)")
+    ap.add_argument("--strong-only", action="store_true", help="only the strong-scaling leg (development aid; prints that object alone)")
+    ap.add_argument("--strong-n", type=int, default=1000)
     a = ap.parse_args()
 
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -200,26 +288,24 @@ def main():
 
     rank, world, local = D.init_distributed_mode() if a.gpus > 1 else (0, 1, 0)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    D.limit_host_threads(world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     dims = synth.ModelDims()
     model = BlimModel(dims, max_positions=1024, dtype=a.dtype)
     model.engine.init_synthetic_weights(0)                       # torch seed 0 of BASELINE.md -> engine seed 0
+    if a.strong_only:
+        ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk)
+        if rank == 0:
+            print(json.dumps({"strong_scaling": ss}), flush=True)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     Q, K = a.queries, a.topk
     n_plans = max(1, min(3, a.steps))
-    plans = []
-    tok = type("T", (), {"pad_token_id": synth.PAD_ID})()
-    for pi in range(n_plans):
-        prob = synth.make_problem(1000 + 17 * rank + pi, Q, dims, tok_per_clip=24, text_len=(32, 32), reference_layout=False)
-        Tt = lambda rows: [torch.from_numpy(r) for r in rows]
-        vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
-        tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
-        scorer = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video],
-                               torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels), dims.num_clips, max_tokens=1 << 20)
-        pairs = RU._topk_pairs(torch.from_numpy(prob.v2t_sims), 0, K, True)
-        (plan,) = scorer.plan_vtg(pairs)
-        plans.append((scorer, plan))
+    plans = [(sc, pl) for sc, pl, _, _ in build_step_plans(model, rank, n_plans, Q, K)]
     plan0 = plans[0][1]
     n_pairs, n_tok, n_rows = plan0.n_pairs, plan0.n_tokens, plan0.n_rows
     model.engine.reserve(n_tok, n_rows)
@@ -253,6 +339,9 @@ def main():
     step(0)
     rep = model.engine.timing_report()
     model.engine.timing_enable(False)
+
+    # ---- strong-scaling leg (all ranks): one fixed-size N = 1000 evaluation, after and outside the timed steps above
+    ss = None if a.no_strong else strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk)
 
     if rank == 0:
         total_pairs = n_pairs * a.steps * world
@@ -288,6 +377,8 @@ def main():
                          "avg_launch_ms": round(d["ms"] / d["calls"], 4), "flop_per_launch": d["flops"] / d["calls"]},
             "kernel_classes_ms": {k: round(v["ms"], 3) for k, v in rep.items() if v["calls"]},
         }
+        if ss is not None:
+            out["strong_scaling"] = ss
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -111,3 +111,29 @@ def merge_row_blocks_many(mats, blocks, world: int, compat_offset: bool = False)
             out = torch.where(out == -100.0, out * world, out - 100.0 * (world - 1))
         outs.append(out); off += step * M
     return outs
+
+
+def host_threads(world: int = 1, cap: int = 8) -> int:
+    """Intra-op threads for the host-side torch ops of the scoring drivers (top-k of the first-stage matrices, padding, stacking):
+    the CPUs this process may use (affinity mask and cgroup quota) shared by the `world` ranks of the node, at most `cap`.  torch's
+    default is one thread per LOGICAL CPU of the machine; inside a 16-CPU quota on a 256-thread host that made a 64 MB torch.stack take
+    170 ms (measured on the GPU boxes), and eight ranks each starting 256 threads is worse."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(q[0]) // int(q[1])))
+    except (OSError, ValueError, IndexError):
+        pass
+    return max(1, min(cap, n // max(1, world)))
+
+
+def limit_host_threads(world: int = 1) -> int:
+    import torch
+    n = host_threads(world)
+    torch.set_num_threads(n)
+    return n

@@ -96,6 +96,7 @@ def main(args):
     from .training_utils import val_one_epoch
 
     rank, world, local = D.init_distributed_mode()
+    D.limit_host_threads(world)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if not args.eval and args.lr is None:

@@ -183,7 +183,7 @@ class PairScorer:
     """Fused scoring of arbitrary (video, text) pairs.  See the module docstring for what is shared."""
 
     def __init__(self, model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video: Sequence, video_vocab,
-                 tvg_video_labels, num_clips: int, max_tokens: int = 24576, precise_tvg: bool = True):
+                 tvg_video_labels, num_clips: int, max_tokens: int = 24576, precise_tvg: bool = True, feat_chunk: int = 64):
         import torch
         self.precise_tvg = bool(precise_tvg)
         eng_ = getattr(model.module if hasattr(model, "module") else model, "engine", None)
@@ -203,6 +203,8 @@ class PairScorer:
         self.tvg_video_labels = np.asarray(tvg_video_labels).astype(np.int32)
         self.vocab_cm = _clip_major_vocab(video_vocab, self.device, self.m.dtype) if video_vocab is not None else None
         self._vfeat: Dict[Tuple[int, bool], object] = {}
+        self._upcoming: Dict[bool, List[int]] = {}; self._upcoming_pos: Dict[bool, int] = {}
+        self.feat_chunk = int(feat_chunk)
         # per-text splits
         self.vtg_split = []
         for ids, lab in self.vtg_rows:
@@ -220,20 +222,49 @@ class PairScorer:
     def video_feat(self, j: int, tvg: bool):
         """Projected feature rows of video j, cached on device.  TVG rows (clip means) are produced in the compensated mode when the TVG
         calls run in it: [clips, 2H] rows of hi | lo -- at 7B depth the 16-bit rounding of the projector output was the largest remaining
-        error of the TVG scores."""
+        error of the TVG scores.
+
+        A miss projects a CHUNK: video j together with the next videos the running pass will ask for (`expect`), one upload and one
+        projector call per `feat_chunk` videos.  A projected row depends on its own input row only, so the values are those of a
+        per-video call; what changes is the fixed cost -- one upload + six launches per video was 0.4 ms x N on EVERY rank of a sharded
+        evaluation (every rank needs the clip features of nearly all videos), the part of the job that did not shrink with the world size."""
         key = (int(j), bool(tvg))
         f = self._vfeat.get(key)
         if f is None:
-            split = bool(tvg) and self.split_tvg
-            if split:
-                self.engine.set_precise(True, embeds=True)
-            try:
-                f = self.m.project(self.video[j].to(self.device), tvg, cache=False)
-            finally:
-                if split:
-                    self.engine.set_precise(False)
-            self._vfeat[key] = f
+            self._project_chunk(int(j), bool(tvg))
+            f = self._vfeat[key]
         return f
+
+    def expect(self, video_ids, tvg: bool) -> None:
+        """Order in which the pass being planned will first ask for its videos (chunked projection looks ahead along it)."""
+        ids = np.asarray(video_ids, dtype=np.int64)
+        _, first = np.unique(ids, return_index=True)
+        self._upcoming[bool(tvg)] = [int(v) for v in ids[np.sort(first)]]
+        self._upcoming_pos[bool(tvg)] = 0
+
+    def _project_chunk(self, j: int, tvg: bool) -> None:
+        shape = tuple(self.video[j].shape)
+        chunk = [j]
+        up, pos = self._upcoming.get(tvg, []), self._upcoming_pos.get(tvg, 0)
+        while pos < len(up) and len(chunk) < self.feat_chunk:
+            v = up[pos]; pos += 1
+            if v != j and (v, tvg) not in self._vfeat and tuple(self.video[v].shape) == shape:
+                chunk.append(v)
+        self._upcoming_pos[tvg] = pos
+        split = tvg and self.split_tvg
+        many = getattr(self.m, "project_many", None)
+        if split:
+            self.engine.set_precise(True, embeds=True)
+        try:
+            if many is not None:
+                outs = many([self.video[v] for v in chunk], tvg)
+            else:                                                            # a model surface with the per-video projector only
+                outs = [self.m.project(self.video[v].to(self.device), tvg, cache=False) for v in chunk]
+        finally:
+            if split:
+                self.engine.set_precise(False)
+        for v, y in zip(chunk, outs):
+            self._vfeat[(v, tvg)] = y
 
     # ---- planning (host) ------------------------------------------------------------------------
     def plan_vtg(self, pairs: np.ndarray, cpn: bool = False) -> List[Plan]:
@@ -261,6 +292,7 @@ class PairScorer:
             items = [(None, nv, [int(texts[t]) for t in g], [np.nonzero(inv == t)[0] for t in g]) for g in groups.values()]
         else:
             order = np.lexsort((pairs[:, 1], pairs[:, 0]))
+            self.expect(pairs[order, 0], False)
             items = []
             j_prev, cur = None, None
             for idx in order:
@@ -318,6 +350,7 @@ class PairScorer:
             by_prefix: Dict[bytes, List[Tuple]] = {}
             for k, v in keyed.items():
                 by_prefix.setdefault(k[0], []).append((k, v))
+            self.expect([k[3] for lst in by_prefix.values() for (k, _) in lst], True)
             for pbytes, lst in by_prefix.items():
                 ptoks = np.frombuffer(pbytes, dtype=np.int64)
                 p0 = None
@@ -334,6 +367,7 @@ class PairScorer:
                     st.add_pair(list(range(s0, s0 + C)), np.array([self.tvg_video_labels[j]], np.int32), np.array(outs))
         else:
             order = np.lexsort((pairs[:, 0], pairs[:, 1]))
+            self.expect(pairs[order, 0], True)
             i_prev, p0, plen = None, None, 0
             for idx in order:
                 j, i = int(pairs[idx, 0]), int(pairs[idx, 1])
@@ -475,6 +509,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
     import torch
     model.eval()
     t_start = time.time()
+    marks = []                                                          # (stage, host seconds since the start): device work is asynchronous,
+    mark = lambda name: marks.append((name, round(time.time() - t_start, 4)))   # so a stage's host time is planning + launching, not its device time
     video, tvg_video_labels = [], []
     vtg_ids, vtg_labels, vtg_masks, tvg_ids, tvg_labels, tvg_masks = [], [], [], [], [], []
     for data in data_loader:                                                # :182-193
@@ -514,6 +550,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
         scorer = PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
                             tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
     stats = {"pairs_requested": 0, "pairs_scored": 0}
+    mark("setup")
 
     def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):
         """One of the reference's six passes over this rank's query rows (literal: its own loops; fused: the PairScorer)."""
@@ -579,10 +616,12 @@ def evaluation(model, data_loader, device, tokenizer, args):
 
         own_v = need.copy(); own_v[:vs] = False; own_v[ve:] = False                            # VTG: rows of my videos
         M_vtg = score_owned("vtg", own_v)
+        mark("vtg")
         M_tvg_T = None
         if finetuned:
             own_t = need.copy(); own_t[:, :ts] = False; own_t[:, te:] = False                  # TVG: columns of my texts
             M_tvg_T = score_owned("tvg", own_t).T.contiguous()                                # text-major: a row block
+            mark("tvg")
         prior_t = None
         if args.cpn:
             # the v2t prior log P(text | masked video) does not depend on the query video: every rank scores its block of TEXTS once
@@ -599,6 +638,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
             else:
                 prior_t = torch.full((Nt,), -100.0, dtype=torch.float32, device=device)
                 prior_t[ts:te] = mine[: te - ts]
+        mark("v2t_prior")
         S_t2v_prior = None
         if finetuned and args.cpn:                                                             # t2v TVG prior: keyed on (prompt, video); rows of my texts
             S_t2v_prior = full(Nt, Nv)
@@ -607,6 +647,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
                 stats["pairs_scored"] += len(pairs)
                 sc = scorer.tvg_device(pairs, True) if hasattr(scorer, "tvg_device") else torch.from_numpy(np.asarray(scorer.tvg(pairs, True), dtype=np.float32)).to(device)
                 S_t2v_prior[to_dev(pairs[:, 1]), to_dev(pairs[:, 0])] = sc
+        mark("t2v_prior")
         if collective:                                                                         # one all-gather for the row blocks of all three
             mats, blocks = [M_vtg], [(vs, ve)]
             if M_tvg_T is not None:
@@ -675,9 +716,11 @@ def evaluation(model, data_loader, device, tokenizer, args):
 
         if collective:                                                                               # :252-262
             merge([(v2t, v_block), (t2v, t_block)])
-    args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank)
+    mark("queued")
     t2v_dict = {k: v.cpu().numpy() for k, v in t2v.items()}                                      # :264-276
     v2t_dict = {k: v.cpu().numpy() for k, v in v2t.items()}
+    mark("done")
+    args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank, host_marks=marks)
     t2v_dict["internvideo2"] = t2v_iv2.cpu().numpy()
     v2t_dict["internvideo2"] = v2t_iv2.cpu().numpy()
     if getattr(args, "verbose", False) and rank == 0:

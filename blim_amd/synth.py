@@ -211,9 +211,13 @@ class ProblemLoader:
         def __len__(self):
             return self._n
 
-    def __init__(self, prob: Problem, batch_size: int):
+    def __init__(self, prob: Problem, batch_size: int, video_dtype=None):
+        """video_dtype: dtype of the per-video feature tensors the loader hands out (converted once, here).  The reference's feature
+        files hold fp16 (extract.py:108 `.cpu().half()`); None keeps the generator's fp32."""
+        import torch
         self.prob, self.bs = prob, int(batch_size)
         self.dataset = ProblemLoader._Dataset(prob)
+        self._video = [torch.from_numpy(v) if video_dtype is None else torch.from_numpy(v).to(video_dtype) for v in prob.video]
 
     def __len__(self):
         return (len(self.prob.video) + self.bs - 1) // self.bs
@@ -223,7 +227,7 @@ class ProblemLoader:
         p, T = self.prob, torch.from_numpy
         for s in range(0, len(p.video), self.bs):
             e = min(len(p.video), s + self.bs)
-            out = {"video": [T(v) for v in p.video[s:e]], "tvg_video_labels": T(p.tvg_video_labels[s:e])}
+            out = {"video": self._video[s:e], "tvg_video_labels": T(p.tvg_video_labels[s:e])}
             for k in ("vtg_ids", "vtg_labels", "vtg_masks", "tvg_ids", "tvg_labels", "tvg_masks"):
                 out[k] = [T(x) for x in getattr(p, k)[s:e]]
             yield out

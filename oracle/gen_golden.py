@@ -57,6 +57,14 @@ CASES = {
     "full7b_ref": dict(dims=dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28,
                                  num_kv_heads=4, mm_hidden_size=1024), wseed=0, pseed=11, n=4, tok_per_clip=64, text_len=(8, 48),
                        topk=4, bs=4, queries=1, sub16=True, lazy=True),
+    # `full7b_bench`: the real 7B model on the problem bench.py's first plan is built from (synth.make_problem(1000, 55, tok_per_clip=24,
+    # text_len=(32, 32), reference_layout=False): 55 videos / texts, 96 video + 32 text tokens, top-16) -- the first 4 query rows of each
+    # direction through the reference's own loops (64 + 64 VTG entries that sit INSIDE the benched 880-pair step).
+    "full7b_bench": dict(dims=dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28,
+                                   num_kv_heads=4, mm_hidden_size=1024), wseed=0, pseed=1000, n=55, tok_per_clip=24, text_len=(32, 32),
+                         topk=16, bs=16, queries=4, lazy=True, syn_only=True,
+                         syn=dict(pseed=1000, n=55, tok_per_clip=24, text_len=(32, 32), topk=16, bs=16, queries=4,
+                                  passes=("v2t_vtg", "t2v_vtg", "v2t_tvg", "t2v_tvg", "t2v_tvg_cpn"))),
 }
 PASS_KINDS = {  # name -> (query is video, forward_type, cpn)
     "v2t_vtg": (True, "vtg", False), "v2t_vtg_cpn": (True, "vtg", True), "v2t_tvg": (True, "tvg", False),
@@ -133,7 +141,7 @@ def run_case(name: str, out_dir: str) -> None:
     ocfg = OracleConfig(**spec["dims"])
     t0 = time.time()
     weights = LazyWeights(dims, spec["wseed"]) if spec.get("lazy") else synth.synthetic_weights(dims, spec["wseed"])
-    prob = problem_of(spec, dims)
+    prob = problem_of(spec, dims, spec["syn"] if spec.get("syn_only") else None)
     print(f"[{name}] weights+problem built in {time.time() - t0:.1f}s", flush=True)
     ns = ref_harness.load()
     RU, TU = ns.RU, ns.TU
@@ -147,6 +155,13 @@ def run_case(name: str, out_dir: str) -> None:
     T = lambda a: torch.from_numpy(np.asarray(a))
     tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
     out = {}
+    if spec.get("syn_only"):             # headline rows only: the SYN passes through the reference's loops, nothing else
+        run_passes(out, "SYN_", RU, ddp, dev, prob, spec["syn"], dims, spec["syn"]["passes"], name)
+        out["meta_case"] = np.array(name)
+        path = os.path.join(out_dir, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)", flush=True)
+        return
 
     # --- padding_ids (retrieval_utils.py:155-167)
     vtg = RU.padding_ids([T(x) for x in prob.vtg_ids], [T(x) for x in prob.vtg_labels], [T(x) for x in prob.vtg_masks], tok)

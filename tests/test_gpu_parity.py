@@ -437,6 +437,48 @@ def test_depth_full_7b_vs_reference_golden(dtype, case, capsys):
     assert max(hid.values()) < (2e-2 if dtype == "f16" else 6e-2)
 
 
+def test_benched_step_plan_meets_the_reference_golden(capsys):
+    """The batch bench.py times, itself: plan 0 of rank 0 (55 video queries x top-16 texts = 880 pairs, 32,560 packed tokens, real 7B
+    configuration, weight seed 0) is built by bench.build_step_plans and run once; `full7b_bench.npz` holds what the REFERENCE's own
+    loops return for the first four query rows of each direction on the same problem (64 + 64 VTG entries + the TVG passes).  The 64
+    v2t entries are read out of the benched step's output; the other passes go through the same scorer.  1e-3 per entry."""
+    import bench
+    path = os.path.join(GOLD, "full7b_bench.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/full7b_bench.npz not generated")
+    g = np.load(path)
+    dims = synth.ModelDims()
+    model = BlimModel(dims, max_positions=1024, dtype="f16")
+    model.engine.init_synthetic_weights(0)
+    try:
+        ((scorer, plan, prob, pairs),) = bench.build_step_plans(model, 0, 1, 55, 16)
+        assert plan.n_pairs == 880 and plan.n_tokens == 32560 and plan.n_rows == 28160       # the step BENCH_r*.json is quoted on
+        model.set_tvg_prefix_length(prob.tvg_prefix_length)
+        sc = scorer.run(plan).float().cpu().numpy()
+        S = np.full((55, 55), -100.0, np.float32)
+        for k, outs in enumerate(plan.out_index):
+            S[pairs[outs, 0], pairs[outs, 1]] = sc[k]
+        worst = {}
+        G = g["SYN_v2t_vtg"]
+        m = G != -100.0
+        assert m.sum() == 64 and m[:4].sum() == 64 and np.array_equal(m[:4], (S != -100.0)[:4])    # the same top-16 entries of query rows 0-3
+        worst["v2t_vtg (inside the benched step)"] = float(np.max(np.abs(S[m] - G[m]) / np.abs(G[m])))
+        for name, transpose, kind, cpn in (("t2v_vtg", True, "vtg", False), ("v2t_tvg", False, "tvg", False), ("t2v_tvg", True, "tvg", False),
+                                          ("t2v_tvg_cpn", True, "tvg", True)):
+            G = g[f"SYN_{name}"]
+            q, c = np.nonzero(G != -100.0)
+            assert len(q) == 64
+            pr = np.stack([c, q], axis=1) if transpose else np.stack([q, c], axis=1)         # (video, text)
+            got = scorer.vtg(pr, cpn) if kind == "vtg" else scorer.tvg(pr, cpn)
+            worst[name] = float(np.max(np.abs(got - G[q, c]) / np.abs(G[q, c])))
+    finally:
+        model.engine.close()
+    with capsys.disabled():
+        print("\n[full7b_bench f16] worst relative deviation vs the fp32 reference on bench.py's own step: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    for k, v in worst.items():
+        assert v < SCORE_RTOL, (k, v)
+
+
 def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
     """Engine option "precise" (hi + lo fp16 activations, GEMMs walk K twice; what the TVG calls run in): on the 28-layer H=1024
     golden batch the final hidden state is several times closer to the fp32 reference than in the plain fp16 mode."""

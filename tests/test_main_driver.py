@@ -90,15 +90,19 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "8"], cwd=root,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "8", "--strong-n", "96"], cwd=root,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline"):
+              "config", "roofline", "cpu_baseline", "strong_scaling"):
         assert k in d, k
+    ss = d["strong_scaling"]                                             # the fixed-size evaluation + the per-rank shares of an 8-process job
+    assert ss["scaling"] == "strong" and ss["world"] == 1 and ss["pairs"] == 6 * 96 * 16 and ss["finite"] is True and ss["seconds"] > 0
+    assert ss["emulated_world"] == 8 and len(ss["emulated_rank_seconds"]) == 8 and ss["predicted_seconds"] == max(ss["emulated_rank_seconds"])
+    assert abs(ss["predicted_speedup"] - ss["seconds"] / ss["predicted_seconds"]) < 0.02 and ss["pairs_scored_rank0"] <= ss["pairs"]
     assert d["metric"].startswith("candidate-pairs/sec") and d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f16"
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -119,14 +123,16 @@ def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
     env = dict(os.environ)
     if torch.cuda.device_count() < 2:
         env.update(BLIM_DIST_BACKEND="gloo", BLIM_FORCE_DEVICE="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "8"], cwd=root,
-                       env=env, capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "8", "--strong-n", "96"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["pairs_per_step_per_gpu"] == 8 * 8 and "cpu_baseline" not in d      # 8 queries x top-min(16, 8 texts)
+    ss = d["strong_scaling"]                                             # the same fixed-size evaluation split over the two ranks, merge inside
+    assert ss["scaling"] == "strong" and ss["world"] == 2 and ss["pairs"] == 6 * 96 * 16 and ss["finite"] is True and "predicted_speedup" not in ss
 
 
 def test_training_driver_on_a_synthetic_tree(tmp_path, monkeypatch, capsys):
