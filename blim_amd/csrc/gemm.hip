@@ -243,6 +243,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             if (GEMM_ABLATE_DMA == 1 && kt >= 2) on = false;
             if (GEMM_ABLATE_DMA == 2) kt &= 1;
 #endif
+#if defined(GEMM_ABLATE_WREAD) && GEMM_ABLATE_WREAD == 2   // ... and no LDS-DMA of W either after the prologue (group 0 stages W)
+            if (grp == 0 && kt >= 4) on = false;
+#endif
             const char* g = gbase + (int64_t)(kt >= wrap ? kt - wrap : kt) * (BK * 2);
             auto dma1 = [&](int q) __attribute__((always_inline)) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -255,11 +258,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                     for (int j = 3 * q; j < 3 * q + 3; ++j) {
                         const int ks = j / 12, r = j % 12;
+#ifdef GEMM_ABLATE_WREAD   // ablation builds only: the W fragments are NOT read from LDS -- an upper bound on what
+                           // fetching them global -> VGPR instead of through LDS could buy (the loads themselves not even charged)
+                        if (r < 4) { }   // (no read; the MFMAs below take copies of A fragments: keeping stale W fragments live across the back edge spills)
+#else
                         if (r < 4) fb[ks][r] = *(const bf16x8*)(bb[ks] + r * 2048);
+#endif
                         else fa[ks][r - 4] = *(const bf16x8*)(ba[ks] + (r - 4) * 2048);
                     }
                     dma1(q);
                 }
+#ifdef GEMM_ABLATE_WREAD
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fb[ks][r] = fa[ks][r + 4];
+#endif
             }
         };
         int sa = 0;

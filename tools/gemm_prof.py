@@ -8,6 +8,9 @@ import torch  # noqa: E402
 
 from blim_amd import engine as eng  # noqa: E402
 
+if os.environ.get("BLIM_LIB"):          # an instrumented / ablation build (tools/bin/*.so) instead of the product library
+    eng.load_library(os.path.join(ROOT, os.environ["BLIM_LIB"]))
+
 shapes = [(32768, 37888, 3584), (32768, 3584, 18944), (32768, 3584, 3584), (32768, 4608, 3584), (8192, 8192, 8192)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for (M, N, K) in shapes:
