@@ -65,6 +65,7 @@ struct blim_trainer {
     std::vector<void*> owned;
     // saved activations of the last forward (per layer, strided by tokens) and workspaces
     DevBuf sv_res, sv_mid, sv_xn1, sv_qkv, sv_attn, sv_gu, sv_lse;
+    DevBuf red_scratch;   // partials of the split reductions (adapter gradients, du, per-row losses): summed in a fixed order, never by float atomics
     DevBuf xn2, act, dres, dy16, dtmp32, dqkv32, dqkv16, du, attn_D, P16, dS16, logits, dlog16, hsel, hsel_t, dhsel;
     DevBuf feats_aug[2], pre16[2], h16[2], vid16, proj16, embeds, dout16[2], dh32, vh32, vhb16, dl32, dvh;      // [2]: projector mlp / tvg_mlp
     int64_t last_T = 0;
@@ -181,7 +182,7 @@ extern "C" void blim_train_destroy(blim_trainer* t) {
     if (!t) return;
     hipDeviceSynchronize();
     for (void* p : t->owned) hipFree(p);
-    DevBuf* bufs[] = {&t->sv_res, &t->sv_mid, &t->sv_xn1, &t->sv_qkv, &t->sv_attn, &t->sv_gu, &t->sv_lse, &t->xn2, &t->act, &t->dres, &t->dy16, &t->dtmp32, &t->dqkv32, &t->dqkv16,
+    DevBuf* bufs[] = {&t->red_scratch, &t->sv_res, &t->sv_mid, &t->sv_xn1, &t->sv_qkv, &t->sv_attn, &t->sv_gu, &t->sv_lse, &t->xn2, &t->act, &t->dres, &t->dy16, &t->dtmp32, &t->dqkv32, &t->dqkv16,
                       &t->du, &t->attn_D, &t->P16, &t->dS16, &t->logits, &t->dlog16, &t->hsel, &t->hsel_t, &t->dhsel, &t->feats_aug[0], &t->feats_aug[1], &t->pre16[0], &t->pre16[1], &t->h16[0], &t->h16[1],
                       &t->vid16, &t->proj16, &t->embeds, &t->dout16[0], &t->dout16[1], &t->dh32, &t->vh32, &t->vhb16, &t->dl32, &t->dvh};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
@@ -246,9 +247,13 @@ extern "C" int blim_train_merge(blim_trainer* t, void* stream) {
 static int lora_backward(blim_trainer* t, const Adapter& a, const uint16_t* dy16, int64_t ldy, const uint16_t* x16, int64_t ldx, int K, int col, int64_t n, float* du,
                          uint64_t seed, uint32_t site, hipStream_t s) {
     const int dt = t->e->c.compute_dtype;
-    TRY(launch_lora_dB(t->grads + a.offB, dy16, ldy, x16 + K + col, ldx, n, a.n_out, t->r, dt, s));
-    TRY(launch_lora_du(du, dy16, ldy, a.Bt16, a.ldb, n, (int)round_up(a.n_out, 16), t->r, t->s, dt, s));     // dy columns beyond n_out (lm_head: up to Vp) are zero
-    return launch_lora_dA(t->grads + a.offA, du, x16, ldx, n, K, t->r, t->p_drop, seed, site, dt, s);
+    const int Np = (int)round_up(a.n_out, 16);
+    // partial sums of the split reductions (summed in a fixed order by the launchers: no float atomics anywhere in the backward)
+    TRY(ensure(t->red_scratch, std::max(std::max(lora_wgrad_scratch_bytes(n, a.n_out, t->r), lora_wgrad_scratch_bytes(n, K, t->r)), lora_du_scratch_bytes(n, Np, t->r))));
+    float* scr = (float*)t->red_scratch.p;
+    TRY(launch_lora_dB(t->grads + a.offB, dy16, ldy, x16 + K + col, ldx, n, a.n_out, t->r, dt, scr, s));
+    TRY(launch_lora_du(du, dy16, ldy, a.Bt16, a.ldb, n, Np, t->r, t->s, dt, scr, s));     // dy columns beyond n_out (lm_head: up to Vp) are zero
+    return launch_lora_dA(t->grads + a.offA, du, x16, ldx, n, K, t->r, t->p_drop, seed, site, dt, scr, s);
 }
 static int lora_dx1(float* dx, int64_t ldd, const float* du, const float* A, int64_t n, int K, int r, float p, uint64_t seed, uint32_t site, hipStream_t s) {
     LoraDxArgs a; a.n = 1; a.du[0] = du; a.A[0] = A; a.du[1] = a.du[2] = nullptr; a.A[1] = a.A[2] = nullptr;
@@ -469,7 +474,8 @@ static int vtg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum,
     LoraDownArgs la; la.n = 1; la.A16[0] = t->lay.lm.A16; la.A16[1] = la.A16[2] = nullptr;
     TRY(launch_lora_down(hsel, Ha, R, H, la, r, t->s, t->p_drop, b->dropout_seed, 2000, dt, s));
     { GemmParams p = gp(dt, hsel, Ha, t->lm_aug, R, V, Ha, logits, Vp); TRY(launch_gemm(EPI_F32, p, s)); }
-    TRY(launch_ce_fwd_bwd(logits, Vp, V, b->labels, 1, R, b->grad_scale / (float)R, dlog, nullptr, Vp, loss_sum, dt, s));
+    TRY(ensure(t->red_scratch, (size_t)R * 4));
+    TRY(launch_ce_fwd_bwd(logits, Vp, V, b->labels, 1, R, b->grad_scale / (float)R, dlog, nullptr, Vp, loss_sum, dt, (float*)t->red_scratch.p, s));
     TRY(lora_backward(t, t->lay.lm, dlog, Vp, hsel, Ha, H, 0, R, du, b->dropout_seed, 2000, s));
     { GemmParams p = gp(dt, dlog, Vp, t->lmT, R, H, Vp, dhsel, H); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(lora_dx1(dhsel, H, du, t->params + t->lay.lm.offA, R, H, r, t->p_drop, b->dropout_seed, 2000, s));
@@ -493,7 +499,8 @@ static int tvg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum,
     { GemmParams p = gp(dt, hsel, H, t->vh16, BC, M, H, vh32, M); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(launch_f32_to_16(vhb, M, vh32, M, BC, M, 1.0f, dt, s));
     TRY(blim_tvg_logits(e, vhb, b->vocab, N, B, logits, stream));
-    TRY(launch_ce_fwd_bwd(logits, N, N, b->tvg_labels, C, BC, b->grad_scale / (float)BC, nullptr, dl, N, loss_sum, dt, s));
+    TRY(ensure(t->red_scratch, (size_t)BC * 4));
+    TRY(launch_ce_fwd_bwd(logits, N, N, b->tvg_labels, C, BC, b->grad_scale / (float)BC, nullptr, dl, N, loss_sum, dt, (float*)t->red_scratch.p, s));
     TRY(launch_tvg_dvh(dvh, dl, (const uint16_t*)b->vocab, BC, C, N, M, 1.0f / sqrtf((float)M), dt, s));
     TRY(launch_outer_acc(t->grads + t->lay.off_vh, dvh, hsel, H, BC, M, H, dt, s));
     TRY(launch_rows_matmul(dhsel, dvh, t->params + t->lay.off_vh, BC, M, H, s));
@@ -525,7 +532,8 @@ extern "C" int blim_train_step(blim_trainer* t, const blim_train_batch* b, float
 
 extern "C" int blim_train_grad_stats(blim_trainer* t, float inv_scale, float* stats, void* stream) {
     ARG_CHECK(t && stats);
-    return launch_grad_stats(t->grads, t->lay.total, inv_scale, stats, (hipStream_t)stream);
+    TRY(ensure(t->red_scratch, 1024 * 4));
+    return launch_grad_stats(t->grads, t->lay.total, inv_scale, stats, (float*)t->red_scratch.p, (hipStream_t)stream);
 }
 
 extern "C" int blim_train_adamw(blim_trainer* t, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay, float inv_scale,

@@ -24,13 +24,17 @@ int launch_lora_a16(uint16_t* A16, const float* A, int K, int r, int dtype, hipS
 // u~[t, seg*r + j] = 16-bit( scale * sum_k drop_seg(x)[t, k] * A_seg[j, k] ), written into x16[t, K + seg*r + j]  (columns K.. of the augmented row)
 int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDownArgs& a, int r, float scale, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s);
 // dB[n, j] += sum_t dy[t, n] * u~[t, j]        (dy16 [T, ldy] columns n0.., u16 = x16 + K + seg*r)
-int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, hipStream_t s);
+// (scratch: lora_wgrad_scratch_bytes(T, N, r) -- the time splits' partials, summed in split order: no float atomics, reproducible bit for bit)
+int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, float* scratch, hipStream_t s);
+size_t lora_wgrad_scratch_bytes(int64_t T, int C, int r);
+size_t lora_du_scratch_bytes(int64_t T, int N, int r);
 // Bt16 [16, ldb] 16-bit <- transposed B [N, r] f32 (rows r.. and columns N.. must already be zero)
 int launch_lora_bt(uint16_t* Bt16, int64_t ldb, const float* B, int N, int r, int dtype, hipStream_t s);
 // du[t, j] = scale * sum_n dy[t, n] * B[n, j]   (N % 16 == 0: pad dy / Bt16 with zero columns)
-int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int N, int r, float scale, int dtype, hipStream_t s);
+int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int N, int r, float scale, int dtype, float* scratch, hipStream_t s);
 // dA[j, k] += sum_t du[t, j] * drop(x)[t, k]
-int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s);
+int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, float* scratch,
+                   hipStream_t s);
 struct LoraDxArgs {
     const float* du[3];  // du_seg [T, r]
     const float* A[3];   // A_seg [r, K]
@@ -56,7 +60,7 @@ int launch_gelu_bwd(uint16_t* dpre16, const float* dh, const uint16_t* pre16, in
 // Cross-entropy over rows of f32 logits: loss[0] += sum_r -log_softmax(logits[r])[label[r]];  d = coef * (softmax - onehot) written as 16-bit
 // (dl16, row stride ldd, columns V..ldd zeroed) or f32 (dl32, row stride ldd).  label per row = labels[r / label_div].
 int launch_ce_fwd_bwd(const float* logits, int64_t ldl, int V, const int32_t* labels, int label_div, int64_t n_rows, float coef, uint16_t* dl16, float* dl32, int64_t ldd,
-                      float* loss, int dtype, hipStream_t s);
+                      float* loss, int dtype, float* scratch, hipStream_t s);     // scratch: n_rows floats (per-row losses, summed in a fixed order)
 
 // TVG head pieces (training_utils.py:76-79): vocab16 is clip-major [C][N][M]
 int launch_tvg_dvh(float* dvh, const float* dl, const uint16_t* vocab16, int n_rows, int C, int N, int M, float scale, int dtype, hipStream_t s);   // dvh[bc, m] = scale * sum_n dl[bc, n] * vocab[c][n][m]
@@ -95,4 +99,4 @@ int launch_rope_bwd(uint16_t* out16, const float* dqkv, int64_t T, int qkv_n, in
 // AdamW (torch.optim.AdamW): g = grad * inv_scale; p *= 1 - lr*wd; m, v updates; p -= lr/c1 * m / (sqrt(v)/sqrt(c2) + eps)
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_scale, float c1, float c2, hipStream_t s);
 // stats[0] += sum (g * inv_scale)^2 ; stats[1] = 1 if any g is inf / nan
-int launch_grad_stats(const float* g, int64_t n, float inv_scale, float* stats, hipStream_t s);
+int launch_grad_stats(const float* g, int64_t n, float inv_scale, float* stats, float* scratch, hipStream_t s);     // scratch: 1024 floats

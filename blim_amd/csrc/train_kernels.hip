@@ -213,9 +213,26 @@ int launch_lora_down(uint16_t* x16, int64_t ldx, int64_t T, int K, const LoraDow
 // rows, 64 rows per stage, wave w owns columns 32 w .. 32 w + 31 and one 32x32 accumulator (n = j < r real, the rest zero padding).
 // An f32 U (du carries the loss scale: up to ~1e4 and down to ~1e-3 in one tensor) enters as hi + lo with hi = 16-bit(u / 256),
 // lo = 16-bit(u - 256 hi): two MFMAs, out = 256 acc_hi + acc_lo, exact to ~3e-5 relative over that whole range in fp16.
+// Time splits meet through PARTIALS, not float atomics: split y stores its [C, r] contribution to part + y * C * r (every element of it is
+// written by exactly one lane) and ordered_sum_kernel adds the splits to `out` in split order -- the gradients are reproducible bit for bit
+// from run to run, like the reference's autograd (training_utils.py:81-91).
+// out[i] = (accumulate ? out[i] : 0) + sum_{s < ns, in order} part[s * stride + i]
+__global__ void ordered_sum_kernel(float* out, const float* part, int64_t n, int ns, int64_t stride, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = accumulate ? out[i] : 0.f;
+    for (int sidx = 0; sidx < ns; ++sidx) a += part[(int64_t)sidx * stride + i];
+    out[i] = a;
+}
+static int launch_ordered_sum(float* out, const float* part, int64_t n, int ns, int64_t stride, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, part, n, ns, stride, accumulate);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
 #define LORA_TSPLIT 1024
+size_t lora_wgrad_scratch_bytes(int64_t T, int C, int r) { return (size_t)((T + LORA_TSPLIT - 1) / LORA_TSPLIT) * C * r * 4; }
 template <int DT, bool U_F32, bool OUT_T>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(float* out, const uint16_t* X, int64_t ldx, const void* Uv, int64_t ldu, int64_t T, int C, int r,
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(float* part, const uint16_t* X, int64_t ldx, const void* Uv, int64_t ldu, int64_t T, int C, int r,
                                                          float drop_p, uint64_t seed, uint32_t site, int drop_k) {
     __shared__ __attribute__((aligned(16))) uint16_t x_lds[64 * 128];
     __shared__ __attribute__((aligned(16))) uint16_t u_hi[64 * 32];
@@ -280,23 +297,24 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(float* out, const uint1
                 const int m = c0 + 32 * w + 8 * g + 4 * hf + jj;
                 if (m >= C) continue;
                 const float v = U_F32 ? 256.0f * acc_hi[4 * g + jj] + acc_lo[4 * g + jj] : acc_hi[4 * g + jj];
-                atomicAdd(out + (OUT_T ? (int64_t)n * C + m : (int64_t)m * r + n), v);
+                part[(int64_t)blockIdx.y * C * r + (OUT_T ? (int64_t)n * C + m : (int64_t)m * r + n)] = v;
             }
     }
 }
-int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R && ldy % 8 == 0 && ldy >= (N + 7) / 8 * 8);      // the last 16-byte chunk of a row may reach into the row's padding columns
+int launch_lora_dB(float* dB, const uint16_t* dy16, int64_t ldy, const uint16_t* u16, int64_t ldu, int64_t T, int N, int r, int dtype, float* scratch, hipStream_t s) {
+    ARG_CHECK(r <= LORA_MAX_R && ldy % 8 == 0 && ldy >= (N + 7) / 8 * 8 && scratch);      // the last 16-byte chunk of a row may reach into the row's padding columns
     dim3 grid((N + 127) / 128, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
-    DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, false, false>), grid, dim3(256), 0, s, dB, dy16, ldy, (const void*)u16, ldu, T, N, r, 0.f, 0ull, 0u, 0));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, false, false>), grid, dim3(256), 0, s, scratch, dy16, ldy, (const void*)u16, ldu, T, N, r, 0.f, 0ull, 0u, 0));
     LAUNCH_CHECK();
-    return BLIM_OK;
+    return launch_ordered_sum(dB, scratch, (int64_t)N * r, (int)grid.y, (int64_t)N * r, 1, s);
 }
-int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R && K % 8 == 0 && ldx % 8 == 0);
+int launch_lora_dA(float* dA, const float* du, const uint16_t* x16, int64_t ldx, int64_t T, int K, int r, float drop_p, uint64_t seed, uint32_t site, int dtype, float* scratch,
+                   hipStream_t s) {
+    ARG_CHECK(r <= LORA_MAX_R && K % 8 == 0 && ldx % 8 == 0 && scratch);
     dim3 grid((K + 127) / 128, (unsigned)((T + LORA_TSPLIT - 1) / LORA_TSPLIT));
-    DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, true, true>), grid, dim3(256), 0, s, dA, x16, ldx, (const void*)du, (int64_t)r, T, K, r, drop_p, seed, site, K));
+    DISPATCH_DT(dtype, hipLaunchKernelGGL((lora_wgrad_kernel<DT, true, true>), grid, dim3(256), 0, s, scratch, x16, ldx, (const void*)du, (int64_t)r, T, K, r, drop_p, seed, site, K));
     LAUNCH_CHECK();
-    return BLIM_OK;
+    return launch_ordered_sum(dA, scratch, (int64_t)K * r, (int)grid.y, (int64_t)K * r, 1, s);
 }
 
 // Bt16[j, n] = 16-bit(B[n, j]) (j < r; rows r..15 and columns N.. stay zero): the B operand of the MFMA below
@@ -315,9 +333,9 @@ int launch_lora_bt(uint16_t* Bt16, int64_t ldb, const float* B, int N, int r, in
 
 // du[t, j] += scale * sum_n dy[t, n] * B[n, j] on the matrix cores: one wave = 32 rows x one slice of N, a 32x32x16 MFMA per 16 columns
 // with B^T (16 rows: j < r real, the rest zero) as the second operand -- 3/4 of the tile is padding, but the kernel is bound by
-// reading dy once.  Slices meet by atomics (du is zeroed first).
+// reading dy once.  Slices of N meet through partials summed in slice order (ordered_sum_kernel above), not atomics.
 template <int DT>
-__global__ __launch_bounds__(256) void lora_du_kernel(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int steps_total, int steps_per_split,
+__global__ __launch_bounds__(256) void lora_du_kernel(float* part, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int steps_total, int steps_per_split,
                                                       int r, float scale) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t t0 = ((int64_t)blockIdx.x * 4 + w) * 32;
@@ -353,21 +371,28 @@ __global__ __launch_bounds__(256) void lora_du_kernel(float* du, const uint16_t*
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int64_t t = t0 + 8 * g + 4 * kg + jj;
-                if (t < T) atomicAdd(du + t * r + row, scale * acc[4 * g + jj]);
+                if (t < T) part[(int64_t)blockIdx.y * T * r + t * r + row] = scale * acc[4 * g + jj];
             }
     }
 }
-int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int N, int r, float scale, int dtype, hipStream_t s) {
-    ARG_CHECK(r <= LORA_MAX_R && T > 0 && ldy % 8 == 0 && ldb % 8 == 0 && N % 16 == 0);
-    HIP_TRY(hipMemsetAsync(du, 0, (size_t)T * r * 4, s));
+static void lora_du_splits(int64_t T, int N, int* per, int* n_slices) {
     const int row_blocks = (int)((T + 127) / 128), steps_total = N / 16;
     int n_split = (1024 + row_blocks - 1) / row_blocks;
     n_split = std::max(1, std::min(n_split, (steps_total + 15) / 16));
-    const int per = (steps_total + n_split - 1) / n_split;
-    dim3 grid(row_blocks, (steps_total + per - 1) / per);
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_du_kernel<DT>, grid, dim3(256), 0, s, du, dy16, ldy, Bt16, ldb, T, steps_total, per, r, scale));
+    *per = (steps_total + n_split - 1) / n_split;
+    *n_slices = (steps_total + *per - 1) / *per;
+}
+size_t lora_du_scratch_bytes(int64_t T, int N, int r) {
+    int per, ns; lora_du_splits(T, N, &per, &ns);
+    return (size_t)ns * T * r * 4;
+}
+int launch_lora_du(float* du, const uint16_t* dy16, int64_t ldy, const uint16_t* Bt16, int64_t ldb, int64_t T, int N, int r, float scale, int dtype, float* scratch, hipStream_t s) {
+    ARG_CHECK(r <= LORA_MAX_R && T > 0 && ldy % 8 == 0 && ldb % 8 == 0 && N % 16 == 0 && scratch);
+    int per, ns; lora_du_splits(T, N, &per, &ns);
+    dim3 grid((unsigned)((T + 127) / 128), ns);
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(lora_du_kernel<DT>, grid, dim3(256), 0, s, scratch, dy16, ldy, Bt16, ldb, T, N / 16, per, r, scale));
     LAUNCH_CHECK();
-    return BLIM_OK;
+    return launch_ordered_sum(du, scratch, T * r, ns, T * r, 0, s);     // every (t < T, j < r) element of every slice was written: no clearing needed
 }
 
 // sum over the adapters reading x of keep_seg(t, k..k+3) / (1 - p) * sum_j du_seg[t, j] * A_seg[j, k..k+3]
@@ -554,7 +579,7 @@ int launch_gelu_bwd(uint16_t* dpre16, const float* dh, const uint16_t* pre16, in
 // ---------------------------------------------------------------------------- cross-entropy forward + backward
 template <int DT>
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* logits, int64_t ldl, int V, const int32_t* labels, int label_div, float coef, uint16_t* dl16, float* dl32,
-                                                         int64_t ldd, float* loss) {
+                                                         int64_t ldd, float* row_loss) {
     __shared__ float red[4];
     const int64_t r = blockIdx.x;
     const float* lg = logits + r * ldl;
@@ -570,7 +595,7 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* logits, in
     for (int v = threadIdx.x; v < V; v += 256) sum += __expf(lg[v] - m);
     sum = block_sum_256(sum, red);
     const float inv = 1.0f / sum;
-    if (threadIdx.x == 0 && lab >= 0 && lab < V) atomicAdd(loss, -(lg[lab] - m - __logf(sum)));
+    if (threadIdx.x == 0) row_loss[r] = (lab >= 0 && lab < V) ? -(lg[lab] - m - __logf(sum)) : 0.f;
     const float c = (lab >= 0 && lab < V) ? coef : 0.f;
     for (int v = threadIdx.x; v < (int)ldd; v += 256) {
         const float d = v < V ? c * (__expf(lg[v] - m) * inv - (v == lab ? 1.0f : 0.0f)) : 0.f;
@@ -578,10 +603,21 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* logits, in
         else dl32[r * ldd + v] = d;
     }
 }
+// *loss += sum of x[0..n) in a fixed order (one workgroup: strided partial sums per thread, then the block tree) -- the loss value is
+// reproducible bit for bit, which a float atomic per row is not
+__global__ __launch_bounds__(256) void fixed_order_sum_kernel(float* loss, const float* x, int64_t n) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) a += x[i];
+    a = block_sum_256(a, red);
+    if (threadIdx.x == 0) *loss += a;
+}
 int launch_ce_fwd_bwd(const float* logits, int64_t ldl, int V, const int32_t* labels, int label_div, int64_t n_rows, float coef, uint16_t* dl16, float* dl32, int64_t ldd,
-                      float* loss, int dtype, hipStream_t s) {
-    ARG_CHECK(n_rows > 0 && ldd >= V && label_div >= 1 && (dl16 || dl32));
-    DISPATCH_DT(dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<DT>, dim3((unsigned)n_rows), dim3(256), 0, s, logits, ldl, V, labels, label_div, coef, dl16, dl32, ldd, loss));
+                      float* loss, int dtype, float* scratch, hipStream_t s) {
+    ARG_CHECK(n_rows > 0 && ldd >= V && label_div >= 1 && (dl16 || dl32) && scratch);          // scratch: n_rows floats (per-row losses)
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(ce_fwd_bwd_kernel<DT>, dim3((unsigned)n_rows), dim3(256), 0, s, logits, ldl, V, labels, label_div, coef, dl16, dl32, ldd, scratch));
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(fixed_order_sum_kernel, dim3(1), dim3(256), 0, s, loss, scratch, n_rows);
     LAUNCH_CHECK();
     return BLIM_OK;
 }
@@ -926,7 +962,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
     LAUNCH_CHECK();
     return BLIM_OK;
 }
-__global__ __launch_bounds__(256) void grad_stats_kernel(const float* g, int64_t n, float inv_scale, float* stats) {
+__global__ __launch_bounds__(256) void grad_stats_kernel(const float* g, int64_t n, float inv_scale, float* stats, float* part) {
     __shared__ float red[4];
     float ss = 0.f; int bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -935,12 +971,15 @@ __global__ __launch_bounds__(256) void grad_stats_kernel(const float* g, int64_t
         ss += v * v;
     }
     ss = block_sum_256(ss, red);
-    if (threadIdx.x == 0) atomicAdd(stats, ss);
+    if (threadIdx.x == 0) part[blockIdx.x] = ss;
     if (bad) stats[1] = 1.0f;
 }
-int launch_grad_stats(const float* g, int64_t n, float inv_scale, float* stats, hipStream_t s) {
+int launch_grad_stats(const float* g, int64_t n, float inv_scale, float* stats, float* scratch, hipStream_t s) {
+    ARG_CHECK(scratch);                                           // 1024 floats: one partial per workgroup, summed in a fixed order
     const int grid = (int)min((int64_t)1024, (n + 255) / 256);
-    hipLaunchKernelGGL(grad_stats_kernel, dim3(grid), dim3(256), 0, s, g, n, inv_scale, stats);
+    hipLaunchKernelGGL(grad_stats_kernel, dim3(grid), dim3(256), 0, s, g, n, inv_scale, stats, scratch);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(fixed_order_sum_kernel, dim3(1), dim3(256), 0, s, stats, scratch, (int64_t)grid);
     LAUNCH_CHECK();
     return BLIM_OK;
 }
