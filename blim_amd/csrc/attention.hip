@@ -291,10 +291,16 @@ int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
     if (G > 8) { blim_set_error("attention: %d query heads per kv head > 8 unsupported", G); return BLIM_ERR_ARG; }
     const dim3 grid(p.n_blocks, p.num_kv_heads), block(64 * G);
     if (p.v_lo_off != 0 || p.out_lo_off != 0) {   // compensated mode (fp16 engines): transposed-read path only
-        ARG_CHECK(p.dtype == DT_F16 && p.v_lo_off > 0 && p.out_lo_off > 0 && p.v_lo_off % 8 == 0 && p.out_lo_off % 4 == 0);
-        if (G >= 4) hipLaunchKernelGGL((attn_kernel<true, 8, DT_F16, true>), grid, block, 0, stream, p);
-        else if (G >= 2) hipLaunchKernelGGL((attn_kernel<true, 16, DT_F16, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((attn_kernel<true, 32, DT_F16, true>), grid, block, 0, stream, p);
+        ARG_CHECK((p.dtype == DT_F16 || p.dtype == DT_BF16) && p.v_lo_off > 0 && p.out_lo_off > 0 && p.v_lo_off % 8 == 0 && p.out_lo_off % 4 == 0);
+#define ATTN_SPLIT(MC)                                                                                               \
+        do {                                                                                                         \
+            if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<true, MC, DT_F16, true>), grid, block, 0, stream, p);  \
+            else hipLaunchKernelGGL((attn_kernel<true, MC, DT_BF16, true>), grid, block, 0, stream, p);               \
+        } while (0)
+        if (G >= 4) ATTN_SPLIT(8);
+        else if (G >= 2) ATTN_SPLIT(16);
+        else ATTN_SPLIT(32);
+#undef ATTN_SPLIT
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { blim_set_error("attention launch failed: %s", hipGetErrorString(e2)); return BLIM_ERR_HIP; }
         return BLIM_OK;

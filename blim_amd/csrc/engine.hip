@@ -449,7 +449,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     float* sx = (float*)e->rscale.p; float* sa = sx ? sx + Tp : nullptr; float* sact = sx ? sx + 2 * Tp : nullptr;
     {
         SpanGuard g(e, s, TC_MISC, 0);
-        if (e->precise && e->precise_embeds) TRY(launch_hilo_to_f32(resid, (const bf16_t*)embeds, T, H, s));     // embeds are [hi | lo] rows
+        if (e->precise && e->precise_embeds) TRY(launch_hilo_to_f32(resid, (const bf16_t*)embeds, T, H, c.compute_dtype, s));     // embeds are [hi | lo] rows
         else TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s));
     }
     const double tok = (double)T;
@@ -463,7 +463,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const int pf = e->precise ? 2 : 1;                              // attention branch
     const bool pm = e->precise && e->precise_mlp;                   // MLP branch (option "precise_mlp")
     const int pfm = pm ? 2 : 1;
-    if (e->precise && (e->f8 || c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_STATE; }
+    if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
         {
@@ -770,7 +770,7 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise")) {
-        if (value && (e->f8 || e->c.compute_dtype != BLIM_COMPUTE_F16)) { blim_set_error("option 'precise' needs an fp16 engine"); return BLIM_ERR_ARG; }
+        if (value && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }
         e->precise = value != 0;
         return BLIM_OK;
     }

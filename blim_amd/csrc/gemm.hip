@@ -818,9 +818,10 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
     if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV || EPI == EPI_SWIGLU) {
-        if (p.lo_off != 0) {   // compensated outputs: fp16 engines only
-            if (p.dtype != DT_F16) { blim_set_error("split (hi|lo) GEMM outputs need an fp16 engine"); return BLIM_ERR_ARG; }
-            hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true>), grid, dim3(NTHREADS), 0, stream, p);
+        if (p.lo_off != 0) {   // compensated outputs: 16-bit engines (fp16: ~21 significant bits per activation, bf16: ~16)
+            if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true>), grid, dim3(NTHREADS), 0, stream, p);
+            else if (p.dtype == DT_BF16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_BF16, true>), grid, dim3(NTHREADS), 0, stream, p);
+            else { blim_set_error("split (hi|lo) GEMM outputs need a 16-bit engine"); return BLIM_ERR_ARG; }
             hipError_t e2 = hipGetLastError();
             if (e2 != hipSuccess) { blim_set_error("gemm launch failed: %s", hipGetErrorString(e2)); return BLIM_ERR_HIP; }
             return BLIM_OK;

@@ -126,19 +126,21 @@ __global__ void f32_to_bf16_kernel(bf16_t* out, const float* in, int64_t n) {
         }
     }
 }
-// resid[t, c] = f32(hi[t, c]) + f32(lo[t, c]) for [hi | lo] rows of width 2H (compensated mode, fp16)
+// resid[t, c] = f32(hi[t, c]) + f32(lo[t, c]) for [hi | lo] rows of width 2H (compensated mode)
+template <int DT>
 __global__ void hilo_to_f32_kernel(float* out, const bf16_t* in, int64_t n_rows, int H) {
     const int64_t total = n_rows * H;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t t = i / H;
         const int c = (int)(i - t * H);
-        out[i] = from16<DT_F16>(in[t * 2 * H + c]) + from16<DT_F16>(in[t * 2 * H + H + c]);
+        out[i] = from16<DT>(in[t * 2 * H + c]) + from16<DT>(in[t * 2 * H + H + c]);
     }
 }
-int launch_hilo_to_f32(float* out, const bf16_t* in, int64_t n_rows, int H, hipStream_t s) {
+int launch_hilo_to_f32(float* out, const bf16_t* in, int64_t n_rows, int H, int dtype, hipStream_t s) {
     ARG_CHECK(out && in && n_rows > 0 && H > 0);
-    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3(grid_for(n_rows * H, 256)), dim3(256), 0, s, out, in, n_rows, H);
+    if (dtype == DT_F16) hipLaunchKernelGGL(hilo_to_f32_kernel<DT_F16>, dim3(grid_for(n_rows * H, 256)), dim3(256), 0, s, out, in, n_rows, H);
+    else hipLaunchKernelGGL(hilo_to_f32_kernel<DT_BF16>, dim3(grid_for(n_rows * H, 256)), dim3(256), 0, s, out, in, n_rows, H);
     LAUNCH_CHECK("hilo_to_f32");
     return BLIM_OK;
 }
@@ -246,7 +248,8 @@ __global__ void group_mean_kernel(bf16_t* out, const bf16_t* in, int64_t n_out, 
         *(uint2*)(out + o * H + 4 * c) = make_uint2(pack2<DT>(a0 * inv, a1 * inv), pack2<DT>(a2 * inv, a3 * inv));
     }
 }
-// compensated mode (fp16): in [n_out * group, 2H] rows of [hi | lo] -> out [n_out, 2H]: the f32 mean of hi + lo, split again
+// compensated mode: in [n_out * group, 2H] rows of [hi | lo] -> out [n_out, 2H]: the f32 mean of hi + lo, split again
+template <int DT>
 __global__ void group_mean_split_kernel(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H) {
     const int64_t total = n_out * H;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -254,18 +257,18 @@ __global__ void group_mean_split_kernel(bf16_t* out, const bf16_t* in, int64_t n
         const int64_t o = i / H;
         const int c = (int)(i - o * H);
         float a = 0.f;
-        for (int j = 0; j < group; ++j) { const bf16_t* r = in + (o * group + j) * 2 * H; a += from16<DT_F16>(r[c]) + from16<DT_F16>(r[H + c]); }
+        for (int j = 0; j < group; ++j) { const bf16_t* r = in + (o * group + j) * 2 * H; a += from16<DT>(r[c]) + from16<DT>(r[H + c]); }
         a *= 1.0f / (float)group;
-        const uint16_t hi = to16<DT_F16>(a);
+        const uint16_t hi = to16<DT>(a);
         out[o * 2 * H + c] = hi;
-        out[o * 2 * H + H + c] = to16<DT_F16>(a - from16<DT_F16>(hi));
+        out[o * 2 * H + H + c] = to16<DT>(a - from16<DT>(hi));
     }
 }
 int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s, bool split) {
     ARG_CHECK(out && in && n_out > 0 && group > 0 && H % 4 == 0);
     if (split) {
-        ARG_CHECK(dtype == DT_F16);
-        hipLaunchKernelGGL(group_mean_split_kernel, dim3(grid_for(n_out * H, 256)), dim3(256), 0, s, out, in, n_out, group, H);
+        if (dtype == DT_F16) hipLaunchKernelGGL(group_mean_split_kernel<DT_F16>, dim3(grid_for(n_out * H, 256)), dim3(256), 0, s, out, in, n_out, group, H);
+        else hipLaunchKernelGGL(group_mean_split_kernel<DT_BF16>, dim3(grid_for(n_out * H, 256)), dim3(256), 0, s, out, in, n_out, group, H);
         LAUNCH_CHECK("group_mean");
         return BLIM_OK;
     }

@@ -232,9 +232,9 @@ class Engine:
 
     @property
     def can_precise(self) -> bool:
-        return self.dtype == "f16"
+        return self.dtype in ("f16", "bf16")
 
-    def set_precise(self, on: bool, embeds: bool = False):
+    def set_precise(self, on: bool, embeds: bool = False, mlp: bool = True):
         """Compensated mode for the following calls (fp16 engines; a no-op request on others): every 16-bit activation travels as
         hi + lo and the GEMMs walk K twice.  The host turns it on for the TVG calls, whose scores are ~10x smaller in magnitude than
         the VTG ones and need the extra bits to hold 1e-3 at 28 layers; 2x GEMM flops on those calls only.
@@ -248,6 +248,10 @@ class Engine:
         if embeds != getattr(self, "_precise_embeds", False):
             self.set_option("precise_embeds", int(embeds))
             self._precise_embeds = embeds
+        mlp = bool(mlp)                                   # mlp=False: only the attention branch (QKV, attention, o_proj) is compensated
+        if on and mlp != getattr(self, "_precise_mlp", True):
+            self.set_option("precise_mlp", int(mlp))
+            self._precise_mlp = mlp
 
     # ---- component ops (torch device tensors in/out)
     def project_video(self, feats, which: int):

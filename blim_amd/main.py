@@ -59,6 +59,9 @@ def get_args_parser():
     # engine-side options
     p.add_argument("--dtype", default=None, choices=["f16", "bf16", "f8"])
     p.add_argument("--max_tokens", default=32768, type=int, help="packed tokens per engine call")
+    p.add_argument("--vtg_precise", default=None, choices=["none", "attn", "full"],
+                   help="compensated (hi + lo) activations on the VTG calls; default: none on fp16 engines, full on bf16 engines (the mode in which "
+                        "bf16 holds 1e-3 against the fp32 reference at 7B depth; `none` = the fast, non-parity bf16 mode)")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")
     p.add_argument("--no_dedup", action="store_false", dest="dedup", help="score the pairs both directions share twice, as the reference does")
@@ -142,6 +145,8 @@ def main(args):
         loader = load_data(args, tokenizer=tokenizer, split="test")
         if not args.eval:
             train_loader = load_data(args, tokenizer=tokenizer, split="train")
+    if args.vtg_precise is not None:
+        model.vtg_precise = None if args.vtg_precise == "none" else args.vtg_precise
     if rank == 0:
         print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")
     if not args.eval:

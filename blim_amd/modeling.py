@@ -11,6 +11,7 @@ other argument combinations raise NotImplementedError.
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import List, Optional
 
@@ -33,6 +34,12 @@ class BlimModel:
         self.training = False
         self._proj_cache = {}
         self._tvg_rows = False          # set by prepare_inputs_labels_for_multimodal(tvg=...): the next forward() is a TVG forward
+        # Compensated (hi + lo) activations on the VTG calls: None = plain 16-bit (fp16 engines hold 1e-3 at 28 layers of the 7B model without),
+        # "attn" = the attention branch only (QKV, attention, o_proj) + the final norm / lm_head rows, "full" = the MLP branch too.  bf16 engines
+        # (8-bit mantissas: 1.0 - 1.7e-3 on the VTG scores at 7B depth when plain) default to the mode that holds the 1e-3 bar.
+        self.vtg_precise = os.environ.get("BLIM_VTG_PRECISE") or ("full" if self.engine.dtype == "bf16" else None)
+        if self.vtg_precise in ("none", "0", ""):
+            self.vtg_precise = None
 
     # ---- nn.Module-ish surface used by the eval loop
     def eval(self):
@@ -169,8 +176,12 @@ class BlimModel:
             m8 = torch.ones((B, L), dtype=torch.uint8, device=self.device)
         else:
             m8 = (attention_mask != 0).to(torch.uint8).contiguous()
-        # a forward over rows prepared with tvg=True runs in the compensated fp16 mode, like the fused TVG calls (engine.set_precise)
-        self.engine.set_precise(self._tvg_rows)
+        # a forward over rows prepared with tvg=True runs in the compensated mode, like the fused TVG calls (engine.set_precise); VTG rows
+        # follow self.vtg_precise
+        if self._tvg_rows:
+            self.engine.set_precise(True)
+        else:
+            self.engine.set_precise(self.vtg_precise is not None, mlp=self.vtg_precise == "full")
         try:
             logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
         finally:

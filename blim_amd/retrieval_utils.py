@@ -188,6 +188,10 @@ class PairScorer:
         self.precise_tvg = bool(precise_tvg)
         eng_ = getattr(model.module if hasattr(model, "module") else model, "engine", None)
         self.split_tvg = self.precise_tvg and eng_ is not None and bool(getattr(eng_, "can_precise", False))   # TVG rows as [hi | lo]
+        # VTG calls: plain 16-bit on fp16 engines; bf16 engines run them compensated too (modeling.py: vtg_precise), feature rows included --
+        # with plain bf16 features the projector's 8-bit rounding alone left 1e-3 on the scores at 7B depth
+        self.vtg_mode = getattr(model.module if hasattr(model, "module") else model, "vtg_precise", None) if (eng_ is not None and getattr(eng_, "can_precise", False)) else None
+        self.split_vtg = self.vtg_mode is not None
         self.m = model.module if hasattr(model, "module") else model
         self.engine = self.m.engine
         self.device = self.m.device
@@ -251,7 +255,7 @@ class PairScorer:
             if v != j and (v, tvg) not in self._vfeat and tuple(self.video[v].shape) == shape:
                 chunk.append(v)
         self._upcoming_pos[tvg] = pos
-        split = tvg and self.split_tvg
+        split = self.split_tvg if tvg else self.split_vtg
         many = getattr(self.m, "project_many", None)
         if split:
             self.engine.set_precise(True, embeds=True)
@@ -389,9 +393,13 @@ class PairScorer:
     def run(self, plan: Plan):
         """One engine call; returns a device f32 tensor [plan.n_pairs]."""
         if plan.kind == "vtg":
-            self.engine.set_precise(False)
-            embeds = self.engine.assemble(plan.src_index, plan.feats)
-            return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
+            mode = self.vtg_mode                                             # None (fp16 engines) | "attn" | "full" (bf16 engines: modeling.py)
+            self.engine.set_precise(mode is not None, embeds=mode is not None, mlp=mode == "full")
+            try:
+                embeds = self.engine.assemble(plan.src_index, plan.feats)
+                return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
+            finally:
+                self.engine.set_precise(False)
         self.engine.set_precise(self.split_tvg, embeds=self.split_tvg)       # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
         try:
             embeds = self.engine.assemble(plan.src_index, plan.feats)
@@ -482,7 +490,7 @@ class _PackState:
         batch = PackedBatch(np.concatenate(self.pos), np.concatenate(self.vis), np.array(self.seq_start), np.array(self.seq_len),
                             np.array(self.pfx_start), np.array(self.pfx_len), device=dev)
         H = self.s.m.dims.hidden_size
-        wide = self.kind == "tvg" and self.s.split_tvg                                       # TVG feature rows are [hi | lo]
+        wide = self.s.split_tvg if self.kind == "tvg" else self.s.split_vtg                   # feature rows are [hi | lo]
         feats = torch.cat(self.feats, dim=0) if self.feats else torch.zeros((1, H * (2 if wide else 1)), dtype=self.s.m.dtype, device=dev)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         labels = np.concatenate(self.labels)

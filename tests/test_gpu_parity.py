@@ -1,12 +1,16 @@
 """GPU (-m gpu): the HIP engine, called through the C ABI, against the numpy oracle and the golden vectors recorded
 from the reference.
 
-Tolerances.  Scores: 1e-3 relative per entry (BASELINE.json north_star) in fp16 -- the engine's default, the reference's own
-autocast dtype and the dtype bench.py runs in -- for every pass kind at every size, including all 28 layers of the real 7B
-configuration (test_depth_*).  The TVG calls (scores ~10x smaller in magnitude) run in the compensated fp16 mode (hi + lo
-activations, engine option "precise").  bf16 (8-bit mantissa) is a NON-PARITY mode like fp8: its deviations are bounded by
-the looser BF16_RTOL and reported (28 layers at 7B: VTG 1 - 2e-3, TVG up to 1.1e-2).  Intermediate 16-bit tensors: 2e-2 of
-the tensor's max."""
+Tolerances.  Scores: 1e-3 relative per entry (BASELINE.json north_star) for every pass kind at every size, including all 28 layers of
+the real 7B configuration (test_depth_*), in BOTH 16-bit engine dtypes on the fused path evaluation() runs:
+* fp16 -- the engine's default, the reference's own autocast dtype and the dtype bench.py runs in: plain 16-bit VTG calls, TVG calls
+  (scores ~10x smaller in magnitude) in the compensated mode (hi + lo activations, engine option "precise");
+* bf16 -- the dtype BASELINE.json's configurations name: 8-bit mantissas miss the bar when plain (1.0 - 1.7e-3 VTG, 7 - 9e-3 TVG at 7B
+  depth), so since round 3 bf16 engines run every call compensated (hi + lo bf16 = 16 significant bits against exact bf16 weights:
+  VTG 2e-6, TVG <= 7e-4 at 7B depth; modeling.py: vtg_precise = "full").
+The literal reference-shaped API keeps the reference's [B, L, H] 16-bit embeddings between prepare_inputs_labels_for_multimodal and
+forward(); in bf16 that rounding alone is ~1e-3 on the scores, so the literal bf16 path is bounded by BF16_LITERAL_RTOL and reported.
+Intermediate 16-bit tensors: 2e-2 of the tensor's max."""
 import os
 import types
 
@@ -37,11 +41,12 @@ def h16(x, dtype):
 DTYPES = ["f16", "bf16"]
 
 
-BF16_RTOL = {"vtg": 5e-3, "tvg": 2e-2}     # non-parity mode: measured <= 3.1e-3 / 1.1e-2 at 28 layers of the 7B configuration
+BF16_LITERAL_RTOL = 6e-3     # literal API in bf16 only: the [B, L, H] bf16 embeddings it hands from prepare_inputs_... to forward() (measured at 7B depth:
+                             # VTG <= 9.7e-4, TVG <= 3.8e-3; the fused path, which carries [hi | lo] feature rows, is held to SCORE_RTOL)
 
 
-def score_rtol(dtype: str, pass_name: str) -> float:
-    return SCORE_RTOL if dtype == "f16" else BF16_RTOL["tvg" if "tvg" in pass_name else "vtg"]
+def score_rtol(dtype: str, pass_name: str, literal: bool = False) -> float:
+    return BF16_LITERAL_RTOL if (dtype == "bf16" and literal) else SCORE_RTOL
 
 
 def relmax(a, b):
@@ -299,12 +304,12 @@ def _worst_rel(got, g, prefix="S_"):
     return worst
 
 
-def _check_passes(got, g, t):
+def _check_passes(got, g, t, literal=False):
     for name, S in got.items():
         G = g[f"S_{name}"]
         assert np.array_equal(S == -100.0, G == -100.0), name          # same entries computed (top-k, leftover batch)
         m = G != -100.0
-        rtol = score_rtol(t.dtype, name)
+        rtol = score_rtol(t.dtype, name, literal)
         np.testing.assert_allclose(S[m], G[m], rtol=rtol, err_msg=f"{name} [{t.dtype}]")
 
 
@@ -312,7 +317,7 @@ def _check_passes(got, g, t):
 def test_six_passes_tiny_vs_reference_golden(tiny, literal):
     g = np.load(os.path.join(GOLD, "tiny.npz"))
     got = _six_passes(tiny, literal)
-    _check_passes(got, g, tiny)
+    _check_passes(got, g, tiny, literal)
     # R@k of the full BLiM ensemble: identical to the reference's matrices'
     n = tiny.spec["n"]
     args = types.SimpleNamespace(cpn=True, alpha=[0.4, 0.8], c=[0.3, 0.6, 0.9, 0.7], resume="ckpt", eval=True)
@@ -327,7 +332,7 @@ def test_six_passes_tiny_vs_reference_golden(tiny, literal):
 def test_six_passes_7b_width_vs_reference_golden(wide, literal):
     """Qwen2-7B width (H=3584, 28/4 heads, I=18944, V=152064), one layer; weights generated ON DEVICE from the seed."""
     g = np.load(os.path.join(GOLD, "wide.npz"))
-    _check_passes(_six_passes(wide, literal), g, wide)
+    _check_passes(_six_passes(wide, literal), g, wide, literal)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -366,7 +371,7 @@ def test_full_size_properties_7b(dtype):
     out = ddp(inputs_embeds=r[4], attention_mask=r[2][0])
     lit = RU.vtg_criterion(out.logits, r[5]).cpu().numpy()[0]
     # (not bitwise: the literal row is one causal segment, the fused one a prefix + own segment, so the 32-key softmax tiles fall differently)
-    np.testing.assert_allclose(full[j * 6 + i], lit, rtol=score_rtol(dtype, "vtg"))
+    np.testing.assert_allclose(full[j * 6 + i], lit, rtol=score_rtol(dtype, "vtg", literal=True))
     alone_all = np.array([sc.vtg(pairs[k:k + 1])[0] for k in range(len(pairs))])
     assert np.array_equal(alone_all, full)                                        # batch composition: bitwise
     model.engine.close()
@@ -419,7 +424,7 @@ def test_depth_28_layers_h1024_vs_reference_golden(dtype, capsys):
     res, hid = _depth_case("deep", dtype, capsys)
     for tag, w in res.items():
         for k, v in w.items():
-            assert v < score_rtol(dtype, k), (dtype, tag, k, v)
+            assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
     assert max(hid.values()) < 2e-2
 
 
@@ -433,7 +438,7 @@ def test_depth_full_7b_vs_reference_golden(dtype, case, capsys):
     res, hid = _depth_case(case, dtype, capsys)
     for tag, w in res.items():
         for k, v in w.items():
-            assert v < score_rtol(dtype, k), (dtype, tag, k, v)
+            assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
     assert max(hid.values()) < (2e-2 if dtype == "f16" else 6e-2)
 
 
@@ -502,9 +507,9 @@ def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
     with capsys.disabled():
         print(f"\n[deep f16] final hidden state, relative rms error vs the fp32 reference: plain {err[False]:.2e}, compensated {err[True]:.2e}")
     assert err[True] < 0.5 * err[False]
-    with pytest.raises(eng.BlimError, match="fp16 engine"):
+    with pytest.raises(eng.BlimError, match="16-bit engine"):         # fp16 and bf16 engines have the mode (round 3), fp8 engines do not
         e = eng.Engine(synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=1, num_heads=2, num_kv_heads=1, mm_hidden_size=64),
-                       max_positions=64, dtype="bf16")
+                       max_positions=64, dtype="f8")
         try:
             e.set_option("precise", 1)
         finally:
@@ -566,7 +571,7 @@ def test_evaluation_and_val_one_epoch_end_to_end(tiny, literal):
     assert set(t2v) == {"candidate_likelihood", "query_likelihood", "internvideo2", "candidate_prior"} and set(v2t) == set(t2v)
     got = {"v2t_vtg": v2t["candidate_likelihood"], "v2t_vtg_cpn": v2t["candidate_prior"], "v2t_tvg": v2t["query_likelihood"],
            "t2v_vtg": t2v["query_likelihood"], "t2v_tvg": t2v["candidate_likelihood"], "t2v_tvg_cpn": t2v["candidate_prior"]}
-    _check_passes(got, g, t)
+    _check_passes(got, g, t, literal)
     res = TU.val_one_epoch(ddp, loader, None, t.model.device, 0, None, tokenizer=tok, args=args)
     ref_t2v = {"candidate_likelihood": g["S_t2v_tvg"], "candidate_prior": g["S_t2v_tvg_cpn"], "query_likelihood": g["S_t2v_vtg"], "internvideo2": t.prob.t2v_sims}
     ref_v2t = {"candidate_likelihood": g["S_v2t_vtg"], "candidate_prior": g["S_v2t_vtg_cpn"], "query_likelihood": g["S_v2t_tvg"], "internvideo2": t.prob.v2t_sims}
