@@ -46,6 +46,13 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
 }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// MODE.FP16_OVFL (hwreg MODE, bit 23) for the rest of this wave: an fp16 VALU result that overflows -- here: the f32 -> f16 conversions of the
+// epilogues -- becomes +-65504 instead of +-inf; true infinities and NaNs pass through unchanged (tools/f16_ovfl_probe.hip, measured on gfx950).
+// Costs one scalar instruction per wave.  The fp16 scoring path sets it wherever it stores 16-bit activations: a q / k / v, a SwiGLU output
+// or a norm output beyond fp16's range saturates (a defined, finite value) instead of turning the row's scores into NaN; the f32
+// residual stream keeps its range.  Gradient stores of the trainer do NOT set it: the loss scaler's overflow detection needs the inf.
+__device__ __forceinline__ void f16_saturate_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
 template <int DT> __device__ __forceinline__ float from16(uint16_t b) {
     if constexpr (DT == DT_BF16) return __uint_as_float(((uint32_t)b) << 16);
     else return (float)__builtin_bit_cast(_Float16, b);

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    if constexpr (out16<DT>::value == DT_F16) { if (p.f16_saturate) f16_saturate_on(); }
     int stamp_vb = blockIdx.x;
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)stamp_vb * 8 + k] = __builtin_amdgcn_s_memrealtime();

@@ -55,6 +55,8 @@ struct GemmParams {
     uint8_t* out_mx;
     const uint8_t* a_mx;
     int64_t mx_stride;
+    int f16_saturate;        // fp16 outputs: saturate to +-65504 instead of +-inf (common.hpp: f16_saturate_on).  engine.hip's gp() sets it; the one
+                             // 16-bit GRADIENT store of the trainer clears it (the loss scaler must see an overflow as inf)
     int group_m;             // M-tiles per band of the tile order (8; BLIM_GEMM_GROUP_M)
     int tile_map;            // 1: 32-tile groups round-robin over the XCDs (default), 0: XCD-contiguous chunks (BLIM_GEMM_TILE_MAP)
     int debug_skip_epilogue; // timing aid only (set from BLIM_GEMM_SKIP_EPI)

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
+    if constexpr (DT == DT_F16) f16_saturate_on();
     const int64_t src = rows ? rows[r] : r;
     const int nv = H / 4;  // float4 per row
     if (src < 0 || src >= n_src) {   // a gather index outside the packed batch: poison the row (NaN score) instead of reading wild memory

@@ -398,7 +398,7 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         uint16_t* attn = (uint16_t*)t->sv_attn.p + (int64_t)li * T * Ha; uint16_t* gu = (uint16_t*)t->sv_gu.p + (int64_t)li * T * 2 * I;
         // ---- MLP block: x_out = x_mid + down(silu(gate(n2)) * up(n2)), n2 = rmsnorm(x_mid); dy16 = 16-bit(dres) comes from the previous RMSNorm backward
         if (li == c.num_layers - 1) TRY(launch_f32_to_16(dy16, H, dres, H, T, H, 1.0f, dt, s));
-        { GemmParams p = gp(dt, dy16, H, x.wdT, T, I, H, t->act.p, I); p.swiglu_gu = gu; p.swiglu_ld = 2 * (int64_t)I; TRY(launch_gemm(EPI_BF16, p, s)); }   // d act = dy . Wd, and in the
+        { GemmParams p = gp(dt, dy16, H, x.wdT, T, I, H, t->act.p, I); p.swiglu_gu = gu; p.swiglu_ld = 2 * (int64_t)I; p.f16_saturate = 0; TRY(launch_gemm(EPI_BF16, p, s)); }   // d act = dy . Wd, and in the
                                                                                                                          // epilogue gu <- [d gate | d up] (no d act round trip)
         { GemmParams p = gp(dt, gu, 2 * (int64_t)I, x.wguT, T, H, 2 * I, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }    // d n2
         TRY(launch_rmsnorm_bwd(dres, dtmp, x_mid, nullptr, T, H, l.norm2, c.rms_eps, 1, dy16, dt, s));                   // dres = d x_mid (+ its 16-bit copy)

@@ -535,6 +535,7 @@ static GemmParams vgp(int dt, const void* A, int64_t lda, const void* W, int64_t
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.dtype = dt; p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.M = (int)M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.scale = 1.0f; p.bias = bias;
+    p.f16_saturate = 1;
     return p;
 }
 

@@ -1,0 +1,89 @@
+"""TEST INFRASTRUCTURE ONLY -- tests/golden/saturation.npz: the REFERENCE on weights whose SwiGLU output leaves fp16's range.
+
+Run in the build container only (needs /root/reference):  python -m oracle.gen_golden_saturation
+
+The tiny 2-layer configuration of gen_golden.py with layer 0's gate_proj / up_proj scaled by SCALE: |gate| and |up| stay below 65,504 but
+silu(gate) * up reaches ~1e6 on some tokens -- the "massive activation" shape real checkpoints show.  The reference's own scoring loops
+(retrieval_utils.compute_v2t_scores_x, VTG and TVG) are run twice: in fp32 (the truth) and as main.py:97 runs the model on GPU, `.half()`
+under autocast(float16) semantics -- here literally `.half()` on CPU.  The fp16 reference overflows to inf in the SwiGLU product and the
+affected scores come out NaN; that fact (which entries) is the fixture.  Outputs only; no reference source text is stored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from blim_amd import synth  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+from oracle.blim_oracle import OracleConfig  # noqa: E402
+
+DIMS = dict(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+WSEED, PSEED, N, TOK, TEXT, TOPK, SCALE = 11, 5, 6, 8, (3, 9), 4, 2000.0
+
+
+def scaled_weights(dims):
+    w = synth.synthetic_weights(dims, WSEED)
+    for k in ("layers.0.gate_proj.w", "layers.0.up_proj.w"):
+        w[k] = synth.bf16_round(w[k] * np.float32(SCALE))
+    return w
+
+
+def main(out_dir):
+    import torch
+    torch.set_num_threads(8)
+    dims = synth.ModelDims(**DIMS)
+    w = scaled_weights(dims)
+    prob = synth.make_problem(PSEED, N, dims, tok_per_clip=TOK, text_len=TEXT)
+    ns = ref_harness.load()
+    RU = ns.RU
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    vtg = RU.padding_ids([T(x) for x in prob.vtg_ids], [T(x) for x in prob.vtg_labels], [T(x) for x in prob.vtg_masks], tok)
+    tvg = RU.padding_ids([T(x) for x in prob.tvg_ids], [T(x) for x in prob.tvg_labels], [T(x) for x in prob.tvg_masks], tok)
+    args = types.SimpleNamespace(topk=TOPK, batch_size_eval=3, num_clips=dims.num_clips)
+    dev = torch.device("cpu")
+    out = {}
+    for tag, half in (("fp32", False), ("fp16", True)):
+        model = ref_harness.build_model(OracleConfig(**DIMS), w)
+        if half:
+            model = model.half()                                      # main.py:97
+        model.set_tvg_prefix_length(prob.tvg_prefix_length)
+        ddp = ref_harness.DDPish(model)
+        dt = torch.float16 if half else torch.float32
+        video = [T(v).to(dt) for v in prob.video]
+        vocab = T(prob.video_vocab).to(dt)
+        with torch.no_grad():
+            for name, ft, (ids, lab, msk) in (("v2t_vtg", "vtg", vtg), ("v2t_tvg", "tvg", tvg)):
+                S = RU.compute_v2t_scores_x(torch.full((N, N), -100.0), T(prob.v2t_sims), 0, ids, msk, lab, video, vocab, T(prob.tvg_video_labels), ddp, dev, args,
+                                            forward_type=ft, cpn=False)
+                out[f"{tag}_{name}"] = S.float().numpy()
+                print(tag, name, "non-finite entries:", int((~np.isfinite(out[f'{tag}_{name}'])).sum()), "of", int((out[f'{tag}_{name}'] != -100).sum()), flush=True)
+        # the largest SwiGLU product of layer 0 on one ragged batch (what overflows)
+        if not half:
+            acts = []
+            h = model.model.layers[0].mlp.act_fn.register_forward_hook(lambda m, i, o: acts.append(float(o.abs().max())))
+            ups = []
+            h2 = model.model.layers[0].mlp.up_proj.register_forward_hook(lambda m, i, o: ups.append(float(o.abs().max())))
+            with torch.no_grad():
+                r = model.prepare_inputs_labels_for_multimodal(vtg[0][:3], None, vtg[2][:3], None, vtg[1][:3], video[:3], ["video"] * 3, image_sizes=None, video_feature=True, cpn=True)
+                model(inputs_embeds=r[4], attention_mask=r[2][0])
+            h.remove(); h2.remove()
+            out["max_abs_silu_gate"] = np.float32(max(acts)); out["max_abs_up"] = np.float32(max(ups))
+            print("max |silu(gate)|", max(acts), "max |up|", max(ups), flush=True)
+    out["scale"] = np.float32(SCALE)
+    path = os.path.join(out_dir, "saturation.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    if not ref_harness.available():
+        sys.exit("reference not present; fixtures can only be generated in the build container")
+    main(os.path.join(ROOT, "tests", "golden"))

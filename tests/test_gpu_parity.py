@@ -516,6 +516,54 @@ def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
             e.close()
 
 
+def test_fp16_stores_saturate_instead_of_overflowing():
+    """fp16 outputs of the scoring kernels saturate to +-65504 (MODE.FP16_OVFL, csrc/common.hpp) instead of overflowing to inf; NaN and
+    true infinities of the inputs pass through.  bf16 outputs have f32's range and are not touched."""
+    M, N, K = 256, 256, 64
+    a = torch.zeros((M, K), dtype=torch.float16, device="cuda"); w = torch.zeros((N, K), dtype=torch.float16, device="cuda")
+    a[:, 0] = 1000.0
+    w[0, 0] = 1000.0; w[1, 0] = -1000.0; w[2, 0] = 65.0; w[3, 0] = 65.6           # 1e6, -1e6, 65000 (in range: 64992 in fp16), 65625 (just beyond 65504 + half an ulp)
+    a[5, 1] = float("inf"); w[4, 1] = 1.0; a[6, 1] = float("nan")
+    out = eng.gemm_bf16(a, w).float().cpu().numpy()
+    assert (out[:5, 0] == 65504.0).all() and (out[:5, 1] == -65504.0).all() and (out[:5, 2] == 64992.0).all() and (out[:5, 3] == 65504.0).all()
+    assert np.isposinf(out[5, 4]) and np.isnan(out[6, 4]) and out[0, 4] == 0.0
+    ob = eng.gemm_bf16(a.to(torch.bfloat16), w.to(torch.bfloat16)).float().cpu().numpy()
+    assert abs(ob[0, 0] - 1.0e6) < 1.0e4 and abs(ob[0, 1] + 1.0e6) < 1.0e4
+
+
+def test_activations_beyond_fp16_range(capsys):
+    """`saturation.npz` (oracle/gen_golden_saturation.py): the tiny configuration with layer 0's gate / up projections scaled so that
+    silu(gate) * up reaches ~7e6 (|gate|, |up| themselves stay in range) -- the shape of the massive activations real checkpoints show.
+    The REFERENCE run as main.py:97 runs it (`.half()`) overflows to inf there and returns NaN for every score (recorded in the fixture); its fp32
+    run is the truth.  The engine: an fp16 engine saturates the 16-bit store and stays finite (a defined value, not the truth); a bf16
+    engine -- f32's range, compensated to 16 significant bits -- reproduces the fp32 reference to 1e-3."""
+    from oracle.gen_golden_saturation import DIMS, N, PSEED, TEXT, TOK, TOPK, scaled_weights
+    g = np.load(os.path.join(GOLD, "saturation.npz"))
+    assert np.isnan(g["fp16_v2t_vtg"][g["fp32_v2t_vtg"] != -100.0]).all() and np.isnan(g["fp16_v2t_tvg"][g["fp32_v2t_tvg"] != -100.0]).all()
+    dims = synth.ModelDims(**DIMS)
+    w = scaled_weights(dims)
+    prob = synth.make_problem(PSEED, N, dims, tok_per_clip=TOK, text_len=TEXT)
+    spec = dict(n=N, topk=TOPK, bs=3)
+    res = {}
+    for dtype in ("f16", "bf16"):
+        model = BlimModel(dims, max_positions=512, dtype=dtype)
+        model.engine.load_weights(w)
+        t = types.SimpleNamespace(model=model, dims=dims, prob=prob, spec=spec, dtype=dtype)
+        try:
+            got = _six_passes(t, False, names=("v2t_vtg", "v2t_tvg"))
+        finally:
+            model.engine.close()
+        for name, S in got.items():
+            G = g[f"fp32_{name}"]
+            m = G != -100.0
+            assert np.array_equal(S != -100.0, m)
+            assert np.isfinite(S[m]).all(), (dtype, name)                      # never NaN / inf, in either dtype
+            res[(dtype, name)] = float(np.max(np.abs(S[m] - G[m]) / np.abs(G[m])))
+    with capsys.disabled():
+        print("\n[saturation] worst relative deviation from the fp32 reference (its fp16 run: all NaN): " + ", ".join(f"{d} {n} {v:.2e}" for (d, n), v in res.items()))
+    assert res[("bf16", "v2t_vtg")] < SCORE_RTOL and res[("bf16", "v2t_tvg")] < SCORE_RTOL
+
+
 @pytest.mark.parametrize("case", ["deep", "full7b"])
 def test_depth_fp8_mode_deltas_vs_reference_golden(case, capsys):
     """fp8 mode against the fp32 REFERENCE at 28 layers (deltas reported; bounded loosely -- a separate mode, never the headline)."""
