@@ -27,7 +27,6 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    if constexpr (DT == DT_F16) f16_saturate_on();     // the 16-bit P and output stores saturate instead of overflowing to inf (common.hpp)
     const int G = p.num_heads / p.num_kv_heads;
     const int kh = blockIdx.y;
     const int head = kh * G + wave;

@@ -51,7 +51,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Costs one scalar instruction per wave.  The fp16 scoring path sets it wherever it stores 16-bit activations: a q / k / v, a SwiGLU output
 // or a norm output beyond fp16's range saturates (a defined, finite value) instead of turning the row's scores into NaN; the f32
 // residual stream keeps its range.  Gradient stores of the trainer do NOT set it: the loss scaler's overflow detection needs the inf.
+// CAUTION (measured, tools/nan_probe.py): while the bit is set the fp16 MFMA reads a NaN operand as 0 and an infinite one as +-65504 -- NaN
+// would no longer propagate through a GEMM.  So the bit is set only AROUND the conversions (after a tile's last MFMA) and cleared before the
+// next MFMA: NaN / inf operands still poison the accumulator, and a NaN accumulator is stored as NaN.
 __device__ __forceinline__ void f16_saturate_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+__device__ __forceinline__ void f16_saturate_off() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 0); }
 
 template <int DT> __device__ __forceinline__ float from16(uint16_t b) {
     if constexpr (DT == DT_BF16) return __uint_as_float(((uint32_t)b) << 16);

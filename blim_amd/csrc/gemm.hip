@@ -52,7 +52,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    if constexpr (out16<DT>::value == DT_F16) { if (p.f16_saturate) f16_saturate_on(); }
     int stamp_vb = blockIdx.x;
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (p.debug_stamps && tid == 0) p.debug_stamps[(size_t)stamp_vb * 8 + k] = __builtin_amdgcn_s_memrealtime();
@@ -80,6 +79,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     }
     stamp_vb = pid;
     stamp(0);
+    if constexpr (out16<DT>::value == DT_F16) { if (p.f16_saturate) f16_saturate_off(); }     // the MFMAs must see NaN / inf operands as such (common.hpp)
     const int width = p.group_m * ntn;
     const int first_m = (pid / width) * p.group_m;
     const int gsz = min(ntm - first_m, p.group_m);
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 
     stamp(2);
     // =========================================================================== epilogues
+    if constexpr (out16<DT>::value == DT_F16) { if (p.f16_saturate) f16_saturate_on(); }      // fp16 stores of this tile saturate instead of overflowing to inf
     if (p.debug_skip_epilogue) {   // timing aid (tools/gemm_k_sweep.py): keep the accumulators live, store nothing
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -800,6 +801,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 static int g_gemm_persistent = getenv("BLIM_GEMM_PERSISTENT") ? atoi(getenv("BLIM_GEMM_PERSISTENT")) : 1;
 static int g_gemm_tile_map = getenv("BLIM_GEMM_TILE_MAP") ? atoi(getenv("BLIM_GEMM_TILE_MAP")) : -1;   // -1: by shape
 static int g_gemm_group_m = getenv("BLIM_GEMM_GROUP_M") ? atoi(getenv("BLIM_GEMM_GROUP_M")) : GROUP_M;   // M-tiles per band of the tile order
+static int g_f16_saturate = getenv("BLIM_F16_SATURATE") ? atoi(getenv("BLIM_F16_SATURATE")) : 1;   // 0: fp16 stores overflow to inf again (diagnostics)
 static int g_gemm_skip_epi = getenv("BLIM_GEMM_SKIP_EPI") ? atoi(getenv("BLIM_GEMM_SKIP_EPI")) : 0;
 static unsigned long long* g_gemm_stamps = nullptr;
 static int g_stamp_epi = getenv("BLIM_GEMM_STAMP_EPI") ? atoi(getenv("BLIM_GEMM_STAMP_EPI")) : -1;   // stamp only this epilogue / this K (tools/epi_stamps.py)
@@ -886,6 +888,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
 static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
+    if (!g_f16_saturate) p.f16_saturate = 0;
     p.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : GROUP_M;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
     // round-robin map, the wide ones (gate|up 37888, lm_head) lose 4 % -- there the XCDs already walk the same W columns in step

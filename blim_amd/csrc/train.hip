@@ -133,7 +133,8 @@ extern "C" int blim_train_create(blim_engine* e, const blim_train_config* cfg, f
     ARG_CHECK(e && cfg && params && grads && out);
     ARG_CHECK(cfg->lora_r > 0 && cfg->lora_r <= 16 && cfg->lora_alpha > 0.f && cfg->lora_dropout >= 0.f && cfg->lora_dropout < 1.f);
     TRY(blim_weights_ready(e));
-    if (e->f8) { blim_set_error("training needs a 16-bit engine (fp16, as the reference's autocast, or bf16), not fp8"); return BLIM_ERR_STATE; }
+    // (an fp8 engine keeps its 16-bit matrices: a trainer on it can load and MERGE adapters -- evaluation of a fine-tuned checkpoint in fp8 mode --
+    // but blim_train_step refuses to run)
     const blim_config& c = e->c;
     const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, M = c.mm_hidden_size;
     const int rope_rows = (c.num_heads + c.num_kv_heads) * 128;
@@ -508,6 +509,7 @@ static int tvg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum,
 }
 
 extern "C" int blim_train_step(blim_trainer* t, const blim_train_batch* b, float* loss_sums, void* stream) {
+    if (t && t->e && t->e->f8) { blim_set_error("training needs a 16-bit engine (fp16, as the reference's autocast, or bf16), not fp8"); return BLIM_ERR_STATE; }
     ARG_CHECK(loss_sums);
     TRY(check_train_batch(t, b));
     hipStream_t s = (hipStream_t)stream;

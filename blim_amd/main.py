@@ -70,6 +70,9 @@ def get_args_parser():
                         "(timing of the 8-GPU configurations on one GPU)")
     p.add_argument("--synthetic", default=0, type=int, help="N > 0: dry run on N synthetic videos/texts (tiny model unless --synthetic_7b)")
     p.add_argument("--synthetic_7b", action="store_true")
+    p.add_argument("--synthetic_same", action="store_true", help="synthetic training: train on the evaluation set itself (a run that memorises its pairs: "
+                                                                 "rankings far from chance, for comparing numeric modes on R@k)")
+    p.add_argument("--dump_scores", default=None, type=str, help="write the evaluation's score matrices to this .npz")
     return p
 
 
@@ -129,7 +132,8 @@ def main(args):
             tr.merge_into_engine()
             tr.close()
         if not args.eval:     # synthetic training set: other videos / captions of the same generator, this rank's share
-            tprob = synth.make_problem(2 + rank, max(args.batch_size, args.synthetic), dims, tok_per_clip=64 if args.synthetic_7b else 8, fast_video=args.synthetic > 256)
+            tprob = prob if args.synthetic_same else \
+                synth.make_problem(2 + rank, max(args.batch_size, args.synthetic), dims, tok_per_clip=64 if args.synthetic_7b else 8, fast_video=args.synthetic > 256)
             train_loader = synth.ProblemLoader(tprob, args.batch_size)
     else:
         from .checkpoint import load_checkpoint, summarize_report

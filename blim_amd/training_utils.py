@@ -89,6 +89,9 @@ def combine_and_rank(t2v_dict, v2t_dict, args, n: int) -> Dict[str, Dict[str, fl
 def val_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler, tokenizer=None, args=None):
     """training_utils.py:140-169 (no autocast: the engine computes in its 16-bit compute dtype -- fp16 by default -- with f32 accumulation)."""
     t2v_dict, v2t_dict = evaluation(model, data_loader, device, tokenizer, args)
+    dump = getattr(args, "dump_scores", None)
+    if dump and dist_utils.is_main_process():                          # engine-side option: the score matrices themselves (mode comparisons)
+        np.savez_compressed(dump, **{f"t2v_{k}": v for k, v in t2v_dict.items()}, **{f"v2t_{k}": v for k, v in v2t_dict.items()})
     if dist_utils.is_main_process():
         return combine_and_rank(t2v_dict, v2t_dict, args, len(data_loader.dataset))
     return None

@@ -98,6 +98,19 @@ def run_case(name: str, out_dir: str):
         print(f"[{name}] tower forward: {time.time() - t0:.1f}s", flush=True)
         vf = [v.reshape(-1, v.shape[-2] // T, v.shape[-1]) for v in torch.split(feat, [4])]   # modeling_videochat_flash.py:153
         tome = proj(vf[0], compress=True, local_num_frames=T, return_video_feature=True)         # [4, 64, D]
+    # The reference's PRODUCTION numerics (extract.py:96, 105-108: `.half()` weights under autocast(float16), features saved as fp16), emulated on CPU:
+    # the same tower and ToMe with fp16 weights inside torch.autocast("cpu", float16).  ToMe makes discrete arg-max / arg-sort choices, so this run
+    # merges a few tokens differently from the fp32 run -- the fixture records by how much the reference disagrees with ITSELF across precisions,
+    # the yardstick for the engine's 16-bit encoder (tests/test_vision_gpu.py).
+    with torch.no_grad():
+        t0 = time.time()
+        tower_h = tower.half()
+        with torch.autocast(device_type="cpu", dtype=torch.float16):
+            feat_h = tower_h(x.half())
+            vf_h = [v.reshape(-1, v.shape[-2] // T, v.shape[-1]) for v in torch.split(feat_h, [4])]
+            tome_h = proj(vf_h[0], compress=True, local_num_frames=T, return_video_feature=True)
+        out["tome_fp16_autocast"] = tome_h.float().numpy().astype(np.float16)
+        print(f"[{name}] fp16-autocast tower + ToMe: {time.time() - t0:.1f}s", flush=True)
     if name == "small":
         out["feat_sub16"] = feat.numpy()[..., ::16].copy()
         out["feat_clip0"] = feat.numpy()[0].copy()
