@@ -18,8 +18,12 @@
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// MAXC = 16-byte staging chunks per thread and tile = ceil(chunks per tile / threads); threads = 64 x (query heads per KV head).  The launch bound follows
+// the head grouping (G >= 4: up to 512 threads; G = 2, 3: <= 192; G = 1: 64), so the few-thread variants -- whose threads each stage a large share of
+// the tile -- get the registers of the waves that are not there instead of spilling (MHA, compensated: 450 VGPRs spilled under a 512-thread bound).
+template <int MAXC, bool SPLIT> struct attn_bound { static constexpr int value = MAXC <= (SPLIT ? 8 : 4) ? 512 : MAXC <= (SPLIT ? 16 : 8) ? 256 : 64; };
 template <bool USE_TR, int MAXC, int DT, bool SPLIT = false>
-__global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t k_lds[(SPLIT ? 2 : 1) * KT * HD];   // SPLIT: K_hi tile, then K_lo tile
     __shared__ __attribute__((aligned(16))) bf16_t v_lds[(SPLIT ? 2 : 1) * KT * HD];   // SPLIT: V_hi tile, then V_lo tile
     __shared__ uint32_t vis_lds[KT / 4];  // 32 visibility bytes
@@ -297,7 +301,8 @@ int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
             if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<true, MC, DT_F16, true>), grid, block, 0, stream, p);  \
             else hipLaunchKernelGGL((attn_kernel<true, MC, DT_BF16, true>), grid, block, 0, stream, p);               \
         } while (0)
-        if (G >= 4) ATTN_SPLIT(8);
+        if (G >= 7) ATTN_SPLIT(5);                  // 2,048 chunks / 448 (512) threads: five per thread, not eight (the 7B model's grouping)
+        else if (G >= 4) ATTN_SPLIT(8);
         else if (G >= 2) ATTN_SPLIT(16);
         else ATTN_SPLIT(32);
 #undef ATTN_SPLIT

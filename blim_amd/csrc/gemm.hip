@@ -646,7 +646,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             const int oc = oc0 + 8 * seg;
             constexpr int RPP = NTHREADS / LPR;                   // rows per pass of the workgroup
             bool fused_done = false;
-            if constexpr (EPI == EPI_BF16) {
+            if constexpr (EPI == EPI_BF16 && !SPLIT) {            // (the trainer's fused SwiGLU forms never meet split outputs: keeps the compensated kernels' register pressure down)
                 if (p.swiglu_gu != nullptr) {
                     // fine-tuning backward (train.hip): this tile is d act = dy . Wd; instead of storing it, turn the saved gate | up
                     // pre-activations (16 gate / 16 up columns interleaved, the fused matrix's stored row order) into [d gate | d up] in place
@@ -676,14 +676,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }
             if (fused_done) {
             } else if (row0 + 256 <= p.M && oc0 + NC <= n_out && (p.ldc & 7) == 0) {   // interior tile: all LDS reads, then all stores, no branches
-                uint4 v[256 / RPP];
+                // (split outputs: the accumulators stay live for the second part, so the rows move in groups of four instead of all at once)
+                constexpr int NV = 256 / RPP, VB = SPLIT ? 4 : NV;
+                uint4 v[NV];
                 const char* lsrc = smem + (tid / LPR) * RS + seg * 16;
-#pragma unroll
-                for (int i = 0; i < 256 / RPP; ++i) v[i] = *(const uint4*)(lsrc + i * RPP * RS);
                 bf16_t* out = (bf16_t*)p.C + c_part + (int64_t)(row0 + tid / LPR) * p.ldc + oc;
 #pragma unroll
-                for (int i = 0; i < 256 / RPP; ++i) *(uint4*)(out + (int64_t)i * RPP * p.ldc) = v[i];
-                if constexpr (EPI == EPI_BF16) {
+                for (int i0 = 0; i0 < NV; i0 += VB) {
+#pragma unroll
+                    for (int i = i0; i < i0 + VB; ++i) v[i] = *(const uint4*)(lsrc + i * RPP * RS);
+#pragma unroll
+                    for (int i = i0; i < i0 + VB; ++i) *(uint4*)(out + (int64_t)i * RPP * p.ldc) = v[i];
+                    if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (EPI == EPI_BF16 && !SPLIT) {
                     // fine-tuning forward (train.hip): the tile is the gate | up pre-activations (kept for the backward); the lanes holding a
                     // gate chunk also form act = silu(gate) * up from the up chunk two 16-byte chunks further in the same LDS row
                     if (p.swiglu_act != nullptr && (seg & 3) < 2) {
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     const bf16_t* e = (const bf16_t*)&v;
                     for (int j = 0; j < 8 && oc + j < n_out; ++j) out[j] = e[j];
                 }
-                if constexpr (EPI == EPI_BF16) {
+                if constexpr (EPI == EPI_BF16 && !SPLIT) {
                     if (p.swiglu_act != nullptr && (seg & 3) < 2) {      // edge tiles: same rule as above (N = 2 I is a multiple of 32)
                         constexpr int ODT = out16<DT>::value;
                         const uint4 ur = *(const uint4*)(smem + rl * RS + seg * 16 + 32);

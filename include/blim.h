@@ -31,7 +31,11 @@ extern "C" {
 
 /* 16-bit compute format of an engine: activations handed across the ABI ("h16" below), the engine's weight copy and the
  * MFMA operand type.  F16 is what the reference itself runs on GPU (main.py:97 .half(), training_utils.py:142 autocast
- * float16) and the default of the Python host; BF16 has the same MFMA rate and an 8-bit mantissa. */
+ * float16) and the default of the Python host; BF16 has the same MFMA rate and an 8-bit mantissa (it holds the 1e-3 bar in the compensated
+ * mode, option "precise").  Range: an fp16 engine's 16-bit activation STORES saturate at +-65504 instead of overflowing to inf (the f32
+ * residual stream keeps f32's range; NaN / inf operands still propagate) -- where the reference's `.half()` forward turns a SwiGLU product
+ * beyond 65504 into NaN scores, the engine returns finite ones; a bf16 engine has f32's range and reproduces the fp32 result
+ * (tests/test_gpu_parity.py::test_activations_beyond_fp16_range, tests/golden/saturation.npz recorded from the reference). */
 #define BLIM_COMPUTE_BF16 0
 #define BLIM_COMPUTE_F16 1
 /* fp8 mode (BASELINE.json config 5, "fp8 weights on CDNA4 fp8 MFMA"): q/k/v, o, gate|up, down and
@@ -176,7 +180,10 @@ int blim_debug_read(blim_engine* e, const char* which, void* dst, int64_t bytes,
  * C staged in LDS, stores issued} to device_buf[workgroup*8 ..] (u64, 100 MHz); NULL turns it off. */
 int blim_debug_gemm_stamps(void* device_buf);
 
-/* "precise" (0/1, fp16 engines): compensated arithmetic for the following calls (activations as hi + lo, GEMMs walk K twice);
+/* "precise" (0/1, fp16 and bf16 engines; fp8 engines refuse it): compensated arithmetic for the following calls (activations as hi + lo,
+ *   GEMMs walk K twice): ~21 significant bits per activation on fp16 engines, 16 on bf16 engines (against exact bf16 weights: VTG 2e-6 / TVG
+ *   <= 7e-4 from the fp32 reference at 28 layers of the 7B configuration).  The host turns it on for the TVG calls of both dtypes and for the
+ *   VTG calls of bf16 engines -- the mode in which BASELINE.json's named dtype holds the 1e-3 bar (blim_amd/modeling.py: vtg_precise);
  * "precise_embeds" (0/1): in precise mode the input embeddings / projector outputs are [hi | lo] rows of width 2 * hidden as well;
  * "precise_mlp" (0/1, default 1): 0 leaves the MLP branch plain in precise mode (TVG calls 1.6x faster; TVG deviation at 7B depth
  *   8e-4 instead of 4e-5: tests/test_gpu_parity.py::test_depth_* with BLIM_PRECISE_MLP=0);
@@ -239,6 +246,7 @@ int64_t blim_train_flat_size(const blim_engine* e, int32_t lora_r);
 int blim_train_param_offset(const blim_engine* e, int32_t lora_r, const char* name, int64_t* offset, int64_t* rows, int64_t* cols);
 /* params / grads: device f32 [blim_train_flat_size].  Builds the training copies of the frozen weights (K-augmented copies that
  * carry the adapters' B matrices as 64 extra K columns, and transposed copies for the input-gradient GEMMs). */
+/* (An fp8 engine accepts a trainer for loading and MERGING adapters only -- evaluating a fine-tuned checkpoint in fp8 mode; blim_train_step refuses it.) */
 int blim_train_create(blim_engine* e, const blim_train_config* cfg, float* params, float* grads, blim_trainer** out);
 void blim_train_destroy(blim_trainer* t);
 /* after `params` changed (load, optimizer step): refresh the 16-bit copies the forward reads */
@@ -268,6 +276,8 @@ typedef struct blim_train_batch {
 /* training_utils.py:57-85 for one batch: forward of both kinds of rows through the decoder in one pass, loss = vtg_loss + tvg_loss, backward;
  * gradients ACCUMULATE into `grads` (scaled by grad_scale); loss_sums[0] += the summed negative log-likelihood over the n_rows VTG label rows,
  * loss_sums[1] += the same over the n_tvg_rows TVG rows (device f32 [2]; the mean losses of training_utils.py:68 / :79 divide by the row counts) */
+/* Reproducible bit for bit from run to run, like the reference's autograd on these shapes: every split reduction (adapter gradients over time
+ * splits, du over column slices, the loss sums, the gradient norm) is summed from per-split partials in a fixed order -- no float atomics. */
 int blim_train_step(blim_trainer* t, const blim_train_batch* b, float* loss_sums, void* stream);
 /* stats[0] += sum((g * inv_scale)^2) over the flat gradient buffer, stats[1] = 1 if any element is inf / nan (device f32 [2]) */
 int blim_train_grad_stats(blim_trainer* t, float inv_scale, float* stats, void* stream);

@@ -5,10 +5,10 @@
 #   3. print the recall tables and the per-pass worst relative deviation of every mode from the fp16 run (tools/compare_scores.py).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/f8trained; CK=/tmp/f8trained          # checkpoints stay on the box (80 MB each)
-N=${1:-64}; EPOCHS=${2:-20}
+N=${1:-64}; EPOCHS=${2:-20}; WARM=${3:-2}
 mkdir -p $OUT $CK; cd $R
 COMMON="--synthetic $N --synthetic_7b --topk 16 --cpn --alpha 0.4 0.8 --c 0.3 0.6 0.9 0.7"
-python3 -m blim_amd.main $COMMON --synthetic_same --lr 2e-4 --epochs $EPOCHS --warmup_epochs 2 --batch_size 16 --output_dir $CK > $OUT/train.log 2>&1
+python3 -m blim_amd.main $COMMON --synthetic_same --lr 2e-4 --epochs $EPOCHS --warmup_epochs $WARM --batch_size 16 --output_dir $CK > $OUT/train.log 2>&1
 grep -E "loss|Training time" $OUT/train.log | tail -8
 for dt in f16 bf16 f8; do
   python3 -m blim_amd.main $COMMON --eval --resume $CK/epoch$((EPOCHS-1)).pth --dtype $dt --dump_scores $OUT/scores_$dt.npz --output_dir $OUT/eval_$dt > $OUT/eval_$dt.log 2>&1
