@@ -175,7 +175,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     if (!e) return;
     hipDeviceSynchronize();
     for (void* p : e->owned) hipFree(p);
-    DevBuf* bufs[] = {&e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
+    DevBuf* bufs[] = {&e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
                       &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -436,13 +436,22 @@ int engine_rope_rows(blim_engine* e, const blim_batch* b, hipStream_t s, float**
     return BLIM_OK;
 }
 
-static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, hipStream_t s) {
+// live_rows / n_live (optional): the rows of the final hidden state the caller will read.  In the LAST layer every other row is dead after the
+// attention (its K / V were needed, its own output is not): the live rows' attention outputs and residuals are gathered and o_proj, the norm
+// and the MLP run on those n_live rows only -- the same values, 1 / num_layers of the post-attention work saved on every row nobody reads
+// (the shared video + prompt prefix of a VTG query: 60 % of the tokens at the reference's shapes; the caption prompt of a TVG text).
+// *final_resid / *final_is_live tell the caller where the last layer's output sits.
+static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, hipStream_t s, const int32_t* live_rows, int64_t n_live, float** final_resid,
+                      bool* final_is_live) {
     const blim_config& c = e->c;
     const int H = c.hidden_size, I = c.intermediate_size;
     const int64_t T = b->n_tokens;
     TRY(reserve_tokens(e, T));
     TRY(finalize_f8(e));
     float* resid = (float*)e->resid.p;
+    const bool prune = e->prune_last && live_rows && n_live > 0 && n_live <= T - T / 16 && !e->f8;
+    if (prune) TRY(ensure(e->resid_live, (size_t)round_up(n_live, 256) * H * 4));
+    *final_resid = resid; *final_is_live = false;
     bf16_t* xn = (bf16_t*)e->xn.p; bf16_t* qkv = (bf16_t*)e->qkv.p; bf16_t* attn = (bf16_t*)e->attn.p; bf16_t* act = (bf16_t*)e->act.p;
     // fp8 mode: quantised inputs of the four GEMMs and their per-token scales
     const int64_t Tp = round_up(T, 256);
@@ -492,6 +501,28 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         }
         const bool fuse_o = o8 && e->f8_fuse;
         if (o8 && !fuse_o) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
+        if (prune && li == c.num_layers - 1) {
+            // ---- last layer, live rows only: gather (attention output -> the free `act` workspace, residual -> resid_live), then the same four kernels on n_live rows
+            bf16_t* attn_live = act;                                         // [n_live, pf * H] 16-bit (act is not in use until the gate|up GEMM below)
+            float* rl = (float*)e->resid_live.p;
+            {
+                SpanGuard g0(e, s, TC_MISC, 0);
+                TRY(launch_gather_rows(attn_live, attn, live_rows, n_live, (int64_t)pf * H * 2, T, 0u, s));
+                TRY(launch_gather_rows(rl, resid, live_rows, n_live, (int64_t)H * 4, T, 0x7fc00000u, s));      // a row outside the batch: NaN (poisoned score)
+            }
+            const double tl = (double)n_live;
+            { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * H * H * pf);
+              GemmParams p = gp2(e, attn_live, H, l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; TRY(launch_gemm(EPI_RESID, p, s)); }
+            { SpanGuard g(e, s, TC_NORM, 0);
+              TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
+            // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
+            { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
+              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); TRY(launch_gemm(EPI_SWIGLU, p, s)); }
+            { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * pfm);
+              GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pm); p.ldc = H; p.lo_off = 0; TRY(launch_gemm(EPI_RESID, p, s)); }
+            *final_resid = rl; *final_is_live = true;
+            break;
+        }
         {
             SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H * pf);
             GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0, e->precise);
@@ -536,13 +567,15 @@ static int decode_impl(blim_engine* e, const blim_batch* b, const void* embeds, 
     TRY(check_batch(b));
     TRY(blim_weights_ready(e));
     hipStream_t s = (hipStream_t)stream;
-    TRY(run_layers(e, b, embeds, s));
     const int64_t n = out_rows ? n_out : b->n_tokens;
     ARG_CHECK(n > 0);
+    float* fr = nullptr; bool is_live = false;
+    TRY(run_layers(e, b, embeds, s, out_rows, out_rows ? n_out : 0, &fr, &is_live));
     SpanGuard g(e, s, TC_NORM, 0);
     const int H = e->c.hidden_size;
-    return launch_rmsnorm((const float*)e->resid.p, H, out_rows, n, H, e->final_norm, e->c.rms_eps, (bf16_t*)out_hidden_bf16, e->c.compute_dtype,
-                          out_hidden_f32, s, b->n_tokens, split ? 2 * H : H, split ? (bf16_t*)out_hidden_bf16 + H : nullptr);
+    // (is_live: run_layers carried exactly the requested rows, in order, through the last layer: the final norm reads them straight)
+    return launch_rmsnorm(fr, H, is_live ? nullptr : out_rows, n, H, e->final_norm, e->c.rms_eps, (bf16_t*)out_hidden_bf16, e->c.compute_dtype,
+                          out_hidden_f32, s, is_live ? n : b->n_tokens, split ? 2 * H : H, split ? (bf16_t*)out_hidden_bf16 + H : nullptr);
 }
 extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
                            void* out_hidden_bf16, float* out_hidden_f32, void* stream) {
@@ -769,6 +802,7 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "f8_mask")) { e->f8_mask = value & 31; return BLIM_OK; }
     if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
+    if (!strcmp(key, "prune_last")) { e->prune_last = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise")) {
         if (value && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }

@@ -54,6 +54,8 @@ struct blim_engine {
     // workspaces
     DevBuf resid, xn, qkv, attn, act, hsel, lse_part, lab_logit, logprob, stage, proj_tmp, vh, tvg_logits, dense_idx;
     DevBuf rope_rows;                     // [T, 128] cos | sin of every token's position (per batch)
+    DevBuf resid_live;                    // f32 [R, H]: the residual rows the caller reads, carried through the LAST layer's o_proj / MLP alone (run_layers)
+    bool prune_last = true;               // option "prune_last"
     DevBuf x8, a8, act8, hsel8, rscale;   // fp8 mode: quantised GEMM inputs and their per-row scales
     DevBuf attn_mx;                       // fp8 mode: E8M0 scale per (token, head), written by the attention kernel (attention.hpp: out_mx)
     DevBuf act_mx;                        // fp8 mode: E8M0 scale per (token, 128 SwiGLU outputs), written by the gate|up epilogue (gemm.hpp: out_mx)

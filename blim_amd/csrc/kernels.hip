@@ -158,6 +158,27 @@ int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s) {
     return BLIM_OK;
 }
 
+// ---------------------------------------------------------------------------- row gather (last-layer pruning, engine.hip run_layers)
+// dst[r] = src[rows[r]] in 16-byte chunks; an index outside [0, n_src) gives a row of `fill` words (NaN bits for the f32 residual stream:
+// the row's score is poisoned instead of wild memory being read, as rmsnorm_kernel does for its gathered rows)
+__global__ void gather_rows_kernel(uint4* dst, const uint4* src, const int32_t* rows, int64_t n_rows, int chunks, int64_t n_src, uint32_t fill) {
+    const int64_t total = n_rows * chunks;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        const int64_t sr = rows[r];
+        dst[i] = (sr >= 0 && sr < n_src) ? src[sr * chunks + c] : make_uint4(fill, fill, fill, fill);
+    }
+}
+int launch_gather_rows(void* dst, const void* src, const int32_t* rows, int64_t n_rows, int64_t row_bytes, int64_t n_src, uint32_t fill, hipStream_t s) {
+    ARG_CHECK(dst && src && rows && n_rows > 0 && row_bytes % 16 == 0);
+    const int chunks = (int)(row_bytes / 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n_rows * chunks, 256)), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, rows, n_rows, chunks, n_src, fill);
+    LAUNCH_CHECK("gather_rows");
+    return BLIM_OK;
+}
+
 // ---------------------------------------------------------------------------- RMSNorm (K3/K9)
 // One wave per row; the row (H f32) is read once in float4 pieces and kept in registers when H <= 64*4*16.
 template <int MAXV, int DT>

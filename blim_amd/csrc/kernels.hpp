@@ -13,6 +13,7 @@ int launch_assemble(bf16_t* out, const int32_t* src_index, int64_t n_tokens, int
 
 // resid[t, :] = f32(embeds[t, :])   (16-bit input of the engine's compute dtype)
 int launch_h16_to_f32(float* out, const bf16_t* in, int64_t n, int dtype, hipStream_t s);
+int launch_gather_rows(void* dst, const void* src, const int32_t* rows, int64_t n_rows, int64_t row_bytes, int64_t n_src, uint32_t fill, hipStream_t s);   // dst[r] = src[rows[r]]
 int launch_hilo_to_f32(float* out, const bf16_t* in, int64_t n_rows, int H, int dtype, hipStream_t s);   // [hi | lo] 16-bit rows of width 2H -> f32 [n_rows, H]
 int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s);
 

@@ -187,6 +187,9 @@ int blim_debug_gemm_stamps(void* device_buf);
  * "precise_embeds" (0/1): in precise mode the input embeddings / projector outputs are [hi | lo] rows of width 2 * hidden as well;
  * "precise_mlp" (0/1, default 1): 0 leaves the MLP branch plain in precise mode (TVG calls 1.6x faster; TVG deviation at 7B depth
  *   8e-4 instead of 4e-5: tests/test_gpu_parity.py::test_depth_* with BLIM_PRECISE_MLP=0);
+ * "prune_last" (0/1, default 1): calls that name the rows they read (blim_decode with out_rows, blim_score_*) run the LAST layer's o_proj / norm / MLP
+ *   on those rows only (same values bit for bit; the other rows' K / V are still produced); after such a call the "resid" / "attn" / "act" workspaces of
+ *   blim_debug_read hold the last layer's state of the live rows only -- bring-up code reads them after calls without out_rows, or sets 0;
  * "f8_fuse" (0/1, fp8 engines): quantise the attention / SwiGLU outputs inside their producers (default 1);
  * tuning switches: "attn_tr_read" (0/1); "f8_mask" (BLIM_COMPUTE_F8 engines: which GEMMs take fp8 operands, bit 0 qkv, 1 o_proj,
  * 2 gate|up, 3 down, 4 lm_head; default 31 = all; the others run in fp16 from the retained 16-bit weights) */

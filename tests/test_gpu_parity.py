@@ -516,6 +516,37 @@ def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
             e.close()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_last_layer_pruning_changes_no_bit(dtype):
+    """Engine option "prune_last" (default on): a call that names the rows it reads runs the last layer's o_proj / norm / MLP on those rows only.
+    Rows are independent in every kernel involved, so every score equals the unpruned one bit for bit -- VTG, TVG and both priors, 7B width,
+    3 layers, ragged reference-shaped rows (the shared prefix is most of the tokens: the case the pruning is for)."""
+    d = dict(CASES["wide"]["dims"], num_layers=3)
+    dims = synth.ModelDims(**d)
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    model.engine.init_synthetic_weights(5)
+    prob = synth.make_problem(31, 6, dims, tok_per_clip=16, text_len=(4, 20))
+    model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    pairs = np.array([[j, i] for j in range(4) for i in range(6)])
+    res = {}
+    try:
+        for on in (1, 0):
+            model.engine.set_option("prune_last", on)
+            sc = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video],
+                               torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels), dims.num_clips)
+            (plan,) = sc.plan_vtg(pairs)
+            assert plan.n_rows <= plan.n_tokens - plan.n_tokens // 16             # the pruned path is the one that runs
+            res[on] = [sc.vtg(pairs), sc.vtg(pairs, cpn=True), sc.tvg(pairs), sc.tvg(pairs, cpn=True)]
+    finally:
+        model.engine.close()
+    for a, b in zip(res[1], res[0]):
+        assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_fp16_stores_saturate_instead_of_overflowing():
     """fp16 outputs of the scoring kernels saturate to +-65504 (MODE.FP16_OVFL, csrc/common.hpp) instead of overflowing to inf; NaN and
     true infinities of the inputs pass through.  bf16 outputs have f32's range and are not touched."""
@@ -568,9 +599,12 @@ def test_activations_beyond_fp16_range(capsys):
 
 @pytest.mark.parametrize("case", ["deep", "full7b"])
 def test_depth_fp8_mode_deltas_vs_reference_golden(case, capsys):
-    """fp8 mode against the fp32 REFERENCE at 28 layers (deltas reported; bounded loosely -- a separate mode, never the headline)."""
+    """fp8 mode against the fp32 REFERENCE at 28 layers (deltas reported -- a separate mode, never the headline, and NOT a parity mode: e4m3's 3-bit
+    mantissa leaves ~5 % noise on every GEMM output whatever the scaling; measured over runs at 7B depth: VTG 1.2 - 3.8e-2, TVG 3.8e-2 - 1.2e-1, and
+    2 - 4 points of R@1 on a fine-tuned weight set, profiles/r03_modes_trained_weights.md).  Bounds = 1.5 - 2x the worst measured."""
     res, _ = _depth_case(case, "f8", capsys, literal_too=False)
-    assert max(res["fused"].values()) < 0.2
+    for k, v in res["fused"].items():
+        assert v < (0.18 if "tvg" in k else 0.08), (k, v)
 
 
 class _SynthDataset:
