@@ -227,6 +227,61 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
         }
     }
 }
+// Wide form (H % 8 == 0, H <= 4096): a lane owns chunks of EIGHT consecutive elements, so the 16-bit output leaves as 16-byte stores (the form above stores
+// 8 bytes per lane: 512 B per wave-instruction) and the row is read as two adjacent float4 per chunk.  Same arithmetic per element; only the order in which the
+// lanes' partial sums of squares are formed differs.
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_wide_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
+                                                           bf16_t* out_bf16, float* out_f32, int64_t n_src, int64_t ldo, bf16_t* out_lo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    if constexpr (DT == DT_F16) f16_saturate_on();
+    const int64_t src = rows ? rows[r] : r;
+    const int nc = H / 8;
+    if (src < 0 || src >= n_src) {
+        const float qnan = __builtin_nanf("");
+        const uint32_t q2 = pack2<DT>(qnan, qnan);
+        for (int c = lane; c < nc; c += 64) {
+            if (out_bf16) *(uint4*)(out_bf16 + r * ldo + 8 * c) = make_uint4(q2, q2, q2, q2);
+            if (out_lo) *(uint4*)(out_lo + r * ldo + 8 * c) = make_uint4(0u, 0u, 0u, 0u);
+            if (out_f32) { *(float4*)(out_f32 + r * H + 8 * c) = make_float4(qnan, qnan, qnan, qnan); *(float4*)(out_f32 + r * H + 8 * c + 4) = make_float4(qnan, qnan, qnan, qnan); }
+        }
+        return;
+    }
+    const float* xr = x + src * ldx;
+    float4 v[8][2];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            v[i][0] = *(const float4*)(xr + 8 * c); v[i][1] = *(const float4*)(xr + 8 * c + 4);
+            ss += v[i][0].x * v[i][0].x + v[i][0].y * v[i][0].y + v[i][0].z * v[i][0].z + v[i][0].w * v[i][0].w;
+            ss += v[i][1].x * v[i][1].x + v[i][1].y * v[i][1].y + v[i][1].z * v[i][1].z + v[i][1].w * v[i][1].w;
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            const float4 g0 = *(const float4*)(w + 8 * c), g1 = *(const float4*)(w + 8 * c + 4);
+            const float o[8] = {g0.x * (v[i][0].x * inv), g0.y * (v[i][0].y * inv), g0.z * (v[i][0].z * inv), g0.w * (v[i][0].w * inv),
+                                g1.x * (v[i][1].x * inv), g1.y * (v[i][1].y * inv), g1.z * (v[i][1].z * inv), g1.w * (v[i][1].w * inv)};
+            if (out_bf16) *(uint4*)(out_bf16 + r * ldo + 8 * c) = make_uint4(pack2<DT>(o[0], o[1]), pack2<DT>(o[2], o[3]), pack2<DT>(o[4], o[5]), pack2<DT>(o[6], o[7]));
+            if (out_lo) {
+                float d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = o[j] - from16<DT>(to16<DT>(o[j]));
+                *(uint4*)(out_lo + r * ldo + 8 * c) = make_uint4(pack2<DT>(d[0], d[1]), pack2<DT>(d[2], d[3]), pack2<DT>(d[4], d[5]), pack2<DT>(d[6], d[7]));
+            }
+            if (out_f32) { *(float4*)(out_f32 + r * H + 8 * c) = make_float4(o[0], o[1], o[2], o[3]); *(float4*)(out_f32 + r * H + 8 * c + 4) = make_float4(o[4], o[5], o[6], o[7]); }
+        }
+    }
+}
+static int g_rmsnorm_wide = getenv("BLIM_RMSNORM_WIDE") ? atoi(getenv("BLIM_RMSNORM_WIDE")) : 1;
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
                    bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src, int64_t ldo, bf16_t* out_lo) {
     if (!rows) n_src = n_rows;
@@ -235,6 +290,12 @@ int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_r
     ARG_CHECK(x && w && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0 && (out_h16 || out_f32));
     const int nv = H / 4;
     const dim3 grid((unsigned)((n_rows + 3) / 4));
+    if (g_rmsnorm_wide && H % 8 == 0 && H <= 4096 && H > 256 && ldo % 8 == 0 && ldx % 4 == 0) {
+        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo);
+        else hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo);
+        LAUNCH_CHECK("rmsnorm");
+        return BLIM_OK;
+    }
 #define RMS_LAUNCH(MV)                                                                                                              \
     do {                                                                                                                            \
         if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo); \
