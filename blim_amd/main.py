@@ -151,6 +151,9 @@ def main(args):
             train_loader = load_data(args, tokenizer=tokenizer, split="train")
     if args.vtg_precise is not None:
         model.vtg_precise = None if args.vtg_precise == "none" else args.vtg_precise
+    if rank == 0 and model.engine.dtype == "f8" and args.resume and os.path.isfile(args.resume):
+        print("warning: fp8 mode on a fine-tuned checkpoint: the adapters are merged into the weights BEFORE the e4m3 quantisation and a rank-8 update is mostly below one "
+              "e4m3 step of the base weight -- measured 2 - 4 points of R@1 lost against fp16 / bf16 (profiles/r03_modes_trained_weights.md); fp8 is not a parity mode")
     if rank == 0:
         print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")
     if not args.eval:
