@@ -44,3 +44,12 @@ for name, scorer, pl in (("SYN VTG", sc, plan), ("REF VTG", rsc, rplan), ("REF T
             res[on].append(t(scorer, pl))
     a, b = np.mean(res[0]), np.mean(res[1])
     print(f"{name}: prune off {a:.2f} ms, on {b:.2f} ms  ({100 * (a - b) / a:+.2f} %)")
+
+# per-class device time of one reference-shaped VTG plan and one TVG plan (HIP-event class timers)
+for name, scorer, pl in (("REF VTG", rsc, rplan), ("REF TVG", rsc, tplan)):
+    model.engine.timing_enable(True)
+    scorer.run(pl); torch.cuda.synchronize()
+    rep = model.engine.timing_report()
+    model.engine.timing_enable(False)
+    tot = sum(v["ms"] for v in rep.values())
+    print(name, "classes (ms, %):", {k: (round(v["ms"], 2), round(100 * v["ms"] / tot, 1)) for k, v in rep.items() if v["calls"]})
