@@ -59,6 +59,11 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
         for (int ks = 0; ks < 8; ++ks) qf_lo[ks] = *(const bf16x8*)(qrow + 16 * ks);
     }
 
+    // Q has landed before the first K/V tile is requested: inside the loop the only vector-memory operations in flight are then the NEXT tile's
+    // loads.  Without this the waitcnt pass could not tell, on the loop's back edge, that the Q loads were long complete and put counted vmcnt
+    // waits in front of the S MFMAs -- which, counting in issue order, waited for the next tile's loads too: the prefetch it was meant to
+    // overlap was serialised in front of the compute (a third of the kernel's time at the reference's shapes, tools/attn_classes.py).
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) expcnt(7) lgkmcnt(15)
     const int n_ptiles = (plen + KT - 1) / KT;
     const int own_keys = min(q0 + QB, slen);
     const int n_tiles = n_ptiles + (own_keys + KT - 1) / KT;
@@ -117,10 +122,17 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
 
     load_tile(0);
     for (int t = 0; t < n_tiles; ++t) {
+#if defined(ATTN_ABLATE) && ATTN_ABLATE == 1     // ablation builds only (timing; wrong results): the tile is staged once, every iteration computes on it
+        if (t == 0) { __syncthreads(); store_tile(t); __syncthreads(); }
+#else
         __syncthreads();  // everyone finished reading the previous tile
         store_tile(t);
         __syncthreads();
         if (t + 1 < n_tiles) load_tile(t + 1);
+#endif
+#if defined(ATTN_ABLATE) && ATTN_ABLATE == 2     // ... or: staging only, no MFMA / softmax work
+        continue;
+#endif
 
         int base_tok, k0, seg_len; bool causal;
         tile_desc(t, base_tok, k0, seg_len, causal);
@@ -165,24 +177,32 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float mc = m_new * c_log2;
-        float rsum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = (sacc[r] > 0.5f * NEG) ? exp2f(fmaf(sacc[r], c_log2, -mc)) : 0.f;   // a fully masked row keeps m = NEG: no exp2(0) = 1
-            pv[r] = e;
-            rsum += e;
-        }
-        rsum += __shfl_xor(rsum, 32);
-        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-            const float alpha = exp2f((m_run - m_new) * c_log2);
+        // Lazy reference maximum: m_run is the exponent's reference, not necessarily the running maximum.  It is moved (and the accumulators
+        // rescaled) only when some query's tile maximum exceeds it by more than 2^8 in the exponent's units -- p then stays below 256, well inside
+        // both 16-bit formats' range, and l_run / the accumulators are sums relative to the same reference, so the result is the same
+        // softmax; what disappears is the 64-multiply rescale on nearly every tile of a row whose maximum creeps up (this VALU work, not
+        // the MFMAs, bounds the kernel: ~300 vector instructions per tile and wave before this change against 16 MFMAs).
+        float m_new = m_run;
+        if (__builtin_amdgcn_ballot_w64(tmax * c_log2 > m_run * c_log2 + 8.0f) != 0) {
+            m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_log2);   // first tile: exp2(-huge) = 0 on zero accumulators
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
         }
+        // a row with no visible key so far keeps m = NEG: its masked scores must give p = 0, not exp2(NEG - NEG) = 1 -- one select per tile on the
+        // reference (mc = 0 there: exp2(NEG * c) = 0) instead of one per element
+        const float mc = m_new > 0.5f * NEG ? m_new * c_log2 : 0.f;
+        float rsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sacc[r], c_log2, -mc));        // native v_exp_f32: arguments <= 8, results below 2^-126 flush to 0
+            pv[r] = e;
+            rsum += e;
+        }
+        rsum += __shfl_xor(rsum, 32);
         l_run += rsum;
         m_run = m_new;
 
