@@ -81,6 +81,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
     // (MAXC * nthreads >= 1024 / 2048: launch_attention picks MAXC from the group size)
     constexpr int NCHUNK = SPLIT ? 2048 : 1024;
     uint4 st[MAXC];
+    uint8_t st_vis = 0;                      // this thread's key-visibility byte of the tile in flight (threads 0 .. 31)
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) st[i] = make_uint4(0, 0, 0, 0);
 
@@ -100,6 +101,10 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
                 st[i] = *(const uint4*)(p.qkv + (int64_t)(base_tok + kk) * p.ldq + (isv == 0 ? koff : isv == 1 ? voff : isv == 2 ? voff + p.v_lo_off : koff + p.v_lo_off) + 8 * ch);
             }
         }
+        if (tid < KT) {                      // requested with the tile (read inside store_tile it was a dependent global load in front of a barrier, every tile)
+            const int kk = k0 + tid;
+            st_vis = (kk < seg_len) ? p.key_visible[base_tok + kk] : (uint8_t)0;
+        }
     };
     auto store_tile = [&](int t) __attribute__((always_inline)) {
         int base_tok, k0, seg_len; bool causal;
@@ -113,11 +118,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
                 else *(uint4*)(k_lds + (isv >> 1) * KT * HD + row * HD + 8 * (ch ^ (row & 15))) = st[i];
             }
         }
-        if (tid < KT) {
-            const int kk = k0 + tid;
-            const uint8_t v = (kk < seg_len) ? p.key_visible[base_tok + kk] : (uint8_t)0;
-            ((uint8_t*)vis_lds)[tid] = v ? 1 : 0;
-        }
+        if (tid < KT) ((uint8_t*)vis_lds)[tid] = st_vis ? 1 : 0;
     };
 
     load_tile(0);
