@@ -42,6 +42,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
 
     const int qi = lane & 31, hf = lane >> 5;
     const int qtok = sstart + min(q0 + qi, slen - 1);
+    const int qstart = p.own_start ? p.own_start[qtok] : 0;      // segmented sequences: this query's first own key
     const int koff = p.num_heads * HD + kh * HD;
     const int voff = (p.num_heads + p.num_kv_heads) * HD + kh * HD;
 
@@ -161,7 +162,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
         // when some lane's running maximum grew: this VALU work, not the MFMAs, is what bounds the kernel.
         float pv[16];
         const bool vis_all = (vis_lds[0] & vis_lds[1] & vis_lds[2] & vis_lds[3] & vis_lds[4] & vis_lds[5] & vis_lds[6] & vis_lds[7]) == 0x01010101u;
-        if (!vis_all || (causal && k0 + KT - 1 > q0)) {
+        if (!vis_all || (causal && (k0 + KT - 1 > q0 || p.own_start != nullptr))) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint32_t vb = vis_lds[2 * g + hf];  // bytes for keys 8g + 4hf + 0..3
@@ -169,8 +170,10 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
                     const int kk = k0 + 8 * g + 4 * hf + j;
-                    const bool ok = ((vb >> (8 * j)) & 0xFF) && (!causal || kk <= q0 + qi);
-                    if (!ok) sacc[r] = NEG;
+                    // branch-free on purpose (bitwise &, |; one select): with short-circuit operators and a conditional store the compiler built this
+                    // as divergent control flow around whole-vector copies of the 16 score registers, and the result was wrong (tools/dbg_wide.py)
+                    const bool ok = (((vb >> (8 * j)) & 0xFF) != 0) & (!causal | ((kk <= q0 + qi) & (kk >= qstart)));
+                    sacc[r] = ok ? sacc[r] : NEG;
                 }
             }
         }
@@ -184,9 +187,10 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
         // softmax; what disappears is the 64-multiply rescale on nearly every tile of a row whose maximum creeps up (this VALU work, not
         // the MFMAs, bounds the kernel: ~300 vector instructions per tile and wave before this change against 16 MFMAs).
         float m_new = m_run;
-        if (__builtin_amdgcn_ballot_w64(tmax * c_log2 > m_run * c_log2 + 8.0f) != 0) {
-            m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_log2);   // first tile: exp2(-huge) = 0 on zero accumulators
+        const bool move = tmax * c_log2 > m_run * c_log2 + 8.0f;                    // per QUERY: a query's reference never depends on its block neighbours
+        if (__builtin_amdgcn_ballot_w64(move) != 0) {
+            m_new = move ? fmaxf(m_run, tmax) : m_run;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_log2);   // first tile: exp2(-huge) = 0 on zero accumulators; queries that stay: exactly 1
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 4; ++i)

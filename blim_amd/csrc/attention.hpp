@@ -19,6 +19,7 @@ struct AttnParams {
     const int32_t* pfx_len;      // [S]
     const int32_t* blk_seq;      // [n_blocks] sequence of each 32-query block
     const int32_t* blk_q0;       // [n_blocks] first query (offset inside the sequence) of the block
+    const int32_t* own_start;    // [T] or nullptr: first own-segment index (inside the sequence) a token attends to (blim.h: blim_batch.own_start)
     int n_blocks;
     bf16_t* out;  // [T, num_heads*128]
     int64_t ldo;

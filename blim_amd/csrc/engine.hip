@@ -493,7 +493,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.dtype = c.compute_dtype;
             a.qkv = qkv; a.ldq = (int64_t)pf * e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
-            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * H; a.scale = 0.08838834764831845f;
+            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * H; a.scale = 0.08838834764831845f;
             a.v_lo_off = e->precise ? e->qkv_n : 0; a.out_lo_off = e->precise ? H : 0;
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
             if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
@@ -723,7 +723,7 @@ extern "C" int blim_forward(blim_engine* e, const void* embeds, const uint8_t* m
     HIP_TRY(hipGetLastError());
     blim_batch b;
     b.n_tokens = T; b.n_seqs = B; b.n_blocks = B * nbs; b.positions = pos; b.key_visible = mask; b.seq_start = seq_start; b.seq_len = seq_len;
-    b.pfx_start = pfx; b.pfx_len = pfx; b.blk_seq = blk_seq; b.blk_q0 = blk_q0;
+    b.pfx_start = pfx; b.pfx_len = pfx; b.blk_seq = blk_seq; b.blk_q0 = blk_q0; b.own_start = nullptr;
     TRY(reserve_rows(e, T));
     TRY(decode_impl(e, &b, embeds, nullptr, 0, e->hsel.p, e->precise, hidden, stream));
     if (logits) TRY(lm_head_impl(e, e->hsel.p, e->precise, T, logits, stream));

@@ -45,7 +45,7 @@ class Batch(C.Structure):
     _fields_ = [("n_tokens", C.c_int64), ("n_seqs", C.c_int32), ("n_blocks", C.c_int32),
                 ("positions", C.c_void_p), ("key_visible", C.c_void_p), ("seq_start", C.c_void_p),
                 ("seq_len", C.c_void_p), ("pfx_start", C.c_void_p), ("pfx_len", C.c_void_p),
-                ("blk_seq", C.c_void_p), ("blk_q0", C.c_void_p)]
+                ("blk_seq", C.c_void_p), ("blk_q0", C.c_void_p), ("own_start", C.c_void_p)]
 
 
 def declared_symbols(header: str = HEADER_PATH) -> Sequence[str]:
@@ -137,7 +137,9 @@ class PackedBatch:
     """Device-side description of packed sequences (blim_batch).  Built from host numpy arrays."""
 
     def __init__(self, positions: np.ndarray, key_visible: np.ndarray, seq_start: np.ndarray, seq_len: np.ndarray,
-                 pfx_start: Optional[np.ndarray] = None, pfx_len: Optional[np.ndarray] = None, device="cuda"):
+                 pfx_start: Optional[np.ndarray] = None, pfx_len: Optional[np.ndarray] = None, device="cuda", own_start: Optional[np.ndarray] = None):
+        """own_start (optional, [n_tokens]): first own-segment index (inside its sequence) each token attends to -- segmented sequences
+        (blim.h: blim_batch.own_start); None or all zeros = plain causal sequences."""
         import torch
         n_seqs = len(seq_start)
         if pfx_start is None:
@@ -160,6 +162,11 @@ class PackedBatch:
         self.positions, self.seq_start, self.seq_len, self.pfx_start, self.pfx_len, self.blk_seq, self.blk_q0 = \
             [flat[offs[i]:offs[i + 1]] for i in range(7)]
         self.key_visible = torch.from_numpy(np.ascontiguousarray(key_visible, dtype=np.uint8)).to(device)
+        self.own_start = None
+        if own_start is not None and np.any(np.asarray(own_start) != 0):
+            own_start = np.asarray(own_start, dtype=np.int32)
+            assert len(own_start) == self.n_tokens
+            self.own_start = torch.from_numpy(np.ascontiguousarray(own_start)).to(device)
 
     def struct(self, max_positions: Optional[int] = None) -> Batch:
         if max_positions is not None and self.max_position >= max_positions:
@@ -171,6 +178,7 @@ class PackedBatch:
         b.seq_start = self.seq_start.data_ptr(); b.seq_len = self.seq_len.data_ptr()
         b.pfx_start = self.pfx_start.data_ptr(); b.pfx_len = self.pfx_len.data_ptr()
         b.blk_seq = self.blk_seq.data_ptr(); b.blk_q0 = self.blk_q0.data_ptr()
+        b.own_start = self.own_start.data_ptr() if self.own_start is not None else None
         return b
 
 

@@ -344,6 +344,11 @@ class PairScorer:
         pairs = np.asarray(pairs, dtype=np.int64)
         C = self.num_clips
         st = _PackState(self, "tvg")
+        # The continuations of one prefix -- the C - 1 clip tokens of every candidate video of a text (prior: last prompt token + clip tokens) -- are
+        # packed into ONE sequence whose segments do not see each other (blim_batch.own_start): the 32-query attention blocks are dense instead of
+        # holding 3 - 4 queries each (2,919 -> ~500 blocks per 13,700-token call at the reference's shapes) and the planner adds one sequence per
+        # group instead of one per pair.  SEG_MAX bounds a merged sequence (own-segment tiles below a query's segment are computed and masked).
+        SEG_MAX = 256
         if cpn:
             # prior depends on (prompt length, last prompt token, first tvg_prefix_length tokens, video) only
             tp = self.m.tvg_prefix_length
@@ -357,35 +362,66 @@ class PairScorer:
             self.expect([k[3] for lst in by_prefix.values() for (k, _) in lst], True)
             for pbytes, lst in by_prefix.items():
                 ptoks = np.frombuffer(pbytes, dtype=np.int64)
-                p0 = None
-                for (k, outs) in lst:
-                    _, plen_full, last_tok, j = k
-                    if p0 is None or st.n_tok + 4 > self.max_tokens:
-                        if st.n_pairs:
-                            yield st.finish(); st = _PackState(self, "tvg")
-                        p0 = st.add_seq(ptoks, np.arange(len(ptoks)), np.ones(len(ptoks), np.uint8), None)
-                    fo = st.add_feat(self.video_feat(j, True))
-                    toks = np.concatenate([[last_tok], -(1 + fo + np.arange(C - 1))])
-                    vis = np.concatenate([[1 if plen_full - 1 < tp else 0], np.ones(C - 1)]).astype(np.uint8)
-                    s0 = st.add_seq(toks, plen_full - 1 + np.arange(C), vis, (p0, len(ptoks)))
-                    st.add_pair(list(range(s0, s0 + C)), np.array([self.tvg_video_labels[j]], np.int32), np.array(outs))
+                pos_in = 0
+                while pos_in < len(lst):
+                    room = (self.max_tokens - st.n_tok - len(ptoks)) // C
+                    if st.n_tok and room < 1:
+                        yield st.finish(); st = _PackState(self, "tvg")
+                        room = (self.max_tokens - len(ptoks)) // C
+                    n = max(1, min(len(lst) - pos_in, room, SEG_MAX // C))
+                    p0 = st.add_seq(ptoks, np.arange(len(ptoks)), np.ones(len(ptoks), np.uint8), None)
+                    toks, posn, vis, own = [], [], [], []
+                    for m_, (k, outs) in enumerate(lst[pos_in:pos_in + n]):
+                        _, plen_full, last_tok, j = k
+                        fo = st.add_feat(self.video_feat(j, True))
+                        toks.append(np.concatenate([[last_tok], -(1 + fo + np.arange(C - 1))]))
+                        posn.append(plen_full - 1 + np.arange(C))
+                        vis.append(np.concatenate([[1 if plen_full - 1 < tp else 0], np.ones(C - 1)]).astype(np.uint8))
+                        own.append(np.full(C, m_ * C, np.int32))
+                    s0 = st.add_seq(np.concatenate(toks), np.concatenate(posn), np.concatenate(vis), (p0, len(ptoks)), own_start=np.concatenate(own))
+                    for m_, (k, outs) in enumerate(lst[pos_in:pos_in + n]):
+                        st.add_pair(list(range(s0 + m_ * C, s0 + (m_ + 1) * C)), np.array([self.tvg_video_labels[k[3]]], np.int32), np.array(outs))
+                    pos_in += n
         else:
             order = np.lexsort((pairs[:, 0], pairs[:, 1]))
             self.expect(pairs[order, 0], True)
-            i_prev, p0, plen = None, None, 0
+            # candidates of each text, in order
+            groups: List[Tuple[int, List[int]]] = []
             for idx in order:
-                j, i = int(pairs[idx, 0]), int(pairs[idx, 1])
+                i = int(pairs[idx, 1])
+                if not groups or groups[-1][0] != i:
+                    groups.append((i, []))
+                groups[-1][1].append(int(idx))
+            for i, idxs in groups:
                 pr = self.tvg_split[i]
-                if i != i_prev or st.n_tok + (C - 1) > self.max_tokens:
-                    if st.n_tok and st.n_tok + len(pr) + (C - 1) > self.max_tokens:
+                plen = len(pr)
+                pos_in = 0
+                while pos_in < len(idxs):
+                    per = max(C - 1, 1)
+                    room = (self.max_tokens - st.n_tok - plen) // per
+                    if st.n_tok and room < 1:
                         yield st.finish(); st = _PackState(self, "tvg")
-                    p0 = st.add_seq(pr, np.arange(len(pr)), np.ones(len(pr), np.uint8), None); plen = len(pr); i_prev = i
-                fo = st.add_feat(self.video_feat(j, True))
-                rows = [p0 + plen - 1]
-                if C > 1:
-                    s0 = st.add_seq(-(1 + fo + np.arange(C - 1)), plen + np.arange(C - 1), np.ones(C - 1, np.uint8), (p0, plen))
-                    rows += list(range(s0, s0 + C - 1))
-                st.add_pair(rows, np.array([self.tvg_video_labels[j]], np.int32), np.array([idx]))
+                        room = (self.max_tokens - plen) // per
+                    n = max(1, min(len(idxs) - pos_in, room, SEG_MAX // per))
+                    p0 = st.add_seq(pr, np.arange(plen), np.ones(plen, np.uint8), None)
+                    chunk = idxs[pos_in:pos_in + n]
+                    s0 = None
+                    if C > 1:
+                        toks, own = [], []
+                        for m_, idx in enumerate(chunk):
+                            fo = st.add_feat(self.video_feat(int(pairs[idx, 0]), True))
+                            toks.append(-(1 + fo + np.arange(C - 1)))
+                            own.append(np.full(C - 1, m_ * (C - 1), np.int32))
+                        s0 = st.add_seq(np.concatenate(toks), np.tile(plen + np.arange(C - 1), n), np.ones(n * (C - 1), np.uint8), (p0, plen),
+                                        own_start=np.concatenate(own))
+                    for m_, idx in enumerate(chunk):
+                        rows = [p0 + plen - 1]
+                        if C > 1:
+                            rows += list(range(s0 + m_ * (C - 1), s0 + (m_ + 1) * (C - 1)))
+                        else:
+                            self.video_feat(int(pairs[idx, 0]), True)
+                        st.add_pair(rows, np.array([self.tvg_video_labels[int(pairs[idx, 0])]], np.int32), np.array([idx]))
+                    pos_in += n
         if st.n_pairs:
             yield st.finish()
 
@@ -455,6 +491,7 @@ class _PackState:
         self.s, self.kind = scorer, kind
         self.tok: List[np.ndarray] = []; self.pos: List[np.ndarray] = []; self.vis: List[np.ndarray] = []
         self.seq_start: List[int] = []; self.seq_len: List[int] = []; self.pfx_start: List[int] = []; self.pfx_len: List[int] = []
+        self.own: List[np.ndarray] = []; self.any_own = False             # per token: first own-segment index it attends to (segmented sequences)
         self.feats: List[object] = []; self.feat_key: Dict[int, int] = {}; self.n_feat = 0
         self.rows: List[int] = []; self.labels: List[np.ndarray] = []; self.row_start: List[int] = [0]
         self.out_index: List[np.ndarray] = []
@@ -468,9 +505,13 @@ class _PackState:
         self.feats.append(f); self.feat_key[k] = off; self.n_feat += int(f.shape[0])
         return off
 
-    def add_seq(self, toks, pos, vis, prefix) -> int:
+    def add_seq(self, toks, pos, vis, prefix, own_start=None) -> int:
         start = self.n_tok
         self.tok.append(np.asarray(toks, np.int64)); self.pos.append(np.asarray(pos, np.int64)); self.vis.append(np.asarray(vis, np.uint8))
+        if own_start is None:
+            self.own.append(np.zeros(len(toks), np.int32))
+        else:
+            self.own.append(np.asarray(own_start, np.int32)); self.any_own = True
         self.seq_start.append(start); self.seq_len.append(len(toks))
         self.pfx_start.append(prefix[0] if prefix else 0); self.pfx_len.append(prefix[1] if prefix else 0)
         self.n_tok += len(toks)
@@ -488,7 +529,7 @@ class _PackState:
         dev = self.s.device
         src = np.concatenate(self.tok).astype(np.int32)
         batch = PackedBatch(np.concatenate(self.pos), np.concatenate(self.vis), np.array(self.seq_start), np.array(self.seq_len),
-                            np.array(self.pfx_start), np.array(self.pfx_len), device=dev)
+                            np.array(self.pfx_start), np.array(self.pfx_len), device=dev, own_start=np.concatenate(self.own) if self.any_own else None)
         H = self.s.m.dims.hidden_size
         wide = self.s.split_tvg if self.kind == "tvg" else self.s.split_vtg                   # feature rows are [hi | lo]
         feats = torch.cat(self.feats, dim=0) if self.feats else torch.zeros((1, H * (2 if wide else 1)), dtype=self.s.m.dtype, device=dev)

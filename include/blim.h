@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 6
+#define BLIM_ABI_VERSION 7
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -78,6 +78,10 @@ typedef struct blim_batch {
     const int32_t* pfx_len;     /* [n_seqs] (0 = no prefix) */
     const int32_t* blk_seq;     /* [n_blocks] */
     const int32_t* blk_q0;      /* [n_blocks] */
+    const int32_t* own_start;   /* [n_tokens] or NULL (ABI v7).  Token i of a sequence attends to its own tokens own_start[i] .. i instead of 0 .. i
+                                 * (index inside the sequence): several short continuations of ONE prefix -- the three clip tokens of every candidate
+                                 * video of a text, retrieval_utils.py:99-107 -- are packed into one sequence whose segments do not see each other, so the
+                                 * 32-query attention blocks are dense instead of holding 3 queries each.  NULL = 0 everywhere (plain causal). */
 } blim_batch;
 
 int blim_abi_version(void);

@@ -547,6 +547,35 @@ def test_last_layer_pruning_changes_no_bit(dtype):
         assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_segmented_tvg_sequences_equal_one_sequence_per_pair():
+    """The candidates of a text are packed into ONE sequence whose 3-token segments do not see each other (blim_batch.own_start): 40 candidate
+    videos of one text = a 120-token sequence over four attention blocks, segments straddling tile boundaries.  Every pair's score equals
+    the score of the pair planned alone (one segment: a plain causal sequence) -- likelihood and prior, 7B width (7 query heads per KV head)."""
+    d = dict(CASES["wide"]["dims"], num_layers=2)
+    dims = synth.ModelDims(**d)
+    model = BlimModel(dims, max_positions=1024, dtype="f16")
+    model.engine.init_synthetic_weights(7)
+    prob = synth.make_problem(33, 40, dims, tok_per_clip=8, text_len=(4, 20))
+    model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    try:
+        sc = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video],
+                           torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels), dims.num_clips)
+        pairs = np.array([[j, 3] for j in range(40)] + [[j, 5] for j in range(7)])
+        (plan,) = sc.plan_tvg(pairs)
+        assert plan.batch.own_start is not None and plan.batch.n_seqs == 4 and int(plan.batch.seq_len.max()) == 120     # 2 prompts + 2 merged sequences
+        for cpn in (False, True):
+            full = sc.tvg(pairs, cpn)
+            alone = np.array([sc.tvg(pairs[k:k + 1], cpn)[0] for k in range(len(pairs))])
+            assert np.isfinite(full).all()
+            np.testing.assert_allclose(full, alone, rtol=2e-6)
+    finally:
+        model.engine.close()
+
+
 def test_fp16_stores_saturate_instead_of_overflowing():
     """fp16 outputs of the scoring kernels saturate to +-65504 (MODE.FP16_OVFL, csrc/common.hpp) instead of overflowing to inf; NaN and
     true infinities of the inputs pass through.  bf16 outputs have f32's range and are not touched."""

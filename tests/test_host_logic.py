@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.blim_abi_version() == 6          # v6: blim_train_step (one merged pass); v5: blim_train_*; v4: blim_vision_*, option "precise"
+    assert lib.blim_abi_version() == 7          # v7: blim_batch.own_start (segmented sequences); v6: blim_train_step (one merged pass); v5: blim_train_*; v4: blim_vision_*, option "precise"
     assert lib.blim_timing_num_classes() >= 8
 
 
@@ -204,9 +204,16 @@ def _check_plan(plan, n_req_seen):
     # sequences tile the packed token range without gaps or overlaps
     order = np.argsort(ss)
     assert ss[order][0] == 0 and np.array_equal(ss[order][1:], (ss[order] + sl[order])[:-1]) and ss[order][-1] + sl[order][-1] == T
+    ost = b.own_start.numpy() if getattr(b, "own_start", None) is not None else np.zeros(T, np.int32)
     for s in range(b.n_seqs):
         own = pos[ss[s]: ss[s] + sl[s]]
-        assert np.all(np.diff(own) >= 1)                                      # positions increase inside a sequence
+        seg = ost[ss[s]: ss[s] + sl[s]]                                       # segmented sequences (TVG: one segment per candidate video of a text)
+        idx = np.arange(sl[s])
+        assert np.all(seg <= idx) and np.all(np.diff(seg) >= 0)
+        starts = np.unique(seg)
+        assert np.array_equal(seg[starts], starts)                            # a segment's first token names itself
+        for a, e in zip(starts, list(starts[1:]) + [sl[s]]):
+            assert np.all(np.diff(own[a:e]) >= 1)                             # positions increase inside a segment
         if pl[s] > 0:                                                        # a prefix is another sequence's tokens, entirely in front of the own tokens
             assert 0 <= ps[s] and ps[s] + pl[s] <= T
             assert pos[ps[s]: ps[s] + pl[s]].max() < own.min()
