@@ -362,14 +362,15 @@ class PairScorer:
             self.expect([k[3] for lst in by_prefix.values() for (k, _) in lst], True)
             for pbytes, lst in by_prefix.items():
                 ptoks = np.frombuffer(pbytes, dtype=np.int64)
-                pos_in = 0
+                pos_in, p0 = 0, None
                 while pos_in < len(lst):
-                    room = (self.max_tokens - st.n_tok - len(ptoks)) // C
+                    room = (self.max_tokens - st.n_tok - (len(ptoks) if p0 is None else 0)) // C
                     if st.n_tok and room < 1:
-                        yield st.finish(); st = _PackState(self, "tvg")
+                        yield st.finish(); st = _PackState(self, "tvg"); p0 = None
                         room = (self.max_tokens - len(ptoks)) // C
                     n = max(1, min(len(lst) - pos_in, room, SEG_MAX // C))
-                    p0 = st.add_seq(ptoks, np.arange(len(ptoks)), np.ones(len(ptoks), np.uint8), None)
+                    if p0 is None:                       # the prefix is packed once per engine call; every merged sequence of the group names it
+                        p0 = st.add_seq(ptoks, np.arange(len(ptoks)), np.ones(len(ptoks), np.uint8), None)
                     toks, posn, vis, own = [], [], [], []
                     for m_, (k, outs) in enumerate(lst[pos_in:pos_in + n]):
                         _, plen_full, last_tok, j = k
@@ -395,15 +396,16 @@ class PairScorer:
             for i, idxs in groups:
                 pr = self.tvg_split[i]
                 plen = len(pr)
-                pos_in = 0
+                pos_in, p0 = 0, None
                 while pos_in < len(idxs):
                     per = max(C - 1, 1)
-                    room = (self.max_tokens - st.n_tok - plen) // per
+                    room = (self.max_tokens - st.n_tok - (plen if p0 is None else 0)) // per
                     if st.n_tok and room < 1:
-                        yield st.finish(); st = _PackState(self, "tvg")
+                        yield st.finish(); st = _PackState(self, "tvg"); p0 = None
                         room = (self.max_tokens - plen) // per
                     n = max(1, min(len(idxs) - pos_in, room, SEG_MAX // per))
-                    p0 = st.add_seq(pr, np.arange(plen), np.ones(plen, np.uint8), None)
+                    if p0 is None:                       # the prompt is packed once per engine call; every merged sequence of the text names it
+                        p0 = st.add_seq(pr, np.arange(plen), np.ones(plen, np.uint8), None)
                     chunk = idxs[pos_in:pos_in + n]
                     s0 = None
                     if C > 1:

@@ -165,6 +165,30 @@ def test_tvg_plan_needs_three_tokens_per_pair():
     assert planc.batch.seq_len.numpy()[0] == prob.tvg_prefix_length
 
 
+def test_tvg_plan_packs_the_candidates_of_a_text_into_segmented_sequences():
+    """100 candidate videos of one text: ONE prompt sequence + merged sequences of at most 256 own tokens whose 3-token segments carry their own
+    first-key index (blim_batch.own_start); the rows of pair m are the prompt's last token + its three clip tokens."""
+    sc, prob = _scorer(n=100)
+    pairs = np.array([[j, 2] for j in range(100)])
+    (plan,) = sc.plan_tvg(pairs)
+    b = plan.batch
+    prompt = len(prob.tvg_ids[2]) - 3
+    assert plan.n_tokens == prompt + 300 and plan.n_pairs == 100 and b.n_seqs == 3            # prompt + 85 x 3 + 15 x 3 tokens
+    sl = sorted(b.seq_len.numpy().tolist())
+    assert sl == sorted([prompt, 255, 45])
+    own = b.own_start.numpy()
+    assert np.array_equal(own[:prompt], np.zeros(prompt, np.int32))
+    assert np.array_equal(own[prompt:prompt + 255], np.repeat(np.arange(85) * 3, 3)) and np.array_equal(own[prompt + 255:], np.repeat(np.arange(15) * 3, 3))
+    assert np.array_equal(b.pfx_len.numpy()[1:], [prompt, prompt]) and np.array_equal(b.pfx_start.numpy()[1:], [0, 0])
+    rows = plan.rows.numpy().reshape(100, 4)
+    assert (rows[:, 0] == prompt - 1).all() and np.array_equal(rows[:, 1:].reshape(-1), prompt + np.arange(300))
+    pos = b.positions.numpy()
+    assert np.array_equal(pos[prompt:], np.tile(prompt + np.arange(3), 100))
+    # a plan with one candidate per text has no segments at all: plain causal sequences, own_start stays NULL
+    (plain,) = sc.plan_tvg(np.array([[0, 1], [1, 2]]))
+    assert plain.batch.own_start is None
+
+
 def test_plans_split_at_the_token_budget():
     sc, prob = _scorer()
     sc.max_tokens = 150
