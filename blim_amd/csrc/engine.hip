@@ -133,6 +133,7 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     if (cfg->compute_dtype == BLIM_COMPUTE_F8) { e->f8 = true; e->c.compute_dtype = BLIM_COMPUTE_F16; }
     if (getenv("BLIM_F8_FUSE")) e->f8_fuse = atoi(getenv("BLIM_F8_FUSE"));
     if (getenv("BLIM_PRECISE_MLP")) e->precise_mlp = atoi(getenv("BLIM_PRECISE_MLP")) != 0;
+    if (getenv("BLIM_PRECISE_ACT")) e->precise_act = atoi(getenv("BLIM_PRECISE_ACT")) != 0;
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -473,6 +474,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const int pf = e->precise ? 2 : 1;                              // attention branch
     const bool pm = e->precise && e->precise_mlp;                   // MLP branch (option "precise_mlp")
     const int pfm = pm ? 2 : 1;
+    const bool pa = pm && e->precise_act;                           // ... including the SwiGLU output / down-proj input (option "precise_act")
     if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
@@ -517,9 +519,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
               TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
-              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); TRY(launch_gemm(EPI_SWIGLU, p, s)); }
-            { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * pfm);
-              GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pm); p.ldc = H; p.lo_off = 0; TRY(launch_gemm(EPI_RESID, p, s)); }
+              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; } TRY(launch_gemm(EPI_SWIGLU, p, s)); }
+            { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * (pa ? 2 : 1));
+              GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pa); p.ldc = H; p.lo_off = 0; TRY(launch_gemm(EPI_RESID, p, s)); }
             *final_resid = rl; *final_is_live = true;
             break;
         }
@@ -539,13 +541,14 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I * pfm);
             GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I, pm);
+            if (pm && !pa) { p.lo_off = 0; p.ldc = I; }                 // A = [hi | lo] (K walked twice), plain 16-bit output
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
         if (d8 && !fuse) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
         {
-            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * pfm);
-            GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0, pm);
+            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * (pa ? 2 : 1));
+            GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0, pa);
             if (fuse) { p.a_mx = (const uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             TRY(launch_gemm(EPI_RESID, p, s));
@@ -804,6 +807,7 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
     if (!strcmp(key, "prune_last")) { e->prune_last = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
+    if (!strcmp(key, "precise_act")) { e->precise_act = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise")) {
         if (value && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }
         e->precise = value != 0;

@@ -242,7 +242,7 @@ class Engine:
     def can_precise(self) -> bool:
         return self.dtype in ("f16", "bf16")
 
-    def set_precise(self, on: bool, embeds: bool = False, mlp: bool = True):
+    def set_precise(self, on: bool, embeds: bool = False, mlp: bool = True, act: Optional[bool] = None):
         """Compensated mode for the following calls (fp16 engines; a no-op request on others): every 16-bit activation travels as
         hi + lo and the GEMMs walk K twice.  The host turns it on for the TVG calls, whose scores are ~10x smaller in magnitude than
         the VTG ones and need the extra bits to hold 1e-3 at 28 layers; 2x GEMM flops on those calls only.
@@ -260,6 +260,13 @@ class Engine:
         if on and mlp != getattr(self, "_precise_mlp", True):
             self.set_option("precise_mlp", int(mlp))
             self._precise_mlp = mlp
+        # act: the SwiGLU output / down-proj input as hi + lo as well.  fp16 engines leave it plain by default -- the down GEMM then walks K once, a
+        # compensated layer costs 1.71x instead of 2x a plain one, and the TVG scores stay within 2.5e-4 of the fp32 reference at 28 layers of the 7B
+        # configuration (3.7e-5 with it; the bar is 1e-3) -- bf16 engines need it (8-bit mantissas: 2e-3 without).  DESIGN.md section 4.
+        act = (self.dtype == "bf16") if act is None else bool(act)
+        if on and act != getattr(self, "_precise_act", True):
+            self.set_option("precise_act", int(act))
+            self._precise_act = act
 
     # ---- component ops (torch device tensors in/out)
     def project_video(self, feats, which: int):
