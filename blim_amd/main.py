@@ -59,6 +59,10 @@ def get_args_parser():
     # engine-side options
     p.add_argument("--dtype", default=None, choices=["f16", "bf16", "f8"])
     p.add_argument("--max_tokens", default=32768, type=int, help="packed tokens per engine call")
+    p.add_argument("--f8_mask", default=None, type=int,
+                   help="fp8 mode: which GEMMs take e4m3 operands (bit 0 qkv, 1 o_proj, 2 gate|up, 3 down, 4 lm_head).  Default 31 (all) on a base checkpoint, "
+                        "12 (the MLP only) when --resume names a fine-tuned checkpoint: LoRA adapts q/k/v/o_proj and lm_head, whose merged rank-8 update is below one "
+                        "e4m3 step of the base weight -- those GEMMs stay in fp16, the MLP (87 %% of a layer's flops, not adapted) runs in fp8")
     p.add_argument("--vtg_precise", default=None, choices=["none", "attn", "full"],
                    help="compensated (hi + lo) activations on the VTG calls; default: none on fp16 engines, full on bf16 engines (the mode in which "
                         "bf16 holds 1e-3 against the fp32 reference at 7B depth; `none` = the fast, non-parity bf16 mode)")
@@ -151,9 +155,15 @@ def main(args):
             train_loader = load_data(args, tokenizer=tokenizer, split="train")
     if args.vtg_precise is not None:
         model.vtg_precise = None if args.vtg_precise == "none" else args.vtg_precise
-    if rank == 0 and model.engine.dtype == "f8" and args.resume and os.path.isfile(args.resume):
-        print("warning: fp8 mode on a fine-tuned checkpoint: the adapters are merged into the weights BEFORE the e4m3 quantisation and a rank-8 update is mostly below one "
-              "e4m3 step of the base weight -- measured 2 - 4 points of R@1 lost against fp16 / bf16 (profiles/r03_modes_trained_weights.md); fp8 is not a parity mode")
+    if model.engine.dtype == "f8":
+        finetuned_file = bool(args.resume) and os.path.isfile(args.resume)
+        mask = args.f8_mask if args.f8_mask is not None else (12 if finetuned_file else 31)
+        model.engine.set_option("f8_mask", mask)
+        if rank == 0 and finetuned_file:
+            print(f"fp8 mode on a fine-tuned checkpoint: f8_mask = {mask} "
+                  + ("(MLP only: the adapted projections q/k/v/o and lm_head stay in fp16, so the merged adapters survive)" if mask == 12 else
+                     "(adapters merged BEFORE the e4m3 quantisation: a rank-8 update is mostly below one e4m3 step of the base weight -- 2 - 4 points of R@1 lost, "
+                     "profiles/r03_modes_trained_weights.md)"))
     if rank == 0:
         print(f"model + data ready in {time.time() - t0:.1f}s ({model.engine.dtype}, world size {world})")
     if not args.eval:
