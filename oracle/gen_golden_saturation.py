@@ -63,8 +63,11 @@ def main(out_dir):
             for name, ft, (ids, lab, msk) in (("v2t_vtg", "vtg", vtg), ("v2t_tvg", "tvg", tvg)):
                 S = RU.compute_v2t_scores_x(torch.full((N, N), -100.0), T(prob.v2t_sims), 0, ids, msk, lab, video, vocab, T(prob.tvg_video_labels), ddp, dev, args,
                                             forward_type=ft, cpn=False)
-                out[f"{tag}_{name}"] = S.float().numpy()
-                print(tag, name, "non-finite entries:", int((~np.isfinite(out[f'{tag}_{name}'])).sum()), "of", int((out[f'{tag}_{name}'] != -100).sum()), flush=True)
+                Sn = S.float().numpy()
+                bad = ~np.isfinite(Sn)
+                out[f"{tag}_{name}"] = np.where(bad, np.float32(0), Sn)          # NaN-free arrays (comparable bit for bit when the fixture is regenerated) ...
+                out[f"{tag}_{name}_nonfinite"] = bad                              # ... and the mask of the entries the run returned as NaN / inf
+                print(tag, name, "non-finite entries:", int(bad.sum()), "of", int((Sn != -100).sum()), flush=True)
         # the largest SwiGLU product of layer 0 on one ragged batch (what overflows)
         if not half:
             acts = []
