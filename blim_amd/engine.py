@@ -359,6 +359,8 @@ class Engine:
         """Literal forward: embeds [B,L,H] bf16, mask [B,L] uint8 -> (logits f32 [B,L,V] | None, hidden f32 [B,L,H] | None)."""
         import torch
         B, L, H = embeds.shape
+        if getattr(self, "_precise_embeds", False):        # [hi | lo] rows of width 2 * hidden (compensated mode with split embeddings)
+            H //= 2
         lg = torch.empty((B, L, self.dims.vocab_size), dtype=torch.float32, device=self.device) if want_logits else None
         hd = torch.empty((B, L, H), dtype=torch.float32, device=self.device) if want_hidden else None
         _check(self.lib.blim_forward(self.h, _ptr(embeds), _ptr(mask), B, L, _ptr(lg), _ptr(hd), _stream()), "blim_forward")

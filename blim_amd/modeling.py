@@ -62,7 +62,7 @@ class BlimModel:
         The cache is keyed on the tensor's storage address AND keeps a reference to the tensor, so the address
         cannot be recycled for different data while the entry lives."""
         import torch
-        key = (feat.data_ptr(), tuple(feat.shape), feat.dtype, bool(tvg), feat._version)
+        key = (feat.data_ptr(), tuple(feat.shape), feat.dtype, bool(tvg), feat._version, bool(getattr(self.engine, "_precise_embeds", False)))
         if cache:
             hit = self._proj_cache.get(key)
             if hit is not None:
@@ -112,6 +112,20 @@ class BlimModel:
         if images is None or input_ids.shape[1] == 1:
             raise NotImplementedError("text-only / single-token inputs are outside the scoring path")
         self._tvg_rows = bool(tvg)
+        # bf16 engines (8-bit mantissas): the spliced embeddings are formed as hi + lo in the compensated mode and handed out as ONE float32 [B, L, H]
+        # tensor (the reference hands its model dtype; a bf16 tensor here would by itself put ~1e-3 on the scores at 7B depth); forward() splits it again.
+        # fp16 engines keep the reference's 16-bit [B, L, H] contract.
+        wide = self.engine.dtype == "bf16" and self.engine.can_precise
+        if wide:
+            self.engine.set_precise(True, embeds=True)
+        try:
+            return self._prepare(input_ids, position_ids, attention_mask, past_key_values, labels, images, tvg, cpn, wide)
+        finally:
+            if wide:
+                self.engine.set_precise(False)
+
+    def _prepare(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, tvg, cpn, wide):
+        import torch
         ids_h = input_ids.detach().cpu().numpy()
         msk_h = (attention_mask.detach().cpu().numpy() != 0) if attention_mask is not None else np.ones_like(ids_h, dtype=bool)
         lab_h = labels.detach().cpu().numpy() if labels is not None else np.full_like(ids_h, IGNORE_INDEX)
@@ -148,8 +162,11 @@ class BlimModel:
         for b in range(B):
             n = len(rows_src[b])
             src[b, :n] = rows_src[b]; out_lab[b, :n] = rows_lab[b]; mask[b, :n] = 1; cpn_mask[b, :n] = rows_cpn[b]
-        feat_all = torch.cat(feats + [torch.zeros((1, self.dims.hidden_size), dtype=self.dtype, device=self.device)], dim=0)
+        Hh = self.dims.hidden_size
+        feat_all = torch.cat(feats + [torch.zeros((1, Hh * (2 if wide else 1)), dtype=self.dtype, device=self.device)], dim=0)
         embeds = self.engine.assemble(torch.from_numpy(src.reshape(-1)).to(self.device), feat_all).reshape(B, L, -1)
+        if wide:                                                          # [hi | lo] -> one float32 tensor (a dtype repack of the literal, non-hot path)
+            embeds = embeds[..., :Hh].float() + embeds[..., Hh:].float()
         mdt = attention_mask.dtype if attention_mask is not None else torch.long
         new_labels = torch.from_numpy(out_lab).to(self.device) if labels is not None else None
         if attention_mask is None:
@@ -171,7 +188,12 @@ class BlimModel:
         if position_ids is not None or past_key_values is not None or labels is not None or use_cache or output_attentions or dpo_forward:
             raise NotImplementedError("forward(): position_ids / cache / labels / attentions are outside the scoring path")
         B, L, _ = inputs_embeds.shape
-        emb = inputs_embeds.to(self.dtype).contiguous()
+        wide = inputs_embeds.dtype == torch.float32 and self.engine.dtype == "bf16" and self.engine.can_precise
+        if wide:                                                          # float32 embeddings of prepare_inputs_labels_for_multimodal on a bf16 engine: back to [hi | lo]
+            hi = inputs_embeds.to(self.dtype)
+            emb = torch.cat([hi, (inputs_embeds - hi.float()).to(self.dtype)], dim=-1).contiguous()
+        else:
+            emb = inputs_embeds.to(self.dtype).contiguous()
         if attention_mask is None:
             m8 = torch.ones((B, L), dtype=torch.uint8, device=self.device)
         else:
@@ -179,9 +201,12 @@ class BlimModel:
         # a forward over rows prepared with tvg=True runs in the compensated mode, like the fused TVG calls (engine.set_precise); VTG rows
         # follow self.vtg_precise
         if self._tvg_rows:
-            self.engine.set_precise(True)
+            self.engine.set_precise(True, embeds=wide)
         else:
-            self.engine.set_precise(self.vtg_precise is not None, mlp=self.vtg_precise == "full")
+            on = self.vtg_precise is not None
+            self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise == "full")
+            if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none): plain embeddings
+                emb = inputs_embeds.to(self.dtype).contiguous()
         try:
             logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
         finally:
