@@ -316,3 +316,27 @@ def test_coefficient_sweeps_match_the_reference_when_present():
         for mine, ref in ((TU.calculate_score(a, b, c, d, ids, ids), R.calculate_score(a, b, c, d, ids, ids)),
                           (TU.calculate_cpn_score(a, b, c, d, ids, ids), R.calculate_cpn_score(a, b, c, d, ids, ids))):
             assert mine[2:] == ref[2:] and np.array_equal(mine[0], ref[0]) and np.array_equal(mine[1], ref[1])
+
+
+def test_host_thread_cap_is_sane():
+    """distributed.host_threads: torch intra-op threads for the drivers = CPUs this process may use / ranks on the node, between 1 and the cap."""
+    from blim_amd import distributed as D
+    n1, n8 = D.host_threads(1), D.host_threads(8)
+    assert 1 <= n8 <= n1 <= 8 and D.host_threads(1, cap=2) <= 2 and D.host_threads(10 ** 6) == 1
+
+
+def test_chunked_projection_follows_the_order_of_first_use():
+    """PairScorer.video_feat projects a CHUNK on a miss: the requested video plus the next ones the running pass will ask for (expect()), at most
+    feat_chunk at a time, every video exactly once."""
+    sc, prob = _scorer(n=12)
+    calls = []
+    orig = sc.m.project
+    sc.m.project = lambda feat, tvg, cache=True: (calls.append(int(feat.reshape(-1)[0] * 0) + len(calls)), orig(feat, tvg, cache))[1]
+    sc.feat_chunk = 5
+    pairs = np.array([[j, i] for i in (3, 1) for j in (7, 2, 9, 2, 11, 0, 4)])
+    sc.plan_tvg(pairs)
+    wanted = [2, 7, 9, 11, 0, 4]                                  # text 1 first (lexsort by text, then video): videos 0 2 4 7 9 11; all distinct videos once
+    assert len(calls) == 6 and sorted(k[0] for k in sc._vfeat) == sorted(set(wanted))
+    n0 = len(calls)
+    sc.plan_tvg(pairs)                                            # second pass: everything cached
+    assert len(calls) == n0
