@@ -246,6 +246,34 @@ class PairScorer:
         self._upcoming[bool(tvg)] = [int(v) for v in ids[np.sort(first)]]
         self._upcoming_pos[bool(tvg)] = 0
 
+    def share_tvg_feats(self, world: int, rank: int) -> bool:
+        """Multi-GPU evaluations: every rank needs the TVG clip features (tvg_mlp projection + clip means, a few KB per video) of nearly ALL videos --
+        its texts' candidates -- which left an upload + projection of N videos on every rank whatever the world size.  Instead each rank projects the
+        videos of its own row block and ONE all-gather ([N / W + 1, clips, width] per rank; 57 MB in total at N = 1000) hands everyone the rest.  The
+        values are those of a local projection (a projected row depends on its own input row only).  Returns False (nothing done) when the videos differ
+        in shape or no process group is up; then video_feat() projects on demand as before."""
+        import torch
+        if world <= 1 or not dist_utils.is_dist_avail_and_initialized() or not hasattr(self.m, "project_many"):
+            return False
+        N = len(self.video)
+        if len({tuple(v.shape) for v in self.video}) != 1:
+            return False
+        s_, e_ = dist_utils.row_block(N, world, rank)
+        step = N // world + 1
+        self.expect(np.arange(s_, e_), True)
+        mine = [self.video_feat(j, True) for j in range(s_, e_)]
+        per, width = (int(mine[0].shape[0]), int(mine[0].shape[1])) if mine else (self.num_clips, self.m.dims.hidden_size * (2 if self.split_tvg else 1))
+        buf = torch.zeros((step * per, width), dtype=self.m.dtype, device=self.device)
+        if mine:
+            buf[: (e_ - s_) * per] = torch.cat(mine, dim=0)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        torch.distributed.all_gather(parts, buf)
+        for r in range(world):
+            rs, re = dist_utils.row_block(N, world, r)
+            for j in range(rs, re):
+                self._vfeat[(j, True)] = parts[r][(j - rs) * per:(j - rs + 1) * per]
+        return True
+
     def _project_chunk(self, j: int, tvg: bool) -> None:
         shape = tuple(self.video[j].shape)
         chunk = [j]
@@ -670,6 +698,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
         mark("vtg")
         M_tvg_T = None
         if finetuned:
+            if collective and hasattr(scorer, "share_tvg_feats"):
+                scorer.share_tvg_feats(W, rank)                                                # each rank projects its block of videos; one all-gather of the clip features
             own_t = need.copy(); own_t[:, :ts] = False; own_t[:, te:] = False                  # TVG: columns of my texts
             M_tvg_T = score_owned("tvg", own_t).T.contiguous()                                # text-major: a row block
             mark("tvg")

@@ -72,16 +72,23 @@ def test_two_ranks_give_the_single_process_recall_table(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--eval", "--synthetic", "19", "--cpn", "--resume", "x", "--alpha", "0.4", "0.8", "--c", "0.3", "0.6", "0.9", "0.7", "--topk", "5"]
     env = dict(os.environ, PYTHONPATH=root)
-    r1 = subprocess.run([sys.executable, "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w1")], cwd=root, env=env,
+    r1 = subprocess.run([sys.executable, "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w1"), "--dump_scores", str(tmp_path / "w1.npz")], cwd=root, env=env,
                         capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
     env2 = dict(env, BLIM_DIST_BACKEND="gloo", BLIM_FORCE_DEVICE="0")
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29541", "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w2")], cwd=root, env=env2,
+                         "--master-port", "29541", "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w2"), "--dump_scores", str(tmp_path / "w2.npz")], cwd=root, env=env2,
                         capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-2000:]
     t1, t2 = open(tmp_path / "w1" / "log.txt").read(), open(tmp_path / "w2" / "log.txt").read()
     assert "blim" in t1 and t1 == t2
+    # ... and every score matrix bit for bit: pair ownership, the text-sharded prior and the all-gathered TVG clip features (each rank projects its own
+    # block of videos, PairScorer.share_tvg_feats) change who computes what, not what is computed
+    import numpy as np
+    a, b = np.load(tmp_path / "w1.npz"), np.load(tmp_path / "w2.npz")
+    assert set(a.files) == set(b.files) and len(a.files) == 8
+    for k in a.files:
+        assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k], b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
