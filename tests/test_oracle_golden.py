@@ -177,3 +177,24 @@ def test_torch_port_of_the_layer_agrees_with_the_numpy_oracle(tiny):
     lp = TP.label_logprobs(rows, w["lm_head"], labels).numpy()
     ref = O.log_softmax(want[0, :5] @ m.w["lm_head"].T)[np.arange(5), labels.numpy()]
     np.testing.assert_allclose(lp, ref, rtol=1e-5)
+
+
+def test_bench_plan_fixture_covers_the_benched_problem():
+    """tests/golden/full7b_bench.npz (the reference's loops on the problem bench.py's first plan is built from): four query rows per direction, each
+    with exactly the top-16 candidates of the synthetic first-stage matrices, finite log-likelihoods; and the v2t / t2v VTG matrices agree where both
+    directions score the same (video, text) pair -- the same forward in the reference."""
+    import torch
+    g = np.load(os.path.join(GOLD, "full7b_bench.npz"))
+    dims = synth.ModelDims()
+    prob = synth.make_problem(1000, 55, dims, tok_per_clip=24, text_len=(32, 32), reference_layout=False)
+    for name, sims in (("SYN_v2t_vtg", prob.v2t_sims), ("SYN_t2v_vtg", prob.t2v_sims), ("SYN_v2t_tvg", prob.v2t_sims), ("SYN_t2v_tvg", prob.t2v_sims),
+                       ("SYN_t2v_tvg_cpn", prob.t2v_sims)):
+        S = g[name]
+        assert S.shape == (55, 55) and (S[4:] == -100.0).all()
+        top = torch.from_numpy(sims[:4]).topk(16, dim=1).indices.numpy()
+        for q in range(4):
+            assert sorted(np.nonzero(S[q] != -100.0)[0].tolist()) == sorted(top[q].tolist())
+            assert np.isfinite(S[q, top[q]]).all() and (S[q, top[q]] < 0).all()
+    a, b = g["SYN_v2t_vtg"], g["SYN_t2v_vtg"].T                       # both indexed (video, text)
+    both = (a != -100.0) & (b != -100.0)
+    assert both.sum() >= 1 and np.allclose(a[both], b[both], rtol=1e-6)
