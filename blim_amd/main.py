@@ -144,7 +144,8 @@ def main(args):
         from .dataloader import load_data
         tokenizer = load_tokenizer(args.model_path)
         dims = dims_from_config(args.model_path, args.num_clips)
-        model = BlimModel(dims, dtype=args.dtype)
+        cfg_json = json.load(open(os.path.join(args.model_path, "config.json")))
+        model = BlimModel(dims, dtype=args.dtype, tokenizer_model_max_length=cfg_json.get("tokenizer_model_max_length"))   # modeling_videochat_flash.py:452
         # evaluation merges the resume file's adapters at load time; training keeps the base weights pristine (the trainer owns the adapters)
         report = load_checkpoint(model.engine, dims, args.model_path, (args.resume or None) if args.eval else None, lora_r=args.lora_r,
                                  lora_alpha=args.lora_alpha, strict_resume=not args.allow_partial_resume)

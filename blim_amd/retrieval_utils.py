@@ -216,10 +216,16 @@ class PairScorer:
             w = np.nonzero(prompt == IMAGE_TOKEN_INDEX)[0]
             assert len(w) == 1, "VTG prompt must hold exactly one <image> placeholder"
             self.vtg_split.append((prompt[: w[0]].astype(np.int64), prompt[w[0] + 1:].astype(np.int64), resp.astype(np.int64)))
+        # rows longer than config.tokenizer_model_max_length lose their tail after the splice (modeling_videochat_flash.py:452-457; None = no limit)
+        self.max_row_len = getattr(self.m, "tokenizer_model_max_length", None)
         self.tvg_split = []
         for ids, lab in self.tvg_rows:
             prompt, resp = _split_prompt_response(ids, lab)
             assert len(resp) >= 1 and resp[0] == IMAGE_TOKEN_INDEX, "TVG response must start with the <image> placeholder"
+            if self.max_row_len is not None and len(ids) - 1 + self.num_clips > self.max_row_len:
+                # the reference reads the clip positions relative to the <|im_end|> label of the row's tail (retrieval_utils.py:99-107); a row cut
+                # inside its clip tokens or tail has no such label any more
+                raise ValueError(f"TVG row of {len(ids) - 1 + self.num_clips} tokens exceeds tokenizer_model_max_length = {self.max_row_len}")
             self.tvg_split.append(prompt.astype(np.int64))
 
     # ---- projected video features, cached on device (K1 once per video instead of once per pair)
@@ -358,6 +364,10 @@ class PairScorer:
             plen = len(ptoks); ppos_end = len(pre) + n_vid + len(post)
             for i, outs in zip(texts_g, outs_g):
                 resp = self.vtg_split[i][2]
+                if self.max_row_len is not None and ppos_end + len(resp) > self.max_row_len:
+                    if ppos_end >= self.max_row_len:                       # no label left: the reference's criterion divides 0 by 0 there
+                        raise ValueError(f"tokenizer_model_max_length = {self.max_row_len} leaves no response token of text {i} ({ppos_end} prompt + video tokens)")
+                    resp = resp[: self.max_row_len - ppos_end]             # :452-457: the row's tail is cut, the score averages the tokens that remain
                 body = resp[:-1]                                           # the last response token predicts nothing
                 rows = [p0 + plen - 1]
                 if len(body):

@@ -140,6 +140,7 @@ class OracleModel:
         self.w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
         self.tvg_prefix_length = 0
         self.video_vocab = None
+        self.tokenizer_model_max_length: Optional[int] = None           # config attribute read at modeling_videochat_flash.py:452
 
     # setters, modeling_videochat_flash.py:589-593
     def set_tvg_prefix_length(self, n: int) -> None:
@@ -197,9 +198,10 @@ class OracleModel:
                     e_parts.append(feat)
                     l_parts.append(np.full(feat.shape[0], IGNORE_INDEX, dtype=np.int64))
                     c_parts.append(np.full(feat.shape[0], 1 if tvg else 0, dtype=np.int64))
-            rows_e.append(np.concatenate(e_parts, axis=0))
-            rows_l.append(np.concatenate(l_parts))
-            rows_c.append(np.concatenate(c_parts))
+            n_max = self.tokenizer_model_max_length                    # :452-457: rows longer than the limit lose their tail (None = no limit)
+            rows_e.append(np.concatenate(e_parts, axis=0)[:n_max])
+            rows_l.append(np.concatenate(l_parts)[:n_max])
+            rows_c.append(np.concatenate(c_parts)[:n_max])
         L = max(r.shape[0] for r in rows_e)                             # :460
         H = self.cfg.hidden_size
         embeds = np.zeros((B, L, H), dtype=np.float32)

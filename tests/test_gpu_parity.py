@@ -324,6 +324,34 @@ def test_six_passes_tiny_vs_reference_golden(tiny, literal):
     assert TU.combine_and_rank(*mk(got, ""), args, n) == TU.combine_and_rank(*mk(g, "S_"), args, n)
 
 
+@pytest.mark.parametrize("literal", [True, False], ids=["literal-api", "fused-pairscorer"])
+def test_rows_cut_at_tokenizer_model_max_length_vs_reference_golden(tiny, literal):
+    """modeling_videochat_flash.py:452-457: with config.tokenizer_model_max_length = 64 four of the six VTG rows lose 1 - 5 response tokens
+    (oracle/gen_golden_truncate.py ran the reference with that limit).  Prepared masks / labels bit-equal, all six passes within the score bar,
+    through the literal API and through the fused planner (which cuts the response before it packs it)."""
+    g = np.load(os.path.join(GOLD, "truncate.npz"))
+    t = tiny
+    t.model.tokenizer_model_max_length = int(g["limit"])
+    try:
+        if literal:
+            g0 = np.load(os.path.join(GOLD, "tiny.npz"))
+            T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+            n = t.spec["n"]
+            r = t.model.prepare_inputs_labels_for_multimodal(T(g0["pad_vtg_ids"]), None, T(g0["pad_vtg_masks"]), None, T(g0["pad_vtg_labels"]),
+                                                             [T(v) for v in t.prob.video], ["video"] * n, image_sizes=None, video_feature=True, tvg=False, cpn=True)
+            (_, _, (m_t, c_t), _, e_t, l_t) = r
+            assert e_t.shape[1] == int(g["limit"])
+            assert np.array_equal(m_t.cpu().numpy(), g["prep_vtg_mask"]) and np.array_equal(c_t.cpu().numpy(), g["prep_vtg_cpn_mask"])
+            assert np.array_equal(l_t.cpu().numpy(), g["prep_vtg_labels"])
+            assert relmax(e_t.float().cpu().numpy(), g["prep_vtg_embeds"]) < 1e-2
+        got = _six_passes(t, literal)
+        _check_passes(got, g, t, literal)
+        base = np.load(os.path.join(GOLD, "tiny.npz"))
+        assert not np.allclose(got["v2t_vtg"], base["S_v2t_vtg"], rtol=5e-3)            # the limit was in force (1.1e-2 on the cut rows)
+    finally:
+        t.model.tokenizer_model_max_length = None
+
+
 @pytest.mark.parametrize("literal", [False, True], ids=["fused-pairscorer", "literal-api"])
 def test_six_passes_7b_width_vs_reference_golden(wide, literal):
     """Qwen2-7B width (H=3584, 28/4 heads, I=18944, V=152064), one layer; weights generated ON DEVICE from the seed."""

@@ -110,14 +110,16 @@ class _FakeModel:
         return torch.zeros((clips if tvg else clips * T, self.dims.hidden_size), dtype=torch.float16)
 
 
-def _scorer(n=6, layout=True):
+def _scorer(n=6, layout=True, limit=None):
     dims = synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64)
     prob = synth.make_problem(5, n, dims, tok_per_clip=8, text_len=(3, 9), reference_layout=layout)
     tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
     T = lambda rows: [torch.from_numpy(r) for r in rows]
     vtg = RU.padding_ids(T(prob.vtg_ids), T(prob.vtg_labels), T(prob.vtg_masks), tok)
     tvg = RU.padding_ids(T(prob.tvg_ids), T(prob.tvg_labels), T(prob.tvg_masks), tok)
-    sc = RU.PairScorer(_FakeModel(dims, prob.tvg_prefix_length), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1],
+    fake = _FakeModel(dims, prob.tvg_prefix_length)
+    fake.tokenizer_model_max_length = limit
+    sc = RU.PairScorer(fake, vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1],
                        [torch.from_numpy(v) for v in prob.video], None, torch.from_numpy(prob.tvg_video_labels), dims.num_clips, max_tokens=4096)
     return sc, prob
 
@@ -139,6 +141,32 @@ def test_vtg_plan_shares_the_video_prefix():
     rows = plan.rows.numpy(); rs = plan.row_start.numpy()
     first_rows = rows[rs[:-1]]
     assert set(first_rows.tolist()) <= {pre_post + nv - 1, plan.batch.seq_start.numpy()[np.nonzero(pl == 0)[0][1]] + pre_post + nv - 1}
+
+
+def test_vtg_plan_cuts_rows_at_tokenizer_model_max_length():
+    """modeling_videochat_flash.py:452-457 in the fused planner: a spliced row longer than the limit loses its last response tokens (labels and
+    body alike); shorter rows are untouched; a limit that leaves no response token, or cuts a TVG row, is refused."""
+    sc0, prob = _scorer()
+    full = [len(prob.vtg_ids[i]) - 1 + 4 * 8 for i in range(6)]                    # spliced row lengths: 63 .. 69
+    resp = [int((prob.vtg_labels[i] != -100).sum()) for i in range(6)]
+    limit = 64
+    sc, _ = _scorer(limit=limit)
+    pairs = np.array([[i, i] for i in range(6)])
+    (p0,), (p1,) = sc0.plan_vtg(pairs), sc.plan_vtg(pairs)
+    kept = [r - max(0, f - limit) for r, f in zip(resp, full)]
+    assert kept != resp and min(kept) >= 1
+    assert p0.n_rows == sum(resp) and p1.n_rows == sum(kept)
+    assert p0.n_tokens - p1.n_tokens == sum(resp) - sum(kept)
+    rs0, rs1 = p0.row_start.numpy(), p1.row_start.numpy()
+    l0, l1 = p0.labels.numpy(), p1.labels.numpy()
+    for k in range(6):                                                              # plans keep the pair order of the request here (one video per pair)
+        assert np.array_equal(l1[rs1[k]:rs1[k + 1]], l0[rs0[k]:rs0[k] + kept[k]])
+    (c1,) = sc.plan_vtg(pairs, cpn=True)                                            # the prior's rows are cut at the same place
+    assert c1.n_rows == sum(kept)
+    with pytest.raises(ValueError, match="leaves no response token"):
+        _scorer(limit=min(full) - max(resp))[0].plan_vtg(pairs)
+    with pytest.raises(ValueError, match="TVG row"):
+        _scorer(limit=30)
 
 
 def test_vtg_cpn_plan_scores_each_text_once():

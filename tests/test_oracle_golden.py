@@ -82,6 +82,37 @@ def test_six_passes(tiny, name, direction, ftype, cpn):
     np.testing.assert_allclose(S, G, rtol=1e-5)
 
 
+def test_row_truncation_at_tokenizer_model_max_length(tiny):
+    """modeling_videochat_flash.py:452-457: spliced rows longer than config.tokenizer_model_max_length lose their tail -- here 1 - 5 response
+    tokens of four VTG rows (oracle/gen_golden_truncate.py); the prepared tensors and all six passes against the reference's."""
+    g = np.load(os.path.join(GOLD, "truncate.npz"))
+    prob, spec, dims = tiny["prob"], tiny["spec"], tiny["dims"]
+    m = O.OracleModel(tiny["cfg"], tiny["w"])
+    m.set_tvg_prefix_length(prob.tvg_prefix_length)
+    m.tokenizer_model_max_length = int(g["limit"])
+    ids, lab, msk = tiny["vtg"]
+    mask, cpn, emb, lab2 = m.prepare_inputs_labels_for_multimodal(ids, msk, lab, prob.video, tvg=False)
+    assert emb.shape[1] == int(g["limit"])
+    assert np.array_equal(mask, g["prep_vtg_mask"]) and np.array_equal(cpn, g["prep_vtg_cpn_mask"]) and np.array_equal(lab2, g["prep_vtg_labels"])
+    assert (lab2 != -100).sum() < (np.asarray(lab) != -100).sum()                      # the limit did cut labels
+    np.testing.assert_allclose(emb, g["prep_vtg_embeds"], atol=1e-6)
+    for tag, mm in (("", mask), ("_cpn", cpn)):
+        np.testing.assert_allclose(m.label_logprobs(m.forward_hidden(emb, mm), lab2), g[f"fwd_vtg{tag}_score"], rtol=1e-5)
+    n = spec["n"]
+    for name, direction, ftype, c in PASSES:
+        i_, l_, m_ = tiny[ftype]
+        fn = O.compute_v2t_scores_x if direction == "v2t" else O.compute_t2v_scores_x
+        sims = prob.v2t_sims if direction == "v2t" else prob.t2v_sims
+        S = fn(np.full((n, n), -100.0, dtype=np.float32), sims, 0, i_, m_, l_, prob.video, prob.video_vocab, prob.tvg_video_labels, m,
+               spec["topk"], spec["bs"], dims.num_clips, ftype, c)
+        G = g[f"S_{name}"]
+        assert np.array_equal(S == -100.0, G == -100.0), name
+        np.testing.assert_allclose(S, G, rtol=2e-5, err_msg=name)
+    # the limit changes the VTG scores of the cut rows and nothing else
+    t = tiny["g"]
+    assert not np.allclose(g["S_v2t_vtg"], t["S_v2t_vtg"], rtol=1e-4) and np.array_equal(g["S_v2t_tvg"], t["S_v2t_tvg"])
+
+
 def test_criteria(tiny):
     g = tiny["g"]
     np.testing.assert_allclose(O.vtg_criterion(g["crit_vtg_logits"], g["crit_vtg_labels"]), g["crit_vtg_out"], rtol=1e-5)
