@@ -10,6 +10,7 @@
 
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/blim.h"
@@ -109,19 +110,34 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t 
 }
 
 // ---------------------------------------------------------------------------- ViT attention: non-causal, head_dim 64
-// One workgroup = 4 waves = 4 consecutive 32-query blocks of ONE (clip, head); the 32-key K / V tiles are staged in LDS once for
-// the 128 queries.  Same swapped-product scheme as attention.hip: S^T = K.Q^T (keys on MFMA rows, a lane owns one query),
-// the exponentiated accumulator packed to 16 bits is the B operand of O^T = V^T.P^T, V^T through ds_read_b64_tr_b16.
+// One workgroup = NW waves = NW consecutive 32-query blocks of ONE (clip, head); the K / V tiles are staged in LDS once for all of them.
+// Same swapped-product scheme as attention.hip: S^T = K.Q^T (keys on MFMA rows, a lane owns one query), the exponentiated accumulator packed
+// to 16 bits is the B operand of O^T = V^T.P^T, V^T through ds_read_b64_tr_b16.
+// At head_dim 64 the softmax's VALU work (one fma + v_exp_f32 + add per score, 660 issue cycles per 64 keys) outweighs the 16 MFMAs (512 pipe
+// cycles, 128 of issue), so the loop is built to issue little else: 64 keys per iteration out of a double-buffered LDS image (ONE barrier per
+// 64 keys; the tile after the next already in flight in registers), every LDS address a per-lane register plus an immediate (the loop is
+// unrolled by two so the buffer index is a constant), the cross-half maximum by v_permlane32_swap instead of a trip through the LDS crossbar,
+// row sums kept per lane half until the end (both halves rescale by the same factor), raw v_exp_f32 (libm's exp2f adds a range check and
+// a ldexp per call), and MFMA results straight into VGPRs (Makefile: FLAGS_vision).  Round-3 history at 8 videos per call (32 clips x 3,136
+// tokens x 16 heads, tools/vit_attn_bench.py): 3.18 ms per layer -> 2.58 (raw v_exp) -> 2.04 (64-key tiles, double buffer, permlane) -> 1.79
+// (VGPR-form MFMA) -> 1.73 (immediate offsets, 8 waves per workgroup) = 746 TFLOP/s.
 #define VHD 64
-#define VKT 32
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-template <int DT>
-__global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* qkv, int64_t ldq, int L, int D, bf16_t* out, int64_t ldo, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t k_lds[VKT * VHD];
-    __shared__ __attribute__((aligned(16))) bf16_t v_lds[VKT * VHD];
+#define VKT2 64
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int DT, int NW>                              // NW waves = 32 * NW queries share the staged K / V tiles
+__global__ __launch_bounds__(64 * NW) void vit_attn_kernel(const bf16_t* qkv, int64_t ldq, int L, int D, bf16_t* out, int64_t ldo, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t kv_lds[2][2][VKT2 * VHD];      // [buffer][K | V][64 keys x 64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, clip = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
     const int qi = lane & 31, hf = lane >> 5;
     const int64_t tok0 = (int64_t)clip * L;
     const int64_t qtok = tok0 + min(q0 + qi, L - 1);
@@ -137,73 +153,90 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* qkv, int64_
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     const float NEG = -1.0e30f;
-    float m_run = NEG, l_run = 0.f;
+    float m_run = NEG, l_run = 0.f;                    // l_run: this lane half's share of the row sum
     const float c_log2 = scale * 1.4426950408889634f;
-    const int n_tiles = (L + VKT - 1) / VKT;
-    // staging: 512 16-B chunks per tile (256 K + 256 V) over 256 threads
-    uint4 st[2];
-    auto load_tile = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int isv = idx >> 8, row = (idx >> 3) & 31, ch = idx & 7;
-            const int kk = min(t * VKT + row, L - 1);
-            st[i] = *(const uint4*)(qkv + (tok0 + kk) * ldq + (isv ? 2 * D : D) + head * VHD + 8 * ch);
+    const int n_tiles = (L + VKT2 - 1) / VKT2;
+    // staging: 1024 16-B chunks per tile (512 K + 512 V): a thread moves the 16-B column tid & 7 of row tid >> 3 of K and of V, and with four waves also
+    // of row + 32.  Named registers, not an array: as an array captured by two lambdas the staging values were kept in scratch memory
+    const int srow = tid >> 3, sch = tid & 7;
+    const bf16_t* gk = qkv + D + head * VHD + 8 * sch;
+    const bf16_t* gv = qkv + 2 * D + head * VHD + 8 * sch;
+    const int lk0 = srow * VHD + 8 * (sch ^ (srow & 7)), lk1 = (srow + 32) * VHD + 8 * (sch ^ (srow & 7));
+    const int lv0 = srow * VHD + 8 * (sch ^ ((srow & 3) << 1)), lv1 = (srow + 32) * VHD + 8 * (sch ^ ((srow & 3) << 1));
+    uint4 st0, st1, st2, st3;
+#define VIT_LOAD_TILE(t)                                                                   \
+    {                                                                                      \
+        const int64_t r0 = (tok0 + min((t) * VKT2 + srow, L - 1)) * ldq;                   \
+        st0 = *(const uint4*)(gk + r0); st2 = *(const uint4*)(gv + r0);                    \
+        if constexpr (NW == 4) {                                                           \
+            const int64_t r1 = (tok0 + min((t) * VKT2 + srow + 32, L - 1)) * ldq;          \
+            st1 = *(const uint4*)(gk + r1); st3 = *(const uint4*)(gv + r1);                \
+        }                                                                                  \
+    }
+#define VIT_STORE_TILE(b)                                                                  \
+    {                                                                                      \
+        *(uint4*)(&kv_lds[b][0][lk0]) = st0; *(uint4*)(&kv_lds[b][1][lv0]) = st2;          \
+        if constexpr (NW == 4) { *(uint4*)(&kv_lds[b][0][lk1]) = st1; *(uint4*)(&kv_lds[b][1][lv1]) = st3; } \
+    }
+    VIT_LOAD_TILE(0);
+    VIT_STORE_TILE(0);
+    if (n_tiles > 1) VIT_LOAD_TILE(1);
+    // one tile; the buffer index is a compile-time constant (the loop below is unrolled by two) so that every LDS address is a per-lane register
+    // plus an immediate offset
+    auto tile = [&](auto BUF, const int t) __attribute__((always_inline)) {
+        constexpr int B = decltype(BUF)::value;
+        __syncthreads();                               // tile t is visible in buffer B; nobody reads buffer B ^ 1 any more
+        if (t + 1 < n_tiles) {
+            VIT_STORE_TILE(B ^ 1);
+            if (t + 2 < n_tiles) VIT_LOAD_TILE(t + 2);
         }
-    };
-    auto store_tile = [&]() __attribute__((always_inline)) {
+        const bf16_t* k_lds = kv_lds[B][0];
+        const bf16_t* v_lds = kv_lds[B][1];
+        const int k0 = t * VKT2;
+        f32x16 sacc[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int isv = idx >> 8, row = (idx >> 3) & 31, ch = idx & 7;
-            if (isv) *(uint4*)(v_lds + row * VHD + 8 * (ch ^ ((row & 3) << 1))) = st[i];
-            else *(uint4*)(k_lds + row * VHD + 8 * (ch ^ (row & 7))) = st[i];
-        }
-    };
-    load_tile(0);
-    for (int t = 0; t < n_tiles; ++t) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (t + 1 < n_tiles) load_tile(t + 1);
-        const int k0 = t * VKT;
-        f32x16 sacc;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sacc[h][r] = 0.f;
         {
             const int key = lane & 31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(k_lds + key * VHD + 8 * ((2 * ks + hf) ^ (key & 7)));
-                sacc = mfma32<DT>(kf, qf[ks], sacc);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bf16x8 kf = *(const bf16x8*)(k_lds + (32 * h + key) * VHD + 8 * ((2 * ks + hf) ^ (key & 7)));
+                    sacc[h] = mfma32<DT>(kf, qf[ks], sacc[h]);
+                }
             }
         }
-        // softmax bookkeeping in RAW score units (the scale * log2(e) factor is folded into the exponent's fma): at head_dim 64 this
-        // VALU work, not the 8 MFMAs, bounds the kernel, so: key-bound masking only in the last tile, one fma + v_exp per score, and
-        // the accumulators are rescaled only when some lane's running maximum actually grew
-        float pv[16];
-        float tmax = NEG;
-        if (k0 + VKT > L) {
+        if (k0 + VKT2 > L) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const int r = 4 * g + j; if (k0 + 8 * g + 4 * hf + j >= L) sacc[r] = NEG; }
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int r = 4 * g + j; if (k0 + 32 * h + 8 * g + 4 * hf + j >= L) sacc[h][r] = NEG; }
         }
+        float tmax = NEG;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[h][r]);
+        tmax = xhalf_max(tmax);
         const float m_new = fmaxf(m_run, tmax);
         const float mc = m_new * c_log2;
+        float pv[2][16];
         float rsum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = exp2f(fmaf(sacc[r], c_log2, -mc));      // masked scores: exp2(-huge) = 0
-            pv[r] = e;
-            rsum += e;
-        }
-        rsum += __shfl_xor(rsum, 32);
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[h][r], c_log2, -mc));      // native v_exp_f32: arguments <= 0, masked scores give exp2(-huge) = 0
+                pv[h][r] = e;
+                rsum += e;
+            }
         if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-            const float alpha = exp2f((m_run - m_new) * c_log2);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_log2);
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -212,33 +245,36 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16_t* qkv, int64_
         }
         l_run += rsum;
         m_run = m_new;
-        bf16x8 pf[2];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
+        for (int s4 = 0; s4 < 4; ++s4) {               // 16 keys per step: s4 >> 1 = the 32-key half, s4 & 1 = its 16-key half
+            const int h = s4 >> 1, s2 = s4 & 1;
             uint32_t w[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = pack2<DT>(pv[8 * s2 + 2 * j], pv[8 * s2 + 2 * j + 1]);
-            pf[s2] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-        }
+            for (int j = 0; j < 4; ++j) w[j] = pack2<DT>(pv[h][8 * s2 + 2 * j], pv[h][8 * s2 + 2 * j + 1]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
+            for (int db = 0; db < 2; ++db) {
                 const int i16 = lane & 15, g16 = (lane >> 4) & 1;
                 const int dcol = 32 * db + 16 * g16 + 4 * (i16 & 3);
                 const int ch = dcol >> 3, within = dcol & 7;
-                const int kr0 = 16 * s2 + 4 * hf + (i16 >> 2);
+                const int kr0 = 32 * h + 16 * s2 + 4 * hf + (i16 >> 2);
                 const int kr1 = kr0 + 8;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) s16x4*)(v_lds + kr0 * VHD + 8 * (ch ^ ((kr0 & 3) << 1)) + within));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) s16x4*)(v_lds + kr1 * VHD + 8 * (ch ^ ((kr1 & 3) << 1)) + within));
                 const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[db] = mfma32<DT>(vf, pf[s2], o[db]);
+                o[db] = mfma32<DT>(vf, pf, o[db]);
             }
+        }
+    };
+    for (int t = 0; t < n_tiles; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < n_tiles) tile(std::integral_constant<int, 1>{}, t + 1);
     }
+    const float l_tot = xhalf_sum(l_run);
     if (q0 + qi < L) {
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         bf16_t* orow = out + (tok0 + q0 + qi) * ldo + head * VHD;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -568,6 +604,27 @@ static int tome_merge_tokens(blim_vision* v, const float* x, int b, int p, int c
     return BLIM_OK;
 }
 
+// softmax(q k^T / sqrt(64)) v per (clip, head) over the fused [tokens, 3 D] projection; out [tokens, D]
+static int launch_vit_attn(int dt, const bf16_t* qkv, int L, int D, int heads, int n_clips, bf16_t* out, hipStream_t s) {
+    // eight waves (256 queries) share a staged tile where the sequence is long enough to fill such workgroups (-1 % at L = 3,136), four otherwise
+    if (L >= 1024) {
+        const dim3 grid((L + 255) / 256, heads, n_clips);
+        if (dt == DT_F16) hipLaunchKernelGGL((vit_attn_kernel<DT_F16, 8>), grid, dim3(512), 0, s, qkv, (int64_t)3 * D, L, D, out, (int64_t)D, 0.125f);
+        else hipLaunchKernelGGL((vit_attn_kernel<DT_BF16, 8>), grid, dim3(512), 0, s, qkv, (int64_t)3 * D, L, D, out, (int64_t)D, 0.125f);
+    } else {
+        const dim3 grid((L + 127) / 128, heads, n_clips);
+        if (dt == DT_F16) hipLaunchKernelGGL((vit_attn_kernel<DT_F16, 4>), grid, dim3(256), 0, s, qkv, (int64_t)3 * D, L, D, out, (int64_t)D, 0.125f);
+        else hipLaunchKernelGGL((vit_attn_kernel<DT_BF16, 4>), grid, dim3(256), 0, s, qkv, (int64_t)3 * D, L, D, out, (int64_t)D, 0.125f);
+    }
+    KCHECK("vit attention");
+    return BLIM_OK;
+}
+
+extern "C" int blim_vit_attention(const void* qkv, int32_t n_clips, int32_t L, int32_t heads, int32_t dtype16, void* out, void* stream) {
+    ARG_CHECK(qkv && out && n_clips > 0 && L > 0 && heads > 0 && (dtype16 == BLIM_COMPUTE_F16 || dtype16 == BLIM_COMPUTE_BF16));
+    return launch_vit_attn(dtype16 == BLIM_COMPUTE_F16 ? DT_F16 : DT_BF16, (const bf16_t*)qkv, L, heads * VHD, heads, n_clips, (bf16_t*)out, (hipStream_t)stream);
+}
+
 extern "C" int blim_tome_merge(blim_vision* v, const float* x, int32_t b, int32_t p, int32_t c, int32_t heads, int32_t target, float* out, void* stream) {
     ARG_CHECK(v && x && out && b > 0);
     return tome_merge_tokens(v, x, b, p, c, heads, target, out, (hipStream_t)stream);
@@ -601,12 +658,7 @@ extern "C" int blim_vision_encode(blim_vision* v, const void* frames, int32_t n_
         const VBlock& b = v->B[i];
         TRY(layernorm(b.n1w, b.n1b, 1e-6f, xn, nullptr));
         { GemmParams p = vgp(dt, xn, D, b.qkv_w, M, 3 * D, D, qkv, 3 * D, b.qkv_b); TRY(launch_gemm(EPI_BF16, p, s)); }
-        {
-            const dim3 grid((L + 127) / 128, c.num_heads, n_clips);
-            if (dt == DT_F16) hipLaunchKernelGGL(vit_attn_kernel<DT_F16>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (int64_t)3 * D, L, D, attn, (int64_t)D, 0.125f);
-            else hipLaunchKernelGGL(vit_attn_kernel<DT_BF16>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (int64_t)3 * D, L, D, attn, (int64_t)D, 0.125f);
-            KCHECK("vit attention");
-        }
+        TRY(launch_vit_attn(dt, qkv, L, D, c.num_heads, n_clips, attn, s));
         { GemmParams p = vgp(dt, attn, D, b.proj_w, M, D, D, resid, D, b.proj_b); TRY(launch_gemm(EPI_RESID, p, s)); }
         TRY(layernorm(b.n2w, b.n2b, 1e-6f, xn, nullptr));
         { GemmParams p = vgp(dt, xn, D, b.fc1_w, M, Hm, D, act, Hm, b.fc1_b); p.act = 1; TRY(launch_gemm(EPI_BF16, p, s)); }

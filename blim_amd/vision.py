@@ -248,6 +248,19 @@ class VisionEncoder:
         return tome.to(torch.float16).cpu()
 
 
+def vit_attention(qkv, n_clips: int, heads: int):
+    """The encoder's attention alone (blim_vit_attention): qkv 16-bit device tensor [n_clips * L, 3 * heads * 64] -> [n_clips * L, heads * 64]."""
+    import torch
+    lib = eng.load_library()
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.blim_vit_attention.argtypes = [vp, i32, i32, i32, i32, vp, vp]; lib.blim_vit_attention.restype = C.c_int
+    assert qkv.dtype in (torch.float16, torch.bfloat16) and qkv.shape[1] == 3 * heads * 64 and qkv.shape[0] % n_clips == 0
+    out = torch.empty((qkv.shape[0], heads * 64), dtype=qkv.dtype, device=qkv.device)
+    eng._check(lib.blim_vit_attention(eng._ptr(qkv), n_clips, qkv.shape[0] // n_clips, heads, eng.COMPUTE_DTYPES["f16" if qkv.dtype == torch.float16 else "bf16"],
+                                      eng._ptr(out), eng._stream()), "blim_vit_attention")
+    return out
+
+
 # ----------------------------------------------------------------------------- preprocessing (host)
 
 def preprocess(frames_u8: np.ndarray, image_size: int = 448):

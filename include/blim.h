@@ -232,6 +232,9 @@ int blim_vision_ready(const blim_vision* v);
 /* frames: device 16-bit (compute dtype) [n_clips, num_frames, 3, S, S], normalised pixels.  out_feat (may be NULL): f32
  * [n_clips, L, hidden] encoder output, L = num_frames * (S/patch)^2; out_tome (may be NULL): f32 [n_clips, tome_tokens, hidden]. */
 int blim_vision_encode(blim_vision* v, const void* frames, int32_t n_clips, float* out_feat, float* out_tome, void* stream);
+/* The encoder's attention alone (tests / bench): qkv 16-bit [n_clips * L, 3 * heads * 64] = [q | k | v] per token, heads of 64; out 16-bit
+ * [n_clips * L, heads * 64] = softmax(q k^T / 8) v within each clip, non-causal (vision_tower_builder.py:100-128). */
+int blim_vit_attention(const void* qkv, int32_t n_clips, int32_t L, int32_t heads, int32_t dtype16, void* out, void* stream);
 /* ToMe alone: x f32 [b, p, c] (c = heads * 64) -> out f32 [b, target, c]; bipartite soft matching + size-weighted merge,
  * mm_projector_builder.py:6-130. */
 int blim_tome_merge(blim_vision* v, const float* x, int32_t b, int32_t p, int32_t c, int32_t heads, int32_t target, float* out, void* stream);

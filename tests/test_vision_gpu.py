@@ -34,6 +34,25 @@ def _encoder(case, dtype="f16"):
     return enc, frames, np.load(os.path.join(GOLD, f"vision_{case}.npz"))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("L", [37, 100, 64 * 17 + 12, 3136], ids=lambda v: f"L{v}")
+def test_attention_kernel_alone(L, dtype):
+    """blim_vit_attention against the oracle's statement of the encoder's attention (oracle/vision_oracle.py:157-162 = vision_tower_builder.py:100-128 'origin'
+    branch) on the same 16-bit q / k / v: both workgroup shapes (four waves below 1,024 tokens, eight from there), sequence lengths that end inside a 64-key
+    tile and inside a 32-query block, and the extraction's own 3,136 tokens."""
+    clips, heads = 2, 16
+    g = torch.Generator().manual_seed(L)
+    x = (torch.randn((clips * L, 3 * heads * 64), generator=g) * 1.5).to(dtype).cuda()
+    got = V.vit_attention(x, clips, heads).float().cpu().numpy()
+    q, k, v = x.float().cpu().numpy().reshape(clips, L, 3, heads, 64).transpose(2, 0, 3, 1, 4)
+    s_ = (q * np.float32(0.125)) @ k.transpose(0, 1, 3, 2)
+    p = np.exp(s_ - s_.max(axis=-1, keepdims=True))
+    want = ((p / p.sum(axis=-1, keepdims=True, dtype=np.float32)) @ v).transpose(0, 2, 1, 3).reshape(clips * L, heads * 64)
+    # the probabilities enter the second product rounded to 16 bits (as in the reference's fp16 run): 2^-11 resp. 2^-8 of a value of order |v|
+    assert np.abs(got - want).max() < (4e-3 if dtype == torch.float16 else 3e-2) * max(1.0, float(np.abs(want).max()) / 4)
+    assert relmax(got, want) < (1.5e-3 if dtype == torch.float16 else 1e-2)
+
+
 def test_tome_alone_on_the_reference_features():
     enc, _, g = _encoder("small")
     try:

@@ -3,7 +3,9 @@ import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for f in sys.argv[1:]:
     out = f"/tmp/{f}.s"
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out, os.path.join(ROOT, "blim_amd", "csrc", f + ".hip")], check=True, stderr=subprocess.DEVNULL)
+    extra = {"vision": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}.get(f, [])          # the Makefile's per-file flags (FLAGS_<file>)
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *extra, "-o", out, os.path.join(ROOT, "blim_amd", "csrc", f + ".hip")],
+                   check=True, stderr=subprocess.DEVNULL)
     s = open(out).read()
     for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.vgpr_spill_count:\s+(\d+)', s, re.S):
         name, blk = m.group(1), m.group(2)
