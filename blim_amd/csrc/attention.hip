@@ -180,7 +180,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
         float tmax = NEG;
 #pragma unroll
         for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        tmax = xhalf_max(tmax);
         // Lazy reference maximum: m_run is the exponent's reference, not necessarily the running maximum.  It is moved (and the accumulators
         // rescaled) only when some query's tile maximum exceeds it by more than 2^8 in the exponent's units -- p then stays below 256, well inside
         // both 16-bit formats' range, and l_run / the accumulators are sums relative to the same reference, so the result is the same
@@ -207,8 +207,9 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
             pv[r] = e;
             rsum += e;
         }
-        rsum += __shfl_xor(rsum, 32);
-        l_run += rsum;
+        // the two lane halves are added per TILE, not once after the loop: a merged sequence's segment lands in either half depending on its offset, and
+        // a deferred sum would associate differently there -- scores would depend on the batch composition in the last bit (two-rank == one-rank test)
+        l_run += xhalf_sum(rsum);
         m_run = m_new;
 
         // ---- P^T fragments: registers 8s..8s+7 are k-step s (k order: 16s + 8(j>>2) + 4hf + (j&3))
@@ -270,7 +271,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[db][r] *= inv; a = fmaxf(a, fabsf(o[db][r])); }
-        a = fmaxf(a, __shfl_xor(a, 32));
+        a = xhalf_max(a);
         int e = 0;
         if (a > 0.f) {
             int ex; const float mant = frexpf(a * (1.0f / FP8_MAX), &ex);

@@ -84,6 +84,17 @@ template <int DT> __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// max / sum of a value over the two 32-lane halves of a wave (lanes l and l ^ 32), in every lane: one v_permlane32_swap (VALU) instead of the
+// ds_bpermute trip through the LDS crossbar that __shfl_xor(v, 32) compiles to
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

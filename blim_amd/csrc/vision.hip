@@ -124,14 +124,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t 
 #define VHD 64
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define VKT2 64
-__device__ __forceinline__ float xhalf_max(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 template <int DT, int NW>                              // NW waves = 32 * NW queries share the staged K / V tiles
 __global__ __launch_bounds__(64 * NW) void vit_attn_kernel(const bf16_t* qkv, int64_t ldq, int L, int D, bf16_t* out, int64_t ldo, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t kv_lds[2][2][VKT2 * VHD];      // [buffer][K | V][64 keys x 64]
