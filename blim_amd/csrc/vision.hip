@@ -109,6 +109,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t 
     }
 }
 
+// Wide form for the encoder's inner norms (16-bit output only, D % 8 == 0, D <= 4096): a lane owns chunks of EIGHT consecutive elements, so the output leaves as
+// 16-byte stores (kernels.hip: rmsnorm_wide_kernel, same reason).  Same arithmetic per element; only the order of the lanes' partial sums differs.
+template <int DT>
+__global__ __launch_bounds__(256) void layernorm_wide_kernel(const float* x, int64_t n_rows, int D, const float* w, const float* b, float eps, bf16_t* out16) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int nc = D / 8;
+    const float* xr = x + r * D;
+    float4 v[8][2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            v[i][0] = *(const float4*)(xr + 8 * c); v[i][1] = *(const float4*)(xr + 8 * c + 4);
+            s += (v[i][0].x + v[i][0].y + v[i][0].z + v[i][0].w) + (v[i][1].x + v[i][1].y + v[i][1].z + v[i][1].w);
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float a0 = v[i][h].x - mu, a1 = v[i][h].y - mu, a2 = v[i][h].z - mu, a3 = v[i][h].w - mu;
+                q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+            }
+        }
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            uint32_t o[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 g = *(const float4*)(w + 8 * c + 4 * h), t = *(const float4*)(b + 8 * c + 4 * h);
+                o[2 * h] = pack2<DT>((v[i][h].x - mu) * inv * g.x + t.x, (v[i][h].y - mu) * inv * g.y + t.y);
+                o[2 * h + 1] = pack2<DT>((v[i][h].z - mu) * inv * g.z + t.z, (v[i][h].w - mu) * inv * g.w + t.w);
+            }
+            *(uint4*)(out16 + r * D + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- ViT attention: non-causal, head_dim 64
 // One workgroup = NW waves = NW consecutive 32-query blocks of ONE (clip, head); the K / V tiles are staged in LDS once for all of them.
 // Same swapped-product scheme as attention.hip: S^T = K.Q^T (keys on MFMA rows, a lane owns one query), the exponentiated accumulator packed
@@ -640,7 +689,14 @@ extern "C" int blim_vision_encode(blim_vision* v, const void* frames, int32_t n_
     KCHECK("patchify");
     { GemmParams p = vgp(dt, v->patches.p, PK, v->patch_w, M, D, PK, resid, D, nullptr); TRY(launch_gemm(EPI_RESID, p, s)); }
     const dim3 ln_grid((unsigned)((M + 3) / 4));
+    static const int ln_wide = getenv("BLIM_LN_WIDE") ? atoi(getenv("BLIM_LN_WIDE")) : 1;
     auto layernorm = [&](const float* w, const float* b, float eps, bf16_t* o16, float* o32) -> int {
+        if (ln_wide && o16 && !o32 && D % 8 == 0 && D <= 4096) {
+            if (dt == DT_F16) hipLaunchKernelGGL(layernorm_wide_kernel<DT_F16>, ln_grid, dim3(256), 0, s, (const float*)resid, M, D, w, b, eps, o16);
+            else hipLaunchKernelGGL(layernorm_wide_kernel<DT_BF16>, ln_grid, dim3(256), 0, s, (const float*)resid, M, D, w, b, eps, o16);
+            KCHECK("layernorm");
+            return BLIM_OK;
+        }
         if (dt == DT_F16) hipLaunchKernelGGL(layernorm_kernel<DT_F16>, ln_grid, dim3(256), 0, s, (const float*)resid, M, D, w, b, eps, o16, o32);
         else hipLaunchKernelGGL(layernorm_kernel<DT_BF16>, ln_grid, dim3(256), 0, s, (const float*)resid, M, D, w, b, eps, o16, o32);
         KCHECK("layernorm");
