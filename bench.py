@@ -345,7 +345,13 @@ def main():
     model.engine.timing_enable(False)
 
     # ---- strong-scaling leg (all ranks): one fixed-size N = 1000 evaluation, after and outside the timed steps above
-    ss = None if a.no_strong else strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk)
+    ss = None
+    if not a.no_strong:
+        try:
+            ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk)
+        except Exception as e:                 # the headline line above is already measured: report the failure inside it instead of losing both
+            import traceback
+            ss = {"error": f"{type(e).__name__}: {e}", "traceback_tail": traceback.format_exc()[-1500:]}
 
     if rank == 0:
         total_pairs = n_pairs * a.steps * world
