@@ -145,6 +145,10 @@ def main(args):
         tokenizer = load_tokenizer(args.model_path)
         dims = dims_from_config(args.model_path, args.num_clips)
         cfg_json = json.load(open(os.path.join(args.model_path, "config.json")))
+        if cfg_json.get("tokenizer_padding_side", "right") != "right":
+            # modeling_videochat_flash.py:472-485: with "left" the reference left-pads the spliced rows and the decoder then numbers positions from the
+            # pad (retrieval_utils.py:93 passes no position_ids), so a row's score depends on its batch neighbours; only the default is built
+            raise NotImplementedError(f"config.tokenizer_padding_side = {cfg_json['tokenizer_padding_side']!r}: only 'right' (the reference's default) is supported")
         model = BlimModel(dims, dtype=args.dtype, tokenizer_model_max_length=cfg_json.get("tokenizer_model_max_length"))   # modeling_videochat_flash.py:452
         # evaluation merges the resume file's adapters at load time; training keeps the base weights pristine (the trainer owns the adapters)
         report = load_checkpoint(model.engine, dims, args.model_path, (args.resume or None) if args.eval else None, lora_r=args.lora_r,
