@@ -85,6 +85,13 @@ def dims_from_config(model_path: str, num_clips: int = 4):
     c = json.load(open(os.path.join(model_path, "config.json")))
     if c.get("mm_llm_compress", False):
         raise NotImplementedError("checkpoint enables PyramidDrop token compression (mm_llm_compress): outside the scoring path")
+    # the one splice the scoring path builds (modeling_videochat_flash.py:209-243): video backbone features, 'spatial_*pad*' merge with no newline
+    # token -> VTG rows take the clips' tokens flattened, TVG rows their per-clip mean.  Any other combination changes the rows; refuse it
+    vet, mpt = c.get("vision_encode_type", "image"), c.get("mm_patch_merge_type", "flat")
+    nlp, far = c.get("mm_newline_position", "nothing"), c.get("frame_aspect_ratio", "square")
+    if vet != "video_image" or not (mpt.startswith("spatial") and "pad" in mpt) or nlp != "nothing" or "anyres" in far:
+        raise NotImplementedError(f"checkpoint config outside the scoring path's splice: vision_encode_type={vet!r} (need 'video_image'), mm_patch_merge_type={mpt!r} "
+                                  f"(need 'spatial_*pad*'), mm_newline_position={nlp!r} (need 'nothing'), frame_aspect_ratio={far!r} (no 'anyres')")
     return ModelDims(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"],
                      num_layers=c["num_hidden_layers"], num_heads=c["num_attention_heads"], num_kv_heads=c["num_key_value_heads"],
                      rms_eps=c.get("rms_norm_eps", 1e-6), rope_theta=c.get("rope_theta", 1e6), mm_hidden_size=c.get("mm_hidden_size", 1024),

@@ -368,3 +368,24 @@ def test_chunked_projection_follows_the_order_of_first_use():
     n0 = len(calls)
     sc.plan_tvg(pairs)                                            # second pass: everything cached
     assert len(calls) == n0
+
+
+def test_driver_refuses_checkpoint_configs_outside_the_scoring_splice(tmp_path):
+    """blim_amd.main.dims_from_config: the splice the path builds is the reference's `video_image` / `spatial_*pad*` / no-newline branch
+    (modeling_videochat_flash.py:209-243); token compression and any other merge type change the rows and are refused, not approximated."""
+    import json
+    from blim_amd.main import dims_from_config
+    base = {"vocab_size": 152064, "hidden_size": 3584, "intermediate_size": 18944, "num_hidden_layers": 28, "num_attention_heads": 28, "num_key_value_heads": 4,
+            "vision_encode_type": "video_image", "mm_patch_merge_type": "spatial_nopad", "mm_newline_position": "nothing"}
+
+    def write(**kw):
+        c = dict(base, **kw)
+        json.dump({k: v for k, v in c.items() if v is not None}, open(tmp_path / "config.json", "w"))
+        return str(tmp_path)
+
+    d = dims_from_config(write(), 4)
+    assert (d.hidden_size, d.num_layers, d.num_kv_heads, d.mm_hidden_size, d.num_clips) == (3584, 28, 4, 1024, 4)
+    for bad in (dict(mm_llm_compress=True), dict(vision_encode_type=None), dict(mm_patch_merge_type="flat"), dict(mm_newline_position="one_token"),
+                dict(frame_aspect_ratio="anyres_max_9")):
+        with pytest.raises(NotImplementedError):
+            dims_from_config(write(**bad), 4)

@@ -24,7 +24,9 @@ def _tree(root):
     CK.save_hf_checkpoint(w, ck, shards=2, dtype="bf16")
     json.dump({"vocab_size": dims.vocab_size, "hidden_size": dims.hidden_size, "intermediate_size": dims.intermediate_size,
                "num_hidden_layers": dims.num_layers, "num_attention_heads": dims.num_heads, "num_key_value_heads": dims.num_kv_heads,
-               "rms_norm_eps": 1e-6, "rope_theta": 1e6, "mm_hidden_size": 1024, "mm_llm_compress": False}, open(os.path.join(ck, "config.json"), "w"))
+               "rms_norm_eps": 1e-6, "rope_theta": 1e6, "mm_hidden_size": 1024, "mm_llm_compress": False, "vision_encode_type": "video_image",
+               "mm_patch_merge_type": "spatial_nopad", "mm_newline_position": "nothing", "tokenizer_padding_side": "right", "tokenizer_model_max_length": 32768},
+              open(os.path.join(ck, "config.json"), "w"))
     build_tree(root, "MSRVTT")
     n = len(CAPTIONS)
     rs = np.random.RandomState(0)
