@@ -466,6 +466,32 @@ def test_depth_full_7b_vs_reference_golden(dtype, case, capsys):
     assert max(hid.values()) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, capsys):
+    """Weights reshaped towards a trained checkpoint's statistics (oracle/gen_golden_heavy.py: heavy-tailed norm weights with channels at 8 and 1/16, q / k
+    biases of order one with +-6 outliers, sharper attention, two 'massive' residual channels 20 - 40 x the stream's rms from layer 2 on), 28 layers at
+    H = 1024, the reference in fp32: every fixture before this one had N(0, 0.02^2) weights.  Same score bar, fused and literal paths."""
+    from oracle.gen_golden_heavy import SPEC, heavy_weights
+    g = np.load(os.path.join(GOLD, "heavy.npz"))
+    dims = synth.ModelDims(**SPEC["dims"])
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    try:
+        model.engine.load_weights(heavy_weights(dims, SPEC["wseed"]))
+        prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
+        model.set_tvg_prefix_length(prob.tvg_prefix_length)
+        t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype=dtype, case="heavy")
+        res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in (("fused", False), ("literal", True))}
+    finally:
+        model.engine.close()
+    with capsys.disabled():
+        for tag, w in res.items():
+            print(f"\n[heavy {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers, residual |max| {float(g['resid_absmax_per_layer'].max()):.0f} at rms "
+                  f"{float(g['resid_rms_per_layer'].max()):.1f}: " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
+    for tag, w in res.items():
+        for k, v in w.items():
+            assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
+
+
 def test_benched_step_plan_meets_the_reference_golden(capsys):
     """The batch bench.py times, itself: plan 0 of rank 0 (55 video queries x top-16 texts = 880 pairs, 32,560 packed tokens, real 7B
     configuration, weight seed 0) is built by bench.build_step_plans and run once; `full7b_bench.npz` holds what the REFERENCE's own

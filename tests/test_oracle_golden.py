@@ -185,6 +185,30 @@ def test_oracle_at_depth_28_layers_h1024():
             np.testing.assert_allclose(S[:q], G[:q], rtol=2e-5)
 
 
+def test_oracle_on_heavy_tailed_weights_28_layers():
+    """The restatement under a trained checkpoint's dynamic ranges (oracle/gen_golden_heavy.py: heavy-tailed norm weights, q / k biases of order one,
+    residual channels at 1,190 against an rms of 17) against what the reference computed on the same weights: one VTG row and one TVG-prior row."""
+    from oracle.gen_golden_heavy import SPEC, heavy_weights
+    g = np.load(os.path.join(GOLD, "heavy.npz"))
+    assert float(g["resid_absmax_per_layer"].max()) > 1000 and float(g["resid_rms_per_layer"].max()) < 20
+    dims = synth.ModelDims(**SPEC["dims"])
+    m = O.OracleModel(O.OracleConfig(**SPEC["dims"]), heavy_weights(dims, SPEC["wseed"]))
+    prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
+    m.set_tvg_prefix_length(prob.tvg_prefix_length)
+    vtg = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+    tvg = O.padding_ids(prob.tvg_ids, prob.tvg_labels, prob.tvg_masks, synth.PAD_ID)
+    n = SPEC["n"]
+    for name, direction, ftype, cpn in (("v2t_vtg", "v2t", "vtg", False), ("t2v_tvg_cpn", "t2v", "tvg", True)):
+        ids, lab, msk = vtg if ftype == "vtg" else tvg
+        fn = O.compute_v2t_scores_x if direction == "v2t" else O.compute_t2v_scores_x
+        sims = (prob.v2t_sims if direction == "v2t" else prob.t2v_sims)[:1]
+        S = fn(np.full((n, n), -100.0, dtype=np.float32), sims, 0, ids, msk, lab, prob.video, prob.video_vocab, prob.tvg_video_labels, m,
+               SPEC["topk"], SPEC["bs"], dims.num_clips, ftype, cpn)
+        G = g[f"S_{name}"]
+        assert np.array_equal(S[:1] == -100.0, G[:1] == -100.0)
+        np.testing.assert_allclose(S[:1], G[:1], rtol=5e-5, err_msg=name)
+
+
 def test_torch_port_of_the_layer_agrees_with_the_numpy_oracle(tiny):
     """oracle/torch_port.py (the threaded CPU statement bench.py times) == oracle/blim_oracle.py on one layer + the LSE head."""
     import torch
