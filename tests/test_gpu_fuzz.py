@@ -1,7 +1,7 @@
 """GPU (-m gpu): seeded random problem shapes through the fused PairScorer AND the literal reference-shaped API, each compared
 entry by entry with the numpy oracle's restatement of compute_*_scores_x (oracle/blim_oracle.py; itself pinned to the reference
 by tests/golden).  Covers the ragged edge cases the golden fixtures do not: a single video/text, top-k larger than N, one-token
-captions, one token per clip, batch size 1, headline-shaped rows without a prompt."""
+captions, one token per clip, batch size 1, headline-shaped rows without a prompt, paragraph-length captions."""
 import types
 
 import numpy as np
@@ -26,14 +26,15 @@ CASES = [(101, 1, 8, (3, 6), 4, 3, True),        # one video, one text; top-k > 
          (107, 3, 40, (33, 70), 3, 2, True),     # captions across the 32- and 64-token query-block boundaries, 160-token video prefix
          (108, 2, 64, (60, 64), 2, 2, True),     # reference-sized rows: 256 video tokens
          (109, 9, 4, (1, 33), 9, 4, True),       # dense: every candidate of every query
-         (110, 4, 8, (31, 33), 4, 3, False)]     # headline-shaped, suffixes straddling one query block
+         (110, 4, 8, (31, 33), 4, 3, False),     # headline-shaped, suffixes straddling one query block
+         (111, 2, 64, (250, 420), 2, 1, True)]   # paragraph-length captions (DiDeMo / ActivityNet rows of ~700 tokens): bodies of many query blocks and key tiles
 
 
 @pytest.fixture(scope="module")
 def models():
     dims = synth.ModelDims(**D)
     w = synth.synthetic_weights(dims, 9)
-    model = BlimModel(dims, max_positions=512, dtype="f16")
+    model = BlimModel(dims, max_positions=1024, dtype="f16")
     model.engine.load_weights(w)
     om = O.OracleModel(O.OracleConfig(**D), w)
     yield dims, model, om
