@@ -87,6 +87,23 @@ def test_random_shapes_fused_and_literal_vs_oracle(models, seed, n, tpc, tl, top
         np.testing.assert_allclose(L[m], want[m], rtol=1e-3, err_msg=f"literal {direction} {ft} cpn={cpn}")
 
 
+@pytest.mark.parametrize("clips", [1, 2, 8])
+def test_num_clips_other_than_four(clips):
+    """args.num_clips (retrieval_utils.py:99: positions p + arange(C) - (C + 1)) is 4 in every golden fixture; the engine, the planner's merged TVG sequences
+    (C - 1 tokens per segment) and the oracle follow the general rule -- one, two and eight clips per video, fused and literal against the oracle."""
+    D2 = dict(D, num_clips=clips)
+    dims = synth.ModelDims(**D2)
+    w = synth.synthetic_weights(dims, 9)
+    model = BlimModel(dims, max_positions=512, dtype="f16")
+    try:
+        model.engine.load_weights(w)
+        om = O.OracleModel(O.OracleConfig(**D2), w)
+        for case in [(301, 5, 8, (3, 12), 4, 3, True), (302, 3, 5, (4, 9), 3, 2, False)]:
+            test_random_shapes_fused_and_literal_vs_oracle((dims, model, om), *case)
+    finally:
+        model.engine.close()
+
+
 @pytest.mark.parametrize("n,topk,bs", [(48, 48, 16), (36, 32, 16)], ids=["dense-48", "top32-of-36"])
 def test_evaluation_dense_and_top32_vs_oracle(models, n, topk, bs):
     """BASELINE configs 3 / 4 in miniature: evaluation() with dense candidates (k = N = 48) and with top-32 + CPN, all six matrices
