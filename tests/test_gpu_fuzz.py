@@ -87,6 +87,22 @@ def test_random_shapes_fused_and_literal_vs_oracle(models, seed, n, tpc, tl, top
         np.testing.assert_allclose(L[m], want[m], rtol=1e-3, err_msg=f"literal {direction} {ft} cpn={cpn}")
 
 
+@pytest.mark.parametrize("heads,kv,hidden,inter,dtype", [(2, 2, 256, 512, "f16"), (6, 2, 768, 1280, "f16"), (8, 1, 1024, 768, "bf16"), (3, 3, 384, 640, "bf16")],
+                         ids=["mha-2", "gqa-3to1", "mqa-8to1-bf16", "mha-3-bf16"])
+def test_other_head_groupings_and_widths(heads, kv, hidden, inter, dtype):
+    """The fixtures cover 2:1 (tiny), 4:1 (deep) and 7:1 (7B) query-to-key-value head ratios; the attention kernel is instantiated per ratio and the GEMM
+    tiles meet other edge shapes at other widths: plain multi-head, 3:1, 8:1 (one K/V head), an odd head count; fp16 and the compensated bf16 engine."""
+    D2 = dict(D, num_heads=heads, num_kv_heads=kv, hidden_size=hidden, intermediate_size=inter)
+    dims = synth.ModelDims(**D2)
+    w = synth.synthetic_weights(dims, 9)
+    model = BlimModel(dims, max_positions=512, dtype=dtype)
+    try:
+        model.engine.load_weights(w)
+        test_random_shapes_fused_and_literal_vs_oracle((dims, model, O.OracleModel(O.OracleConfig(**D2), w)), 401, 4, 8, (3, 40), 3, 2, True)
+    finally:
+        model.engine.close()
+
+
 @pytest.mark.parametrize("clips", [1, 2, 8])
 def test_num_clips_other_than_four(clips):
     """args.num_clips (retrieval_utils.py:99: positions p + arange(C) - (C + 1)) is 4 in every golden fixture; the engine, the planner's merged TVG sequences
