@@ -466,7 +466,7 @@ def test_depth_full_7b_vs_reference_golden(dtype, case, capsys):
     assert max(hid.values()) < 2e-2
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", DTYPES + ["f8"])
 def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, capsys):
     """Weights reshaped towards a trained checkpoint's statistics (oracle/gen_golden_heavy.py: heavy-tailed norm weights with channels at 8 and 1/16, q / k
     biases of order one with +-6 outliers, sharper attention, two 'massive' residual channels 20 - 40 x the stream's rms from layer 2 on), 28 layers at
@@ -480,7 +480,7 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, capsys):
         prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
         model.set_tvg_prefix_length(prob.tvg_prefix_length)
         t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype=dtype, case="heavy")
-        res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in (("fused", False), ("literal", True))}
+        res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in ((("fused", False), ("literal", True)) if dtype != "f8" else (("fused", False),))}
     finally:
         model.engine.close()
     with capsys.disabled():
@@ -489,7 +489,10 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, capsys):
                   f"{float(g['resid_rms_per_layer'].max()):.1f}: " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
     for tag, w in res.items():
         for k, v in w.items():
-            assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
+            if dtype == "f8":      # reported, non-parity mode: the outliers must not make it WORSE than on N(0, 0.02^2) weights (same bounds as test_depth_fp8_mode_deltas_*)
+                assert v < (0.18 if "tvg" in k else 0.08), (dtype, tag, k, v)
+            else:
+                assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
 
 
 def test_benched_step_plan_meets_the_reference_golden(capsys):
