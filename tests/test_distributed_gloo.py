@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -141,6 +142,29 @@ def test_evaluation_world2_equals_single_process_and_shards_the_prior_over_texts
     assert ("vtg", True, n) in ref_calls                               # single process: the prior of every text, once
     # pooled pairs: one VTG call and one TVG call over the union of both directions' pairs (41 of 2 x 33 requests here)
     assert [c[:2] for c in ref_calls] == [("vtg", False), ("tvg", False), ("vtg", True), ("tvg", True)] and ref_calls[0][2] == ref_calls[1][2] < 2 * n * 3
+
+
+@pytest.mark.parametrize("n,world", [(11, 8), (19, 4)], ids=["11-items-8-ranks", "19-items-4-ranks"])
+def test_evaluation_with_more_ranks_than_the_row_blocks_fill(n, world):
+    """step = N // W + 1 (retrieval_utils.py:213-215) leaves the last ranks short or EMPTY (N = 11, W = 8: blocks of 2 2 2 2 2 1 0 0 rows): every rank still
+    joins every collective and ends with the single-process matrices, bit for bit."""
+    ref_t2v, ref_v2t, _ = _run_eval(n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, t2v, v2t, calls in res:
+        for k in ref_t2v:
+            assert np.array_equal(t2v[k], ref_t2v[k]), ("t2v", k, rank)
+        for k in ref_v2t:
+            assert np.array_equal(v2t[k], ref_v2t[k]), ("v2t", k, rank)
 
 
 def _run_eval_with(n, **kw):
