@@ -97,8 +97,17 @@ class BlimModel:
     def forward_visual(self, visual_token_embeds):               # modeling_videochat_flash.py:598-599
         import torch
         shp = visual_token_embeds.shape
-        x = visual_token_embeds.reshape(-1, shp[-1]).to(self.dtype).contiguous()
-        return self.engine.visual_head(x).float().reshape(*shp[:-1], self.dims.mm_hidden_size)
+        x = visual_token_embeds.reshape(-1, shp[-1])
+        if x.dtype == torch.float32 and self.engine.can_precise:
+            # the literal API hands the final hidden states over as float32: keep their bits through the head as hi + lo 16-bit operands (two passes of a
+            # [B * clips, H] x [H, mm_hidden] product) -- a plain 16-bit cast here was the largest error of the literal TVG scores on weights with a trained
+            # checkpoint's dynamic ranges (heavy7b: 1.0e-3 fp16 / 1.2e-3 bf16 on the TVG prior)
+            hi = x.to(self.dtype)
+            lo = (x - hi.float()).to(self.dtype)
+            out = self.engine.visual_head(hi.contiguous()).float() + self.engine.visual_head(lo.contiguous()).float()
+        else:
+            out = self.engine.visual_head(x.to(self.dtype).contiguous()).float()
+        return out.reshape(*shp[:-1], self.dims.mm_hidden_size)
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images,
                                              modalities=["image"], image_sizes=None, video_feature=False, tvg=False, cpn=False):
@@ -115,7 +124,9 @@ class BlimModel:
         # bf16 engines (8-bit mantissas): the spliced embeddings are formed as hi + lo in the compensated mode and handed out as ONE float32 [B, L, H]
         # tensor (the reference hands its model dtype; a bf16 tensor here would by itself put ~1e-3 on the scores at 7B depth); forward() splits it again.
         # fp16 engines keep the reference's 16-bit [B, L, H] contract.
-        wide = self.engine.dtype == "bf16" and self.engine.can_precise
+        # TVG rows on fp16 engines likewise: their forward runs compensated, and the clip tokens (means of projected features) rounded to fp16 alone left 1.0e-3 on
+        # the literal TVG scores of heavy7b.npz; VTG rows on fp16 engines keep the 16-bit tensor (plain forward).
+        wide = self.engine.can_precise and (self.engine.dtype == "bf16" or bool(tvg))
         if wide:
             self.engine.set_precise(True, embeds=True)
         try:
@@ -188,8 +199,8 @@ class BlimModel:
         if position_ids is not None or past_key_values is not None or labels is not None or use_cache or output_attentions or dpo_forward:
             raise NotImplementedError("forward(): position_ids / cache / labels / attentions are outside the scoring path")
         B, L, _ = inputs_embeds.shape
-        wide = inputs_embeds.dtype == torch.float32 and self.engine.dtype == "bf16" and self.engine.can_precise
-        if wide:                                                          # float32 embeddings of prepare_inputs_labels_for_multimodal on a bf16 engine: back to [hi | lo]
+        wide = inputs_embeds.dtype == torch.float32 and self.engine.can_precise and (self.engine.dtype == "bf16" or self._tvg_rows)
+        if wide:                                                          # float32 embeddings of prepare_inputs_labels_for_multimodal (bf16 engines; TVG rows on fp16 ones): back to [hi | lo]
             hi = inputs_embeds.to(self.dtype)
             emb = torch.cat([hi, (inputs_embeds - hi.float()).to(self.dtype)], dim=-1).contiguous()
         else:

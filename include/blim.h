@@ -192,7 +192,8 @@ int blim_debug_gemm_stamps(void* device_buf);
  * "precise_mlp" (0/1, default 1): 0 leaves the MLP branch plain in precise mode (TVG calls 1.6x faster; TVG deviation at 7B depth
  *   8e-4 instead of 4e-5: tests/test_gpu_parity.py::test_depth_* with BLIM_PRECISE_MLP=0);
  * "precise_act" (0/1, default 1): 0 leaves the SwiGLU output / down-proj input plain in precise mode (the down GEMM walks K once: a compensated layer costs
- *   1.71x instead of 2x a plain one); the Python host sets 0 on fp16 engines (TVG 2.5e-4 instead of 3.7e-5 at 7B depth) and 1 on bf16 engines (2e-3 without);
+ *   1.71x instead of 2x a plain one).  Leave it on: with 0 the TVG scores are 2.5e-4 instead of 3.7e-5 off at 7B depth on Gaussian weights, but 2.5e-3 on weights with a
+ *   trained checkpoint's dynamic ranges (tests/golden/heavy7b.npz); bf16 engines lose 2e-3 without it on any weights;
  * "prune_last" (0/1, default 1): calls that name the rows they read (blim_decode with out_rows, blim_score_*) run the LAST layer's o_proj / norm / MLP
  *   on those rows only (same values bit for bit; the other rows' K / V are still produced); after such a call the "resid" / "attn" / "act" workspaces of
  *   blim_debug_read hold the last layer's state of the live rows only -- bring-up code reads them after calls without out_rows, or sets 0;

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- generates tests/golden/heavy.npz by running the REFERENCE's own code.
 
-Run in the build container only (needs /root/reference):  python -m oracle.gen_golden_heavy
+Run in the build container only (needs /root/reference):  python -m oracle.gen_golden_heavy [--case heavy|heavy7b]
 
 Every other fixture uses N(0, 0.02^2) weights (initializer_range).  Trained decoders do not look like that: norm weights are
 heavy-tailed, Qwen2's q / k biases are of order one, and a few residual channels carry 'massive' activations from an early layer
@@ -26,52 +26,81 @@ from blim_amd import synth  # noqa: E402
 
 SPEC = dict(dims=dict(vocab_size=152064, hidden_size=1024, intermediate_size=2816, num_layers=28, num_heads=8, num_kv_heads=2, mm_hidden_size=256),
             wseed=14, pseed=15, n=8, tok_per_clip=16, text_len=(4, 24), topk=4, bs=3)
+# the same reshaping on the REAL 7B configuration (the `full7b` problem: 2 query rows x top-4 per pass kind; fp32 reference = 30.5 GB of weights, streamed)
+SPEC7B = dict(dims=dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28, num_kv_heads=4, mm_hidden_size=1024),
+              wseed=0, pseed=9, n=6, tok_per_clip=6, text_len=(4, 10), topk=4, bs=3, queries=2)
+CASES = {"heavy": SPEC, "heavy7b": SPEC7B}
 MASSIVE_LAYER, MASSIVE_CHANNELS, MASSIVE_GAIN = 2, (37, 611), 1000.0
 
 
-def heavy_weights(dims, seed: int):
-    """synth.synthetic_weights(dims, seed) reshaped towards a trained checkpoint's statistics (all values stay bf16-representable):
+def _changed(name: str) -> bool:
+    return (name.endswith("_norm") or name.endswith("q_proj.b") or name.endswith("k_proj.b") or name.endswith("q_proj.w") or name.endswith("k_proj.w")
+            or name == f"layers.{MASSIVE_LAYER}.down_proj.w")
+
+
+def _reshape(name: str, base, shape, rs, H: int):
+    """One tensor of the rule below; `base` = the seeded tensor (a callable, evaluated only where the rule needs it).  Draws from `rs` in tensor order."""
+    if name.endswith("_norm"):
+        g = np.exp(rs.randn(H).astype(np.float32) * 0.4)
+        idx = rs.choice(H, 6, replace=False)
+        g[idx[:3]] = 8.0; g[idx[3:]] = 0.0625
+        return synth.bf16_round(g.astype(np.float32))
+    if name.endswith("q_proj.b") or name.endswith("k_proj.b"):
+        b = rs.randn(shape[0]).astype(np.float32) * 0.5
+        idx = rs.choice(shape[0], 4, replace=False)
+        b[idx] = np.array([6.0, -6.0, 6.0, -6.0], np.float32)
+        return synth.bf16_round(b)
+    if name.endswith("q_proj.w") or name.endswith("k_proj.w"):
+        return synth.bf16_round(base() * np.float32(1.5))
+    if name == f"layers.{MASSIVE_LAYER}.down_proj.w":
+        a = base().copy()
+        a[list(MASSIVE_CHANNELS)] *= np.float32(MASSIVE_GAIN)
+        return synth.bf16_round(a)
+    return base()
+
+
+def heavy_items(dims, seed: int, only_changed: bool = False):
+    """(name, tensor) of synth.synthetic_weights(dims, seed) reshaped towards a trained checkpoint's statistics, one tensor at a time (all values stay
+    bf16-representable):
     * every RMSNorm weight: exp(N(0, 0.4^2)) per channel, three channels at 8 and three at 1/16;
     * q / k biases ~ N(0, 0.5^2) with four entries at +-6 per layer, q / k weights x 1.5 (sharper attention);
-    * layer MASSIVE_LAYER's down_proj rows MASSIVE_CHANNELS x MASSIVE_GAIN: two residual channels carry activations one to two orders
-      above the rest from that layer on."""
-    w = synth.synthetic_weights(dims, seed)
+    * layer MASSIVE_LAYER's down_proj rows MASSIVE_CHANNELS x MASSIVE_GAIN: two residual channels carry activations far above the rest from that layer on.
+    only_changed = True yields just the tensors the rule touches (a GPU test fills the rest on device from the same seed)."""
+    from oracle.gen_golden import fast_tensor
     rs = np.random.RandomState(seed)
-    H = dims.hidden_size
-    for name in list(w):
-        a = w[name]
-        if name.endswith("_norm"):
-            g = np.exp(rs.randn(H).astype(np.float32) * 0.4)
-            idx = rs.choice(H, 6, replace=False)
-            g[idx[:3]] = 8.0; g[idx[3:]] = 0.0625
-            w[name] = synth.bf16_round(g.astype(np.float32))
-        elif name.endswith("q_proj.b") or name.endswith("k_proj.b"):
-            b = rs.randn(a.shape[0]).astype(np.float32) * 0.5
-            idx = rs.choice(a.shape[0], 4, replace=False)
-            b[idx] = np.array([6.0, -6.0, 6.0, -6.0], np.float32)
-            w[name] = synth.bf16_round(b)
-        elif name.endswith("q_proj.w") or name.endswith("k_proj.w"):
-            w[name] = synth.bf16_round(a * np.float32(1.5))
-        elif name == f"layers.{MASSIVE_LAYER}.down_proj.w":
-            a = a.copy()
-            a[list(MASSIVE_CHANNELS)] *= np.float32(MASSIVE_GAIN)
-            w[name] = synth.bf16_round(a)
-    return w
+    for name, shape in synth.weight_shapes(dims).items():
+        if only_changed and not _changed(name):
+            continue
+        yield name, _reshape(name, lambda: fast_tensor(seed, name, shape, *synth.weight_dist(name)), shape, rs, dims.hidden_size)
 
 
-def main(out_dir: str) -> None:
+def heavy_weights(dims, seed: int):
+    return dict(heavy_items(dims, seed))
+
+
+class _Lazy:
+    def __init__(self, dims, seed):
+        self.dims, self.seed = dims, seed
+
+    def items(self):
+        return heavy_items(self.dims, self.seed)
+
+
+def main(out_dir: str, case: str = "heavy") -> None:
     import torch
     from oracle import gen_golden as G
     from oracle import ref_harness
     from oracle.blim_oracle import OracleConfig
     torch.set_num_threads(8)
+    SPEC = CASES[case]
     dims = synth.ModelDims(**SPEC["dims"])
     t0 = time.time()
-    weights = heavy_weights(dims, SPEC["wseed"])
+    weights = _Lazy(dims, SPEC["wseed"])
     prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
     ns = ref_harness.load()
     model = ref_harness.build_model(OracleConfig(**SPEC["dims"]), weights)
-    print(f"[heavy] weights + reference model built in {time.time() - t0:.1f}s", flush=True)
+    del weights
+    print(f"[{case}] weights + reference model built in {time.time() - t0:.1f}s", flush=True)
     model.set_tvg_prefix_length(prob.tvg_prefix_length)
     out = {}
     # residual-stream statistics of one VTG row, for the record (how 'massive' the massive channels are)
@@ -88,20 +117,21 @@ def main(out_dir: str) -> None:
             h.remove()
         out["resid_absmax_per_layer"] = np.array([float(h.abs().max()) for h in hs], np.float32)
         out["resid_rms_per_layer"] = np.array([float(h.pow(2).mean().sqrt()) for h in hs], np.float32)
-    print("[heavy] residual |max| per layer:", np.round(out["resid_absmax_per_layer"], 1).tolist(), flush=True)
-    print("[heavy] residual rms per layer:", np.round(out["resid_rms_per_layer"], 2).tolist(), flush=True)
-    G.run_passes(out, "S_", ns.RU, ref_harness.DDPish(model), torch.device("cpu"), prob, SPEC, dims, list(G.PASS_KINDS), "heavy")
-    out["meta_case"] = np.array("heavy")
-    path = os.path.join(out_dir, "heavy.npz")
+    print(f"[{case}] residual |max| per layer:", np.round(out["resid_absmax_per_layer"], 1).tolist(), flush=True)
+    print(f"[{case}] residual rms per layer:", np.round(out["resid_rms_per_layer"], 2).tolist(), flush=True)
+    G.run_passes(out, "S_", ns.RU, ref_harness.DDPish(model), torch.device("cpu"), prob, SPEC, dims, list(G.PASS_KINDS), case)
+    out["meta_case"] = np.array(case)
+    path = os.path.join(out_dir, f"{case}.npz")
     np.savez_compressed(path, **out)
-    print(f"[heavy] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)", flush=True)
+    print(f"[{case}] wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)", flush=True)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--case", default="heavy", choices=sorted(CASES))
     a = ap.parse_args()
     from oracle import ref_harness
     if not ref_harness.available():
         sys.exit("reference not present; fixtures can only be generated in the build container")
-    main(a.out)
+    main(a.out, a.case)

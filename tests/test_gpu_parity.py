@@ -495,6 +495,36 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, capsys):
                 assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_heavy_tailed_weights_full_7b_vs_reference_golden(dtype, capsys):
+    """The same reshaping on the REAL Qwen2-7B configuration, all 28 layers (oracle/gen_golden_heavy.py --case heavy7b: the reference in fp32, 30.5 GB of weights).
+    The engine fills its weights on device from the seed and takes the reshaped tensors (norms, q / k biases and weights, layer 2's down_proj) from the host."""
+    from oracle.gen_golden_heavy import SPEC7B, heavy_items
+    path = os.path.join(GOLD, "heavy7b.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/heavy7b.npz not generated")
+    g = np.load(path)
+    dims = synth.ModelDims(**SPEC7B["dims"])
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    try:
+        model.engine.init_synthetic_weights(SPEC7B["wseed"])
+        for name, arr in heavy_items(dims, SPEC7B["wseed"], only_changed=True):
+            model.engine.load_weight(name, arr)
+        prob = synth.make_problem(SPEC7B["pseed"], SPEC7B["n"], dims, tok_per_clip=SPEC7B["tok_per_clip"], text_len=SPEC7B["text_len"])
+        model.set_tvg_prefix_length(prob.tvg_prefix_length)
+        t = types.SimpleNamespace(spec=SPEC7B, dims=dims, model=model, prob=prob, dtype=dtype, case="heavy7b")
+        res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in (("fused", False), ("literal", True))}
+    finally:
+        model.engine.close()
+    with capsys.disabled():
+        for tag, w in res.items():
+            print(f"\n[heavy7b {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers of the 7B configuration, residual |max| "
+                  f"{float(g['resid_absmax_per_layer'].max()):.0f} at rms {float(g['resid_rms_per_layer'].max()):.1f}: " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
+    for tag, w in res.items():
+        for k, v in w.items():
+            assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
+
+
 def test_benched_step_plan_meets_the_reference_golden(capsys):
     """The batch bench.py times, itself: plan 0 of rank 0 (55 video queries x top-16 texts = 880 pairs, 32,560 packed tokens, real 7B
     configuration, weight seed 0) is built by bench.build_step_plans and run once; `full7b_bench.npz` holds what the REFERENCE's own
