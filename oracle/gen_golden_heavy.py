@@ -29,17 +29,26 @@ SPEC = dict(dims=dict(vocab_size=152064, hidden_size=1024, intermediate_size=281
 # the same reshaping on the REAL 7B configuration (the `full7b` problem: 2 query rows x top-4 per pass kind; fp32 reference = 30.5 GB of weights, streamed)
 SPEC7B = dict(dims=dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28, num_kv_heads=4, mm_hidden_size=1024),
               wseed=0, pseed=9, n=6, tok_per_clip=6, text_len=(4, 10), topk=4, bs=3, queries=2)
-CASES = {"heavy": SPEC, "heavy7b": SPEC7B}
+# `sink`: the heavy rule plus delimiter tokens whose EMBEDDINGS carry two channels at +-250 (<|im_start|>, which opens every row and every turn) / 120 ("\n"):
+# massive activations on specific positions only, which the sharpened attention then uses as sinks -- the pattern trained decoders show on their first token
+SPEC_SINK = dict(SPEC, sink=True)
+CASES = {"heavy": SPEC, "heavy7b": SPEC7B, "sink": SPEC_SINK}
+SINK_ROWS = ((151644, (5, 900), (250.0, -250.0)), (198, (5,), (120.0,)))
 MASSIVE_LAYER, MASSIVE_CHANNELS, MASSIVE_GAIN = 2, (37, 611), 1000.0
 
 
-def _changed(name: str) -> bool:
-    return (name.endswith("_norm") or name.endswith("q_proj.b") or name.endswith("k_proj.b") or name.endswith("q_proj.w") or name.endswith("k_proj.w")
+def _changed(name: str, sink: bool = False) -> bool:
+    return ((sink and name == "embed_tokens") or name.endswith("_norm") or name.endswith("q_proj.b") or name.endswith("k_proj.b") or name.endswith("q_proj.w") or name.endswith("k_proj.w")
             or name == f"layers.{MASSIVE_LAYER}.down_proj.w")
 
 
-def _reshape(name: str, base, shape, rs, H: int):
+def _reshape(name: str, base, shape, rs, H: int, sink: bool = False):
     """One tensor of the rule below; `base` = the seeded tensor (a callable, evaluated only where the rule needs it).  Draws from `rs` in tensor order."""
+    if sink and name == "embed_tokens":
+        a = base().copy()
+        for tok, chans, vals in SINK_ROWS:
+            a[tok, [c % H for c in chans]] = np.array(vals, np.float32)
+        return a
     if name.endswith("_norm"):
         g = np.exp(rs.randn(H).astype(np.float32) * 0.4)
         idx = rs.choice(H, 6, replace=False)
@@ -59,7 +68,7 @@ def _reshape(name: str, base, shape, rs, H: int):
     return base()
 
 
-def heavy_items(dims, seed: int, only_changed: bool = False):
+def heavy_items(dims, seed: int, only_changed: bool = False, sink: bool = False):
     """(name, tensor) of synth.synthetic_weights(dims, seed) reshaped towards a trained checkpoint's statistics, one tensor at a time (all values stay
     bf16-representable):
     * every RMSNorm weight: exp(N(0, 0.4^2)) per channel, three channels at 8 and three at 1/16;
@@ -69,21 +78,21 @@ def heavy_items(dims, seed: int, only_changed: bool = False):
     from oracle.gen_golden import fast_tensor
     rs = np.random.RandomState(seed)
     for name, shape in synth.weight_shapes(dims).items():
-        if only_changed and not _changed(name):
+        if only_changed and not _changed(name, sink):
             continue
-        yield name, _reshape(name, lambda: fast_tensor(seed, name, shape, *synth.weight_dist(name)), shape, rs, dims.hidden_size)
+        yield name, _reshape(name, lambda: fast_tensor(seed, name, shape, *synth.weight_dist(name)), shape, rs, dims.hidden_size, sink)
 
 
-def heavy_weights(dims, seed: int):
-    return dict(heavy_items(dims, seed))
+def heavy_weights(dims, seed: int, sink: bool = False):
+    return dict(heavy_items(dims, seed, sink=sink))
 
 
 class _Lazy:
-    def __init__(self, dims, seed):
-        self.dims, self.seed = dims, seed
+    def __init__(self, dims, seed, sink=False):
+        self.dims, self.seed, self.sink = dims, seed, sink
 
     def items(self):
-        return heavy_items(self.dims, self.seed)
+        return heavy_items(self.dims, self.seed, sink=self.sink)
 
 
 def main(out_dir: str, case: str = "heavy") -> None:
@@ -95,7 +104,7 @@ def main(out_dir: str, case: str = "heavy") -> None:
     SPEC = CASES[case]
     dims = synth.ModelDims(**SPEC["dims"])
     t0 = time.time()
-    weights = _Lazy(dims, SPEC["wseed"])
+    weights = _Lazy(dims, SPEC["wseed"], SPEC.get("sink", False))
     prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
     ns = ref_harness.load()
     model = ref_harness.build_model(OracleConfig(**SPEC["dims"]), weights)
@@ -120,6 +129,30 @@ def main(out_dir: str, case: str = "heavy") -> None:
     print(f"[{case}] residual |max| per layer:", np.round(out["resid_absmax_per_layer"], 1).tolist(), flush=True)
     print(f"[{case}] residual rms per layer:", np.round(out["resid_rms_per_layer"], 2).tolist(), flush=True)
     G.run_passes(out, "S_", ns.RU, ref_harness.DDPish(model), torch.device("cpu"), prob, SPEC, dims, list(G.PASS_KINDS), case)
+    if SPEC["dims"]["hidden_size"] <= 1024:
+        # the reference's PRODUCTION numerics on the same weights: `.half()` (main.py:97), here literally on CPU -- how far its own fp16 run is from its fp32
+        # run is the yardstick for the engine's plain fp16 mode on these statistics (keys H16_*; non-finite entries stored as 0 with a mask)
+        model = model.half()
+        ddp = ref_harness.DDPish(model)
+        vtg = ns.RU.padding_ids([T(x) for x in prob.vtg_ids], [T(x) for x in prob.vtg_labels], [T(x) for x in prob.vtg_masks], tok)
+        tvg = ns.RU.padding_ids([T(x) for x in prob.tvg_ids], [T(x) for x in prob.tvg_labels], [T(x) for x in prob.tvg_masks], tok)
+        video = [T(v).half() for v in prob.video]
+        vocab, vlab = T(prob.video_vocab).half(), T(prob.tvg_video_labels)
+        args = types.SimpleNamespace(topk=SPEC["topk"], batch_size_eval=SPEC["bs"], num_clips=dims.num_clips)
+        n = SPEC["n"]
+        with torch.no_grad():
+            for pname in G.PASS_KINDS:
+                qv, ftype, cpn = G.PASS_KINDS[pname]
+                fn = ns.RU.compute_v2t_scores_x if qv else ns.RU.compute_t2v_scores_x
+                ids, lab, msk = vtg if ftype == "vtg" else tvg
+                t1 = time.time()
+                S = fn(torch.full((n, n), -100.0), T(prob.v2t_sims if qv else prob.t2v_sims), 0, ids, msk, lab, video, vocab, vlab, ddp, torch.device("cpu"), args,
+                       forward_type=ftype, cpn=cpn).float().numpy()
+                bad = ~np.isfinite(S)
+                out[f"H16_{pname}"] = np.where(bad, np.float32(0), S); out[f"H16_{pname}_nonfinite"] = bad
+                m = (out[f"S_{pname}"] != -100.0) & ~bad
+                dev = float((np.abs(S[m] - out[f"S_{pname}"][m]) / np.abs(out[f"S_{pname}"][m])).max()) if m.any() else float("nan")
+                print(f"[{case}] reference .half() pass {pname}: {time.time() - t1:.1f}s, non-finite {int(bad.sum())}, worst deviation from its own fp32 run {dev:.2e}", flush=True)
     out["meta_case"] = np.array(case)
     path = os.path.join(out_dir, f"{case}.npz")
     np.savez_compressed(path, **out)

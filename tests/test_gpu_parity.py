@@ -466,33 +466,61 @@ def test_depth_full_7b_vs_reference_golden(dtype, case, capsys):
     assert max(hid.values()) < 2e-2
 
 
+@pytest.mark.parametrize("case", ["heavy", "sink"])
 @pytest.mark.parametrize("dtype", DTYPES + ["f8"])
-def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, capsys):
+def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys):
     """Weights reshaped towards a trained checkpoint's statistics (oracle/gen_golden_heavy.py: heavy-tailed norm weights with channels at 8 and 1/16, q / k
     biases of order one with +-6 outliers, sharper attention, two 'massive' residual channels 20 - 40 x the stream's rms from layer 2 on), 28 layers at
     H = 1024, the reference in fp32: every fixture before this one had N(0, 0.02^2) weights.  Same score bar, fused and literal paths."""
-    from oracle.gen_golden_heavy import SPEC, heavy_weights
-    g = np.load(os.path.join(GOLD, "heavy.npz"))
+    from oracle.gen_golden_heavy import CASES as HEAVY_CASES, heavy_weights
+    SPEC = HEAVY_CASES[case]      # `sink`: additionally, delimiter tokens whose embeddings carry +-250 in two channels (position-specific massive activations, attention sinks)
+    g = np.load(os.path.join(GOLD, f"{case}.npz"))
     dims = synth.ModelDims(**SPEC["dims"])
     model = BlimModel(dims, max_positions=1024, dtype=dtype)
     try:
-        model.engine.load_weights(heavy_weights(dims, SPEC["wseed"]))
+        model.engine.load_weights(heavy_weights(dims, SPEC["wseed"], sink=SPEC.get("sink", False)))
         prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
         model.set_tvg_prefix_length(prob.tvg_prefix_length)
-        t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype=dtype, case="heavy")
+        t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype=dtype, case=case)
         res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in ((("fused", False), ("literal", True)) if dtype != "f8" else (("fused", False),))}
     finally:
         model.engine.close()
     with capsys.disabled():
         for tag, w in res.items():
-            print(f"\n[heavy {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers, residual |max| {float(g['resid_absmax_per_layer'].max()):.0f} at rms "
+            print(f"\n[{case} {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers, residual |max| {float(g['resid_absmax_per_layer'].max()):.0f} at rms "
                   f"{float(g['resid_rms_per_layer'].max()):.1f}: " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
+    # the reference's OWN .half() run (main.py:97) against its fp32 run on these weights: the yardstick for a plain 16-bit mode (keys H16_*)
+    own = {}
+    for k in ("v2t_vtg", "t2v_vtg"):
+        if f"H16_{k}" in g.files:
+            m = (g[f"S_{k}"] != -100.0) & ~g[f"H16_{k}_nonfinite"]
+            own[k] = float((np.abs(g[f"H16_{k}"][m] - g[f"S_{k}"][m]) / np.abs(g[f"S_{k}"][m])).max())
     for tag, w in res.items():
         for k, v in w.items():
             if dtype == "f8":      # reported, non-parity mode: the outliers must not make it WORSE than on N(0, 0.02^2) weights (same bounds as test_depth_fp8_mode_deltas_*)
                 assert v < (0.18 if "tvg" in k else 0.08), (dtype, tag, k, v)
+            elif case == "sink" and dtype == "f16" and k in ("v2t_vtg", "t2v_vtg"):
+                # Plain fp16 VTG calls with massive activations on sink positions: 3.2e-3 -- what 16-bit activations do there; the reference's own fp16 run is 3.7e-3
+                # from its fp32 run on the same weights.  Held to the reference's own spread here, and to the 1e-3 bar in the compensated modes below.
+                assert v < max(SCORE_RTOL, 1.25 * own[k]), (dtype, tag, k, v, own)
             else:
                 assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
+    if case == "sink" and dtype == "f16":
+        # ... and the engine has a mode that holds the bar on such weights without leaving fp16: the attention branch compensated on the VTG calls too
+        # (BlimModel.vtg_precise = "attn" / --vtg_precise attn: -16 % on the headline step), besides the bf16 parity mode above (4.8e-6)
+        model = BlimModel(dims, max_positions=1024, dtype=dtype)
+        try:
+            model.engine.load_weights(heavy_weights(dims, SPEC["wseed"], sink=True))
+            model.set_tvg_prefix_length(prob.tvg_prefix_length)
+            model.vtg_precise = "attn"
+            t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype=dtype, case=case)
+            w = _worst_rel(_six_passes(t, False, names=("v2t_vtg", "t2v_vtg", "v2t_vtg_cpn")), g)
+        finally:
+            model.engine.close()
+        with capsys.disabled():
+            print(f"[sink f16 fused, vtg_precise = attn] " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()) + f"; the reference's own fp16 run vs its fp32 run: " +
+                  ", ".join(f"{k} {v:.2e}" for k, v in own.items()))
+        assert max(w.values()) < SCORE_RTOL, w
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
