@@ -337,7 +337,7 @@ static int finalize_f8(blim_engine* e) {
 // ---------------------------------------------------------------------------- workspaces
 static int reserve_tokens(blim_engine* e, int64_t T) {
     const blim_config& c = e->c;
-    const int64_t Tp = round_up(T, 256) * (e->precise ? 2 : 1);      // precise mode: [hi | lo] rows of twice the width
+    const int64_t Tp = round_up(T, 256) * ((e->precise || e->precise_qk) ? 2 : 1);      // precise modes: [hi | lo] rows of twice the width
     if (e->f8) {
         TRY(ensure(e->x8, (size_t)Tp * c.hidden_size));
         TRY(ensure(e->a8, (size_t)Tp * c.hidden_size));
@@ -475,6 +475,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const bool pm = e->precise && e->precise_mlp;                   // MLP branch (option "precise_mlp")
     const int pfm = pm ? 2 : 1;
     const bool pa = pm && e->precise_act;                           // ... including the SwiGLU output / down-proj input (option "precise_act")
+    const bool pq = !e->precise && e->precise_qk && !e->f8;         // plain mode with hi + lo q / k / v and attention output (option "precise_qk")
+    const int pfq = (e->precise || pq) ? 2 : 1;                     // width factor of the qkv / attention-output rows
     if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
@@ -486,6 +488,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * pf);
             GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise);
+            if (pq) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
         }
@@ -493,10 +496,10 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             SpanGuard g(e, s, TC_ATTN, 0);
             AttnParams a;
             a.dtype = c.compute_dtype;
-            a.qkv = qkv; a.ldq = (int64_t)pf * e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
+            a.qkv = qkv; a.ldq = (int64_t)pfq * e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
-            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * H; a.scale = 0.08838834764831845f;
-            a.v_lo_off = e->precise ? e->qkv_n : 0; a.out_lo_off = e->precise ? H : 0;
+            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pfq * H; a.scale = 0.08838834764831845f;
+            a.v_lo_off = pfq == 2 ? e->qkv_n : 0; a.out_lo_off = pfq == 2 ? H : 0;
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
             if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
@@ -509,12 +512,13 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             float* rl = (float*)e->resid_live.p;
             {
                 SpanGuard g0(e, s, TC_MISC, 0);
-                TRY(launch_gather_rows(attn_live, attn, live_rows, n_live, (int64_t)pf * H * 2, T, 0u, s));
+                TRY(launch_gather_rows(attn_live, attn, live_rows, n_live, (int64_t)pfq * H * 2, T, 0u, s));
                 TRY(launch_gather_rows(rl, resid, live_rows, n_live, (int64_t)H * 4, T, 0x7fc00000u, s));      // a row outside the batch: NaN (poisoned score)
             }
             const double tl = (double)n_live;
             { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * H * H * pf);
-              GemmParams p = gp2(e, attn_live, H, l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; TRY(launch_gemm(EPI_RESID, p, s)); }
+              GemmParams p = gp2(e, attn_live, H, l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * (int64_t)H;   // pq: the hi halves of [hi | lo] rows
+              TRY(launch_gemm(EPI_RESID, p, s)); }
             { SpanGuard g(e, s, TC_NORM, 0);
               TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
@@ -530,6 +534,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0, e->precise);
             if (fuse_o) { p.a_mx = (const uint8_t*)e->attn_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
+            if (pq) p.lda = 2 * (int64_t)H;                               // the hi halves of the attention output's [hi | lo] rows
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         {
@@ -808,6 +813,10 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "prune_last")) { e->prune_last = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_act")) { e->precise_act = value != 0; return BLIM_OK; }
+    if (!strcmp(key, "precise_qk")) {
+        if (value && e->f8) { blim_set_error("option 'precise_qk' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }
+        e->precise_qk = value != 0; return BLIM_OK;
+    }
     if (!strcmp(key, "precise")) {
         if (value && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }
         e->precise = value != 0;

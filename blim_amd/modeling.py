@@ -214,14 +214,19 @@ class BlimModel:
         if self._tvg_rows:
             self.engine.set_precise(True, embeds=wide)
         else:
-            on = self.vtg_precise is not None
+            on = self.vtg_precise in ("attn", "full")
             self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise == "full")
-            if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none): plain embeddings
+            if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none / qk): plain embeddings
                 emb = inputs_embeds.to(self.dtype).contiguous()
+        qk = (not self._tvg_rows) and self.vtg_precise == "qk"           # plain activations, q / k / v and the attention as hi + lo (engine option precise_qk)
+        if qk:
+            self.engine.set_option("precise_qk", 1)
         try:
             logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
         finally:
             self.engine.set_precise(False)
+            if qk:
+                self.engine.set_option("precise_qk", 0)
         return SimpleNamespace(loss=None, logits=logits, past_key_values=None, hidden_states=hidden, attentions=None)
 
     __call__ = forward

@@ -191,7 +191,7 @@ class PairScorer:
         # VTG calls: plain 16-bit on fp16 engines; bf16 engines run them compensated too (modeling.py: vtg_precise), feature rows included --
         # with plain bf16 features the projector's 8-bit rounding alone left 1e-3 on the scores at 7B depth
         self.vtg_mode = getattr(model.module if hasattr(model, "module") else model, "vtg_precise", None) if (eng_ is not None and getattr(eng_, "can_precise", False)) else None
-        self.split_vtg = self.vtg_mode is not None
+        self.split_vtg = self.vtg_mode in ("attn", "full")               # "qk": plain activations, only q / k / v and the attention run as hi + lo (engine option precise_qk)
         self.m = model.module if hasattr(model, "module") else model
         self.engine = self.m.engine
         self.device = self.m.device
@@ -469,13 +469,18 @@ class PairScorer:
     def run(self, plan: Plan):
         """One engine call; returns a device f32 tensor [plan.n_pairs]."""
         if plan.kind == "vtg":
-            mode = self.vtg_mode                                             # None (fp16 engines) | "attn" | "full" (bf16 engines: modeling.py)
-            self.engine.set_precise(mode is not None, embeds=mode is not None, mlp=mode == "full")
+            mode = self.vtg_mode                                             # None (fp16 engines) | "qk" | "attn" | "full" (bf16 engines: modeling.py)
+            comp = mode in ("attn", "full")
+            self.engine.set_precise(comp, embeds=comp, mlp=mode == "full")
+            if mode == "qk":
+                self.engine.set_option("precise_qk", 1)
             try:
                 embeds = self.engine.assemble(plan.src_index, plan.feats)
                 return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
             finally:
                 self.engine.set_precise(False)
+                if mode == "qk":
+                    self.engine.set_option("precise_qk", 0)
         self.engine.set_precise(self.split_tvg, embeds=self.split_tvg)       # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
         try:
             embeds = self.engine.assemble(plan.src_index, plan.feats)

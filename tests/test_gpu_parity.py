@@ -512,15 +512,23 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
         try:
             model.engine.load_weights(heavy_weights(dims, SPEC["wseed"], sink=True))
             model.set_tvg_prefix_length(prob.tvg_prefix_length)
-            model.vtg_precise = "attn"
             t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype=dtype, case=case)
+            model.vtg_precise = "attn"
             w = _worst_rel(_six_passes(t, False, names=("v2t_vtg", "t2v_vtg", "v2t_vtg_cpn")), g)
+            # the cheap intermediate: plain activations, only q / k / v (a hi + lo split of the QKV GEMM's f32 accumulator) and the attention compensated
+            # (engine option precise_qk, -2.5 % on the headline step): removes two thirds of the deviation, not enough for the bar on this fixture
+            model.vtg_precise = "qk"
+            wq = {tag: _worst_rel(_six_passes(t, lit, names=("v2t_vtg", "t2v_vtg", "v2t_vtg_cpn")), g) for tag, lit in (("fused", False), ("literal", True))}
         finally:
             model.engine.close()
         with capsys.disabled():
             print(f"[sink f16 fused, vtg_precise = attn] " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()) + f"; the reference's own fp16 run vs its fp32 run: " +
                   ", ".join(f"{k} {v:.2e}" for k, v in own.items()))
+            for tag, x in wq.items():
+                print(f"[sink f16 {tag}, vtg_precise = qk] " + ", ".join(f"{k} {v:.2e}" for k, v in x.items()))
         assert max(w.values()) < SCORE_RTOL, w
+        for tag, x in wq.items():
+            assert max(x.values()) < 2e-3 and x["v2t_vtg"] < 0.6 * res[tag]["v2t_vtg"], (tag, x, res[tag])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
