@@ -337,7 +337,7 @@ static int finalize_f8(blim_engine* e) {
 // ---------------------------------------------------------------------------- workspaces
 static int reserve_tokens(blim_engine* e, int64_t T) {
     const blim_config& c = e->c;
-    const int64_t Tp = round_up(T, 256) * ((e->precise || e->precise_qk) ? 2 : 1);      // precise modes: [hi | lo] rows of twice the width
+    const int64_t Tp = round_up(T, 256) * ((e->precise || e->precise_qk > 0) ? 2 : 1);      // precise modes: [hi | lo] rows of twice the width
     if (e->f8) {
         TRY(ensure(e->x8, (size_t)Tp * c.hidden_size));
         TRY(ensure(e->a8, (size_t)Tp * c.hidden_size));
@@ -475,7 +475,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const bool pm = e->precise && e->precise_mlp;                   // MLP branch (option "precise_mlp")
     const int pfm = pm ? 2 : 1;
     const bool pa = pm && e->precise_act;                           // ... including the SwiGLU output / down-proj input (option "precise_act")
-    const bool pq = !e->precise && e->precise_qk && !e->f8;         // plain mode with hi + lo q / k / v and attention output (option "precise_qk")
+    const bool pq = !e->precise && e->precise_qk > 0 && !e->f8;     // plain mode with hi + lo q / k / v and attention output (option "precise_qk")
+    const bool pqx = pq && e->precise_qk > 1;                       // ... and a hi + lo input of the QKV GEMM (its K walked twice)
     const int pfq = (e->precise || pq) ? 2 : 1;                     // width factor of the qkv / attention-output rows
     if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
     for (int li = 0; li < c.num_layers; ++li) {
@@ -483,12 +484,12 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * H, e->precise ? xn + H : nullptr));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, (pqx ? 2 : pf) * H, (e->precise || pqx) ? xn + H : nullptr));
         }
         {
-            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * pf);
-            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise);
-            if (pq) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
+            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * (pqx ? 2 : pf));
+            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise || pqx);
+            if (pq && !pqx) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
         }
@@ -815,7 +816,7 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "precise_act")) { e->precise_act = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_qk")) {
         if (value && e->f8) { blim_set_error("option 'precise_qk' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }
-        e->precise_qk = value != 0; return BLIM_OK;
+        e->precise_qk = value < 0 ? 0 : value > 2 ? 2 : value; return BLIM_OK;
     }
     if (!strcmp(key, "precise")) {
         if (value && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }

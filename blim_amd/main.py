@@ -63,11 +63,11 @@ def get_args_parser():
                    help="fp8 mode: which GEMMs take e4m3 operands (bit 0 qkv, 1 o_proj, 2 gate|up, 3 down, 4 lm_head).  Default 31 (all) on a base checkpoint, "
                         "12 (the MLP only) when --resume names a fine-tuned checkpoint: LoRA adapts q/k/v/o_proj and lm_head, whose merged rank-8 update is below one "
                         "e4m3 step of the base weight -- those GEMMs stay in fp16, the MLP (87 %% of a layer's flops, not adapted) runs in fp8")
-    p.add_argument("--vtg_precise", default=None, choices=["none", "qk", "attn", "full"],
+    p.add_argument("--vtg_precise", default=None, choices=["none", "qk", "qkx", "attn", "full"],
                    help="compensated (hi + lo) activations on the VTG calls; default: none on fp16 engines, full on bf16 engines (the mode in which "
                         "bf16 holds 1e-3 against the fp32 reference at 7B depth; `none` = the fast, non-parity bf16 mode).  `attn` on an fp16 engine compensates "
                         "the attention branch of the VTG calls: for checkpoints with massive activations on sink tokens, where plain fp16 -- the reference's own numerics -- "
-                        "is ~3e-3 from the fp32 result (tests/golden/sink.npz: 5e-4 with attn, -16 %% speed; `qk` = only q / k / v and the attention as hi + lo: 1.2e-3, -2.5 %%)")
+                        "is ~3e-3 from the fp32 result (tests/golden/sink.npz: 5e-4 with attn, -16 %% speed; `qkx` = q / k / v, the attention and the QKV GEMM's input as hi + lo: 6.6e-4, -8.4 %%; `qk` = without the input: 1.2e-3, -2.5 %%)")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")
     p.add_argument("--no_dedup", action="store_false", dest="dedup", help="score the pairs both directions share twice, as the reference does")

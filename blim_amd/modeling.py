@@ -218,9 +218,9 @@ class BlimModel:
             self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise == "full")
             if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none / qk): plain embeddings
                 emb = inputs_embeds.to(self.dtype).contiguous()
-        qk = (not self._tvg_rows) and self.vtg_precise == "qk"           # plain activations, q / k / v and the attention as hi + lo (engine option precise_qk)
+        qk = (not self._tvg_rows) and self.vtg_precise in ("qk", "qkx")          # plain activations, q / k / v and the attention as hi + lo (engine option precise_qk)
         if qk:
-            self.engine.set_option("precise_qk", 1)
+            self.engine.set_option("precise_qk", 2 if self.vtg_precise == "qkx" else 1)
         try:
             logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
         finally:

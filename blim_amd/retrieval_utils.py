@@ -472,14 +472,14 @@ class PairScorer:
             mode = self.vtg_mode                                             # None (fp16 engines) | "qk" | "attn" | "full" (bf16 engines: modeling.py)
             comp = mode in ("attn", "full")
             self.engine.set_precise(comp, embeds=comp, mlp=mode == "full")
-            if mode == "qk":
-                self.engine.set_option("precise_qk", 1)
+            if mode in ("qk", "qkx"):
+                self.engine.set_option("precise_qk", 2 if mode == "qkx" else 1)
             try:
                 embeds = self.engine.assemble(plan.src_index, plan.feats)
                 return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
             finally:
                 self.engine.set_precise(False)
-                if mode == "qk":
+                if mode in ("qk", "qkx"):
                     self.engine.set_option("precise_qk", 0)
         self.engine.set_precise(self.split_tvg, embeds=self.split_tvg)       # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
         try:

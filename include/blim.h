@@ -194,10 +194,11 @@ int blim_debug_gemm_stamps(void* device_buf);
  * "precise_act" (0/1, default 1): 0 leaves the SwiGLU output / down-proj input plain in precise mode (the down GEMM walks K once: a compensated layer costs
  *   1.71x instead of 2x a plain one).  Leave it on: with 0 the TVG scores are 2.5e-4 instead of 3.7e-5 off at 7B depth on Gaussian weights, but 2.5e-3 on weights with a
  *   trained checkpoint's dynamic ranges (tests/golden/heavy7b.npz); bf16 engines lose 2e-3 without it on any weights;
- * "precise_qk" (0/1, default 0; plain mode only): q / k / v leave the QKV GEMM as [hi | lo] (a split of its f32 accumulator: no extra GEMM flops) and the attention runs
+ * "precise_qk" (0/1/2, default 0; plain mode only): q / k / v leave the QKV GEMM as [hi | lo] (a split of its f32 accumulator: no extra GEMM flops) and the attention runs
  *   on them compensated; everything else stays plain 16-bit.  For checkpoints whose attention sees keys with massive activations (sink tokens): the logits there amplify
  *   the 16-bit rounding of q and k (tests/golden/sink.npz: plain fp16 VTG 3.2e-3 off the fp32 reference, 1.2e-3 with this option at -2.5 % speed, 5.3e-4 with
- *   "precise" + "precise_mlp" = 0 at -16.5 %);
+ *   "precise" + "precise_mlp" = 0 at -16.5 %).  2: the QKV GEMM's input (the first norm's output) travels as hi + lo as well -- that GEMM walks K twice, nothing
+ *   else changes: 6.6e-4 on the same fixture at -8.4 %, the cheapest setting inside the 1e-3 bar there;
  * "prune_last" (0/1, default 1): calls that name the rows they read (blim_decode with out_rows, blim_score_*) run the LAST layer's o_proj / norm / MLP
  *   on those rows only (same values bit for bit; the other rows' K / V are still produced); after such a call the "resid" / "attn" / "act" workspaces of
  *   blim_debug_read hold the last layer's state of the live rows only -- bring-up code reads them after calls without out_rows, or sets 0;
