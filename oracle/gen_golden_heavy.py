@@ -32,7 +32,7 @@ SPEC7B = dict(dims=dict(vocab_size=152064, hidden_size=3584, intermediate_size=1
 # `sink`: the heavy rule plus delimiter tokens whose EMBEDDINGS carry two channels at +-250 (<|im_start|>, which opens every row and every turn) / 120 ("\n"):
 # massive activations on specific positions only, which the sharpened attention then uses as sinks -- the pattern trained decoders show on their first token
 SPEC_SINK = dict(SPEC, sink=True)
-CASES = {"heavy": SPEC, "heavy7b": SPEC7B, "sink": SPEC_SINK}
+CASES = {"heavy": SPEC, "heavy7b": SPEC7B, "sink": SPEC_SINK, "sink7b": dict(SPEC7B, sink=True)}
 SINK_ROWS = ((151644, (5, 900), (250.0, -250.0)), (198, (5,), (120.0,)))
 MASSIVE_LAYER, MASSIVE_CHANNELS, MASSIVE_GAIN = 2, (37, 611), 1000.0
 

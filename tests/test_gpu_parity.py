@@ -537,34 +537,48 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
         assert max(max(x.values()) for x in wx.values()) < SCORE_RTOL, wx
 
 
+@pytest.mark.parametrize("case", ["heavy7b", "sink7b"])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_heavy_tailed_weights_full_7b_vs_reference_golden(dtype, capsys):
-    """The same reshaping on the REAL Qwen2-7B configuration, all 28 layers (oracle/gen_golden_heavy.py --case heavy7b: the reference in fp32, 30.5 GB of weights).
-    The engine fills its weights on device from the seed and takes the reshaped tensors (norms, q / k biases and weights, layer 2's down_proj) from the host."""
-    from oracle.gen_golden_heavy import SPEC7B, heavy_items
-    path = os.path.join(GOLD, "heavy7b.npz")
+def test_heavy_tailed_weights_full_7b_vs_reference_golden(dtype, case, capsys):
+    """The same reshaping on the REAL Qwen2-7B configuration, all 28 layers (oracle/gen_golden_heavy.py --case heavy7b | sink7b: the reference in fp32, 30.5 GB of weights).
+    The engine fills its weights on device from the seed and takes the reshaped tensors (norms, q / k biases and weights, layer 2's down_proj; sink7b: the embedding table)
+    from the host.  sink7b on fp16: the plain VTG calls hold the bar at this size (7.7e-4; the H = 1024 `sink` case, 3.2e-3, is the harsher one) and the qkx / attn modes
+    are measured beside them (3.7e-4 / 9.6e-5)."""
+    from oracle.gen_golden_heavy import CASES as HEAVY_CASES, heavy_items
+    SPEC7B = HEAVY_CASES[case]
+    path = os.path.join(GOLD, f"{case}.npz")
     if not os.path.exists(path):
-        pytest.skip("tests/golden/heavy7b.npz not generated")
+        pytest.skip(f"tests/golden/{case}.npz not generated")
     g = np.load(path)
+    sink = bool(SPEC7B.get("sink", False))
     dims = synth.ModelDims(**SPEC7B["dims"])
     model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    extra = {}
     try:
         model.engine.init_synthetic_weights(SPEC7B["wseed"])
-        for name, arr in heavy_items(dims, SPEC7B["wseed"], only_changed=True):
+        for name, arr in heavy_items(dims, SPEC7B["wseed"], only_changed=True, sink=sink):
             model.engine.load_weight(name, arr)
         prob = synth.make_problem(SPEC7B["pseed"], SPEC7B["n"], dims, tok_per_clip=SPEC7B["tok_per_clip"], text_len=SPEC7B["text_len"])
         model.set_tvg_prefix_length(prob.tvg_prefix_length)
-        t = types.SimpleNamespace(spec=SPEC7B, dims=dims, model=model, prob=prob, dtype=dtype, case="heavy7b")
+        t = types.SimpleNamespace(spec=SPEC7B, dims=dims, model=model, prob=prob, dtype=dtype, case=case)
         res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in (("fused", False), ("literal", True))}
+        if sink and dtype == "f16":
+            for mode in ("qkx", "attn"):
+                model.vtg_precise = mode
+                extra[mode] = _worst_rel(_six_passes(t, False, names=("v2t_vtg", "t2v_vtg", "v2t_vtg_cpn")), g)
     finally:
         model.engine.close()
     with capsys.disabled():
         for tag, w in res.items():
-            print(f"\n[heavy7b {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers of the 7B configuration, residual |max| "
+            print(f"\n[{case} {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers of the 7B configuration, residual |max| "
                   f"{float(g['resid_absmax_per_layer'].max()):.0f} at rms {float(g['resid_rms_per_layer'].max()):.1f}: " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
+        for mode, w in extra.items():
+            print(f"[{case} {dtype} fused, vtg_precise = {mode}] " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
     for tag, w in res.items():
         for k, v in w.items():
-            assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
+            assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)      # at this size plain fp16 holds the bar in front of the sinks too (7.7e-4)
+    if extra:
+        assert max(extra["qkx"].values()) < SCORE_RTOL and max(extra["attn"].values()) < SCORE_RTOL, extra
 
 
 def test_benched_step_plan_meets_the_reference_golden(capsys):
