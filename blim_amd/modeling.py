@@ -114,7 +114,9 @@ class BlimModel:
         """modeling_videochat_flash.py:185-515, eval branch (video_feature=True, one <image> per row).
 
         input_ids / attention_mask / labels: LEFT-padded [B, Lt] device tensors; images: list of B feature tensors.
-        Returns (None, position_ids, mask | (mask, cpn_mask), past_key_values, embeds [B,L,H] (compute dtype), labels [B,L])."""
+        Returns (None, position_ids, mask | (mask, cpn_mask), past_key_values, embeds [B,L,H], labels [B,L]).  embeds: the engine's 16-bit dtype for VTG rows on
+        fp16 engines (the reference's contract); float32 (hi + lo formed in the compensated mode, one tensor of the same shape) for every row of a bf16 engine and for
+        TVG rows of an fp16 engine -- forward() takes either."""
         import torch
         if not video_feature:
             raise NotImplementedError("only pre-extracted video features (video_feature=True) are supported")
