@@ -6,8 +6,9 @@ What the reference does at start-up (main.py:96-111, 125-128; util/misc.py:276-3
   2. LoRA (r = --lora_r 8, alpha = --lora_alpha 32) on the projector `mlp` Linear "0" and "2"; `tvg_mlp = deepcopy(mlp)`;
      LoRA on every q/k/v/o_proj and lm_head; `visual_head` trainable in fp32;
   3. `--resume`: a torch file whose `['model']` holds ONLY the trainable tensors (LoRA A/B, visual_head), loaded strict=False.
-The engine has no adapter path: deltas are merged at load time, W' = W + (alpha / r) * B @ A, and the merged matrix goes
-through `blim_load_weight` (which rounds to the engine's 16-bit format and lays it out for the kernels).
+The engine keeps the adapters APART by default, as the reference does (`blim_load_adapter`: y = W x + (alpha / r) B (A x), the rank-r term in
+the base product's accumulation); lora_mode = "merge" instead folds W' = W + (alpha / r) * B @ A on the host and hands the merged matrix to
+`blim_load_weight` (which rounds it to the engine's 16-bit format and lays it out for the kernels).
 
 Key naming of the resume file follows peft's convention (`base_model.model.<path>.lora_{A,B}.default.weight`, wrapped
 Linear at `<path>.base_layer`); the inner projector adapters sit under `mm_projector.{mlp,tvg_mlp}.base_model.model.{0,2}`.
@@ -140,16 +141,82 @@ def expected_adapters(dims: ModelDims):
     return names
 
 
-def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Optional[str] = None, lora_r: int = 8, lora_alpha: float = 32.0,
-                    allow_missing_visual_head: bool = True, verbose: bool = False, strict_resume: bool = True) -> Dict[str, str]:
-    """Streams the base checkpoint (+ merged LoRA / visual_head of `resume_path`) into `engine`, one tensor at a time.
-    Returns {canonical name: provenance} for every tensor loaded.
+def default_lora_mode(engine) -> str:
+    """'apart' (the reference's own arithmetic: y = W x + s B (A x), blim.h: blim_load_adapter) wherever the engine offers it; 'merge' is the
+    explicit opt-in that folds W + s B A into the engine's 16-bit weight on the host (no per-call cost; rounds the sum -- fine in fp16 for a bf16
+    base checkpoint, 8 % of the update in bf16, most of it in e4m3: DESIGN.md section 8, f-2)."""
+    return "apart" if hasattr(engine, "load_adapter") else "merge"
 
-    A resume file is checked the way the reference checks it (main.py:127 asserts that the number of checkpoint parameters equals
+
+def read_resume(resume_path: str, dims: ModelDims, lora_r: int = 8, strict_resume: bool = True):
+    """The reference's resume file (util/misc.py:276-297: {'model': {peft-named trainable tensors}}) -> (adapters {weight name: {'A', 'B'}},
+    full tensors {name: array}).  Checked the way the reference checks it (main.py:127 asserts that the number of checkpoint parameters equals
     the number of trainable parameters): every key must map onto an engine tensor, every expected adapter (`expected_adapters`) and
-    `visual_head` must be present, and the parameter total must equal the trainable total.  A naming drift therefore raises instead
-    of silently evaluating the base model; strict_resume=False downgrades the checks to warnings (partial adapter files)."""
+    `visual_head` must be present, and the parameter total must equal the trainable total.  A naming drift therefore raises instead of
+    silently evaluating the base model; strict_resume=False downgrades the checks to warnings (partial adapter files)."""
     import torch
+    shapes = weight_shapes(dims)
+    adapters: Dict[str, Dict[str, np.ndarray]] = {}
+    full: Dict[str, np.ndarray] = {}
+    ck = torch.load(resume_path, map_location="cpu", weights_only=False)
+    sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+    unparsed, n_params = [], 0
+    for k, v in sd.items():
+        parsed = parse_resume_key(k)
+        if parsed is None or parsed[0] not in shapes:
+            unparsed.append(k)
+            continue
+        name, kind = parsed
+        n_params += int(np.prod(v.shape))
+        if kind == "full":
+            full[name] = _to_f32(v)
+        else:
+            adapters.setdefault(name, {})[kind] = _to_f32(v)
+    problems = []
+    if unparsed:
+        problems.append(f"{len(unparsed)} key(s) map onto no engine tensor, e.g. {unparsed[:3]}")
+    missing = [n for n in expected_adapters(dims) if n not in adapters]
+    if missing:
+        problems.append(f"{len(missing)} expected LoRA adapter(s) absent, e.g. {missing[:3]}")
+    if "visual_head" not in full:
+        problems.append("visual_head absent")
+    want = sum(lora_r * (shapes[n][0] + shapes[n][1]) for n in expected_adapters(dims)) + int(np.prod(shapes["visual_head"]))
+    if not missing and not unparsed and "visual_head" in full and n_params != want:
+        problems.append(f"{n_params} parameters in the file, {want} trainable parameters expected (main.py:127)")
+    if problems:
+        msg = f"resume file {resume_path}: " + "; ".join(problems)
+        if strict_resume:
+            raise ValueError(msg + " -- refusing to evaluate a partially adapted model (strict_resume=False to override)")
+        import warnings
+        warnings.warn(msg)
+    for name, ad in adapters.items():
+        if "A" not in ad or "B" not in ad:
+            raise KeyError(f"incomplete LoRA adapter for {name}")
+    stray = sorted(n for n in adapters if n not in expected_adapters(dims))
+    if stray:
+        raise KeyError(f"LoRA adapters for tensors the engine does not adapt: {stray[:3]}")
+    return adapters, full
+
+
+def apply_resume(engine, dims: ModelDims, resume_path: str, lora_r: int = 8, lora_alpha: float = 32.0, strict_resume: bool = True) -> Dict[str, str]:
+    """Adapters + visual_head of a resume file onto an engine whose BASE weights are already loaded, adapters kept apart (blim_load_adapter)."""
+    adapters, full = read_resume(resume_path, dims, lora_r, strict_resume)
+    report = {}
+    for name, w in full.items():
+        engine.load_weight(name, w)
+        report[name] = "resume"
+    for name, ad in adapters.items():
+        engine.load_adapter(name, ad["A"], ad["B"], lora_r, lora_alpha)
+        report[name] = "base + LoRA (apart)"
+    return report
+
+
+def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Optional[str] = None, lora_r: int = 8, lora_alpha: float = 32.0,
+                    allow_missing_visual_head: bool = True, verbose: bool = False, strict_resume: bool = True, lora_mode: Optional[str] = None) -> Dict[str, str]:
+    """Streams the base checkpoint (+ the LoRA adapters / visual_head of `resume_path`) into `engine`, one tensor at a time.
+    Returns {canonical name: provenance} for every tensor loaded.  lora_mode: 'apart' (default: adapters stay separate matrices, as in the
+    reference) or 'merge' (W + (alpha / r) B A in fp32 on the host, rounded once by blim_load_weight); see `default_lora_mode`.
+    The resume file is checked as `read_resume` describes."""
     shapes = weight_shapes(dims)
     keys, get = open_base_checkpoint(base_path)
     have = {}
@@ -157,40 +224,15 @@ def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Option
         n = hf_to_canonical(k)
         if n is not None and n in shapes:
             have[n] = k
+    mode = lora_mode or default_lora_mode(engine)
+    if mode not in ("apart", "merge"):
+        raise ValueError(f"lora_mode {mode!r}: 'apart' or 'merge'")
     adapters: Dict[str, Dict[str, np.ndarray]] = {}
     full: Dict[str, np.ndarray] = {}
     if resume_path:
-        ck = torch.load(resume_path, map_location="cpu", weights_only=False)
-        sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
-        unparsed, n_params = [], 0
-        for k, v in sd.items():
-            parsed = parse_resume_key(k)
-            if parsed is None or parsed[0] not in shapes:
-                unparsed.append(k)
-                continue
-            name, kind = parsed
-            n_params += int(np.prod(v.shape))
-            if kind == "full":
-                full[name] = _to_f32(v)
-            else:
-                adapters.setdefault(name, {})[kind] = _to_f32(v)
-        problems = []
-        if unparsed:
-            problems.append(f"{len(unparsed)} key(s) map onto no engine tensor, e.g. {unparsed[:3]}")
-        missing = [n for n in expected_adapters(dims) if n not in adapters]
-        if missing:
-            problems.append(f"{len(missing)} expected LoRA adapter(s) absent, e.g. {missing[:3]}")
-        if "visual_head" not in full:
-            problems.append("visual_head absent")
-        want = sum(lora_r * (shapes[n][0] + shapes[n][1]) for n in expected_adapters(dims)) + int(np.prod(shapes["visual_head"]))
-        if not missing and not unparsed and "visual_head" in full and n_params != want:
-            problems.append(f"{n_params} parameters in the file, {want} trainable parameters expected (main.py:127)")
-        if problems:
-            msg = f"resume file {resume_path}: " + "; ".join(problems)
-            if strict_resume:
-                raise ValueError(msg + " -- refusing to evaluate a partially adapted model (strict_resume=False to override)")
-            import warnings
-            warnings.warn(msg)
+        adapters, full = read_resume(resume_path, dims, lora_r, strict_resume)
+    if hasattr(engine, "clear_adapters"):
+        engine.clear_adapters()
     report: Dict[str, str] = {}
     for name, shape in shapes.items():
         src = name
@@ -209,19 +251,16 @@ def load_checkpoint(engine, dims: ModelDims, base_path: str, resume_path: Option
             raise KeyError(f"tensor '{name}' ({canonical_to_hf(name)}) not found in {base_path}")
         assert tuple(w.shape) == tuple(shape), (name, w.shape, shape)
         ad = adapters.get(name)
-        if ad is not None:
-            if "A" not in ad or "B" not in ad:
-                raise KeyError(f"incomplete LoRA adapter for {name}")
+        if ad is not None and mode == "merge":
             w = w + lora_delta(ad["A"], ad["B"], lora_r, lora_alpha)
             prov += " + LoRA"
         engine.load_weight(name, w)
+        if ad is not None and mode == "apart":
+            engine.load_adapter(name, ad["A"], ad["B"], lora_r, lora_alpha)
+            prov += " + LoRA (apart)"
         report[name] = prov
         if verbose:
             print(f"{name:32s} {str(tuple(shape)):20s} {prov}")
-    applied = sorted(n for n, p in report.items() if "LoRA" in p)
-    stray = sorted(set(adapters) - set(applied))
-    if stray:
-        raise KeyError(f"LoRA adapters for tensors the engine does not hold: {stray[:3]}")
     return report
 
 

@@ -176,7 +176,9 @@ extern "C" void blim_destroy(blim_engine* e) {
     if (!e) return;
     hipDeviceSynchronize();
     for (void* p : e->owned) hipFree(p);
-    DevBuf* bufs[] = {&e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
+    for (void* p : e->aug_owned) hipFree(p);
+    for (void* p : e->ad_owned) hipFree(p);
+    DevBuf* bufs[] = {&e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
                       &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -248,6 +250,7 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
     HIP_TRY(hipGetLastError());
     e->loaded[name] = true;
     e->f8_ready = false;
+    e->aug_ready = false;          // the augmented copies of adapted weights are rebuilt from the placed base weights on the next call
     return BLIM_OK;
 }
 
@@ -334,6 +337,143 @@ static int finalize_f8(blim_engine* e) {
     return BLIM_OK;
 }
 
+// ---------------------------------------------------------------------------- LoRA adapters kept apart (adapters.hpp)
+// main.py:96-105: peft LoRA on the projector MLPs' Linear "0" / "2", on every q/k/v/o_proj and on lm_head; main.py:125-128 loads the fine-tuned
+// A / B.  The reference evaluates with the adapters APART (y = W x + b + (alpha / r) B (A x)); so does this engine once adapters are loaded.
+static AdapterW* find_adapter(blim_engine* e, const std::string& name, int* n_out, int* n_in) {
+    const blim_config& c = e->c;
+    const int H = c.hidden_size, M = c.mm_hidden_size, V = c.vocab_size, qn = c.num_heads * 128, kn = c.num_kv_heads * 128;
+    auto hit = [&](AdapterW* a, int o, int i) { *n_out = o; *n_in = i; return a; };
+    if (name == "lm_head") return hit(&e->ad_lm, V, H);
+    for (int w = 0; w < 2; ++w) {
+        const std::string p = w ? "tvg_mlp." : "mlp.";
+        if (name == p + "0.w") return hit(&e->ad_mlp[w][0], H, M);
+        if (name == p + "2.w") return hit(&e->ad_mlp[w][1], H, H);
+    }
+    int li = -1; char rest[64] = "";
+    if (sscanf(name.c_str(), "layers.%d.%63s", &li, rest) == 2 && li >= 0 && li < c.num_layers) {
+        const std::string r(rest);
+        if (r == "q_proj.w") return hit(&e->AD[li].ad[0], qn, H);
+        if (r == "k_proj.w") return hit(&e->AD[li].ad[1], kn, H);
+        if (r == "v_proj.w") return hit(&e->AD[li].ad[2], kn, H);
+        if (r == "o_proj.w") return hit(&e->AD[li].ad[3], H, H);
+    }
+    return nullptr;
+}
+
+static void free_aug(blim_engine* e) {
+    for (void* p : e->aug_owned) hipFree(p);
+    e->aug_owned.clear();
+    for (auto& l : e->AD) { l.wqkv_aug = l.wo_aug = nullptr; for (auto& a : l.ad) a.A16 = nullptr; }
+    e->lm_aug = nullptr; e->ad_lm.A16 = nullptr;
+    for (int w = 0; w < 2; ++w) { e->w0_aug[w] = e->w2_aug[w] = nullptr; e->ad_mlp[w][0].A16 = e->ad_mlp[w][1].A16 = nullptr; }
+    e->aug_ready = false;
+}
+
+extern "C" int blim_clear_adapters(blim_engine* e) {
+    ARG_CHECK(e);
+    HIP_TRY(hipDeviceSynchronize());
+    free_aug(e);
+    for (void* p : e->ad_owned) hipFree(p);
+    e->ad_owned.clear();
+    e->AD.clear();
+    e->ad_lm = AdapterW();
+    for (int w = 0; w < 2; ++w) e->ad_mlp[w][0] = e->ad_mlp[w][1] = AdapterW();
+    e->lora_r = 0; e->lora_scale = 0.f; e->aug = 0;
+    return BLIM_OK;
+}
+
+static std::vector<AdapterW*> all_adapters(blim_engine* e) {
+    std::vector<AdapterW*> v = {&e->ad_lm, &e->ad_mlp[0][0], &e->ad_mlp[0][1], &e->ad_mlp[1][0], &e->ad_mlp[1][1]};
+    for (auto& l : e->AD) for (auto& a : l.ad) v.push_back(&a);
+    return v;
+}
+extern "C" int blim_num_adapters(blim_engine* e) {
+    if (!e) return -1;
+    int n = 0;
+    for (AdapterW* a : all_adapters(e)) n += a->A != nullptr;
+    return n;
+}
+
+extern "C" int blim_load_adapter(blim_engine* e, const char* weight_name, const float* A, const float* B, int32_t lora_r, float lora_alpha) {
+    ARG_CHECK(e && weight_name && A && B && lora_r > 0 && lora_r <= 16 && lora_alpha > 0.f);
+    const float scale = lora_alpha / (float)lora_r;
+    if (e->lora_r && (e->lora_r != lora_r || e->lora_scale != scale)) {
+        blim_set_error("adapter '%s': r = %d, alpha / r = %g, but the engine's adapters have r = %d, alpha / r = %g (one LoraConfig per model, main.py:96-101)", weight_name, lora_r,
+                       scale, e->lora_r, e->lora_scale);
+        return BLIM_ERR_ARG;
+    }
+    if (e->AD.empty()) e->AD.resize(e->c.num_layers);
+    int n_out = 0, n_in = 0;
+    AdapterW* a = find_adapter(e, weight_name, &n_out, &n_in);
+    if (!a) { blim_set_error("'%s' is not a LoRA-adapted weight (q/k/v/o_proj, lm_head, mlp / tvg_mlp Linear 0 / 2: main.py:96-101)", weight_name); return BLIM_ERR_ARG; }
+    if (!a->A) {
+        HIP_TRY(hipMalloc((void**)&a->A, (size_t)lora_r * n_in * 4)); e->ad_owned.push_back(a->A);
+        HIP_TRY(hipMalloc((void**)&a->B, (size_t)n_out * lora_r * 4)); e->ad_owned.push_back(a->B);
+        a->n_in = n_in; a->n_out = n_out;
+    }
+    HIP_TRY(hipMemcpy(a->A, A, (size_t)lora_r * n_in * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(a->B, B, (size_t)n_out * lora_r * 4, hipMemcpyHostToDevice));
+    e->lora_r = lora_r; e->lora_scale = scale;
+    e->aug = 6 * lora_r <= 64 ? 64 : 128;        // three adapters (q, k, v) x r columns x (B_hi, B_lo)
+    e->aug_ready = false;
+    return BLIM_OK;
+}
+
+// (re)builds the augmented weight copies [W | B_hi | B_lo | 0] and the adapters' 16-bit A operands from the placed base weights
+static int build_aug(blim_engine* e) {
+    if (!e->aug || e->aug_ready) return BLIM_OK;
+    TRY(blim_weights_ready(e));
+    HIP_TRY(hipDeviceSynchronize());
+    free_aug(e);
+    const blim_config& c = e->c;
+    const int H = c.hidden_size, M = c.mm_hidden_size, V = c.vocab_size, dt = c.compute_dtype, r = e->lora_r, G = e->aug;
+    const int64_t qn = (int64_t)c.num_heads * 128, kn = (int64_t)c.num_kv_heads * 128;
+    auto aalloc = [&](uint16_t** p, size_t elems) -> int {
+        HIP_TRY(hipMalloc((void**)p, elems * 2));
+        e->aug_owned.push_back(*p);
+        return BLIM_OK;
+    };
+    auto copy = [&](uint16_t** dst, const bf16_t* src, int64_t N, int K) -> int {
+        TRY(aalloc(dst, (size_t)N * (K + G)));
+        return launch_make_aug(*dst, src, N, K, G, 0);
+    };
+    // B columns of adapter `seg` of `nseg` sharing one augmented matrix: hi at K + seg r, lo at K + nseg r + seg r; its A operand
+    auto place = [&](AdapterW& a, uint16_t* w_aug, int K, int64_t row0, int seg, int nseg, int row_mode) -> int {
+        if (!a.A) return BLIM_OK;
+        TRY(launch_adapter_b_aug(w_aug, K + G, row0, K + seg * r, K + nseg * r + seg * r, a.B, a.n_out, r, row_mode, dt, 0));
+        TRY(aalloc(&a.A16, (size_t)32 * K));
+        return launch_adapter_a16(a.A16, a.A, K, r, dt, 0);
+    };
+    for (int li = 0; li < c.num_layers; ++li) {
+        const LayerW& l = e->L[li]; LayerAd& d = e->AD[li];
+        TRY(copy(&d.wqkv_aug, l.wqkv, e->qkv_n, H));
+        TRY(copy(&d.wo_aug, l.wo, H, H));
+        TRY(place(d.ad[0], d.wqkv_aug, H, 0, 0, 3, 1));
+        TRY(place(d.ad[1], d.wqkv_aug, H, qn, 1, 3, 1));
+        TRY(place(d.ad[2], d.wqkv_aug, H, qn + kn, 2, 3, 0));
+        TRY(place(d.ad[3], d.wo_aug, H, 0, 0, 1, 0));
+    }
+    TRY(copy(&e->lm_aug, e->lm_head, V, H));
+    TRY(place(e->ad_lm, e->lm_aug, H, 0, 0, 1, 0));
+    for (int w = 0; w < 2; ++w) {
+        TRY(copy(&e->w0_aug[w], e->mlp_w0[w], H, M));
+        TRY(copy(&e->w2_aug[w], e->mlp_w2[w], H, H));
+        TRY(place(e->ad_mlp[w][0], e->w0_aug[w], M, 0, 0, 1, 0));
+        TRY(place(e->ad_mlp[w][1], e->w2_aug[w], H, 0, 0, 1, 0));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    e->aug_ready = true;
+    return BLIM_OK;
+}
+// u columns of the augmented rows x16 [n, ldx] (K real columns; hi + lo halves when lo_off > 0) for one adapter / the q, k, v triple
+static int adapter_u(blim_engine* e, void* x16, int64_t ldx, int64_t lo_off, int64_t n, int K, const AdapterW* a0, const AdapterW* a1, const AdapterW* a2, hipStream_t s) {
+    AdapterDownArgs d;
+    d.n = a1 ? 3 : 1;
+    d.A16[0] = a0->A16; d.A16[1] = a1 ? a1->A16 : nullptr; d.A16[2] = a2 ? a2->A16 : nullptr;
+    return launch_adapter_down((uint16_t*)x16, ldx, lo_off, n, K, d, e->lora_r, e->lora_scale, e->aug, e->c.compute_dtype, s);
+}
+
 // ---------------------------------------------------------------------------- workspaces
 static int reserve_tokens(blim_engine* e, int64_t T) {
     const blim_config& c = e->c;
@@ -346,18 +486,19 @@ static int reserve_tokens(blim_engine* e, int64_t T) {
         TRY(ensure(e->act_mx, (size_t)Tp * (c.intermediate_size / 128)));
         TRY(ensure(e->attn_mx, (size_t)Tp * c.num_heads));
     }
+    const int64_t Hq = c.hidden_size + e->aug;        // adapters apart: the QKV / o_proj inputs carry `aug` extra columns (adapters.hpp)
     TRY(ensure(e->resid, (size_t)round_up(T, 256) * c.hidden_size * 4));
-    TRY(ensure(e->xn, (size_t)Tp * c.hidden_size * 2));
+    TRY(ensure(e->xn, (size_t)Tp * Hq * 2));
     TRY(ensure(e->qkv, (size_t)Tp * e->qkv_n * 2));
-    TRY(ensure(e->attn, (size_t)Tp * c.hidden_size * 2));
-    TRY(ensure(e->act, (size_t)Tp * c.intermediate_size * 2));
+    TRY(ensure(e->attn, (size_t)Tp * Hq * 2));
+    TRY(ensure(e->act, (size_t)Tp * std::max<int64_t>(c.intermediate_size, Hq) * 2));     // (also holds the last layer's gathered attention rows)
     return BLIM_OK;
 }
 static int reserve_rows(blim_engine* e, int64_t R) {
     const blim_config& c = e->c;
     const int64_t Rp = round_up(R, 256);
     const int ntn = (c.vocab_size + 255) / 256;
-    TRY(ensure(e->hsel, (size_t)Rp * c.hidden_size * 2 * (e->precise ? 2 : 1)));
+    TRY(ensure(e->hsel, (size_t)Rp * (c.hidden_size + e->aug) * 2 * (e->precise ? 2 : 1)));
     if (e->f8) TRY(ensure(e->hsel8, (size_t)Rp * c.hidden_size + (size_t)Rp * 4));   // e4m3 rows, then their scales
     TRY(ensure(e->lse_part, (size_t)Rp * ntn * sizeof(float2)));
     TRY(ensure(e->lab_logit, (size_t)Rp * 4));
@@ -392,18 +533,28 @@ static GemmParams gp2(const blim_engine* e, const void* A, int64_t K1, const voi
 extern "C" int blim_project_video(blim_engine* e, const void* feats, int64_t n_rows, int32_t which, void* out, void* stream) {
     ARG_CHECK(e && feats && out && n_rows > 0 && (which == 0 || which == 1));
     TRY(blim_weights_ready(e));
+    TRY(build_aug(e));
     hipStream_t s = (hipStream_t)stream;
-    const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
+    const int H = e->c.hidden_size, M = e->c.mm_hidden_size, G = e->aug;
+    const int Ha = H + G, Ma = M + G;
     const int pf = e->precise ? 2 : 1;            // compensated mode: the hidden layer and the output travel as [hi | lo] rows of width 2H
-    TRY(ensure(e->proj_tmp, (size_t)round_up(n_rows, 256) * H * 2 * pf));
-    SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_rows * ((double)M * H + (double)H * H));
-    GemmParams p1 = gp(e->c.compute_dtype, feats, M, e->mlp_w0[which], n_rows, H, M, e->proj_tmp.p, (int64_t)pf * H);
+    TRY(ensure(e->proj_tmp, (size_t)round_up(n_rows, 256) * Ha * 2 * pf));
+    SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_rows * ((double)Ma * H + (double)Ha * H));
+    const void* a1 = feats;
+    if (G) {    // adapters apart: [feats | u | 0] rows against [W0 | B | 0]
+        TRY(ensure(e->feats_aug, (size_t)round_up(n_rows, 256) * Ma * 2));
+        TRY(launch_copy_rows16((uint16_t*)e->feats_aug.p, Ma, (const uint16_t*)feats, M, n_rows, M, s));
+        TRY(adapter_u(e, e->feats_aug.p, Ma, 0, n_rows, M, &e->ad_mlp[which][0], nullptr, nullptr, s));
+        a1 = e->feats_aug.p;
+    }
+    GemmParams p1 = gp(e->c.compute_dtype, a1, Ma, G ? (const void*)e->w0_aug[which] : (const void*)e->mlp_w0[which], n_rows, H, Ma, e->proj_tmp.p, (int64_t)pf * Ha);
     p1.bias = e->mlp_b0[which]; p1.act = 1;
-    if (e->precise) p1.lo_off = H;
+    if (e->precise) p1.lo_off = Ha;
     TRY(launch_gemm(EPI_BF16, p1, s));
-    GemmParams p2 = gp(e->c.compute_dtype, e->proj_tmp.p, (int64_t)pf * H, e->mlp_w2[which], n_rows, H, pf * H, out, (int64_t)pf * H);
+    if (G) TRY(adapter_u(e, e->proj_tmp.p, (int64_t)pf * Ha, e->precise ? Ha : 0, n_rows, H, &e->ad_mlp[which][1], nullptr, nullptr, s));
+    GemmParams p2 = gp(e->c.compute_dtype, e->proj_tmp.p, (int64_t)pf * Ha, G ? (const void*)e->w2_aug[which] : (const void*)e->mlp_w2[which], n_rows, H, pf * Ha, out, (int64_t)pf * H);
     p2.bias = e->mlp_b2[which];
-    if (e->precise) { p2.w_wrap_k = H; p2.lo_off = H; }
+    if (e->precise) { p2.w_wrap_k = Ha; p2.lo_off = H; }
     TRY(launch_gemm(EPI_BF16, p2, s));
     return BLIM_OK;
 }
@@ -447,6 +598,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const blim_config& c = e->c;
     const int H = c.hidden_size, I = c.intermediate_size;
     const int64_t T = b->n_tokens;
+    TRY(build_aug(e));
     TRY(reserve_tokens(e, T));
     TRY(finalize_f8(e));
     float* resid = (float*)e->resid.p;
@@ -464,7 +616,11 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         else TRY(launch_h16_to_f32(resid, (const bf16_t*)embeds, T * H, c.compute_dtype, s));
     }
     const double tok = (double)T;
-    const bool q8 = e->f8 && (e->f8_mask & 1), o8 = e->f8 && (e->f8_mask & 2), g8 = e->f8 && (e->f8_mask & 4), d8 = e->f8 && (e->f8_mask & 8);
+    // adapters apart (adapters.hpp): the QKV and o_proj GEMMs take [x | u | u | 0] rows of width Hq against [W | B_hi | B_lo | 0]; they then run in the
+    // 16-bit format even on an fp8 engine (the rank-r update would not survive an e4m3 K-step; the MLP, 87 % of a layer's flops and not adapted, stays fp8)
+    const int G = e->aug;
+    const int64_t Hq = H + G;
+    const bool q8 = e->f8 && (e->f8_mask & 1) && !G, o8 = e->f8 && (e->f8_mask & 2) && !G, g8 = e->f8 && (e->f8_mask & 4), d8 = e->f8 && (e->f8_mask & 8);
     float* rope_rows = nullptr;
     {
         SpanGuard g(e, s, TC_MISC, 0);
@@ -484,11 +640,13 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, (pqx ? 2 : pf) * H, (e->precise || pqx) ? xn + H : nullptr));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, (pqx ? 2 : pf) * Hq, (e->precise || pqx) ? xn + Hq : nullptr));
+            if (G) TRY(adapter_u(e, xn, (pqx ? 2 : pf) * Hq, (e->precise || pqx) ? Hq : 0, T, H, &e->AD[li].ad[0], &e->AD[li].ad[1], &e->AD[li].ad[2], s));
         }
         {
-            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * H * e->qkv_n * (pqx ? 2 : pf));
-            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n) : gp2(e, xn, H, l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise || pqx);
+            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * Hq * e->qkv_n * (pqx ? 2 : pf));
+            GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n)
+                              : gp2(e, xn, Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise || pqx);
             if (pq && !pqx) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -499,8 +657,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.dtype = c.compute_dtype;
             a.qkv = qkv; a.ldq = (int64_t)pfq * e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
-            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pfq * H; a.scale = 0.08838834764831845f;
-            a.v_lo_off = pfq == 2 ? e->qkv_n : 0; a.out_lo_off = pfq == 2 ? H : 0;
+            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pfq * Hq; a.scale = 0.08838834764831845f;
+            a.v_lo_off = pfq == 2 ? e->qkv_n : 0; a.out_lo_off = pfq == 2 ? Hq : 0;
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
             if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
@@ -509,16 +667,17 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         if (o8 && !fuse_o) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
         if (prune && li == c.num_layers - 1) {
             // ---- last layer, live rows only: gather (attention output -> the free `act` workspace, residual -> resid_live), then the same four kernels on n_live rows
-            bf16_t* attn_live = act;                                         // [n_live, pf * H] 16-bit (act is not in use until the gate|up GEMM below)
+            bf16_t* attn_live = act;                                         // [n_live, pfq * Hq] 16-bit (act is not in use until the gate|up GEMM below)
             float* rl = (float*)e->resid_live.p;
             {
                 SpanGuard g0(e, s, TC_MISC, 0);
-                TRY(launch_gather_rows(attn_live, attn, live_rows, n_live, (int64_t)pfq * H * 2, T, 0u, s));
+                TRY(launch_gather_rows(attn_live, attn, live_rows, n_live, (int64_t)pfq * Hq * 2, T, 0u, s));
+                if (G) TRY(adapter_u(e, attn_live, (int64_t)pfq * Hq, e->precise ? Hq : 0, n_live, H, &e->AD[li].ad[3], nullptr, nullptr, s));
                 TRY(launch_gather_rows(rl, resid, live_rows, n_live, (int64_t)H * 4, T, 0x7fc00000u, s));      // a row outside the batch: NaN (poisoned score)
             }
             const double tl = (double)n_live;
-            { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * H * H * pf);
-              GemmParams p = gp2(e, attn_live, H, l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * (int64_t)H;   // pq: the hi halves of [hi | lo] rows
+            { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * Hq * H * pf);
+              GemmParams p = gp2(e, attn_live, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * Hq;   // pq: the hi halves of [hi | lo] rows
               TRY(launch_gemm(EPI_RESID, p, s)); }
             { SpanGuard g(e, s, TC_NORM, 0);
               TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
@@ -530,12 +689,14 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             *final_resid = rl; *final_is_live = true;
             break;
         }
+        if (G) { SpanGuard g(e, s, TC_MISC, 0); TRY(adapter_u(e, attn, (int64_t)pfq * Hq, e->precise ? Hq : 0, T, H, &e->AD[li].ad[3], nullptr, nullptr, s)); }
         {
-            SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * H * H * pf);
-            GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H) : gp2(e, attn, H, l.wo, T, H, resid, H, 0, e->precise);
+            SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * Hq * H * pf);
+            GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H)
+                              : gp2(e, attn, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, T, H, resid, H, 0, e->precise);
             if (fuse_o) { p.a_mx = (const uint8_t*)e->attn_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
-            if (pq) p.lda = 2 * (int64_t)H;                               // the hi halves of the attention output's [hi | lo] rows
+            if (pq) p.lda = 2 * Hq;                                       // the hi halves of the attention output's [hi | lo] rows
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         {
@@ -569,9 +730,10 @@ int check_batch(const blim_batch* b) {
     return BLIM_OK;
 }
 
-// final-norm hidden states of the selected rows; `split` (precise mode): out16 rows are [hi | lo] of width 2H
+// final-norm hidden states of the selected rows; `split` (precise mode): out16 rows are [hi | lo] of width 2 W; W = width of one half
+// (H, or H + aug when the rows go on to the adapted lm_head: adapters.hpp)
 static int decode_impl(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
-                       void* out_hidden_bf16, bool split, float* out_hidden_f32, void* stream) {
+                       void* out_hidden_bf16, bool split, float* out_hidden_f32, void* stream, int64_t W = 0) {
     ARG_CHECK(e && embeds && (out_hidden_bf16 || out_hidden_f32));
     TRY(check_batch(b));
     TRY(blim_weights_ready(e));
@@ -582,29 +744,51 @@ static int decode_impl(blim_engine* e, const blim_batch* b, const void* embeds, 
     TRY(run_layers(e, b, embeds, s, out_rows, out_rows ? n_out : 0, &fr, &is_live));
     SpanGuard g(e, s, TC_NORM, 0);
     const int H = e->c.hidden_size;
+    if (W == 0) W = H;
     // (is_live: run_layers carried exactly the requested rows, in order, through the last layer: the final norm reads them straight)
     return launch_rmsnorm(fr, H, is_live ? nullptr : out_rows, n, H, e->final_norm, e->c.rms_eps, (bf16_t*)out_hidden_bf16, e->c.compute_dtype,
-                          out_hidden_f32, s, is_live ? n : b->n_tokens, split ? 2 * H : H, split ? (bf16_t*)out_hidden_bf16 + H : nullptr);
+                          out_hidden_f32, s, is_live ? n : b->n_tokens, split ? 2 * W : W, split && out_hidden_bf16 ? (bf16_t*)out_hidden_bf16 + W : nullptr);
 }
 extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
                            void* out_hidden_bf16, float* out_hidden_f32, void* stream) {
     return decode_impl(e, b, embeds, out_rows, n_out, out_hidden_bf16, false, out_hidden_f32, stream);
 }
 
-static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split, const int32_t* labels, int64_t n_rows, float* logprob, void* stream);
+// lm_head's A operand.  Adapters apart: rows [x | u | u | 0] of width H + aug per half -- `hidden` either has that layout already (`wide`: the engine's
+// own hsel) or is a caller's [n, (split ? 2 : 1) * H] buffer, staged into hid_aug first; then the u columns are formed.  -> *A, *ld_half
+static int lm_head_input(blim_engine* e, const void* hidden, bool split, bool wide, int64_t n_rows, hipStream_t s, const void** A, int64_t* ld_half) {
+    const int H = e->c.hidden_size, G = e->aug, pf = split ? 2 : 1;
+    *A = hidden; *ld_half = H;
+    if (!G) return BLIM_OK;
+    TRY(build_aug(e));
+    const int64_t Ha = H + G;
+    void* x = (void*)hidden;
+    if (!wide) {
+        TRY(ensure(e->hid_aug, (size_t)round_up(n_rows, 256) * Ha * 2 * pf));
+        x = e->hid_aug.p;
+        TRY(launch_copy_rows16((uint16_t*)x, pf * Ha, (const uint16_t*)hidden, (int64_t)pf * H, n_rows, H, s));
+        if (split) TRY(launch_copy_rows16((uint16_t*)x + Ha, pf * Ha, (const uint16_t*)hidden + H, (int64_t)pf * H, n_rows, H, s));
+    }
+    TRY(adapter_u(e, x, pf * Ha, split ? Ha : 0, n_rows, H, &e->ad_lm, nullptr, nullptr, s));
+    *A = x; *ld_half = Ha;
+    return BLIM_OK;
+}
+static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split, const int32_t* labels, int64_t n_rows, float* logprob, void* stream, bool wide = false);
 extern "C" int blim_vtg_logprobs(blim_engine* e, const void* hidden_bf16, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
     return vtg_logprobs_impl(e, hidden_bf16, false, labels, n_rows, logprob, stream);
 }
-static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split, const int32_t* labels, int64_t n_rows, float* logprob, void* stream) {
+static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split, const int32_t* labels, int64_t n_rows, float* logprob, void* stream, bool wide) {
     ARG_CHECK(e && hidden_bf16 && labels && logprob && n_rows > 0);
     TRY(blim_weights_ready(e));
     hipStream_t s = (hipStream_t)stream;
     const int H = e->c.hidden_size, V = e->c.vocab_size;
-    TRY(reserve_rows(e, n_rows));
+    if (!wide) TRY(reserve_rows(e, n_rows));
     const int ntn = (V + 255) / 256;
     HIP_TRY(hipMemsetAsync(e->lab_logit.p, 0, (size_t)n_rows * 4, s));
     uint8_t* h8 = nullptr; float* hs = nullptr;
-    const bool l8 = e->f8 && (e->f8_mask & 16);
+    const bool l8 = e->f8 && (e->f8_mask & 16) && !e->aug;      // adapters apart: lm_head is adapted and runs in the 16-bit format
+    const void* A = hidden_bf16; int64_t Hl = H;
+    if (!l8) TRY(lm_head_input(e, hidden_bf16, split, wide, n_rows, s, &A, &Hl));
     if (l8) {
         TRY(finalize_f8(e));
         h8 = (uint8_t*)e->hsel8.p; hs = (float*)(h8 + (size_t)round_up(n_rows, 256) * H);
@@ -612,9 +796,10 @@ static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split
         TRY(launch_quant_rows((const bf16_t*)hidden_bf16, H, n_rows, H, e->c.compute_dtype, h8, hs, s));
     }
     {
-        SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)H * V * (split ? 2 : 1));
-        GemmParams p = l8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0) : gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, nullptr, 0);
-        if (split) { ARG_CHECK(!l8); p.lda = 2 * H; p.K = 2 * H; p.w_wrap_k = H; }
+        SpanGuard g(e, s, TC_LMHEAD_LSE, 2.0 * n_rows * (double)Hl * V * (split ? 2 : 1));
+        GemmParams p = l8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0)
+                          : gp(e->c.compute_dtype, A, Hl, e->aug ? (const void*)e->lm_aug : (const void*)e->lm_head, n_rows, V, (int)Hl, nullptr, 0);
+        if (split) { ARG_CHECK(!l8); p.lda = 2 * Hl; p.K = (int)(2 * Hl); p.w_wrap_k = (int)Hl; }
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
     }
@@ -627,13 +812,15 @@ extern "C" int blim_segment_mean(blim_engine* e, const float* logprob, const int
     return launch_segment_mean(logprob, row_start, n_pairs, mode, score, (hipStream_t)stream);
 }
 
-static int lm_head_impl(blim_engine* e, const void* hidden_bf16, bool split, int64_t n_rows, float* logits, void* stream) {
+static int lm_head_impl(blim_engine* e, const void* hidden_bf16, bool split, int64_t n_rows, float* logits, void* stream, bool wide = false) {
     ARG_CHECK(e && hidden_bf16 && logits && n_rows > 0);
     TRY(blim_weights_ready(e));
     const int H = e->c.hidden_size, V = e->c.vocab_size;
-    SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * V);
-    GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->lm_head, n_rows, V, H, logits, V);
-    if (split) { p.lda = 2 * H; p.K = 2 * H; p.w_wrap_k = H; }
+    const void* A = hidden_bf16; int64_t Hl = H;
+    TRY(lm_head_input(e, hidden_bf16, split, wide, n_rows, (hipStream_t)stream, &A, &Hl));
+    SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)Hl * V);
+    GemmParams p = gp(e->c.compute_dtype, A, Hl, e->aug ? (const void*)e->lm_aug : (const void*)e->lm_head, n_rows, V, (int)Hl, logits, V);
+    if (split) { p.lda = 2 * Hl; p.K = (int)(2 * Hl); p.w_wrap_k = (int)Hl; }
     return launch_gemm(EPI_F32, p, (hipStream_t)stream);
 }
 extern "C" int blim_lm_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, float* logits, void* stream) {
@@ -699,8 +886,8 @@ extern "C" int blim_score_vtg(blim_engine* e, const blim_batch* b, const void* e
                               int64_t n_rows, const int32_t* row_start, int32_t n_pairs, float* score, void* stream) {
     ARG_CHECK(e && rows && labels && row_start && score && n_rows > 0 && n_pairs > 0);
     TRY(reserve_rows(e, n_rows));
-    TRY(decode_impl(e, b, embeds, rows, n_rows, e->hsel.p, e->precise, nullptr, stream));
-    TRY(vtg_logprobs_impl(e, e->hsel.p, e->precise, labels, n_rows, (float*)e->logprob.p, stream));
+    TRY(decode_impl(e, b, embeds, rows, n_rows, e->hsel.p, e->precise, nullptr, stream, e->c.hidden_size + e->aug));     // rows laid out for the adapted lm_head
+    TRY(vtg_logprobs_impl(e, e->hsel.p, e->precise, labels, n_rows, (float*)e->logprob.p, stream, true));
     return blim_segment_mean(e, (const float*)e->logprob.p, row_start, n_pairs, 0, score, stream);
 }
 
@@ -734,8 +921,8 @@ extern "C" int blim_forward(blim_engine* e, const void* embeds, const uint8_t* m
     b.n_tokens = T; b.n_seqs = B; b.n_blocks = B * nbs; b.positions = pos; b.key_visible = mask; b.seq_start = seq_start; b.seq_len = seq_len;
     b.pfx_start = pfx; b.pfx_len = pfx; b.blk_seq = blk_seq; b.blk_q0 = blk_q0; b.own_start = nullptr;
     TRY(reserve_rows(e, T));
-    TRY(decode_impl(e, &b, embeds, nullptr, 0, e->hsel.p, e->precise, hidden, stream));
-    if (logits) TRY(lm_head_impl(e, e->hsel.p, e->precise, T, logits, stream));
+    TRY(decode_impl(e, &b, embeds, nullptr, 0, e->hsel.p, e->precise, hidden, stream, e->c.hidden_size + e->aug));
+    if (logits) TRY(lm_head_impl(e, e->hsel.p, e->precise, T, logits, stream, true));
     return BLIM_OK;
 }
 

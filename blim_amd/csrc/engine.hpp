@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../include/blim.h"
+#include "adapters.hpp"
 #include "attention.hpp"
 #include "common.hpp"
 #include "gemm.hpp"
@@ -34,6 +35,10 @@ struct LayerW {
     uint8_t* wqkv8 = nullptr; uint8_t* wo8 = nullptr; uint8_t* wgu8 = nullptr; uint8_t* wd8 = nullptr;
     float* sqkv = nullptr; float* so = nullptr; float* sgu = nullptr; float* sd = nullptr;
 };
+
+// LoRA adapters kept apart (adapters.hpp): the f32 matrices as loaded + their 16-bit MFMA operand
+struct AdapterW { float* A = nullptr; float* B = nullptr; uint16_t* A16 = nullptr; int n_in = 0, n_out = 0; };
+struct LayerAd { AdapterW ad[4]; uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr; };      // ad: q, k, v, o
 
 struct blim_engine {
     blim_config c;
@@ -78,6 +83,16 @@ struct blim_engine {
                                    // forward() keeps the reference's [B, L, H] embeddings)
     bool timing = false;
     std::vector<TimedSpan> spans;
+    // ---- LoRA adapters kept apart (blim_load_adapter; adapters.hpp).  aug = extra K columns of every adapted Linear's operands (0 = none loaded);
+    // the augmented weight copies [W | B_hi | B_lo | 0] are (re)built lazily from the placed base weights (build_aug), so base weights and
+    // adapters may be loaded in any order.
+    int lora_r = 0; float lora_scale = 0.f; int aug = 0;
+    std::vector<LayerAd> AD; AdapterW ad_lm, ad_mlp[2][2];       // ad_mlp[mlp | tvg_mlp][Linear 0 | Linear 2]
+    uint16_t* lm_aug = nullptr; uint16_t* w0_aug[2] = {nullptr, nullptr}; uint16_t* w2_aug[2] = {nullptr, nullptr};
+    bool aug_ready = false;
+    std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)
+    std::vector<void*> ad_owned;                                 // the f32 A / B matrices
+    DevBuf feats_aug, hid_aug;                                   // staging: caller-provided rows copied into augmented rows
 };
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

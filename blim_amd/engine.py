@@ -78,6 +78,9 @@ def load_library(path: str = LIB_PATH):
         "blim_load_weight": ([vp, C.c_char_p, vp, i32, i32], C.c_int),
         "blim_init_synthetic_weights": ([vp, u64], C.c_int),
         "blim_weights_ready": ([vp], C.c_int),
+        "blim_load_adapter": ([vp, C.c_char_p, vp, vp, i32, f32], C.c_int),
+        "blim_clear_adapters": ([vp], C.c_int),
+        "blim_num_adapters": ([vp], C.c_int),
         "blim_reserve": ([vp, i64, i64], C.c_int),
         "blim_project_video": ([vp, vp, i64, i32, vp, vp], C.c_int),
         "blim_group_mean": ([vp, vp, i64, i32, vp, vp], C.c_int),
@@ -231,6 +234,20 @@ class Engine:
 
     def init_synthetic_weights(self, seed: int):
         _check(self.lib.blim_init_synthetic_weights(self.h, seed), "blim_init_synthetic_weights")
+
+    # ---- LoRA adapters kept apart (blim.h: blim_load_adapter; the reference's --resume flow, main.py:96-105, 125-128)
+    def load_adapter(self, weight_name: str, A: np.ndarray, B: np.ndarray, lora_r: int, lora_alpha: float):
+        """A [r, in], B [out, r] float32 (peft's lora_A.weight / lora_B.weight) of the adapter on canonical weight `weight_name`."""
+        n_out, n_in = weight_shapes(self.dims)[weight_name]
+        assert tuple(A.shape) == (lora_r, n_in) and tuple(B.shape) == (n_out, lora_r), (weight_name, A.shape, B.shape, (n_out, n_in), lora_r)
+        a = np.ascontiguousarray(A, dtype=np.float32); b = np.ascontiguousarray(B, dtype=np.float32)
+        _check(self.lib.blim_load_adapter(self.h, weight_name.encode(), a.ctypes.data, b.ctypes.data, int(lora_r), float(lora_alpha)), f"blim_load_adapter({weight_name})")
+
+    def clear_adapters(self):
+        _check(self.lib.blim_clear_adapters(self.h), "blim_clear_adapters")
+
+    def num_adapters(self) -> int:
+        return int(self.lib.blim_num_adapters(self.h))
 
     def reserve(self, max_tokens: int, max_rows: int):
         _check(self.lib.blim_reserve(self.h, max_tokens, max_rows), "blim_reserve")

@@ -79,3 +79,30 @@ def init_trainable(dims: ModelDims, r: int, seed: int, visual_head: np.ndarray =
         for k in ("A", "B"):
             out[f"tvg_mlp.{i}.w:{k}"] = out[f"mlp.{i}.w:{k}"].copy()
     return out
+
+
+def synthetic_trainable(dims: ModelDims, r: int, seed: int, rel: float = 5e-2, alpha: float = 32.0, w_std: float = 0.02) -> Dict[str, np.ndarray]:
+    """Seeded NON-ZERO adapters shaped like the outcome of a fine-tuning run (tests, golden fixtures, dry runs): A keeps peft's init scale
+    (std 1 / sqrt(3 in) = the std of U(-1/sqrt(in), 1/sqrt(in))), B is scaled so that || (alpha / r) B A ||_F = rel * || W ||_F for a base
+    weight of std w_std -- rel = 5e-2 is what this repo's own fine-tuning runs produce.  Values are plain float32
+    (not 16-bit representable), as trained adapters are.  tvg_mlp's adapters are their own tensors (trained apart after main.py:98's deepcopy);
+    visual_head is a full fp32 tensor (main.py:104-107)."""
+    from .synth import bell_f32
+    s = alpha / r
+    out = {}
+    shapes = trainable_shapes(dims, r)
+    for n, shape in shapes.items():
+        if n == "visual_head":
+            out[n] = bell_f32(seed, "adapter/" + n, int(np.prod(shape)), w_std).reshape(shape)
+            continue
+        n_in = shapes[n[:-1] + "A"][1]
+        a_std = 1.0 / math.sqrt(3.0 * n_in)
+        std = a_std if n.endswith(":A") else rel * w_std / (s * a_std * math.sqrt(r))
+        out[n] = bell_f32(seed, "adapter/" + n, int(np.prod(shape)), std).reshape(shape)
+    return out
+
+
+def resume_state(trainable: Dict[str, np.ndarray]) -> Dict[str, object]:
+    """The reference's resume-file layout (util/misc.py:276-297: {'model': {peft-named trainable tensors}, ...}) for a set of trainables."""
+    import torch
+    return {"model": {resume_key(n): torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for n, v in trainable.items()}}

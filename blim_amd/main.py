@@ -55,6 +55,11 @@ def get_args_parser():
     for flag, kw in (("--device", dict(default="cuda")), ("--world_size", dict(default=1, type=int)), ("--local_rank", dict(default=-1, type=int)),
                      ("--dist_on_itp", dict(action="store_true")), ("--dist_url", dict(default="env://"))):
         p.add_argument(flag, help="accepted for compatibility with the reference's command lines; unused", **kw)
+    p.add_argument("--lora_mode", default="apart", choices=["apart", "merge"],
+                   help="how --resume's LoRA adapters enter the scoring path.  apart (default): kept as separate matrices, y = W x + (alpha / r) B (A x), as the "
+                        "reference evaluates them (main.py:96-105) -- the rank-r term rides in the base GEMM's accumulation (64 extra K columns on q/k/v/o_proj, lm_head "
+                        "and the projector MLPs: about +1 %% time).  merge: W + (alpha / r) B A folded into the engine's 16-bit weight at load time (no per-call cost; the sum "
+                        "is rounded to the engine's format: fine in fp16 for a bf16 base checkpoint, 8 %% of the update in bf16, most of it in e4m3)")
     p.add_argument("--allow_partial_resume", action="store_true", help="load a resume file that lacks some of the expected adapters (warn instead of fail)")
     # engine-side options
     p.add_argument("--dtype", default=None, choices=["f16", "bf16", "f8"])
@@ -137,13 +142,17 @@ def main(args):
         # scores are sums of integers and hit 0.0 about once per 10^5 entries, real InternVideo2 similarities do not
         nz = lambda a: np.where(a == 0, np.float32(1e-6), a)
         args.iv2_scores = {"v2t": T(nz(prob.v2t_sims)), "t2v": T(nz(prob.t2v_sims))}
-        if args.eval and args.resume and os.path.isfile(args.resume):     # adapters of a (synthetic) training run: merged by the trainer's own merge kernel
+        if args.eval and args.resume and os.path.isfile(args.resume):     # adapters of a (synthetic) training run
             # (any other non-empty --resume only selects the fine-tuned score combination, training_utils.py:150-167)
-            from .training import Trainer
-            tr = Trainer(model.engine, lora_r=args.lora_r, lora_alpha=float(args.lora_alpha), lora_dropout=0.0)
-            tr.load_checkpoint_state(torch.load(args.resume, map_location="cpu", weights_only=False))
-            tr.merge_into_engine()
-            tr.close()
+            if args.lora_mode == "apart":
+                from .checkpoint import apply_resume
+                apply_resume(model.engine, dims, args.resume, lora_r=args.lora_r, lora_alpha=float(args.lora_alpha), strict_resume=not args.allow_partial_resume)
+            else:                                                         # merged on the device by the trainer's own merge kernel
+                from .training import Trainer
+                tr = Trainer(model.engine, lora_r=args.lora_r, lora_alpha=float(args.lora_alpha), lora_dropout=0.0)
+                tr.load_checkpoint_state(torch.load(args.resume, map_location="cpu", weights_only=False))
+                tr.merge_into_engine()
+                tr.close()
         if not args.eval:     # synthetic training set: other videos / captions of the same generator, this rank's share
             tprob = prob if args.synthetic_same else \
                 synth.make_problem(2 + rank, max(args.batch_size, args.synthetic), dims, tok_per_clip=64 if args.synthetic_7b else 8, fast_video=args.synthetic > 256)
@@ -161,7 +170,7 @@ def main(args):
         model = BlimModel(dims, dtype=args.dtype, tokenizer_model_max_length=cfg_json.get("tokenizer_model_max_length"))   # modeling_videochat_flash.py:452
         # evaluation merges the resume file's adapters at load time; training keeps the base weights pristine (the trainer owns the adapters)
         report = load_checkpoint(model.engine, dims, args.model_path, (args.resume or None) if args.eval else None, lora_r=args.lora_r,
-                                 lora_alpha=args.lora_alpha, strict_resume=not args.allow_partial_resume)
+                                 lora_alpha=args.lora_alpha, strict_resume=not args.allow_partial_resume, lora_mode=args.lora_mode)
         if rank == 0:
             print("weights: " + summarize_report(report))
         loader = load_data(args, tokenizer=tokenizer, split="test")
@@ -174,8 +183,10 @@ def main(args):
         mask = args.f8_mask if args.f8_mask is not None else (12 if finetuned_file else 31)
         model.engine.set_option("f8_mask", mask)
         if rank == 0 and finetuned_file:
-            print(f"fp8 mode on a fine-tuned checkpoint: f8_mask = {mask} "
-                  + ("(MLP only: the adapted projections q/k/v/o and lm_head stay in fp16, so the merged adapters survive)" if mask == 12 else
+            print(f"fp8 mode on a fine-tuned checkpoint: f8_mask = {mask}, lora_mode = {args.lora_mode} "
+                  + ("(adapters apart: the adapted projections q/k/v/o and lm_head run in fp16 with the adapters as separate 16-bit operands whatever the mask says; "
+                     "the MLP, 87 % of a layer's flops and not adapted, runs in e4m3)" if args.lora_mode == "apart" else
+                     "(MLP only: the adapted projections q/k/v/o and lm_head stay in fp16, so the merged adapters survive)" if mask == 12 else
                      "(adapters merged BEFORE the e4m3 quantisation: a rank-8 update is mostly below one e4m3 step of the base weight -- 2 - 4 points of R@1 lost, "
                      "profiles/r03_modes_trained_weights.md)"))
     if rank == 0:

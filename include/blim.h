@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 7
+#define BLIM_ABI_VERSION 8
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -100,6 +100,23 @@ int blim_load_weight(blim_engine* e, const char* name, const void* data, int32_t
 int blim_init_synthetic_weights(blim_engine* e, uint64_t seed);
 /* 0 when every tensor has been loaded, BLIM_ERR_STATE (message lists a missing tensor) otherwise. */
 int blim_weights_ready(const blim_engine* e);
+
+/* ---- LoRA adapters of a fine-tuned checkpoint, KEPT APART as the reference keeps them.  Replaces main.py:96-105 (peft get_peft_model on the
+ * projector `mlp` / `tvg_mlp` Linear "0" / "2", on every q/k/v/o_proj and on lm_head) + main.py:125-128 (load_state_dict of the resume file): the
+ * reference evaluates y = W x + b + (alpha / r) B (A x) with A, B as separate matrices; so does the engine for every `weight_name` an adapter was
+ * loaded for -- the rank-r term rides in the base product's accumulation (K-augmented operands [x | u] . [W | B]^T, u = (alpha / r) A x, 64 extra K
+ * columns), W stays exactly the checkpoint's value and A, B, u travel as hi + lo 16-bit pairs.  `A` [lora_r, in] and `B` [out, lora_r] are HOST
+ * float32 arrays in peft's layout (lora_A.weight / lora_B.weight); weight_name is the canonical name of the adapted weight
+ * ("layers.<i>.q_proj.w", "lm_head", "mlp.0.w", "tvg_mlp.2.w", ...).  All adapters of an engine share lora_r (<= 16) and lora_alpha (one LoraConfig,
+ * main.py:96-101).  Base weights and adapters may be loaded in any order; the augmented weight copies are rebuilt on the next call after either
+ * changes.  On an fp8 engine the adapted projections (q/k/v/o, lm_head) run in fp16 once adapters are loaded (the MLP, not adapted, stays e4m3).
+ * The alternative -- folding W + (alpha / r) B A into the engine's 16-bit weight on the host before blim_load_weight (blim_amd/checkpoint.py,
+ * lora_mode = "merge") -- needs no entry point; it rounds the sum to the engine's format. */
+int blim_load_adapter(blim_engine* e, const char* weight_name, const float* A, const float* B, int32_t lora_r, float lora_alpha);
+/* Drops every loaded adapter (the engine scores with the base weights again). */
+int blim_clear_adapters(blim_engine* e);
+/* Number of adapters currently loaded (negative on a NULL engine). */
+int blim_num_adapters(blim_engine* e);
 
 /* Pre-size workspaces (optional; they grow on demand, which synchronises the device). */
 int blim_reserve(blim_engine* e, int64_t max_tokens, int64_t max_rows);

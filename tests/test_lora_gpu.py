@@ -1,0 +1,199 @@
+"""GPU (-m gpu): scoring with LoRA adapters loaded -- the flow the reference ships (`main.py --eval --resume`, main.py:96-105, 125-128) --
+against goldens recorded from the reference's own loops with the adapters kept APART in fp32 (oracle/gen_golden_lora.py).
+
+The engine is loaded the way a user loads it: a HF-layout base checkpoint + a peft-layout resume file through blim_amd/checkpoint.py
+(`lora_tiny`, `lora_deep`: real files on disk; `lora7b`: the 15-GB base comes from the device-side seeded generator, the resume file is real).
+Both ways of carrying the adapters are held to the 1e-3 bar per entry where they are offered as parity modes:
+  * apart (default, blim_load_adapter): fp16 and bf16, fused and literal paths;
+  * merge (W + s B A rounded to the engine's 16-bit format): fp16 only -- in bf16 the rounding keeps 8 bits of the sum (reported, bounded).
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import lora_fixture as LF
+import test_gpu_parity as P
+from blim_amd import checkpoint as CK
+from blim_amd import synth
+from blim_amd.modeling import BlimModel
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def _ns(model, spec, dims, prob, dtype, case):
+    model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    return types.SimpleNamespace(spec=spec, dims=dims, model=model, w=None, prob=prob, d=spec["dims"], dtype=dtype, case=case)
+
+
+_FILES = {}
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    """case -> (base checkpoint dir, resume file), written once per module (the 28-layer base is 1.3 GB of safetensors)."""
+    def get(case):
+        if case not in _FILES:
+            spec, g, dims, prob = LF.load_case(case)
+            _FILES[case] = LF.write_files(tmp_path_factory.mktemp(case), LF.base_weights_host(spec, dims), LF.trainable_of(spec, dims))
+        return _FILES[case]
+    yield get
+    _FILES.clear()
+
+
+def _from_files(case, dtype, files, mode):
+    spec, g, dims, prob = LF.load_case(case)
+    base, resume = files(case)
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    rep = CK.load_checkpoint(model.engine, dims, base, resume, lora_r=LF.R, lora_alpha=LF.ALPHA, lora_mode=mode)
+    n_ad = len(CK.expected_adapters(dims))
+    assert sum("LoRA" in p for p in rep.values()) == n_ad and rep["visual_head"] == "resume" and rep["tvg_mlp.2.b"].startswith("base (copy of mlp)")
+    assert model.engine.num_adapters() == (n_ad if mode == "apart" else 0)
+    return _ns(model, spec, dims, prob, dtype, case), g
+
+
+def _report(capsys, tag, res):
+    with capsys.disabled():
+        for path, w in res.items():
+            print(f"\n[{tag} {path}] worst relative score deviation vs the reference (adapters apart, fp32): " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
+
+
+@pytest.mark.parametrize("mode", ["apart", "merge"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_lora_tiny_through_checkpoint_files(dtype, mode, files, capsys):
+    t, g = _from_files("lora_tiny", dtype, files, mode)
+    try:
+        res = {("literal" if lit else "fused"): P._worst_rel(P._six_passes(t, lit), g) for lit in (False, True)}
+    finally:
+        t.model.engine.close()
+    _report(capsys, f"lora_tiny {dtype} {mode}", res)
+    bar = RTOL if (mode == "apart" or dtype == "f16") else 4e-3         # bf16 + merge: the sum is rounded to 8 bits (reported mode)
+    assert max(max(w.values()) for w in res.values()) < bar
+
+
+@pytest.mark.parametrize("mode", ["apart", "merge"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_lora_deep_28_layers_through_checkpoint_files(dtype, mode, files, capsys):
+    """28 layers at H = 1024: a 1.3-GB sharded safetensors base + the resume file, both read back through blim_amd/checkpoint.py."""
+    t, g = _from_files("lora_deep", dtype, files, mode)
+    try:
+        res = {("literal" if lit else "fused"): P._worst_rel(P._six_passes(t, lit), g) for lit in (False, True)}
+    finally:
+        t.model.engine.close()
+    _report(capsys, f"lora_deep {dtype} {mode}", res)
+    if mode == "apart" or dtype == "f16":
+        assert max(max(w.values()) for w in res.values()) < RTOL
+    else:
+        assert max(max(w.values()) for w in res.values()) < 2e-2            # bf16 + merge: non-parity, bounded
+
+
+def _seven_b(dtype, mode, tmp_path):
+    import torch as _t
+    from blim_amd import lora
+    spec, g, dims, prob = LF.load_case("lora7b")
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    E = model.engine
+    E.init_synthetic_weights(spec["wseed"])                                         # 15 GB of base weights from the seeded rule, on the device
+    for k in ("0.w", "0.b", "2.w", "2.b"):                                          # main.py:98: tvg_mlp = deepcopy(mlp) of the base checkpoint
+        E.load_weight("tvg_mlp." + k, synth.tensor(spec["wseed"], "mlp." + k, synth.weight_shapes(dims)["mlp." + k], *synth.weight_dist("mlp." + k)))
+    tr = LF.trainable_of(spec, dims)
+    resume = os.path.join(str(tmp_path), "resume.pth")
+    _t.save(lora.resume_state(tr), resume)
+    if mode == "apart":
+        rep = CK.apply_resume(E, dims, resume, lora_r=LF.R, lora_alpha=LF.ALPHA)
+        assert E.num_adapters() == len(CK.expected_adapters(dims)) == len(rep) - 1
+    else:                                                                           # merged on the device by the trainer's merge kernel (what --lora_mode merge does on --synthetic runs)
+        from blim_amd.training import Trainer
+        trn = Trainer(E, lora_r=LF.R, lora_alpha=LF.ALPHA, lora_dropout=0.0)
+        trn.load_checkpoint_state(_t.load(resume, map_location="cpu", weights_only=False))
+        trn.merge_into_engine()
+        trn.close()
+    return _ns(model, spec, dims, prob, dtype, "lora7b"), g
+
+
+@pytest.mark.parametrize("dtype,mode", [("f16", "apart"), ("bf16", "apart"), ("f16", "merge"), ("bf16", "merge")])
+def test_lora_full_7b_vs_reference_golden(dtype, mode, tmp_path, capsys):
+    """The real Qwen2-7B configuration with NON-ZERO adapters on all 28 layers' q/k/v/o_proj, lm_head and both projector MLPs (the resume file
+    in peft's key layout), six pass kinds, fused and literal paths, against the reference run with the adapters apart in fp32."""
+    if not os.path.exists(os.path.join(LF.GOLD, "lora7b.npz")):
+        pytest.skip("tests/golden/lora7b.npz not generated")
+    t, g = _seven_b(dtype, mode, tmp_path)
+    try:
+        res = {("literal" if lit else "fused"): P._worst_rel(P._six_passes(t, lit), g) for lit in (False, True)}
+        base = np.load(os.path.join(LF.GOLD, "full7b.npz"))                          # same problem, base weights: the adapters are not a no-op
+        m = g["S_v2t_vtg"] != -100.0
+        moved = float(np.max(np.abs(g["S_v2t_vtg"][m] - base["S_v2t_vtg"][m]) / np.abs(g["S_v2t_vtg"][m])))
+    finally:
+        t.model.engine.close()
+    _report(capsys, f"lora7b {dtype} {mode} (adapters move the VTG scores by {moved:.1e})", res)
+    assert moved > 3e-3
+    worst = max(max(w.values()) for w in res.values())
+    if mode == "apart" or dtype == "f16":
+        assert worst < RTOL, res
+    else:
+        assert worst < 2e-2, res                                                     # bf16 + merge: W + s B A rounded to 8 bits (reported mode)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_zero_adapters_change_no_bit_and_apart_equals_merge_closely(dtype):
+    """(1) peft's initial state (B = 0) kept apart: the augmented K columns add exact zeros -- every score bit-equal to the base engine's;
+    (2) non-zero adapters: apart and merge agree to the rounding of the merged weights; (3) clear_adapters() restores the base scores bit for bit."""
+    spec, g, dims, prob = LF.load_case("lora_tiny")
+    w = LF.base_weights_host(spec, dims)
+    tr = LF.trainable_of(spec, dims)
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    E = model.engine
+    try:
+        E.load_weights(w)
+        t = _ns(model, spec, dims, prob, dtype, "lora_tiny")
+        base = {lit: P._six_passes(t, lit) for lit in (False, True)}
+        for n in CK.expected_adapters(dims):
+            E.load_adapter(n, tr[n + ":A"], np.zeros_like(tr[n + ":B"]), LF.R, LF.ALPHA)
+        model.clear_cache()
+        for lit in (False, True):
+            z = P._six_passes(t, lit)
+            for k in z:
+                assert np.array_equal(z[k], base[lit][k]), (k, lit)
+        for n in CK.expected_adapters(dims):
+            E.load_adapter(n, tr[n + ":A"], tr[n + ":B"], LF.R, LF.ALPHA)
+        model.clear_cache()
+        apart = P._six_passes(t, False)
+        assert not np.allclose(apart["v2t_vtg"], base[False]["v2t_vtg"], rtol=1e-3)
+        E.clear_adapters()
+        model.clear_cache()
+        again = P._six_passes(t, False)
+        for k in again:
+            assert np.array_equal(again[k], base[False][k]), k
+        merged_w = LF.merged_fp32(w, {**tr, "visual_head": w["visual_head"]})
+        E.load_weights(merged_w)
+        model.clear_cache()
+        merged = P._six_passes(t, False)
+        for k in merged:
+            m = merged[k] != -100.0
+            assert np.max(np.abs(merged[k][m] - apart[k][m]) / np.abs(apart[k][m])) < (1e-3 if dtype == "f16" else 8e-3), k
+    finally:
+        E.close()
+
+
+def test_adapter_abi_errors():
+    spec, g, dims, prob = LF.load_case("lora_tiny")
+    tr = LF.trainable_of(spec, dims)
+    model = BlimModel(dims, max_positions=256)
+    E = model.engine
+    try:
+        from blim_amd.engine import BlimError
+        n = "layers.0.q_proj.w"
+        E.load_adapter(n, tr[n + ":A"], tr[n + ":B"], 8, 32.0)
+        with pytest.raises(BlimError, match="one LoraConfig"):
+            E.load_adapter("layers.1.q_proj.w", tr[n + ":A"][:4], tr[n + ":B"][:, :4], 4, 32.0)
+        a = np.zeros((8, dims.hidden_size), np.float32); b = np.zeros((dims.hidden_size, 8), np.float32)
+        rc = E.lib.blim_load_adapter(E.h, b"layers.0.gate_proj.w", a.ctypes.data, b.ctypes.data, 8, 32.0)
+        assert rc != 0 and b"not a LoRA-adapted weight" in E.lib.blim_last_error()
+        assert E.num_adapters() == 1
+        E.clear_adapters()
+        assert E.num_adapters() == 0
+    finally:
+        E.close()

@@ -253,3 +253,30 @@ def test_bench_plan_fixture_covers_the_benched_problem():
     a, b = g["SYN_v2t_vtg"], g["SYN_t2v_vtg"].T                       # both indexed (video, text)
     both = (a != -100.0) & (b != -100.0)
     assert both.sum() >= 1 and np.allclose(a[both], b[both], rtol=1e-6)
+
+
+def test_lora_adapted_scoring_six_passes():
+    """tests/golden/lora_tiny.npz = the reference's own loops on a model with NON-ZERO LoRA adapters kept apart (oracle/gen_golden_lora.py: the
+    `--eval --resume` flow of main.py:96-105, 125-128).  The oracle on W + (alpha / r) B A merged in fp32 must give the same six matrices:
+    pins the merge rule (scaling, A / B orientation, which modules are adapted, visual_head from the resume file, tvg_mlp = copy of mlp)."""
+    import lora_fixture as LF
+    spec, g, dims, prob = LF.load_case("lora_tiny")
+    w = LF.merged_fp32(LF.base_weights_host(spec, dims), LF.trainable_of(spec, dims))
+    m = O.OracleModel(O.OracleConfig(**spec["dims"]), w)
+    m.set_tvg_prefix_length(prob.tvg_prefix_length)
+    vtg = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+    tvg = O.padding_ids(prob.tvg_ids, prob.tvg_labels, prob.tvg_masks, synth.PAD_ID)
+    n = spec["n"]
+    base = np.load(os.path.join(GOLD, "tiny.npz"))        # the same problem on the base weights (tvg_mlp differs there: VTG passes only)
+    for name, direction, ftype, c in LF.PASSES:
+        ids, lab, msk = vtg if ftype == "vtg" else tvg
+        fn = O.compute_v2t_scores_x if direction == "v2t" else O.compute_t2v_scores_x
+        sims = prob.v2t_sims if direction == "v2t" else prob.t2v_sims
+        S = fn(np.full((n, n), -100.0, dtype=np.float32), sims, 0, ids, msk, lab, prob.video, prob.video_vocab, prob.tvg_video_labels, m,
+               spec["topk"], spec["bs"], dims.num_clips, ftype, c)
+        G = g[f"S_{name}"]
+        assert np.array_equal(S == -100.0, G == -100.0), name
+        np.testing.assert_allclose(S, G, rtol=2e-5, err_msg=name)
+        if ftype == "vtg":      # the adapters are not a no-op: the scores moved
+            on = G != -100.0
+            assert np.max(np.abs(G[on] - base[f"S_{name}"][on]) / np.abs(G[on])) > 1e-3, name
