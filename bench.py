@@ -158,7 +158,7 @@ def tiny_config_evaluation():
     return {"pairs": 4 * n * topk, "oracle_s": round(t_cpu, 3), "engine_s": round(t_gpu, 4), "max_rel_diff": float(f"{worst:.2e}"), "agree_1e-3": worst < 1e-3}
 
 
-def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8):
+def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False):
     """The fixed-size job north_star's scaling clause names: ONE complete evaluation of an MSRVTT-1kA-shaped test set (N = 1000 videos and
     texts, top-16 re-rank, all six passes of the fine-tuned + CPN flow = 96,000 (query, candidate) pairs, reference-shaped rows with
     4 x 64 = 256 video tokens, the full 7B model) through blim_amd.retrieval_utils.evaluation -- data handling, planning, pair ownership
@@ -172,6 +172,8 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8):
     from blim_amd import synth
     from blim_amd.modeling import DDPLike
     dims = model.dims
+    pg = pg or world > 1                                                     # a process group is up (world 1 + BLIM_FORCE_COLLECTIVE: the RCCL smoke run)
+    peak = (PEAK_FP8_TFLOPS if model.engine.dtype == "f8" else PEAK_BF16_TFLOPS) * 1e12
     prob = synth.make_problem(1, n, dims, tok_per_clip=64, fast_video=True)
     loader = synth.ProblemLoader(prob, 64, video_dtype=torch.float16)        # fp16 per-video feature tensors, as the reference's files hold
     tokenizer = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
@@ -183,18 +185,23 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8):
                                      iv2_scores={"v2t": torch.from_numpy(nz(prob.v2t_sims)), "t2v": torch.from_numpy(nz(prob.t2v_sims))},
                                      max_tokens=32768, dedup=True, shard=shard)
         model.clear_cache()
-        if world > 1:
+        if pg:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         t2v, v2t = RU.evaluation(ddp, loader, dev, tokenizer, args)          # ends with the matrices on the host: synchronises
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        st = args._eval_stats
+        st["executed_flops_job"] = st.get("executed_flops", 0.0)
+        if pg:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, args._eval_stats, (t2v, v2t)
+            f = torch.tensor([st.get("executed_flops", 0.0)], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.SUM)      # the whole job's executed FLOPs (every rank's own calls)
+            st["executed_flops_job"] = float(f.item())
+        return dt, st, (t2v, v2t)
 
     run((4 * max(world, emulate), rank))                                      # warm-up: workspaces, allocator, first-call costs (a small share)
     dt, st, (t2v, v2t) = run(None)
@@ -204,16 +211,22 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8):
                        "(query, candidate) pairs, reference-shaped rows (256 video tokens), full 7B; host planning, pair ownership and the RCCL "
                        "all-gather of score blocks inside the timed region",
            "scaling": "strong", "world": world, "seconds": round(dt, 3), "pairs_per_s": round(pairs / dt, 1), "pairs": pairs,
+           # the fixed job's roofline fraction: GEMM FLOPs executed by ALL ranks' engine calls (RU.executed_flops: the per-token constants on the token
+           # counts launched, compensated TVG calls counted twice, last-layer pruning subtracted) / wall time of the job / (world x dense peak)
+           "executed_tflop_job": round(st["executed_flops_job"] / 1e12, 1),
+           "executed_tflops_per_gpu": round(st["executed_flops_job"] / dt / 1e12 / world, 1),
+           "frac_mfma_peak": round(st["executed_flops_job"] / dt / (world * peak), 4),
            "pairs_scored_rank0": st["pairs_scored"], "finite": bool(ok), "host_marks_rank0": st["host_marks"]}
     if world == 1 and emulate > 1:
-        per_rank = []
+        per_rank, per_rank_frac = [], []
         for r in range(emulate):
             d_r, st_r, _ = run((emulate, r))
             per_rank.append(round(d_r, 3))
+            per_rank_frac.append(round(st_r.get("executed_flops", 0.0) / d_r / peak, 4))
             if r == 0:
                 out["emulated_rank0_host_marks"] = st_r["host_marks"]
         out.update({"emulated_world": emulate, "emulated_rank_seconds": per_rank, "predicted_seconds": max(per_rank),
-                    "predicted_speedup": round(dt / max(per_rank), 2),
+                    "predicted_speedup": round(dt / max(per_rank), 2), "emulated_rank_frac_mfma_peak": per_rank_frac,
                     "predicted_note": f"slowest of the {emulate} ranks' own shares run one after another on this GPU; merge (one all-gather of < 1 MB) excluded"})
     return out
 
@@ -289,8 +302,12 @@ def main():
     from blim_amd import synth
     from blim_amd.modeling import BlimModel, DDPLike
 
-    rank, world, local = D.init_distributed_mode() if a.gpus > 1 else (0, 1, 0)
+    # BLIM_FORCE_COLLECTIVE=1 with RANK / WORLD_SIZE = 0 / 1 in the environment: a process group (backend nccl = RCCL) at world size 1, and every
+    # collective below runs -- the one-GPU smoke run of the multi-GPU path (tests/test_main_driver.py)
+    forced = os.environ.get("BLIM_FORCE_COLLECTIVE", "0") == "1" and "RANK" in os.environ
+    rank, world, local = D.init_distributed_mode() if (a.gpus > 1 or forced) else (0, 1, 0)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    pg = world > 1 or (forced and D.is_dist_avail_and_initialized())
     D.limit_host_threads(world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -300,10 +317,10 @@ def main():
     model.engine.init_synthetic_weights(0)                       # torch seed 0 of BASELINE.md -> engine seed 0
     model.vtg_precise = None if (a.vtg_precise == "none" or a.dtype == "f8") else a.vtg_precise
     if a.strong_only:
-        ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk)
+        ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk, pg=pg)
         if rank == 0:
             print(json.dumps({"strong_scaling": ss}), flush=True)
-        if world > 1:
+        if pg:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         return
@@ -320,22 +337,23 @@ def main():
 
     for i in range(a.warmup):
         step(i)
-    if world > 1:
+    if pg:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     outs = [step(i) for i in range(a.steps)]
     mine = torch.stack(outs)                                      # [steps, pairs] score rows of this rank
-    if world > 1:
+    if pg:
         gathered = [torch.empty_like(mine) for _ in range(world)]
         torch.distributed.all_gather(gathered, mine)              # RCCL all-gather of the score rows (north_star)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if pg:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        assert torch.equal(gathered[rank], mine), "all_gather returned other rows than this rank sent"
     assert torch.isfinite(mine).all(), "non-finite scores"
 
     # ---- per-kernel timing (HIP events on the launch stream) of one more step, for the roofline object
@@ -345,22 +363,24 @@ def main():
     model.engine.timing_enable(False)
 
     # ---- strong-scaling leg (all ranks): one fixed-size N = 1000 evaluation, after and outside the timed steps above
-    ss = None
+    ss, ss_failed = None, False
     if not a.no_strong:
         try:
-            ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk)
+            ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk, pg=pg)
         except Exception as e:                 # the headline line above is already measured: report the failure inside it instead of losing both
             import traceback
             ss = {"error": f"{type(e).__name__}: {e}", "traceback_tail": traceback.format_exc()[-1500:]}
+            ss_failed = True
+            print(f"[bench rank {rank}] strong-scaling leg failed: {ss['error']}", file=sys.stderr, flush=True)
 
     if rank == 0:
         total_pairs = n_pairs * a.steps * world
         value = total_pairs / dt
-        exec_flops_step = LAYERS * (FLOP_TOKEN_LAYER * n_tok) + FLOP_HEAD_ROW * n_rows      # attention excluded (<1 %)
-        if model.vtg_precise == "full":                                  # [hi | lo] A operands: every GEMM walks K twice
-            exec_flops_step *= 2
-        elif model.vtg_precise == "attn":                                # QKV, o_proj and the lm_head rows only
-            exec_flops_step += LAYERS * (2 * H * (H + 2 * 512) + 2 * H * H) * n_tok + FLOP_HEAD_ROW * n_rows
+        # executed GEMM FLOPs of one step (attention excluded, < 1 %): the per-token constants on the packed tokens, the compensated modes' doubled GEMMs,
+        # MINUS the last layer's o_proj / MLP on the rows nobody reads (engine option prune_last: 4,400 of the 32,560 tokens of a step are video-prefix rows)
+        exec_flops_step = RU.executed_flops(dims, n_tok, n_rows, "vtg", model.vtg_precise, prune=model.engine.dtype != "f8")
+        assert model.vtg_precise is not None or model.engine.dtype == "f8" or \
+            abs(exec_flops_step - (LAYERS * FLOP_TOKEN_LAYER * n_tok + FLOP_HEAD_ROW * n_rows - (FLOP_TOKEN_LAYER - 2 * H * (H + 2 * 512)) * (n_tok - n_rows))) < 1e6
         dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
         d = rep[dom]
         ach = d["flops"] / d["calls"] / (d["ms"] / d["calls"] * 1e-3) / 1e12
@@ -396,7 +416,12 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ss_failed and pg:
+        # a rank that failed inside the leg may have left the others inside one of its collectives: no barrier here (it could never complete).  The failed rank
+        # exits non-zero without tearing the group down, so the launcher ends the job instead of hanging; rank 0's line above (if it is the one that failed) says why
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(3)
+    if pg:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

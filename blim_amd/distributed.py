@@ -57,6 +57,14 @@ def init_distributed_mode(backend: str = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def force_collective() -> bool:
+    """BLIM_FORCE_COLLECTIVE=1 with a process group up: run every collective branch of the multi-GPU flow even at world size 1 -- the merge of the
+    score blocks, the prior-vector gather, the clip-feature gather, bench.py's score-row all_gather -- so that a ONE-GPU box executes the same RCCL
+    calls (backend 'nccl', device tensors) the 8-GPU job makes, with results that must equal the non-collective path bit for bit
+    (tests/test_main_driver.py).  The reference's counterpart: util/misc.py:199-229 + retrieval_utils.py:252-262 run under torchrun even with one process."""
+    return os.environ.get("BLIM_FORCE_COLLECTIVE", "0") == "1" and is_dist_avail_and_initialized()
+
+
 def row_block(n: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row block of `rank`: step = n // W + 1 (retrieval_utils.py:213-215)."""
     step = n // world + 1
@@ -69,7 +77,7 @@ def merge_row_blocks(S, block: Tuple[int, int], world: int, compat_offset: bool 
     Returns the merged matrix on every rank."""
     import torch
     d = _dist()
-    if world == 1 or not is_dist_avail_and_initialized():
+    if (world == 1 and not force_collective()) or not is_dist_avail_and_initialized():
         return S
     N, M = S.shape
     step = N // world + 1
@@ -91,7 +99,7 @@ def merge_row_blocks_many(mats, blocks, world: int, compat_offset: bool = False)
     matrices of an evaluation travel together).  mats[i]: [N_i, M_i]; blocks[i]: this rank's row range."""
     import torch
     d = _dist()
-    if world == 1 or not is_dist_avail_and_initialized() or not mats:
+    if (world == 1 and not force_collective()) or not is_dist_avail_and_initialized() or not mats:
         return list(mats)
     parts, shapes = [], []
     for S, (s, e) in zip(mats, blocks):
@@ -113,11 +121,21 @@ def merge_row_blocks_many(mats, blocks, world: int, compat_offset: bool = False)
     return outs
 
 
-def host_threads(world: int = 1, cap: int = 8) -> int:
-    """Intra-op threads for the host-side torch ops of the scoring drivers (top-k of the first-stage matrices, padding, stacking):
-    the CPUs this process may use (affinity mask and cgroup quota) shared by the `world` ranks of the node, at most `cap`.  torch's
-    default is one thread per LOGICAL CPU of the machine; inside a 16-CPU quota on a 256-thread host that made a 64 MB torch.stack take
-    170 ms (measured on the GPU boxes), and eight ranks each starting 256 threads is worse."""
+def local_world_size(world: int = 1) -> int:
+    """Ranks sharing THIS node's CPUs: LOCAL_WORLD_SIZE (torchrun sets it), else min(world, GPUs of the node)."""
+    v = os.environ.get("LOCAL_WORLD_SIZE")
+    if v and v.isdigit() and int(v) > 0:
+        return int(v)
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:
+        n = 0
+    return max(1, min(world, n) if n > 0 else world)
+
+
+def usable_cpus() -> int:
+    """CPUs this process may use: the affinity mask and the cgroup CPU quota (v2: cpu.max; v1: cpu.cfs_quota_us / cpu.cfs_period_us)."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
@@ -128,8 +146,23 @@ def host_threads(world: int = 1, cap: int = 8) -> int:
         if q[0] != "max":
             n = min(n, max(1, int(q[0]) // int(q[1])))
     except (OSError, ValueError, IndexError):
-        pass
-    return max(1, min(cap, n // max(1, world)))
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def host_threads(world: int = 1, cap: int = 8) -> int:
+    """Intra-op threads for the host-side torch ops of the scoring drivers (top-k of the first-stage matrices, padding, stacking):
+    the CPUs this process may use (`usable_cpus`) shared by the ranks of THIS NODE (`local_world_size`: on a multi-node job the global world
+    size would throttle every rank to one thread), at most `cap`.  torch's default is one thread per LOGICAL CPU of the machine; inside a
+    16-CPU quota on a 256-thread host that made a 64 MB torch.stack take 170 ms (measured on the GPU boxes), and eight ranks each starting 256
+    threads is worse."""
+    return max(1, min(cap, usable_cpus() // local_world_size(world)))
 
 
 def limit_host_threads(world: int = 1) -> int:

@@ -68,11 +68,13 @@ def get_args_parser():
                    help="fp8 mode: which GEMMs take e4m3 operands (bit 0 qkv, 1 o_proj, 2 gate|up, 3 down, 4 lm_head).  Default 31 (all) on a base checkpoint, "
                         "12 (the MLP only) when --resume names a fine-tuned checkpoint: LoRA adapts q/k/v/o_proj and lm_head, whose merged rank-8 update is below one "
                         "e4m3 step of the base weight -- those GEMMs stay in fp16, the MLP (87 %% of a layer's flops, not adapted) runs in fp8")
-    p.add_argument("--vtg_precise", default=None, choices=["none", "qk", "qkx", "attn", "full"],
-                   help="compensated (hi + lo) activations on the VTG calls; default: none on fp16 engines, full on bf16 engines (the mode in which "
-                        "bf16 holds 1e-3 against the fp32 reference at 7B depth; `none` = the fast, non-parity bf16 mode).  `attn` on an fp16 engine compensates "
-                        "the attention branch of the VTG calls: for checkpoints with massive activations on sink tokens, where plain fp16 -- the reference's own numerics -- "
-                        "is ~3e-3 from the fp32 result (tests/golden/sink.npz: 5e-4 with attn, -16 %% speed; `qkx` = q / k / v, the attention and the QKV GEMM's input as hi + lo: 6.6e-4, -8.4 %%; `qk` = without the input: 1.2e-3, -2.5 %%)")
+    p.add_argument("--vtg_precise", default="auto", choices=["auto", "none", "qk", "qkx", "attn", "full"],
+                   help="compensated (hi + lo) activations on the VTG calls.  auto (default): measured on the loaded checkpoint before the first pass -- up to 256 pairs of the "
+                        "evaluation are scored in every mode against the fully compensated one (which sits at 2e-6 .. 1e-5 of the fp32 reference) and the cheapest mode "
+                        "within 7.5e-4 is kept (PairScorer.calibrate_vtg; the table is printed).  none = plain 16-bit (what auto picks on an fp16 engine unless the checkpoint "
+                        "has massive activations on sink tokens: tests/golden/sink.npz, where plain fp16 -- the reference's own numerics -- is ~3e-3 from the fp32 result); "
+                        "qk = q / k / v and the attention as hi + lo (-2.5 %% speed); qkx = and the QKV GEMM's input (-8.4 %%); attn = the whole attention branch (-16 %%); "
+                        "full = every activation (2x the GEMM flops: the mode in which a bf16 engine holds 1e-3 at 7B depth)")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")
     p.add_argument("--no_dedup", action="store_false", dest="dedup", help="score the pairs both directions share twice, as the reference does")
@@ -176,8 +178,8 @@ def main(args):
         loader = load_data(args, tokenizer=tokenizer, split="test")
         if not args.eval:
             train_loader = load_data(args, tokenizer=tokenizer, split="train")
-    if args.vtg_precise is not None:
-        model.vtg_precise = None if args.vtg_precise == "none" else args.vtg_precise
+    if args.vtg_precise is not None and model.engine.can_precise:
+        model.vtg_precise = None if args.vtg_precise == "none" else args.vtg_precise        # "auto": resolved by evaluation() on the loaded weights
     if model.engine.dtype == "f8":
         finetuned_file = bool(args.resume) and os.path.isfile(args.resume)
         mask = args.f8_mask if args.f8_mask is not None else (12 if finetuned_file else 31)
@@ -221,7 +223,7 @@ def main(args):
         print(table.to_string())
         with open(os.path.join(args.output_dir, "log.txt"), "a") as f:
             f.write(table.to_string() + "\n")
-    if world > 1:
+    if D.is_dist_avail_and_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     model.engine.close()

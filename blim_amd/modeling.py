@@ -186,6 +186,8 @@ class BlimModel:
             m_t, c_t = None, torch.from_numpy(cpn_mask).to(self.device)
         else:
             m_t = torch.from_numpy(mask).to(self.device).to(mdt); c_t = torch.from_numpy(cpn_mask).to(self.device).to(mdt)
+        # the row kind travels WITH the tensor (forward() reads it): prepare(tvg) / prepare(vtg) / forward(tvg embeds) may be interleaved freely
+        embeds._blim_rows = "tvg" if tvg else "vtg"
         if cpn:
             return None, position_ids, (m_t, c_t), past_key_values, embeds, new_labels
         return None, position_ids, m_t, past_key_values, embeds, new_labels
@@ -201,7 +203,15 @@ class BlimModel:
         if position_ids is not None or past_key_values is not None or labels is not None or use_cache or output_attentions or dpo_forward:
             raise NotImplementedError("forward(): position_ids / cache / labels / attentions are outside the scoring path")
         B, L, _ = inputs_embeds.shape
-        wide = inputs_embeds.dtype == torch.float32 and self.engine.can_precise and (self.engine.dtype == "bf16" or self._tvg_rows)
+        # row kind: the tag prepare_inputs_labels_for_multimodal put on the tensor; an untagged tensor (the caller derived a new one) falls back to the
+        # last prepare call -- except that on an fp16 engine only TVG rows are ever handed out as float32, so a float32 tensor there IS a TVG batch
+        # (treating it as VTG rows would silently round it to fp16 and run it plain: ~1e-3 on the scores)
+        kind = getattr(inputs_embeds, "_blim_rows", None)
+        tvg_rows = (kind == "tvg") if kind is not None else (self._tvg_rows or (inputs_embeds.dtype == torch.float32 and self.engine.dtype == "f16" and self.engine.can_precise))
+        if self.vtg_precise == "auto" and not tvg_rows:
+            raise RuntimeError("vtg_precise = 'auto' has not been resolved yet: evaluation() measures it on the loaded checkpoint before its first pass "
+                               "(PairScorer.calibrate_vtg); set BlimModel.vtg_precise to none / qk / qkx / attn / full to call forward() directly")
+        wide = inputs_embeds.dtype == torch.float32 and self.engine.can_precise and (self.engine.dtype == "bf16" or tvg_rows)
         if wide:                                                          # float32 embeddings of prepare_inputs_labels_for_multimodal (bf16 engines; TVG rows on fp16 ones): back to [hi | lo]
             hi = inputs_embeds.to(self.dtype)
             emb = torch.cat([hi, (inputs_embeds - hi.float()).to(self.dtype)], dim=-1).contiguous()
@@ -213,14 +223,14 @@ class BlimModel:
             m8 = (attention_mask != 0).to(torch.uint8).contiguous()
         # a forward over rows prepared with tvg=True runs in the compensated mode, like the fused TVG calls (engine.set_precise); VTG rows
         # follow self.vtg_precise
-        if self._tvg_rows:
+        if tvg_rows:
             self.engine.set_precise(True, embeds=wide)
         else:
             on = self.vtg_precise in ("attn", "full")
             self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise == "full")
             if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none / qk): plain embeddings
                 emb = inputs_embeds.to(self.dtype).contiguous()
-        qk = (not self._tvg_rows) and self.vtg_precise in ("qk", "qkx")          # plain activations, q / k / v and the attention as hi + lo (engine option precise_qk)
+        qk = (not tvg_rows) and self.vtg_precise in ("qk", "qkx")          # plain activations, q / k / v and the attention as hi + lo (engine option precise_qk)
         if qk:
             self.engine.set_option("precise_qk", 2 if self.vtg_precise == "qkx" else 1)
         try:

@@ -288,6 +288,23 @@ def _six_passes(t, literal, prob=None, spec=None, names=None, max_tokens=4096):
     return out
 
 
+def _resolve_auto(t, prob=None, spec=None):
+    """`--vtg_precise auto` as evaluation() resolves it: PairScorer.calibrate_vtg on the calibration pairs of the problem -> (mode, table)."""
+    prob = prob or t.prob
+    spec = spec or t.spec
+    t.model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    t.model.vtg_precise = "auto"
+    sc = RU.PairScorer(DDPLike(t.model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video], torch.from_numpy(prob.video_vocab),
+                       torch.from_numpy(prob.tvg_video_labels), t.dims.num_clips)
+    chosen, table = sc.calibrate_vtg(RU.calibration_pairs(torch.from_numpy(prob.v2t_sims), spec["topk"]))
+    assert (t.model.vtg_precise or "none") == chosen
+    return chosen, table
+
+
 def _worst_rel(got, g, prefix="S_"):
     """{pass: worst relative deviation over the computed entries}; the computed-entry pattern must equal the golden one."""
     worst = {}
@@ -434,6 +451,11 @@ def _depth_case(case, dtype, capsys, literal_too=True):
             for tag, mm in (("", r[2][0]), ("_cpn", r[2][1])):
                 out = t.model(inputs_embeds=r[4], attention_mask=mm, want_logits=False)
                 hid[f"{kind}{tag}"] = relmax(out.hidden_states.cpu().numpy()[..., ::16][valid], g[f"fwd_{kind}{tag}_hidden_sub16"][valid])
+        if dtype == "f16":      # `--vtg_precise auto` (the driver's default): on these weights the plain fp16 VTG calls are kept
+            chosen, table = _resolve_auto(t)
+            with capsys.disabled():
+                print(f"\n[{case} f16] vtg_precise auto: " + ", ".join(f"{k} {v:.1e}" for k, v in table.items()) + f" -> {chosen}")
+            assert chosen == "none", (case, table)
     finally:
         t.model.engine.close()
     with capsys.disabled():
@@ -482,9 +504,21 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
         prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
         model.set_tvg_prefix_length(prob.tvg_prefix_length)
         t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype=dtype, case=case)
+        plain, auto = None, None
+        if case == "sink" and dtype == "f16":
+            # massive activations on sink positions: plain fp16 VTG calls -- the library default and the reference's own numerics -- read 3.2e-3 here (reported below, not
+            # asserted).  The driver's default is `--vtg_precise auto`: the mode is MEASURED on the loaded weights (PairScorer.calibrate_vtg), must come out as qkx on
+            # this fixture, and every pass is then held to the same 1e-3 as everywhere else -- no carve-out.
+            plain = {tag: _worst_rel(_six_passes(t, lit, names=("v2t_vtg", "t2v_vtg")), g) for tag, lit in (("fused", False), ("literal", True))}
+            auto = _resolve_auto(t)
         res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in ((("fused", False), ("literal", True)) if dtype != "f8" else (("fused", False),))}
     finally:
         model.engine.close()
+    if auto is not None:
+        with capsys.disabled():
+            print(f"\n[sink f16] plain fp16 VTG calls (library default), fused: " + ", ".join(f"{k} {v:.2e}" for k, v in plain["fused"].items())
+                  + "; vtg_precise auto: " + ", ".join(f"{k} {v:.1e}" for k, v in auto[1].items()) + f" -> {auto[0]} (the passes below ran in it)")
+        assert auto[0] == "qkx", auto
     with capsys.disabled():
         for tag, w in res.items():
             print(f"\n[{case} {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers, residual |max| {float(g['resid_absmax_per_layer'].max()):.0f} at rms "
@@ -499,10 +533,6 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
         for k, v in w.items():
             if dtype == "f8":      # reported, non-parity mode: the outliers must not make it WORSE than on N(0, 0.02^2) weights (same bounds as test_depth_fp8_mode_deltas_*)
                 assert v < (0.18 if "tvg" in k else 0.08), (dtype, tag, k, v)
-            elif case == "sink" and dtype == "f16" and k in ("v2t_vtg", "t2v_vtg"):
-                # Plain fp16 VTG calls with massive activations on sink positions: 3.2e-3 -- what 16-bit activations do there; the reference's own fp16 run is 3.7e-3
-                # from its fp32 run on the same weights.  Held to the reference's own spread here, and to the 1e-3 bar in the compensated modes below.
-                assert v < max(SCORE_RTOL, 1.25 * own[k]), (dtype, tag, k, v, own)
             else:
                 assert v < score_rtol(dtype, k, tag == "literal"), (dtype, tag, k, v)
     if case == "sink" and dtype == "f16":
@@ -533,7 +563,7 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
                 print(f"[sink f16 {tag}, vtg_precise = qkx] " + ", ".join(f"{k} {v:.2e}" for k, v in x.items()))
         assert max(w.values()) < SCORE_RTOL, w
         for tag, x in wq.items():
-            assert max(x.values()) < 2e-3 and x["v2t_vtg"] < 0.6 * res[tag]["v2t_vtg"], (tag, x, res[tag])
+            assert max(x.values()) < 2e-3 and x["v2t_vtg"] < 0.6 * plain[tag]["v2t_vtg"], (tag, x, plain[tag])
         assert max(max(x.values()) for x in wx.values()) < SCORE_RTOL, wx
 
 

@@ -346,11 +346,19 @@ def test_coefficient_sweeps_match_the_reference_when_present():
             assert mine[2:] == ref[2:] and np.array_equal(mine[0], ref[0]) and np.array_equal(mine[1], ref[1])
 
 
-def test_host_thread_cap_is_sane():
-    """distributed.host_threads: torch intra-op threads for the drivers = CPUs this process may use / ranks on the node, between 1 and the cap."""
+def test_host_thread_cap_is_sane(monkeypatch):
+    """distributed.host_threads: torch intra-op threads for the drivers = CPUs this process may use / ranks on THIS node, between 1 and the cap."""
     from blim_amd import distributed as D
-    n1, n8 = D.host_threads(1), D.host_threads(8)
-    assert 1 <= n8 <= n1 <= 8 and D.host_threads(1, cap=2) <= 2 and D.host_threads(10 ** 6) == 1
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    n1 = D.host_threads(1)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    n8 = D.host_threads(8)
+    assert 1 <= n8 <= n1 <= 8 and D.host_threads(1, cap=2) <= 2
+    # a 4-node x 8-GPU job: the division is by the node's 8 ranks, not by the global 32 (which throttled every rank to one thread)
+    assert D.host_threads(32) == n8 and D.local_world_size(32) == 8
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", str(10 ** 6))
+    assert D.host_threads(10 ** 6) == 1
+    assert D.usable_cpus() >= 1
 
 
 def test_chunked_projection_follows_the_order_of_first_use():

@@ -93,6 +93,64 @@ def test_two_ranks_give_the_single_process_recall_table(tmp_path):
         assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k], b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
 
 
+def _rccl_env(root, port):
+    """One rank, world size 1, backend nccl (= RCCL) on cuda:0, every collective branch forced (blim_amd/distributed.py:force_collective)."""
+    env = dict(os.environ, PYTHONPATH=root, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               BLIM_FORCE_COLLECTIVE="1", NCCL_DEBUG="VERSION", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("BLIM_DIST_BACKEND", None); env.pop("BLIM_FORCE_DEVICE", None)
+    return env
+
+
+def test_rccl_runs_every_collective_of_the_evaluation_at_world_size_one(tmp_path, capsys):
+    """The multi-GPU flow's collectives on the REAL backend: a process group with backend 'nccl' (RCCL) at world size 1 on cuda:0 and
+    BLIM_FORCE_COLLECTIVE=1, so that the evaluation runs merge_row_blocks_many (the all-gather of the score blocks), the text-sharded prior's
+    gather and PairScorer.share_tvg_feats on device tensors through RCCL -- the calls an 8-GPU job makes (util/misc.py:199-229,
+    retrieval_utils.py:252-262) -- and every score matrix must equal the run without a process group bit for bit.  NCCL_DEBUG=VERSION makes
+    the library announce itself: the log must carry its version line."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--eval", "--synthetic", "19", "--cpn", "--resume", "x", "--alpha", "0.4", "0.8", "--c", "0.3", "0.6", "0.9", "0.7", "--topk", "5"]
+    r1 = subprocess.run([sys.executable, "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w1"), "--dump_scores", str(tmp_path / "w1.npz")], cwd=root,
+                        env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "rc"), "--dump_scores", str(tmp_path / "rc.npz")], cwd=root,
+                        env=_rccl_env(root, 29561), capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    log = r2.stdout + r2.stderr
+    m = re.search(r"(RCCL|NCCL) version[^\n]*", log)
+    with capsys.disabled():
+        print("\n[rccl world-size-1 evaluation] " + (m.group(0) if m else "no version line; log tail: " + log[-400:]))
+    assert m, log[-2000:]
+    a, b = np.load(tmp_path / "w1.npz"), np.load(tmp_path / "rc.npz")
+    assert set(a.files) == set(b.files) and len(a.files) == 8
+    for k in a.files:
+        assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k], b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
+    assert open(tmp_path / "w1" / "log.txt").read() == open(tmp_path / "rc" / "log.txt").read()
+
+
+def test_rccl_runs_the_bench_collectives_at_world_size_one(tmp_path, capsys):
+    """bench.py under the same environment: the timed region's all_gather of the score rows, the MAX all-reduce of the step time, the barriers and the
+    strong-scaling leg's collectives all go through RCCL on cuda:0; the JSON line keeps its contract."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "8", "--strong-n", "96", "--no-cpu-baseline"], cwd=root,
+                       env=_rccl_env(root, 29563), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = re.search(r"(RCCL|NCCL) version[^\n]*", r.stdout + r.stderr)
+    with capsys.disabled():
+        print("\n[rccl world-size-1 bench] " + (m.group(0) if m else "no version line"))
+    assert m, (r.stdout + r.stderr)[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["strong_scaling"]["finite"] is True and d["strong_scaling"]["world"] == 1
+    assert "RCCL" in d["config"]["parallelism"]
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     """bench.py's output contract: exactly one JSON line on stdout with the driver's keys, the roofline and (at N = 1) the CPU
     baseline objects.  Small workload (8 queries) so that the test takes seconds; the numbers themselves are not checked."""
@@ -112,6 +170,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert ss["scaling"] == "strong" and ss["world"] == 1 and ss["pairs"] == 6 * 96 * 16 and ss["finite"] is True and ss["seconds"] > 0
     assert ss["emulated_world"] == 8 and len(ss["emulated_rank_seconds"]) == 8 and ss["predicted_seconds"] == max(ss["emulated_rank_seconds"])
     assert abs(ss["predicted_speedup"] - ss["seconds"] / ss["predicted_seconds"]) < 0.02 and ss["pairs_scored_rank0"] <= ss["pairs"]
+    # the fixed job has a roofline fraction of its own (executed GEMM FLOPs of all its engine calls / time / peak), and so has every emulated rank
+    assert 0 < ss["frac_mfma_peak"] < 1 and abs(ss["frac_mfma_peak"] - ss["executed_tflops_per_gpu"] / 2500.0) < 2e-3 and len(ss["emulated_rank_frac_mfma_peak"]) == 8
+    assert abs(ss["executed_tflop_job"] / ss["seconds"] - ss["executed_tflops_per_gpu"]) < 0.02 * ss["executed_tflops_per_gpu"] + 0.2
+    # the headline step's executed FLOPs leave out the last layer's o_proj / MLP on the rows nobody reads (prune_last)
+    tok, pairs_ = d["config"]["tokens_per_step_per_gpu"], d["config"]["pairs_per_step_per_gpu"]
+    assert d["executed_gflop_per_pair"] * pairs_ * 1e9 < 28 * 466092032 * tok + 1089994752 * 32 * pairs_
     assert d["metric"].startswith("candidate-pairs/sec") and d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f16"
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -171,8 +235,10 @@ def test_training_driver_on_a_synthetic_tree(tmp_path, monkeypatch, capsys):
     assert "base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight" in keys
     assert "base_model.model.model.mm_projector.tvg_mlp.base_model.model.2.lora_B.default.weight" in keys
     assert ckpt["epoch"] == 1 and "scaler" in ckpt and ckpt["optimizer"]["step"] == 6
-    again = _run(["--eval", "--resume", os.path.join(out_dir, "epoch1.pth")] + common)
+    again = _run(["--eval", "--resume", os.path.join(out_dir, "epoch1.pth")] + common)                              # adapters kept apart (the default)
     assert again == last, (again, last)
+    merged = _run(["--eval", "--resume", os.path.join(out_dir, "epoch1.pth"), "--lora_mode", "merge"] + common)      # ... and merged on the host at load
+    assert merged == last, (merged, last)
 
 
 def test_two_ranks_train_with_averaged_gradients(tmp_path):
