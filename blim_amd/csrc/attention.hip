@@ -33,7 +33,11 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
     const int wave = tid >> 6;
     const int G = p.num_heads / p.num_kv_heads;
     const int kh = blockIdx.y;
-    const int head = kh * G + wave;
+    // Waves beyond the G query heads of this KV head are HELPERS (compensated kernels with few heads per group, launch_attention): they take their share
+    // of every tile's staging -- 2,048 16-byte chunks in the compensated mode, which G <= 6 waves had to hold as 8 - 32 staging registers each (7 - 64
+    // spilled VGPRs) -- and the barriers, and compute nothing.
+    const bool worker = wave < G;
+    const int head = kh * G + (worker ? wave : 0);
     const int blk = blockIdx.x;
     const int s = p.blk_seq[blk], q0 = p.blk_q0[blk];
     const int sstart = p.seq_start[s], slen = p.seq_len[s];
@@ -135,6 +139,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
 #if defined(ATTN_ABLATE) && ATTN_ABLATE == 2     // ... or: staging only, no MFMA / softmax work
         continue;
 #endif
+        if (!worker) continue;                       // (wave-uniform)
 
         int base_tok, k0, seg_len; bool causal;
         tile_desc(t, base_tok, k0, seg_len, causal);
@@ -262,6 +267,7 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
     }
 
     // ---- normalise and store: o[db][r] is O[q = lane&31][d = 32db + (r&3) + 8(r>>2) + 4hf]
+    if (!worker) return;
     if (p.out8 != nullptr) {
         // fp8 mode: this wave's 128 outputs of a token are one K-step of the o_proj GEMM -> e4m3 with one power-of-two scale (E8M0):
         // the query's maximum is in two lanes (hf = 0, 1)
@@ -322,15 +328,14 @@ int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
     const dim3 grid(p.n_blocks, p.num_kv_heads), block(64 * G);
     if (p.v_lo_off != 0 || p.out_lo_off != 0) {   // compensated mode (fp16 engines): transposed-read path only
         ARG_CHECK((p.dtype == DT_F16 || p.dtype == DT_BF16) && p.v_lo_off > 0 && p.out_lo_off > 0 && p.v_lo_off % 8 == 0 && p.out_lo_off % 4 == 0);
-#define ATTN_SPLIT(MC)                                                                                               \
+#define ATTN_SPLIT(MC, BLOCK)                                                                                          \
         do {                                                                                                         \
-            if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<true, MC, DT_F16, true>), grid, block, 0, stream, p);  \
-            else hipLaunchKernelGGL((attn_kernel<true, MC, DT_BF16, true>), grid, block, 0, stream, p);               \
+            if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<true, MC, DT_F16, true>), grid, BLOCK, 0, stream, p);  \
+            else hipLaunchKernelGGL((attn_kernel<true, MC, DT_BF16, true>), grid, BLOCK, 0, stream, p);               \
         } while (0)
-        if (G >= 7) ATTN_SPLIT(5);                  // 2,048 chunks / 448 (512) threads: five per thread, not eight (the 7B model's grouping)
-        else if (G >= 4) ATTN_SPLIT(8);
-        else if (G >= 2) ATTN_SPLIT(16);
-        else ATTN_SPLIT(32);
+        if (G >= 7) ATTN_SPLIT(5, block);           // 2,048 chunks / 448 (512) threads: five per thread, not eight (the 7B model's grouping)
+        else ATTN_SPLIT(4, dim3(512));              // fewer heads per group: eight waves, G of them compute and the rest only help staging (four chunks per thread;
+                                                    // as G waves with 8 / 16 / 32 staging chunks each these kernels spilled 7 / 11 / 64 VGPRs)
 #undef ATTN_SPLIT
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { blim_set_error("attention launch failed: %s", hipGetErrorString(e2)); return BLIM_ERR_HIP; }

@@ -157,7 +157,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         // MXA: this lane's eight A-side E8M0 bytes of the current K-step (one per 16-row fragment) and of the next one
         uint2 mx_cur = make_uint2(0x7f7f7f7fu, 0x7f7f7f7fu), mx_nxt = mx_cur;
         const uint8_t* mx_base = nullptr;
-        if constexpr (MXA) mx_base = p.a_mx + (int64_t)tm * 256 + (wm * 16 + fr) * 8;
+        if constexpr (MXA) {
+            int frm = fr;
+            asm volatile("" : "+v"(frm));          // (per tile: the hoisted 64-bit lane address was spilled)
+            mx_base = p.a_mx + (int64_t)tm * 256 + (wm * 16 + frm) * 8;
+        }
         auto mx_request = [&](int kt) __attribute__((always_inline)) {
             if constexpr (MXA) mx_nxt = *(const uint2*)(mx_base + (int64_t)min(kt, nk - 1) * p.mx_stride);
         };
@@ -367,6 +371,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 
     stamp(2);
     // =========================================================================== epilogues
+    int tid_e = tid;                        // the epilogue's copy of the thread index, formed per tile: its derived indices (row / segment / scale slots) are kernel
+    asm volatile("" : "+v"(tid_e));         // invariants that LICM hoists out of the persistent loop and, in the fp8 kernels, spills across the K loop
     if constexpr (out16<DT>::value == DT_F16) { if (p.f16_saturate) f16_saturate_on(); }      // fp16 stores of this tile saturate instead of overflowing to inf
     if (p.debug_skip_epilogue) {   // timing aid (tools/gemm_k_sweep.py): keep the accumulators live, store nothing
 #pragma unroll
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     if constexpr (DT == DT_F8) {
         // dequantise: acc[row][col] *= row_scale[row] * col_scale[col].  The tile's 256 + 256 scales go through LDS (free now).
         float* sc = (float*)smem;
-        sc[tid] = f8_scale;
+        sc[tid_e] = f8_scale;
         __syncthreads();
         float4 cs[4];
 #pragma unroll
@@ -430,10 +436,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             if (q4 == 0) red[wn * 256 + rl] = make_float2(mx, sm);
         }
         __syncthreads();
-        if (tid < 256) {
-            const int row = row0 + tid;
+        if (tid_e < 256) {
+            const int row = row0 + tid_e;
             if (row < p.M) {
-                float2 a0 = red[tid], a1 = red[256 + tid], a2 = red[512 + tid], a3 = red[768 + tid];
+                float2 a0 = red[tid_e], a1 = red[256 + tid_e], a2 = red[512 + tid_e], a3 = red[768 + tid_e];
                 const float mx = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
                 float sm = 0.f;
                 if (mx > -INFINITY) {
@@ -448,8 +454,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     } else {
         // ---- C tile staged through LDS so that global stores are whole rows (512 B / 1 KiB per row), 16 B per lane.
         // (Direct stores from the MFMA layout touch 32-B row segments: measured 10-13 us per tile, 12 % of a K=3584 tile.)
-        const int tq = lane >> 4;               // which 4-col group of a fragment this lane owns
-        const int rsub = lane & 15;             // which of its 16 rows
+        // (formed per tile: as kernel invariants they and everything derived from them -- bias / RoPE-table / LDS addresses -- were hoisted out of the
+        // persistent loop and, in the fullest kernels, spilled across the K loop)
+        int tq = lane >> 4;                     // which 4-col group of a fragment this lane owns
+        int rsub = lane & 15;                   // which of its 16 rows
+        asm volatile("" : "+v"(tq), "+v"(rsub));
         __syncthreads();                        // every wave is out of the main loop: LDS is reusable
         if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV || EPI == EPI_SWIGLU) {
             constexpr int NC = (EPI == EPI_SWIGLU) ? 128 : 256;   // output columns of this tile
@@ -480,8 +489,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     }
                     __syncthreads();
                     float* qinv = (float*)(smem + 4096);                    // [256 rows] 2^-e
-                    if (tid < 256) {                                        // one thread per row: the scale, once
-                        const float a = fmaxf(fmaxf(red[tid], red[256 + tid]), fmaxf(red[512 + tid], red[768 + tid]));
+                    if (tid_e < 256) {                                        // one thread per row: the scale, once
+                        const float a = fmaxf(fmaxf(red[tid_e], red[256 + tid_e]), fmaxf(red[512 + tid_e], red[768 + tid_e]));
                         int e = 0;
                         if (a > 0.f) {
                             int ex; const float mant = frexpf(a * (1.0f / FP8_MAX), &ex);
@@ -489,8 +498,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             if (ldexpf(a, -e) > FP8_MAX) e += 1;
                             e = max(-127, min(127, e));
                         }
-                        qinv[tid] = ldexpf(1.0f, -e);
-                        p.out_mx[(int64_t)tn * p.mx_stride + (int64_t)tm * 256 + ((tid >> 7) * 16 + (tid & 15)) * 8 + ((tid >> 4) & 7)] = (uint8_t)(e + 127);
+                        qinv[tid_e] = ldexpf(1.0f, -e);
+                        p.out_mx[(int64_t)tn * p.mx_stride + (int64_t)tm * 256 + ((tid_e >> 7) * 16 + (tid_e & 15)) * 8 + ((tid_e >> 4) & 7)] = (uint8_t)(e + 127);
                     }
                     __syncthreads();
 #pragma unroll
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     const int64_t ob0 = col0 / 2;                           // first output byte column of the tile
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int chunk = tid + NTHREADS * i, rl = chunk >> 3, seg = chunk & 7;
+                        const int chunk = tid_e + NTHREADS * i, rl = chunk >> 3, seg = chunk & 7;
                         const int row = row0 + rl;
                         if (row < p.M && ob0 + seg * 16 + 15 < p.N / 2)
                             *(uint4*)((uint8_t*)p.C + (int64_t)row * p.ldc + ob0 + seg * 16) = *(const uint4*)(st8 + rl * RS8 + seg * 16);
@@ -516,15 +525,38 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     continue;
                 }
             }
-#pragma unroll 1
-            for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {
-            // compensated mode: part 0 stores hi = f16(x), part 1 stores lo = f16(x - f32(hi)) at C + lo_off
-            auto PK = [&](float a_, float b_) __attribute__((always_inline)) {
-                if (SPLIT && part) { a_ -= from16<ODT>(to16<ODT>(a_)); b_ -= from16<ODT>(to16<ODT>(b_)); }
-                return pack2<ODT>(a_, b_);
+            // compensated mode (SPLIT): every output leaves as hi = f16(x) at C and lo = f16(x - f32(hi)) at C + lo_off.  Both halves are formed in ONE sweep
+            // over a wave's accumulators, which die as they are consumed, exactly as in the plain kernels, and are staged side by side in LDS -- the hi tile
+            // and, LO_OFF bytes further, the lo tile -- which fits for 128 rows at a time: two passes, pass hp covering every wave's row groups
+            // 4 hp .. 4 hp + 3 (tile rows 128 wm + 64 hp + [0, 64)).  The pass loop is NOT unrolled (one copy of the sweep: the epilogue's code must not push
+            // the K loop out of the instruction cache -- unrolled, the SwiGLU form cost 3 us per tile); pass 1 first moves accumulator groups 4 - 7 into
+            // 0 - 3 (64 register moves), so that the sweep indexes its registers with compile-time constants.  (Round 3 swept all accumulators twice, once
+            // per output half, keeping the 128 of them live across the first sweep and its stores: 12 - 60 spilled VGPRs in the QKV / plain-output kernels
+            // that every TVG call and the bf16 parity mode run.)
+            constexpr int PROWS = SPLIT ? 128 : 256;              // rows staged per pass
+            constexpr int LO_OFF = PROWS * RS;                    // byte offset of the lo tile in LDS (SPLIT)
+            static_assert(!SPLIT || 2 * LO_OFF <= 5 * TILE_BYTES, "hi + lo tiles of a half must fit the ring");
+            auto ST = [&](char* o_, float a_, float b_, float c_, float d_) __attribute__((always_inline)) {
+                const uint2 hi_ = make_uint2(pack2<ODT>(a_, b_), pack2<ODT>(c_, d_));
+                *(uint2*)o_ = hi_;
+                if constexpr (SPLIT) {
+                    const uint16_t* h16_ = (const uint16_t*)&hi_;
+                    *(uint2*)(o_ + LO_OFF) = make_uint2(pack2<ODT>(a_ - from16<ODT>(h16_[0]), b_ - from16<ODT>(h16_[1])), pack2<ODT>(c_ - from16<ODT>(h16_[2]), d_ - from16<ODT>(h16_[3])));
+                }
             };
-            const int64_t c_part = (SPLIT && part) ? p.lo_off : 0;
-            if (SPLIT && part) __syncthreads();               // part 0's LDS reads are complete
+            constexpr int NMI = SPLIT ? 4 : 8;                    // row groups swept per pass
+#pragma unroll 1
+            for (int hp = 0; hp < (SPLIT ? 2 : 1); ++hp) {
+            const int mg0 = SPLIT ? 4 * hp : 0;                   // tile row group of this pass's accumulator group 0
+            const int lrow0 = SPLIT ? 64 * wm : 128 * wm;         // staged row of (mi, rsub) = lrow0 + 16 mi + rsub
+            if (SPLIT && hp) {
+                __syncthreads();                                  // pass 0's LDS reads are complete
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = acc[(mi + 4) & 7][ni];
+            }
+            {
             float4 qkv_bias[4];                               // EPI_QKV: this lane's 16 bias values (the same for all eight mi)
             if constexpr (EPI == EPI_QKV) {
 #pragma unroll
@@ -536,9 +568,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 for (int ni = 0; ni < 4; ++ni) {
                     const int col = wcol0 + 16 * ni + 4 * tq;
                     bf16_bias[ni] = (p.bias && col + 3 < p.N) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.bias && col < p.N && col + 3 >= p.N) {   // ragged last columns
-                        float* bb = (float*)&bf16_bias[ni];
-                        for (int j = 0; j < 4 && col + j < p.N; ++j) bb[j] = p.bias[col + j];
+                    if (p.bias && col < p.N && col + 3 >= p.N) {   // ragged last columns (static component indices: a dynamic one sends the vector to scratch)
+                        bf16_bias[ni].x = p.bias[col];
+                        if (col + 1 < p.N) bf16_bias[ni].y = p.bias[col + 1];
+                        if (col + 2 < p.N) bf16_bias[ni].z = p.bias[col + 2];
                     }
                 }
             }
@@ -557,17 +590,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     // it touched 16 half-used lines per instruction: 4,096 line requests per tile, the whole 8 us of this epilogue)
                     const int64_t cstride = p.rope_stride * 16;            // floats per chunk
                     auto request = [&](int mi, int buf) __attribute__((always_inline)) {
-                        const int row = min(row0 + 128 * wm + 16 * mi + rsub, p.M - 1);
+                        const int row = min(row0 + 128 * wm + 16 * (mg0 + mi) + rsub, p.M - 1);
                         const float* base = p.rope_rows + (int64_t)row * 16 + 4 * tq;
                         cs[buf][0] = *(const float4*)(base + (gbase + 0) * cstride); cs[buf][1] = *(const float4*)(base + (gbase + 1) * cstride);
                         sn[buf][0] = *(const float4*)(base + (4 + gbase + 0) * cstride); sn[buf][1] = *(const float4*)(base + (4 + gbase + 1) * cstride);
                     };
                     request(0, 0);
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) {
-                        if (mi + 1 < 8) request(mi + 1, (mi + 1) & 1);
+                    for (int mi = 0; mi < NMI; ++mi) {
+                        if (mi + 1 < NMI) request(mi + 1, (mi + 1) & 1);
                         __builtin_amdgcn_sched_barrier(0);     // keep the next group's loads in front of this group's arithmetic
-                        char* lrow = smem + (128 * wm + 16 * mi + rsub) * RS;
+                        char* lrow = smem + (lrow0 + 16 * mi + rsub) * RS;
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) {
                             const float4 c = cs[mi & 1][pr], sv = sn[mi & 1][pr];
@@ -583,26 +616,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                                 hi[j] = x2 * c4[j] + x1 * s4[j];
                             }
                             char* o = lrow + (hl * 128 + d0 + 16 * pr) * 2;
-                            *(uint2*)o = make_uint2(PK(lo[0], lo[1]), PK(lo[2], lo[3]));
-                            *(uint2*)(o + 128) = make_uint2(PK(hi[0], hi[1]), PK(hi[2], hi[3]));
+                            ST(o, lo[0], lo[1], lo[2], lo[3]);
+                            ST(o + 128, hi[0], hi[1], hi[2], hi[3]);
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) {
-                        char* lrow = smem + (128 * wm + 16 * mi + rsub) * RS;
+                    for (int mi = 0; mi < NMI; ++mi) {
+                        char* lrow = smem + (lrow0 + 16 * mi + rsub) * RS;
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
                             const float4 bv = qkv_bias[ni];
-                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(PK(acc[mi][ni][0] + bv.x, acc[mi][ni][1] + bv.y), PK(acc[mi][ni][2] + bv.z, acc[mi][ni][3] + bv.w));
+                            ST(lrow + (64 * wn + 16 * ni + 4 * tq) * 2, acc[mi][ni][0] + bv.x, acc[mi][ni][1] + bv.y, acc[mi][ni][2] + bv.z, acc[mi][ni][3] + bv.w);
                         }
                     }
                 }
             } else
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int rl = 128 * wm + 16 * mi + rsub;         // row inside the tile
-                const int row = min(row0 + rl, p.M - 1);
+            for (int mi = 0; mi < NMI; ++mi) {
+                const int rl = lrow0 + 16 * mi + rsub;            // row inside the staged block
                 float t[4][4];
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) { t[ni][0] = acc[mi][ni][0]; t[ni][1] = acc[mi][ni][1]; t[ni][2] = acc[mi][ni][2]; t[ni][3] = acc[mi][ni][3]; }
@@ -611,19 +643,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     if (p.bias == nullptr && p.act == 0) {         // wave-uniform fast path: convert and stage
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
-                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(PK(t[ni][0], t[ni][1]), PK(t[ni][2], t[ni][3]));
+                            ST(lrow + (64 * wn + 16 * ni + 4 * tq) * 2, t[ni][0], t[ni][1], t[ni][2], t[ni][3]);
                     } else if (p.act == 1) {                       // bias (hoisted: bf16_bias) + GELU, wave-uniform branch, unrolled
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
                             const float4 b = bf16_bias[ni];
-                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) =
-                                make_uint2(PK(gelu_erf(t[ni][0] + b.x), gelu_erf(t[ni][1] + b.y)), PK(gelu_erf(t[ni][2] + b.z), gelu_erf(t[ni][3] + b.w)));
+                            ST(lrow + (64 * wn + 16 * ni + 4 * tq) * 2, gelu_erf(t[ni][0] + b.x), gelu_erf(t[ni][1] + b.y), gelu_erf(t[ni][2] + b.z), gelu_erf(t[ni][3] + b.w));
                         }
                     } else {
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
                             const float4 b = bf16_bias[ni];
-                            *(uint2*)(lrow + (64 * wn + 16 * ni + 4 * tq) * 2) = make_uint2(PK(t[ni][0] + b.x, t[ni][1] + b.y), PK(t[ni][2] + b.z, t[ni][3] + b.w));
+                            ST(lrow + (64 * wn + 16 * ni + 4 * tq) * 2, t[ni][0] + b.x, t[ni][1] + b.y, t[ni][2] + b.z, t[ni][3] + b.w);
                         }
                     }
                 } else {  // EPI_SWIGLU: fragments (2p, 2p+1) = gate / up of the same 16 intermediate columns
@@ -633,16 +664,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         float x[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x[j] = silu_f(t[2 * pr][j]) * t[2 * pr + 1][j];
-                        *(uint2*)(lrow + cl * 2) = make_uint2(PK(x[0], x[1]), PK(x[2], x[3]));
+                        ST(lrow + cl * 2, x[0], x[1], x[2], x[3]);
                     }
                 }
             }
+            }   // staging by the waves of this pass
             __syncthreads();
             stamp(4);
             constexpr int LPR = NC * 2 / 16;                      // lanes (16 B each) per output row
             const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
             const int oc0 = (EPI == EPI_SWIGLU) ? col0 / 2 : col0;
-            const int seg = tid % LPR;
+            const int seg = tid_e % LPR;
             const int oc = oc0 + 8 * seg;
             constexpr int RPP = NTHREADS / LPR;                   // rows per pass of the workgroup
             bool fused_done = false;
@@ -651,11 +683,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     // fine-tuning backward (train.hip): this tile is d act = dy . Wd; instead of storing it, turn the saved gate | up
                     // pre-activations (16 gate / 16 up columns interleaved, the fused matrix's stored row order) into [d gate | d up] in place
                     constexpr int ODT = out16<DT>::value;
+                    int lds0 = (tid_e / LPR) * RS + seg * 16;       // formed per tile (hoisted out of the persistent loop it was spilled across the K loop)
+                    asm volatile("" : "+v"(lds0));
 #pragma unroll 2
-                    for (int rl = tid / LPR; rl < 256; rl += RPP) {
+                    for (int rl = tid_e / LPR; rl < 256; rl += RPP) {
                         const int row = row0 + rl;
                         if (row >= p.M || oc >= n_out) continue;
-                        const uint4 dv = *(const uint4*)(smem + rl * RS + seg * 16);
+                        const uint4 dv = *(const uint4*)(smem + lds0 + (rl - tid_e / LPR) * RS);
                         uint16_t* gp = p.swiglu_gu + (int64_t)row * p.swiglu_ld + 32 * (oc >> 4) + (oc & 15);
                         const uint4 gr = *(const uint4*)gp, ur = *(const uint4*)(gp + 16);
                         const uint16_t* dh = (const uint16_t*)&dv; const uint16_t* gh = (const uint16_t*)&gr; const uint16_t* uh = (const uint16_t*)&ur;
@@ -674,27 +708,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     fused_done = true;
                 }
             }
+            // staged row rl of this pass -> tile row: plain: rl; SPLIT: staged rows [64 wm', 64 wm' + 64) are tile rows 128 wm' + 64 hp + [0, 64)
+            auto tile_row = [&](int rl_) __attribute__((always_inline)) { return SPLIT ? 128 * (rl_ >> 6) + 64 * hp + (rl_ & 63) : rl_; };
             if (fused_done) {
             } else if (row0 + 256 <= p.M && oc0 + NC <= n_out && (p.ldc & 7) == 0) {   // interior tile: all LDS reads, then all stores, no branches
-                // (split outputs: the accumulators stay live for the second part, so the rows move in groups of four instead of all at once)
-                constexpr int NV = 256 / RPP, VB = SPLIT ? 4 : NV;
+                constexpr int NV = PROWS / RPP;
                 uint4 v[NV];
-                const char* lsrc = smem + (tid / LPR) * RS + seg * 16;
-                bf16_t* out = (bf16_t*)p.C + c_part + (int64_t)(row0 + tid / LPR) * p.ldc + oc;
+                static_assert(64 % RPP == 0, "a thread's rows i * RPP must not straddle a 64-row staging block");
+                const char* lsrc = smem + (tid_e / LPR) * RS + seg * 16;
+                bf16_t* out = (bf16_t*)p.C + (int64_t)(row0 + tid_e / LPR) * p.ldc + oc;       // + tile_row(i * RPP) rows: a compile-time row count per i
 #pragma unroll
-                for (int i0 = 0; i0 < NV; i0 += VB) {
+                for (int i = 0; i < NV; ++i) v[i] = *(const uint4*)(lsrc + i * RPP * RS);
 #pragma unroll
-                    for (int i = i0; i < i0 + VB; ++i) v[i] = *(const uint4*)(lsrc + i * RPP * RS);
+                for (int i = 0; i < NV; ++i) *(uint4*)(out + (int64_t)tile_row(i * RPP) * p.ldc) = v[i];
+                if constexpr (SPLIT) {                            // ... and the lo tile of the same rows
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = i0; i < i0 + VB; ++i) *(uint4*)(out + (int64_t)i * RPP * p.ldc) = v[i];
-                    if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < NV; ++i) v[i] = *(const uint4*)(lsrc + LO_OFF + i * RPP * RS);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) *(uint4*)(out + p.lo_off + (int64_t)tile_row(i * RPP) * p.ldc) = v[i];
                 }
                 if constexpr (EPI == EPI_BF16 && !SPLIT) {
                     // fine-tuning forward (train.hip): the tile is the gate | up pre-activations (kept for the backward); the lanes holding a
                     // gate chunk also form act = silu(gate) * up from the up chunk two 16-byte chunks further in the same LDS row
                     if (p.swiglu_act != nullptr && (seg & 3) < 2) {
                         constexpr int ODT = out16<DT>::value;
-                        uint16_t* aout = p.swiglu_act + (int64_t)(row0 + tid / LPR) * p.swiglu_act_ld + oc0 / 2 + 16 * (seg >> 2) + 8 * (seg & 3);
+                        uint16_t* aout = p.swiglu_act + (int64_t)(row0 + tid_e / LPR) * p.swiglu_act_ld + oc0 / 2 + 16 * (seg >> 2) + 8 * (seg & 3);
 #pragma unroll
                         for (int i = 0; i < 256 / RPP; ++i) {
                             const uint4 ur = *(const uint4*)(lsrc + i * RPP * RS + 32);
@@ -708,16 +747,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 }
             } else
 #pragma unroll 1
-            for (int rl = tid / LPR; rl < 256; rl += RPP) {
-                const int row = row0 + rl;
+            for (int rl = tid_e / LPR; rl < PROWS; rl += RPP) {
+                const int row = row0 + tile_row(rl);
                 if (row >= p.M || oc >= n_out) continue;
                 const uint4 v = *(const uint4*)(smem + rl * RS + seg * 16);
-                bf16_t* out = (bf16_t*)p.C + c_part + (int64_t)row * p.ldc + oc;
-                if (oc + 7 < n_out && (p.ldc & 7) == 0) *(uint4*)out = v;
-                else {
-                    const bf16_t* e = (const bf16_t*)&v;
-                    for (int j = 0; j < 8 && oc + j < n_out; ++j) out[j] = e[j];
-                }
+                bf16_t* out = (bf16_t*)p.C + (int64_t)row * p.ldc + oc;
+                auto store8 = [&](bf16_t* o_, const uint4 v_) __attribute__((always_inline)) {
+                    if (oc + 7 < n_out && (p.ldc & 7) == 0) *(uint4*)o_ = v_;
+                    else {      // ragged columns: element stores with STATIC component indices (a dynamic index sends the vector through scratch)
+                        const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (oc + j < n_out) o_[j] = (bf16_t)(w_[j >> 1] >> (16 * (j & 1)));
+                    }
+                };
+                store8(out, v);
+                if constexpr (SPLIT) store8(out + p.lo_off, *(const uint4*)(smem + LO_OFF + rl * RS + seg * 16));
                 if constexpr (EPI == EPI_BF16 && !SPLIT) {
                     if (p.swiglu_act != nullptr && (seg & 3) < 2) {      // edge tiles: same rule as above (N = 2 I is a multiple of 32)
                         constexpr int ODT = out16<DT>::value;
@@ -776,7 +821,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             const float x[4] = {v.x, v.y, v.z, v.w};
                             float* out = (float*)p.C + (int64_t)row * p.ldc + col;
                             const float* in = rsrc + (int64_t)row * p.ldc + col;
-                            for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = in[j] + x[j] + (p.bias ? p.bias[col + j] : 0.f);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (col + j < p.N) out[j] = in[j] + x[j] + (p.bias ? p.bias[col + j] : 0.f);
                         }
                     }
                 } else {
@@ -789,7 +836,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                         float x[4] = {v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale};
                         float* out = (float*)p.C + (int64_t)row * p.ldc + col;
                         if (vec) *(float4*)out = make_float4(x[0], x[1], x[2], x[3]);
-                        else for (int j = 0; j < 4 && col + j < p.N; ++j) out[j] = x[j];
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (col + j < p.N) out[j] = x[j];
+                        }
                     }
                 }
                 __syncthreads();

@@ -71,7 +71,7 @@ def get_args_parser():
     p.add_argument("--vtg_precise", default="auto", choices=["auto", "none", "qk", "qkx", "attn", "full"],
                    help="compensated (hi + lo) activations on the VTG calls.  auto (default): measured on the loaded checkpoint before the first pass -- up to 256 pairs of the "
                         "evaluation are scored in every mode against the fully compensated one (which sits at 2e-6 .. 1e-5 of the fp32 reference) and the cheapest mode "
-                        "within 7.5e-4 is kept (PairScorer.calibrate_vtg; the table is printed).  none = plain 16-bit (what auto picks on an fp16 engine unless the checkpoint "
+                        "whose largest deviation AND 4.5 x its RMS deviation are inside 1e-3 is kept (PairScorer.calibrate_vtg; the table is printed).  none = plain 16-bit (what auto picks on an fp16 engine unless the checkpoint "
                         "has massive activations on sink tokens: tests/golden/sink.npz, where plain fp16 -- the reference's own numerics -- is ~3e-3 from the fp32 result); "
                         "qk = q / k / v and the attention as hi + lo (-2.5 %% speed); qkx = and the QKV GEMM's input (-8.4 %%); attn = the whole attention branch (-16 %%); "
                         "full = every activation (2x the GEMM flops: the mode in which a bf16 engine holds 1e-3 at 7B depth)")

@@ -577,15 +577,17 @@ class PairScorer:
         self.vtg_mode, self.split_vtg = mode, split
         self.m.vtg_precise = mode
 
-    def calibrate_vtg(self, pairs, threshold: float = 7.5e-4):
+    def calibrate_vtg(self, pairs, bar: float = 1e-3, z: float = 4.5):
         """The reference has ONE numeric mode (training_utils.py:142: autocast fp16) and no decision to make; this engine's plain 16-bit VTG
         calls are the fastest of five modes, and whether they hold the 1e-3 bar depends on the checkpoint's statistics (attention sinks,
-        massive activations: tests/golden/sink.npz).  So the decision is MEASURED on the loaded weights: `pairs` (a few dozen (video, text)
+        massive activations: tests/golden/sink.npz).  So the decision is MEASURED on the loaded weights: `pairs` (up to 256 (video, text)
         pairs of the evaluation itself) are scored in every mode, cheapest first, against the fully compensated mode -- which sits at
         2e-6 .. 1e-5 of the fp32 reference on every fixture, i.e. is a yardstick that needs no oracle on the box -- and the cheapest mode
-        whose worst relative deviation is <= threshold is kept.  The threshold sits below the 1e-3 bar because the bar is per ENTRY of the whole
-        evaluation and the calibration sees a sample: for near-Gaussian deviations the largest of 16,000 entries is ~1.3x the largest of 256
-        (4.0 vs 3.0 sigma), hence 7.5e-4.  Returns (mode name, {mode: worst deviation} for the modes tried)."""
+        that passes is kept.  The bar is per ENTRY of the whole evaluation while the calibration sees a sample, and the sample's maximum is a
+        noisy statistic (on sink.npz the same mode reads 7e-4 or 1.2e-3 depending on last-bit differences upstream), so a mode passes when
+        (a) the sample's largest relative deviation is inside the bar AND (b) z x the sample's RMS deviation is: for near-Gaussian deviations
+        the largest of the ~10^4 .. 10^5 entries of an evaluation is 4 - 4.8 sigma; z = 4.5.  Returns (mode name, {mode: {max, rms}} for the
+        modes tried)."""
         pairs = np.asarray(pairs, dtype=np.int64)
         if not bool(getattr(self.engine, "can_precise", False)):              # fp8 engines have no compensated modes
             return "none", {}
@@ -595,9 +597,9 @@ class PairScorer:
         chosen = "full"
         for mode in VTG_MODES[:-1]:
             self.set_vtg_mode(mode)
-            got = self.vtg(pairs).astype(np.float64)
-            table[mode] = float(np.max(np.abs(got - ref) / np.abs(ref)))
-            if chosen == "full" and np.isfinite(table[mode]) and table[mode] <= threshold:
+            dev = np.abs(self.vtg(pairs).astype(np.float64) - ref) / np.abs(ref)
+            table[mode] = {"max": float(np.max(dev)), "rms": float(np.sqrt(np.mean(dev * dev)))}
+            if np.all(np.isfinite(dev)) and table[mode]["max"] <= bar and z * table[mode]["rms"] <= bar:
                 chosen = mode
                 break                                                          # the dearer modes are not needed
         self.set_vtg_mode(chosen)
@@ -735,11 +737,11 @@ def evaluation(model, data_loader, device, tokenizer, args):
         # `--vtg_precise auto` (the driver's default): measure on this checkpoint which compensation the VTG calls need (PairScorer.calibrate_vtg)
         cal = scorer if isinstance(scorer, PairScorer) else PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
                                                                        tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
-        chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk), threshold=float(getattr(args, "vtg_auto_threshold", 7.5e-4)))
+        chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk))
         stats["vtg_precise"] = chosen; stats["vtg_precise_table"] = table
         if rank == 0:
-            print("vtg_precise auto: worst deviation from the fully compensated mode on the calibration pairs: "
-                  + ", ".join(f"{k} {v:.1e}" for k, v in table.items()) + f" -> {chosen}")
+            print("vtg_precise auto: deviation from the fully compensated mode on the calibration pairs (max / rms): "
+                  + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in table.items()) + f" -> {chosen}")
     mark("setup")
 
     def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):

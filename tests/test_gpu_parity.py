@@ -454,7 +454,7 @@ def _depth_case(case, dtype, capsys, literal_too=True):
         if dtype == "f16":      # `--vtg_precise auto` (the driver's default): on these weights the plain fp16 VTG calls are kept
             chosen, table = _resolve_auto(t)
             with capsys.disabled():
-                print(f"\n[{case} f16] vtg_precise auto: " + ", ".join(f"{k} {v:.1e}" for k, v in table.items()) + f" -> {chosen}")
+                print(f"\n[{case} f16] vtg_precise auto (max / rms vs the fully compensated mode): " + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in table.items()) + f" -> {chosen}")
             assert chosen == "none", (case, table)
     finally:
         t.model.engine.close()
@@ -507,8 +507,8 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
         plain, auto = None, None
         if case == "sink" and dtype == "f16":
             # massive activations on sink positions: plain fp16 VTG calls -- the library default and the reference's own numerics -- read 3.2e-3 here (reported below, not
-            # asserted).  The driver's default is `--vtg_precise auto`: the mode is MEASURED on the loaded weights (PairScorer.calibrate_vtg), must come out as qkx on
-            # this fixture, and every pass is then held to the same 1e-3 as everywhere else -- no carve-out.
+            # asserted).  The driver's default is `--vtg_precise auto`: the mode is MEASURED on the loaded weights (PairScorer.calibrate_vtg), must come out as one of
+            # the cheap compensated modes on this fixture, and every pass is then held to the same 1e-3 as everywhere else -- no carve-out.
             plain = {tag: _worst_rel(_six_passes(t, lit, names=("v2t_vtg", "t2v_vtg")), g) for tag, lit in (("fused", False), ("literal", True))}
             auto = _resolve_auto(t)
         res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in ((("fused", False), ("literal", True)) if dtype != "f8" else (("fused", False),))}
@@ -517,8 +517,11 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
     if auto is not None:
         with capsys.disabled():
             print(f"\n[sink f16] plain fp16 VTG calls (library default), fused: " + ", ".join(f"{k} {v:.2e}" for k, v in plain["fused"].items())
-                  + "; vtg_precise auto: " + ", ".join(f"{k} {v:.1e}" for k, v in auto[1].items()) + f" -> {auto[0]} (the passes below ran in it)")
-        assert auto[0] == "qkx", auto
+                  + "; vtg_precise auto (max / rms vs the fully compensated mode): " + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in auto[1].items())
+                  + f" -> {auto[0]} (the passes below ran in it)")
+        # which compensated mode comes out depends on last-bit differences upstream (the sample maximum of the same mode varies by 1.5x between builds); what is
+        # required is that plain fp16 is rejected, that something cheaper than `full` suffices, and that the passes below hold 1e-3 in the chosen mode
+        assert auto[0] in ("qk", "qkx", "attn"), auto
     with capsys.disabled():
         for tag, w in res.items():
             print(f"\n[{case} {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers, residual |max| {float(g['resid_absmax_per_layer'].max()):.0f} at rms "
