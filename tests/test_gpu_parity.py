@@ -670,7 +670,7 @@ def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
         want = g["fwd_tvg_hidden_sub16"][valid]
         err = {}
         for precise in (False, True):
-            t.model._tvg_rows = precise
+            r[4]._blim_rows = "tvg" if precise else "vtg"     # the row kind travels with the tensor (modeling.py); rows tagged VTG run plain on an fp16 engine
             out = t.model(inputs_embeds=r[4], attention_mask=r[2][0], want_logits=False)
             got = out.hidden_states.cpu().numpy()[..., ::16][valid]
             err[precise] = float(np.sqrt(np.mean((got - want) ** 2)) / np.sqrt(np.mean(want ** 2)))
