@@ -279,3 +279,22 @@ def test_training_resumes_from_an_epoch_checkpoint(tmp_path, monkeypatch):
         a, b = A["model"][k].float(), B["model"][k].float()
         d = (a - b).abs()
         assert d.median() <= 1e-6 and d.max() <= 3e-4, (k, d.median().item(), d.max().item())   # Adam normalises: an element with ~zero gradient moves by O(lr) on atomics' rounding order
+
+
+def test_first_contact_go_and_no_go(tmp_path, monkeypatch, capsys):
+    """blim_amd/first_contact.py on the synthetic on-disk tree (stand-in tokenizer): config / tokenizer constants / row shapes / key naming / resume-file
+    checks, the numeric-mode table measured on the loaded checkpoint and the fused-vs-literal comparison end in GO; a resume file whose keys carry an
+    unknown wrapper prefix is a NO-GO before any weight is loaded."""
+    from blim_amd import first_contact as FC
+    ck = _tree(str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    argv = ["--model_path", ck, "--resume", "./checkpoint/msrvtt.pth", "--dataset", "MSRVTT", "--topk", "4", "--batch_size_eval", "3"]
+    assert FC.main(argv, tokenizer=StubTokenizer()) == 0
+    out = capsys.readouterr().out
+    assert "GO:" in out and "NO-GO" not in out and "vtg_precise auto" in out and "fused PairScorer == literal" in out and "adapters kept apart" in out
+    st = torch.load("./checkpoint/msrvtt.pth", map_location="cpu", weights_only=False)
+    st["model"] = {"module." + k: v for k, v in st["model"].items()}
+    torch.save(st, "./checkpoint/drift.pth")
+    assert FC.main(["--model_path", ck, "--resume", "./checkpoint/drift.pth", "--dataset", "MSRVTT", "--topk", "4"], tokenizer=StubTokenizer()) == 1
+    out = capsys.readouterr().out
+    assert "NO-GO" in out and "map onto no engine tensor" in out
