@@ -439,8 +439,12 @@ static int build_aug(blim_engine* e) {
         return launch_make_aug(*dst, src, N, K, G, 0);
     };
     // B columns of adapter `seg` of `nseg` sharing one augmented matrix: hi at K + seg r, lo at K + nseg r + seg r; its A operand
+    // an adapter that was not loaded (partial resume files): its u columns must read as zeros -- a shared all-zero A operand
+    uint16_t* zero_a16 = nullptr;
+    TRY(aalloc(&zero_a16, (size_t)32 * std::max(H, M)));
+    HIP_TRY(hipMemset(zero_a16, 0, (size_t)32 * std::max(H, M) * 2));
     auto place = [&](AdapterW& a, uint16_t* w_aug, int K, int64_t row0, int seg, int nseg, int row_mode) -> int {
-        if (!a.A) return BLIM_OK;
+        if (!a.A) { a.A16 = zero_a16; return BLIM_OK; }
         TRY(launch_adapter_b_aug(w_aug, K + G, row0, K + seg * r, K + nseg * r + seg * r, a.B, a.n_out, r, row_mode, dt, 0));
         TRY(aalloc(&a.A16, (size_t)32 * K));
         return launch_adapter_a16(a.A16, a.A, K, r, dt, 0);
