@@ -241,3 +241,41 @@ int launch_copy_rows16(uint16_t* dst, int64_t ldd, const uint16_t* src, int64_t 
     LAUNCH_CHECK();
     return BLIM_OK;
 }
+
+template <int DT>
+__global__ void split3_f32_kernel(uint16_t* dst, uint16_t* dst1, const float* src, int64_t n, int K, int w_side) {
+    const int64_t total = n * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / K;
+        const int k = (int)(i - r * K);
+        const float x = src[i];
+        const uint16_t hi = to16<DT>(x), lo = to16<DT>(x - from16<DT>(hi));
+        uint16_t* d = dst + r * 3 * K + k;
+        d[0] = hi; d[K] = w_side ? lo : hi; d[2 * K] = w_side ? hi : lo;
+        if (dst1) dst1[i] = hi;
+    }
+}
+int launch_split3_f32(uint16_t* dst, uint16_t* dst1, const float* src, int64_t n, int K, int w_side, int dtype, hipStream_t s) {
+    ARG_CHECK(dst && src && n > 0 && K > 0);
+    const int64_t total = n * K;
+    DISPATCH_DT(dtype, hipLaunchKernelGGL(split3_f32_kernel<DT>, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, s, dst, dst1, src, n, K, w_side));
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}
+__global__ void split3_hilo_kernel(uint16_t* dst, const uint16_t* src, int64_t lds, int64_t n, int K) {
+    const int64_t total = n * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / K;
+        const int k = (int)(i - r * K);
+        const uint16_t hi = src[r * lds + k], lo = src[r * lds + K + k];
+        uint16_t* d = dst + r * 3 * K + k;
+        d[0] = hi; d[K] = hi; d[2 * K] = lo;
+    }
+}
+int launch_split3_hilo(uint16_t* dst, const uint16_t* src, int64_t lds, int64_t n, int K, hipStream_t s) {
+    ARG_CHECK(dst && src && n > 0 && K > 0 && lds >= 2 * K);
+    const int64_t total = n * K;
+    hipLaunchKernelGGL(split3_hilo_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, s, dst, src, lds, n, K);
+    LAUNCH_CHECK();
+    return BLIM_OK;
+}

@@ -27,3 +27,11 @@ int launch_adapter_down(uint16_t* x16, int64_t ldx, int64_t lo_off, int64_t T, i
 int launch_make_aug(uint16_t* dst, const uint16_t* src, int64_t N, int K, int aug, hipStream_t s);
 // dst [n, ldd] (first K columns) <- src [n, lds]; 16-bit rows
 int launch_copy_rows16(uint16_t* dst, int64_t ldd, const uint16_t* src, int64_t lds, int64_t n, int K, hipStream_t s);
+
+// ---- three-term compensated product of two f32-valued operands on 16-bit MFMAs: (a_hi + a_lo) . (w_hi + w_lo) ~ a_hi w_hi + a_hi w_lo + a_lo w_hi as ONE
+// GEMM of depth 3 K: A rows [hi | hi | lo] against W rows [hi | lo | hi].  Used for the TVG logits (retrieval_utils.py:106: visual-head output . video vocabulary),
+// whose W side -- the vocabulary of clip-mean features -- is data, not a 16-bit checkpoint tensor.
+// dst [n, 3 K] 16-bit <- src f32 [n, K] (w_side = 0: [hi | hi | lo], 1: [hi | lo | hi]); dst1 (optional) [n, K] = hi alone
+int launch_split3_f32(uint16_t* dst, uint16_t* dst1, const float* src, int64_t n, int K, int w_side, int dtype, hipStream_t s);
+// dst [n, 3 K] = [hi | hi | lo] <- src 16-bit rows [hi | lo] of width 2 K (row stride lds)
+int launch_split3_hilo(uint16_t* dst, const uint16_t* src, int64_t lds, int64_t n, int K, hipStream_t s);

@@ -178,7 +178,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     for (void* p : e->owned) hipFree(p);
     for (void* p : e->aug_owned) hipFree(p);
     for (void* p : e->ad_owned) hipFree(p);
-    DevBuf* bufs[] = {&e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
+    DevBuf* bufs[] = {&e->visual_head3, &e->hs3, &e->vocab3, &e->vocab1, &e->vh3, &e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
                       &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
@@ -225,6 +225,19 @@ static bool find_slot(blim_engine* e, const std::string& name, WeightSlot& s) {
     return false;
 }
 
+// visual_head is trained in fp32 (main.py:104-107) and arrives as a full tensor of the resume file: besides its 16-bit copy the engine keeps it as
+// [hi | lo | hi] rows (3 H wide) -- the W side of the three-term product the compensated TVG calls form with the final hidden states (adapters.hpp).
+// A 16-bit rounding of the head alone left 2e-4 on the bf16 engine's TVG scores of a fine-tuned checkpoint (tests/golden/lora7b.npz).
+int engine_set_visual_head3(blim_engine* e, const void* dev_src, int dtype, hipStream_t s) {
+    const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
+    TRY(ensure(e->visual_head3, (size_t)M * 3 * H * 2));
+    if (dtype == BLIM_DTYPE_F32) return launch_split3_f32((uint16_t*)e->visual_head3.p, nullptr, (const float*)dev_src, M, H, 1, e->c.compute_dtype, s);
+    // bf16 source: the placed 16-bit copy is exact, lo = 0
+    HIP_TRY(hipMemsetAsync(e->visual_head3.p, 0, (size_t)M * 3 * H * 2, s));
+    TRY(launch_copy_rows16((uint16_t*)e->visual_head3.p, 3 * (int64_t)H, (const uint16_t*)e->visual_head, H, M, H, s));
+    return launch_copy_rows16((uint16_t*)e->visual_head3.p + 2 * H, 3 * (int64_t)H, (const uint16_t*)e->visual_head, H, M, H, s);
+}
+
 static int place_weight(blim_engine* e, const std::string& name, const void* dev_src, int dtype) {
     WeightSlot s;
     if (!find_slot(e, name, s)) { blim_set_error("unknown weight name '%s'", name.c_str()); return BLIM_ERR_ARG; }
@@ -248,6 +261,7 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
         else hipLaunchKernelGGL(place_vec_kernel<false>, dim3(grid), dim3(256), 0, 0, dst, dev_src, s.rows, s.mode);
     }
     HIP_TRY(hipGetLastError());
+    if (name == "visual_head") TRY(engine_set_visual_head3(e, dev_src, dtype, 0));
     e->loaded[name] = true;
     e->f8_ready = false;
     e->aug_ready = false;          // the augmented copies of adapted weights are rebuilt from the placed base weights on the next call
@@ -841,21 +855,71 @@ static int visual_head_impl(blim_engine* e, const void* hidden_bf16, bool split,
     ARG_CHECK(e && hidden_bf16 && out_bf16 && n_rows > 0);
     TRY(blim_weights_ready(e));
     const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
-    SpanGuard g(e, (hipStream_t)stream, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * M);
+    hipStream_t s = (hipStream_t)stream;
+    SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_rows * (double)H * M * (split ? 3 : 1));
+    if (split) {    // [hi | hi | lo] hidden rows against the head's [hi | lo | hi] rows: one GEMM of depth 3 H, outputs [hi | lo] of width 2 M
+        TRY(ensure(e->hs3, (size_t)round_up(n_rows, 256) * 3 * H * 2));
+        TRY(launch_split3_hilo((uint16_t*)e->hs3.p, (const uint16_t*)hidden_bf16, 2 * (int64_t)H, n_rows, H, s));
+        GemmParams p = gp(e->c.compute_dtype, e->hs3.p, 3 * (int64_t)H, e->visual_head3.p, n_rows, M, 3 * H, out_bf16, 2 * (int64_t)M);
+        p.lo_off = M;
+        return launch_gemm(EPI_BF16, p, s);
+    }
     GemmParams p = gp(e->c.compute_dtype, hidden_bf16, H, e->visual_head, n_rows, M, H, out_bf16, M);
-    if (split) { p.lda = 2 * H; p.K = 2 * H; p.w_wrap_k = H; p.ldc = 2 * M; p.lo_off = M; }
-    return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
+    return launch_gemm(EPI_BF16, p, s);
+}
+// modeling_videochat_flash.py:598-599 on FLOAT32 hidden states (the literal path hands the final norm's output over as float32): float32 out, three-term product
+extern "C" int blim_visual_head_f32(blim_engine* e, const float* hidden_f32, int64_t n_rows, float* out_f32, void* stream) {
+    ARG_CHECK(e && hidden_f32 && out_f32 && n_rows > 0);
+    TRY(blim_weights_ready(e));
+    const int H = e->c.hidden_size, M = e->c.mm_hidden_size;
+    hipStream_t s = (hipStream_t)stream;
+    TRY(ensure(e->hs3, (size_t)round_up(n_rows, 256) * 3 * H * 2));
+    TRY(launch_split3_f32((uint16_t*)e->hs3.p, nullptr, hidden_f32, n_rows, H, 0, e->c.compute_dtype, s));
+    SpanGuard g(e, s, TC_GEMM_OTHER, 6.0 * n_rows * (double)H * M);
+    GemmParams p = gp(e->c.compute_dtype, e->hs3.p, 3 * (int64_t)H, e->visual_head3.p, n_rows, M, 3 * H, out_f32, M);
+    return launch_gemm(EPI_F32, p, s);
 }
 extern "C" int blim_visual_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, void* out_bf16, void* stream) {
     return visual_head_impl(e, hidden_bf16, false, n_rows, out_bf16, stream);
 }
 
-static int tvg_logits_impl(blim_engine* e, const void* vh_bf16, bool split, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream) {
-    ARG_CHECK(e && vh_bf16 && vocab_bf16 && logits && n_vocab > 0 && n_pairs > 0);
+// The TVG logits' W operand when the caller passes no vocabulary: the one registered with blim_set_video_vocab.
+extern "C" int blim_set_video_vocab(blim_engine* e, const float* vocab_f32, int32_t n_vocab, void* stream) {
+    ARG_CHECK(e && vocab_f32 && n_vocab > 0);
+    const int M = e->c.mm_hidden_size, C = e->c.num_clips;
+    const int64_t rows = (int64_t)C * n_vocab;
+    TRY(ensure(e->vocab3, (size_t)rows * 3 * M * 2));
+    TRY(ensure(e->vocab1, (size_t)rows * M * 2));
+    TRY(launch_split3_f32((uint16_t*)e->vocab3.p, (uint16_t*)e->vocab1.p, vocab_f32, rows, M, 1, e->c.compute_dtype, (hipStream_t)stream));
+    e->n_vocab = n_vocab;
+    return BLIM_OK;
+}
+
+// vh rows: plain [n_pairs * C, M]; split: [hi | lo] of width 2 M.  vocab_bf16 == NULL: the registered vocabulary (then the split form runs the three-term
+// product (vh_hi + vh_lo) . (v_hi + v_lo) as one GEMM of depth 3 M: adapters.hpp); vh3_ready: e->vh3 already holds the [hi | hi | lo] rows.
+static int tvg_logits_impl(blim_engine* e, const void* vh_bf16, bool split, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream, bool vh3_ready = false) {
+    ARG_CHECK(e && (vh_bf16 || vh3_ready) && logits && n_vocab > 0 && n_pairs > 0);
     hipStream_t s = (hipStream_t)stream;
     const int M = e->c.mm_hidden_size, C = e->c.num_clips;
     const int pf = split ? 2 : 1;
     SpanGuard g(e, s, TC_GEMM_OTHER, 2.0 * n_pairs * C * (double)M * n_vocab);
+    if (!vocab_bf16) {
+        if (!e->vocab3.p || e->n_vocab != n_vocab) { blim_set_error("no video vocabulary of %d entries registered (blim_set_video_vocab)", n_vocab); return BLIM_ERR_STATE; }
+        if (split || vh3_ready) {
+            if (!vh3_ready) {
+                TRY(ensure(e->vh3, (size_t)round_up((int64_t)n_pairs * C, 256) * 3 * M * 2));
+                TRY(launch_split3_hilo((uint16_t*)e->vh3.p, (const uint16_t*)vh_bf16, 2 * (int64_t)M, (int64_t)n_pairs * C, M, s));
+            }
+            for (int c = 0; c < C; ++c) {
+                GemmParams p = gp(e->c.compute_dtype, (const bf16_t*)e->vh3.p + (int64_t)c * 3 * M, (int64_t)C * 3 * M, (const bf16_t*)e->vocab3.p + (int64_t)c * n_vocab * 3 * M, n_pairs, n_vocab,
+                                  3 * M, logits + (int64_t)c * n_vocab, (int64_t)C * n_vocab);
+                p.scale = 1.0f / sqrtf((float)M);
+                TRY(launch_gemm(EPI_F32, p, s));
+            }
+            return BLIM_OK;
+        }
+        vocab_bf16 = e->vocab1.p;
+    }
     for (int c = 0; c < C; ++c) {
         GemmParams p = gp(e->c.compute_dtype, (const bf16_t*)vh_bf16 + (int64_t)c * pf * M, (int64_t)C * pf * M, (const bf16_t*)vocab_bf16 + (int64_t)c * n_vocab * M, n_pairs, n_vocab,
                           pf * M, logits + (int64_t)c * n_vocab, (int64_t)C * n_vocab);
@@ -864,6 +928,15 @@ static int tvg_logits_impl(blim_engine* e, const void* vh_bf16, bool split, cons
         TRY(launch_gemm(EPI_F32, p, s));
     }
     return BLIM_OK;
+}
+// Literal path (retrieval_utils.py:104-106 on float32 visual-head outputs): logits of vh_f32 [n_pairs * C, M] against the registered vocabulary, three-term product
+extern "C" int blim_tvg_logits_f32(blim_engine* e, const float* vh_f32, int32_t n_pairs, float* logits, void* stream) {
+    ARG_CHECK(e && vh_f32 && logits && n_pairs > 0);
+    if (!e->vocab3.p) { blim_set_error("no video vocabulary registered (blim_set_video_vocab)"); return BLIM_ERR_STATE; }
+    const int M = e->c.mm_hidden_size, C = e->c.num_clips;
+    TRY(ensure(e->vh3, (size_t)round_up((int64_t)n_pairs * C, 256) * 3 * M * 2));
+    TRY(launch_split3_f32((uint16_t*)e->vh3.p, nullptr, vh_f32, (int64_t)n_pairs * C, M, 0, e->c.compute_dtype, (hipStream_t)stream));
+    return tvg_logits_impl(e, nullptr, true, nullptr, e->n_vocab, n_pairs, logits, stream, true);
 }
 extern "C" int blim_tvg_logits(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream) {
     return tvg_logits_impl(e, vh_bf16, false, vocab_bf16, n_vocab, n_pairs, logits, stream);
@@ -897,7 +970,7 @@ extern "C" int blim_score_vtg(blim_engine* e, const blim_batch* b, const void* e
 
 extern "C" int blim_score_tvg(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* rows, const void* vocab_bf16,
                               int32_t n_vocab, const int32_t* labels, int32_t n_pairs, float* score, void* stream) {
-    ARG_CHECK(e && rows && vocab_bf16 && labels && score && n_pairs > 0);
+    ARG_CHECK(e && rows && labels && score && n_pairs > 0);       // vocab_bf16 == NULL: the vocabulary registered with blim_set_video_vocab
     const int64_t n_rows = (int64_t)n_pairs * e->c.num_clips;
     TRY(reserve_rows(e, n_rows));
     TRY(ensure(e->vh, (size_t)round_up(n_rows, 256) * e->c.mm_hidden_size * 2 * (e->precise ? 2 : 1)));

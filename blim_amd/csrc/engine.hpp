@@ -93,6 +93,12 @@ struct blim_engine {
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)
     std::vector<void*> ad_owned;                                 // the f32 A / B matrices
     DevBuf feats_aug, hid_aug;                                   // staging: caller-provided rows copied into augmented rows
+    // ---- registered video vocabulary (blim_set_video_vocab; modeling_videochat_flash.py:589-590): clip-major [C][N][M] as f32-derived 16-bit operands --
+    // vocab3 rows [hi | lo | hi] (3 M wide) for the three-term compensated TVG logits, vocab1 rows = hi alone for plain calls
+    DevBuf vocab3, vocab1, vh3;
+    int n_vocab = 0;
+    // visual_head (a full fp32 tensor of the resume file, main.py:104-107) as [hi | lo | hi] rows of width 3 H for the three-term product in compensated calls
+    DevBuf visual_head3, hs3;
 };
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -116,3 +122,4 @@ int ensure(DevBuf& b, size_t bytes);   // grow-only workspace
 GemmParams gp(int dt, const void* A, int64_t lda, const void* W, int64_t M, int N, int K, void* C, int64_t ldc);
 int engine_rope_rows(blim_engine* e, const blim_batch* b, hipStream_t s, float** out, int64_t* stride);
 int check_batch(const blim_batch* b);
+int engine_set_visual_head3(blim_engine* e, const void* dev_src, int dtype, hipStream_t s);   // dev_src [M, H]: BLIM_DTYPE_F32 (hi + lo kept) or BLIM_DTYPE_BF16 (lo = 0)

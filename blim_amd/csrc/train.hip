@@ -239,6 +239,7 @@ extern "C" int blim_train_merge(blim_trainer* t, void* stream) {
         TRY(launch_lora_merge(e->mlp_w2[w], t->w2_aug[w], H + AUG, 0, P + t->lay.mlp[w][1].offB, P + t->lay.mlp[w][1].offA, H, H, r, t->s, 0, dt, s));
     }
     TRY(launch_f32_to_16(e->visual_head, H, P + t->lay.off_vh, H, M, H, 1.0f, dt, s));
+    TRY(engine_set_visual_head3(e, P + t->lay.off_vh, BLIM_DTYPE_F32, s));      // the scoring path's hi + lo copy of the head
     e->f8_ready = false;
     return BLIM_OK;
 }

@@ -91,8 +91,11 @@ def load_library(path: str = LIB_PATH):
         "blim_lm_head": ([vp, vp, i64, vp, vp], C.c_int),
         "blim_ce_rows": ([vp, vp, i64, i32, vp, i64, vp, vp], C.c_int),
         "blim_visual_head": ([vp, vp, i64, vp, vp], C.c_int),
+        "blim_visual_head_f32": ([vp, vp, i64, vp, vp], C.c_int),
         "blim_tvg_scores": ([vp, vp, vp, i32, vp, i32, vp, vp], C.c_int),
         "blim_tvg_logits": ([vp, vp, vp, i32, i32, vp, vp], C.c_int),
+        "blim_set_video_vocab": ([vp, vp, i32, vp], C.c_int),
+        "blim_tvg_logits_f32": ([vp, vp, i32, vp, vp], C.c_int),
         "blim_score_vtg": ([vp, C.POINTER(Batch), vp, vp, vp, i64, vp, i32, vp, vp], C.c_int),
         "blim_score_tvg": ([vp, C.POINTER(Batch), vp, vp, vp, i32, vp, i32, vp, vp], C.c_int),
         "blim_forward": ([vp, vp, vp, i32, i32, vp, vp, vp], C.c_int),
@@ -333,6 +336,23 @@ class Engine:
                "blim_tvg_logits")
         return out
 
+    def set_video_vocab(self, video_vocab):
+        """video_vocab [N, clips, M] (any float dtype, host or device): registered with the engine as hi + lo 16-bit operands (blim_set_video_vocab);
+        score_tvg / tvg_scores / tvg_logits called without a vocabulary then use it."""
+        import torch
+        v = torch.as_tensor(video_vocab).to(device=self.device, dtype=torch.float32).permute(1, 0, 2).contiguous()      # clip-major [clips, N, M]
+        assert v.shape[0] == self.dims.num_clips and v.shape[2] == self.dims.mm_hidden_size, tuple(v.shape)
+        _check(self.lib.blim_set_video_vocab(self.h, _ptr(v), int(v.shape[1]), _stream()), "blim_set_video_vocab")
+        self.n_vocab = int(v.shape[1])
+        self._vocab_key = (video_vocab.data_ptr() if hasattr(video_vocab, "data_ptr") else id(video_vocab), tuple(video_vocab.shape))
+
+    def tvg_logits_f32(self, vh_f32, n_pairs: int):
+        """vh_f32 [n_pairs * clips, M] float32 -> logits [n_pairs, clips, n_vocab] against the registered vocabulary (three-term compensated product)."""
+        import torch
+        out = torch.empty((n_pairs, self.dims.num_clips, self.n_vocab), dtype=torch.float32, device=self.device)
+        _check(self.lib.blim_tvg_logits_f32(self.h, _ptr(vh_f32), n_pairs, _ptr(out), _stream()), "blim_tvg_logits_f32")
+        return out
+
     def lm_head(self, hidden_bf16):
         import torch
         n = hidden_bf16.shape[0]
@@ -345,6 +365,14 @@ class Engine:
         n = hidden_bf16.shape[0]
         out = torch.empty((n, self.dims.mm_hidden_size), dtype=self.torch_dtype, device=self.device)
         _check(self.lib.blim_visual_head(self.h, _ptr(hidden_bf16), n, _ptr(out), _stream()), "blim_visual_head")
+        return out
+
+    def visual_head_f32(self, hidden_f32):
+        """float32 [n, H] -> float32 [n, M]: head and hidden rows as hi + lo 16-bit operands (blim_visual_head_f32)."""
+        import torch
+        n = hidden_f32.shape[0]
+        out = torch.empty((n, self.dims.mm_hidden_size), dtype=torch.float32, device=self.device)
+        _check(self.lib.blim_visual_head_f32(self.h, _ptr(hidden_f32), n, _ptr(out), _stream()), "blim_visual_head_f32")
         return out
 
     def tvg_scores(self, vh_bf16, vocab_clip_major, labels):
@@ -366,11 +394,13 @@ class Engine:
         return out
 
     def score_tvg(self, batch: PackedBatch, embeds, rows, vocab_clip_major, labels):
+        """vocab_clip_major None: the vocabulary registered with set_video_vocab()."""
         import torch
         n_pairs = labels.shape[0]
         out = torch.empty(n_pairs, dtype=torch.float32, device=self.device)
         bs = batch.struct(self.max_positions)
-        _check(self.lib.blim_score_tvg(self.h, C.byref(bs), _ptr(embeds), _ptr(rows), _ptr(vocab_clip_major), vocab_clip_major.shape[1],
+        n_vocab = self.n_vocab if vocab_clip_major is None else vocab_clip_major.shape[1]
+        _check(self.lib.blim_score_tvg(self.h, C.byref(bs), _ptr(embeds), _ptr(rows), _ptr(vocab_clip_major), n_vocab,
                                        _ptr(labels), n_pairs, _ptr(out), _stream()), "blim_score_tvg")
         return out
 

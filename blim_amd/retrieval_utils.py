@@ -76,8 +76,16 @@ def _tvg_logits_literal(model, hidden_states, tvg_labels, video_vocab, num_clips
     idx = (tvg_labels == IMAGE_TOKEN_ID).nonzero()[:, 1][:, None].repeat(1, num_clips) + (torch.arange(num_clips) - (num_clips + 1)).to(device)
     emb = torch.gather(hidden_states, 1, idx[..., None].repeat(1, 1, hidden_states.shape[-1]))
     emb = model.module.forward_visual(emb)                                    # [B, clips, M] f32
+    eng_ = model.module.engine
+    if getattr(eng_, "can_precise", False):
+        # 16-bit engines: float32 visual-head outputs against the vocabulary registered as hi + lo operands (three-term compensated product: a 16-bit cast of
+        # either side alone left 2 - 8e-4 on the bf16 engine's literal TVG scores)
+        key = (video_vocab.data_ptr(), tuple(video_vocab.shape))
+        if getattr(eng_, "_vocab_key", None) != key:
+            eng_.set_video_vocab(video_vocab)
+        return eng_.tvg_logits_f32(emb.reshape(-1, emb.shape[-1]).float().contiguous(), emb.shape[0])
     vh = emb.to(model.module.dtype).reshape(-1, emb.shape[-1]).contiguous()
-    return model.module.engine.tvg_logits(vh, _clip_major_vocab(video_vocab, device, model.module.dtype), emb.shape[0])
+    return eng_.tvg_logits(vh, _clip_major_vocab(video_vocab, device, model.module.dtype), emb.shape[0])
 
 
 def compute_v2t_scores_x(v2t_scores_x, iterator, start, input_ids, attention_masks, labels, video, video_vocab, tvg_video_labels,
@@ -244,7 +252,17 @@ class PairScorer:
         self.tvg_rows = strip(tvg_ids, tvg_masks, tvg_labels)
         self.video = video
         self.tvg_video_labels = np.asarray(tvg_video_labels).astype(np.int32)
-        self.vocab_cm = _clip_major_vocab(video_vocab, self.device, self.m.dtype) if video_vocab is not None else None
+        # 16-bit engines: the vocabulary is registered with the engine as hi + lo operands (blim_set_video_vocab) and the TVG calls name none; fp8 engines take the
+        # plain 16-bit clip-major copy
+        self.vocab_cm, self.n_vocab, self._vocab_src, self._vocab_key = None, 0, None, None
+        if video_vocab is not None:
+            self.n_vocab = int(video_vocab.shape[0])
+            if self.split_tvg and hasattr(self.engine, "set_video_vocab"):
+                self._vocab_src = video_vocab
+                self.engine.set_video_vocab(video_vocab)
+                self._vocab_key = self.engine._vocab_key
+            else:
+                self.vocab_cm = _clip_major_vocab(video_vocab, self.device, self.m.dtype)
         self.exec_flops = 0.0            # GEMM FLOPs of the engine calls run so far (executed_flops; bench.py's roofline fractions)
         self.exec_tokens = 0
         self._vfeat: Dict[Tuple[int, bool], object] = {}
@@ -526,7 +544,9 @@ class PairScorer:
                 if mode in ("qk", "qkx"):
                     self.engine.set_option("precise_qk", 0)
         self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", "full" if self.split_tvg else None,
-                                          n_vocab=int(self.vocab_cm.shape[1]) if self.vocab_cm is not None else 0, prune=not f8)
+                                          n_vocab=self.n_vocab, prune=not f8)
+        if self.vocab_cm is None and getattr(self.engine, "_vocab_key", None) != self._vocab_key:
+            self.engine.set_video_vocab(self._vocab_src)                     # another scorer / the literal path registered its own vocabulary since
         self.engine.set_precise(self.split_tvg, embeds=self.split_tvg)       # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
         try:
             embeds = self.engine.assemble(plan.src_index, plan.feats)

@@ -152,6 +152,9 @@ int blim_ce_rows(blim_engine* e, const float* logits, int64_t ld, int32_t n_cols
 
 /* ---- K13: visual_head, bf16 [n_rows, hidden] -> bf16 [n_rows, mm_hidden] (modeling_videochat_flash.py:598-599). */
 int blim_visual_head(blim_engine* e, const void* hidden_bf16, int64_t n_rows, void* out_bf16, void* stream);
+/* The same on FLOAT32 hidden states with a float32 result (device pointers): the head -- an fp32 tensor of the resume file, main.py:104-107 -- and the
+ * hidden rows both enter as hi + lo 16-bit operands (three-term product).  What the literal path's forward_visual calls on 16-bit engines. */
+int blim_visual_head_f32(blim_engine* e, const float* hidden_f32, int64_t n_rows, float* out_f32, void* stream);
 /* ---- K14+K15: vh bf16 [n_pairs, clips, mm_hidden]; vocab bf16 [clips, n_vocab, mm_hidden] (clip-major copy of
  * video_vocab); score[p] = mean_c log_softmax_n(vh[p,c].vocab[c,n] / sqrt(mm_hidden))[labels[p]].
  * Replaces the bmm + TVGCriterion of retrieval_utils.py:106-107, 40-43. */
@@ -159,6 +162,15 @@ int blim_tvg_scores(blim_engine* e, const void* vh_bf16, const void* vocab_bf16,
                     int32_t n_pairs, float* score, void* stream);
 /* the logits alone: f32 [n_pairs, clips, n_vocab] (literal path, retrieval_utils.py:106) */
 int blim_tvg_logits(blim_engine* e, const void* vh_bf16, const void* vocab_bf16, int32_t n_vocab, int32_t n_pairs, float* logits, void* stream);
+/* Registers the video vocabulary (model.module.set_video_vocab, modeling_videochat_flash.py:589-590; retrieval_utils.py:209): `vocab_f32` = DEVICE float32
+ * [num_clips][n_vocab][mm_hidden] (clip-major), the clip-mean features of every test video (base_dataset.py:33-37).  The engine keeps it as hi + lo 16-bit
+ * operands; blim_tvg_logits / blim_tvg_scores / blim_score_tvg called with vocab_bf16 == NULL then score against it, and in the compensated mode (option
+ * "precise": every TVG call of a 16-bit engine) the logits are the three-term product (vh_hi + vh_lo) . (v_hi + v_lo) -- a 16-bit vocabulary alone bounded the
+ * bf16 engine's TVG scores at 2 - 7e-4 of the fp32 reference. */
+int blim_set_video_vocab(blim_engine* e, const float* vocab_f32, int32_t n_vocab, void* stream);
+/* retrieval_utils.py:104-106 for the literal path: logits [n_pairs, num_clips, n_vocab] of FLOAT32 visual-head outputs vh_f32 [n_pairs * num_clips, mm_hidden]
+ * (device) against the registered vocabulary, three-term compensated product, / sqrt(mm_hidden). */
+int blim_tvg_logits_f32(blim_engine* e, const float* vh_f32, int32_t n_pairs, float* logits, void* stream);
 
 /* ---- Fused scoring: decode + head + criterion in one call.
  * VTG: rows[r] = packed token whose hidden state predicts labels[r]; pair p owns rows [row_start[p], row_start[p+1]). */
