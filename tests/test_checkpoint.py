@@ -1,6 +1,6 @@
 """Checkpoint loader (blim_amd/checkpoint.py): HF key mapping, sharded safetensors reading, LoRA merge W' = W + (alpha/r) B A,
 tvg_mlp = copy of mlp, resume-file parsing (peft naming).  CPU part uses a recording stand-in engine; the GPU part loads a
-synthetic checkpoint + adapters into the real engine and checks a score against the oracle run on the merged weights."""
+synthetic checkpoint + adapters into the real engine (adapters apart / merged) and checks scores against the oracle run on weights merged in fp32."""
 import os
 import types
 
@@ -144,7 +144,11 @@ def test_resume_file_is_checked_like_the_reference_checks_it(tmp_path):
 
 
 @pytest.mark.gpu
-def test_engine_scores_with_merged_checkpoint(tmp_path):
+@pytest.mark.parametrize("lora_mode", ["apart", "merge"])
+def test_engine_scores_with_adapted_checkpoint(tmp_path, lora_mode):
+    """Base checkpoint + resume file -> engine (adapters kept apart, the default, or merged on the host) against the numpy oracle on W + (alpha / r) B A merged in
+    FLOAT32 -- what the reference's adapters-apart forward equals in exact arithmetic (pinned by tests/golden/lora_tiny.npz; the 28-layer and 7B-size cases
+    against the reference's own run are tests/test_lora_gpu.py).  No rounding on the oracle's side: the reference never merges."""
     from blim_amd import retrieval_utils as RU
     from blim_amd.modeling import BlimModel, DDPLike
     from oracle import blim_oracle as O
@@ -156,14 +160,13 @@ def test_engine_scores_with_merged_checkpoint(tmp_path):
     ad = _adapters(dims, 3, names)
     torch.save(_resume_state(ad, w["visual_head"]), tmp_path / "resume.pth")
     model = BlimModel(dims, max_positions=512)
-    CK.load_checkpoint(model.engine, dims, str(tmp_path / "base"), str(tmp_path / "resume.pth"))
-    assert model.engine.weights_ready()
+    CK.load_checkpoint(model.engine, dims, str(tmp_path / "base"), str(tmp_path / "resume.pth"), lora_mode=lora_mode)
+    assert model.engine.weights_ready() and model.engine.num_adapters() == (len(names) if lora_mode == "apart" else 0)
     merged = dict(w)
     for n in ("0.w", "0.b", "2.w", "2.b"):
         merged["tvg_mlp." + n] = w["mlp." + n].copy()
     for n, (A, B) in ad.items():
-        # the reference holds the merged weight in fp16 (.half()); so does the engine (default compute dtype) and the oracle here
-        merged[n] = (merged[n] + 4.0 * (B @ A)).astype(np.float16).astype(np.float32)
+        merged[n] = (merged[n] + np.float32(4.0) * (B @ A)).astype(np.float32)
     prob = synth.make_problem(4, 4, dims, tok_per_clip=8, text_len=(3, 8))
     model.set_tvg_prefix_length(prob.tvg_prefix_length)
     tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
