@@ -7,7 +7,7 @@
 Reads ./data/<DS>/..., ./scores/<ds>[_zeroshot].pth exactly as the reference does.  `--synthetic N` replaces checkpoint,
 tokenizer, dataset and first-stage scores by seeded synthetic ones (no downloads): an end-to-end dry run of the same code path.
 Without --eval it fine-tunes as the reference's main.py:155-195 does: per epoch train_one_epoch (blim_amd/training.py: LoRA adapters +
-visual_head on the engine's trainer), save `epoch<N>.pth`, merge the adapters into the scoring weights,
+visual_head on the engine's trainer), save `epoch<N>.pth`, hand the adapters to the scoring engine (apart; --lora_mode merge folds them in),
 val_one_epoch, keep `checkpoint_best.pth`, append to <output_dir>/log.txt.
 """
 from __future__ import annotations
@@ -272,7 +272,10 @@ def train_loop(args, model, train_loader, val_loader, tokenizer, device, rank: i
         stats = train_one_epoch(trainer, train_loader, epoch, args, world_size=world, log=print if rank == 0 else (lambda *_: None))
         if rank == 0:
             save_model(args, epoch, trainer, name=f"epoch{epoch}")                                   # main.py:165
-        trainer.merge_into_engine()
+        if args.lora_mode == "merge":
+            trainer.merge_into_engine()                                                              # W + alpha/r * B A folded into the scoring weights (rounded to the engine's format)
+        else:
+            trainer.adapters_into_engine()                                                           # adapters apart on the pristine base weights, like the reference's live peft model
         model.clear_cache()                                                                          # projector outputs cached under the previous weights
         results = val_one_epoch(DDPLike(model), val_loader, None, device, epoch, None, tokenizer=tokenizer, args=args)
         if rank == 0:

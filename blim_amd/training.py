@@ -5,7 +5,7 @@ Mirrors the reference's training step (training_utils.py:39-104), optimizer set-
 
     trainer = Trainer(model.engine, lora_r=8, lora_alpha=32, lora_dropout=0.05)         # main.py:96-111
     stats = train_one_epoch(trainer, data_loader_train, epoch, args)                   # training_utils.py:39
-    trainer.merge_into_engine()                                                        # then evaluation() scores the fine-tuned model
+    trainer.adapters_into_engine()                                                     # then evaluation() scores the fine-tuned model (adapters apart; merge_into_engine() folds them in)
     save_model(args, epoch, trainer, name=f"epoch{epoch}")                             # util/misc.py:276
 
 A batch is the reference's collate output (dataloader/base_dataset.py:119-163, train split: left-padded id / label / mask tensors, a
@@ -251,6 +251,17 @@ class Trainer:
     def merge_into_engine(self) -> None:
         """Engine weights <- W + alpha/r * B A (+ visual_head): what evaluation() then scores (val_one_epoch after every epoch, main.py:166)."""
         _check(self.lib.blim_train_merge(self.h, _stream()), "blim_train_merge")
+
+    def adapters_into_engine(self) -> None:
+        """The current adapters + visual_head handed to the scoring engine as SEPARATE matrices (blim_load_adapter): the in-training validation then scores
+        y = W x + (alpha / r) B (A x) on the pristine base weights, as the reference's live peft model does (main.py:166 -> val_one_epoch)."""
+        st = self.state()
+        for name, arr in st.items():
+            if name == "visual_head":
+                self.engine.load_weight("visual_head", arr)
+            elif name.endswith(":A"):
+                w = name[:-2]
+                self.engine.load_adapter(w, arr, st[w + ":B"], self.r, self.alpha)
 
     # ---- one batch
     def set_video_vocab(self, video_vocab) -> None:
