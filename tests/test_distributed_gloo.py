@@ -237,3 +237,39 @@ def test_pair_ownership_with_unequal_numbers_of_videos_and_texts():
             if k != "internvideo2":
                 m = part_d[k] != -100.0
                 assert np.array_equal(part_d[k][m], full_d[k][m]), k
+
+
+def _forced_worker(port, n, out_q):
+    """World size 1 with a process group up and BLIM_FORCE_COLLECTIVE=1: the collective branches run (what the -m gpu tests do over RCCL on a one-GPU box)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", BLIM_FORCE_COLLECTIVE="1")
+    D.init_distributed_mode(backend="gloo")
+    assert D.force_collective()
+    calls = []
+    orig = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    t2v, v2t, _ = _run_eval(n)
+    full = torch.from_numpy(np.random.RandomState(0).randn(n, 5).astype(np.float32) - 5.0)
+    merged = D.merge_row_blocks(full.clone(), (0, n), 1)
+    out_q.put(({k: v for k, v in t2v.items()}, {k: v for k, v in v2t.items()}, len(calls), torch.equal(merged, full)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_one_change_no_bit():
+    """distributed.force_collective: at W = 1 every collective of the evaluation runs (the score-block all-gather, the text-sharded prior's gather) and
+    the matrices equal the run without a process group bit for bit."""
+    n = 11
+    assert not D.force_collective()                                  # no process group in this process
+    ref_t2v, ref_v2t, _ = _run_eval(n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), n, q))
+    p.start()
+    t2v, v2t, n_gathers, merged_ok = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and merged_ok
+    assert n_gathers >= 3                                            # merge of the blocks + the prior vector + merge_row_blocks above
+    for k in ref_t2v:
+        assert np.array_equal(t2v[k], ref_t2v[k]), ("t2v", k)
+    for k in ref_v2t:
+        assert np.array_equal(v2t[k], ref_v2t[k]), ("v2t", k)

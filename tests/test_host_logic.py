@@ -397,3 +397,28 @@ def test_driver_refuses_checkpoint_configs_outside_the_scoring_splice(tmp_path):
                 dict(frame_aspect_ratio="anyres_max_9")):
         with pytest.raises(NotImplementedError):
             dims_from_config(write(**bad), 4)
+
+
+def test_executed_flops_formula_and_calibration_pairs():
+    """retrieval_utils.executed_flops: the per-token constants of SURVEY.md section 8a on the token counts launched, the compensated modes' doubled GEMMs,
+    the last layer's pruned rows; calibration_pairs: the same pairs on every rank, inside the top-k."""
+    import torch
+    from blim_amd import retrieval_utils as RU
+    d = synth.ModelDims()
+    F, qkv, head = 466092032, 2 * 3584 * (3584 + 2 * 512), 1089994752
+    tok, rows = 32560, 28160
+    assert RU.executed_flops(d, tok, rows, "vtg", None, prune=False) == 28 * F * tok + head * rows
+    assert RU.executed_flops(d, tok, rows, "vtg", None) == 28 * F * tok + head * rows - (F - qkv) * (tok - rows)
+    assert RU.executed_flops(d, tok, tok, "vtg", None) == 28 * F * tok + head * tok                    # nothing to prune when every row is read
+    assert RU.executed_flops(d, tok, rows, "vtg", "full", prune=False) == 2 * (28 * F * tok + head * rows)
+    assert RU.executed_flops(d, tok, rows, "vtg", "qkx", prune=False) == 28 * (F + qkv) * tok + head * rows
+    assert RU.executed_flops(d, tok, rows, "vtg", "attn", prune=False) == 28 * (F + qkv + 2 * 3584 * 3584) * tok + 2 * head * rows
+    assert RU.executed_flops(d, tok, rows, "vtg", "qk", prune=False) == RU.executed_flops(d, tok, rows, "vtg", None, prune=False)
+    assert RU.executed_flops(d, 1000, 400, "tvg", "full", n_vocab=1000, prune=False) == 2 * (28 * F * 1000 + (2 * 3584 * 1024 + 2 * 1024 * 1000) * 400)
+    sims = torch.from_numpy(np.random.RandomState(0).randn(40, 50).astype(np.float32))
+    p = RU.calibration_pairs(sims, topk=5)
+    assert p.shape == (16 * 5, 2) and len(np.unique(p[:, 0])) == 16 and p[:, 0].min() == 0 and p[:, 0].max() == 39
+    top = sims.topk(5, dim=1).indices.numpy()
+    assert all(c in top[q] for q, c in p)
+    assert np.array_equal(p, RU.calibration_pairs(sims, topk=5))                                        # deterministic: the same on every rank
+    assert RU.calibration_pairs(sims[:3], topk=64).shape == (3 * 16, 2)                                 # at most 16 per query, at most Nt

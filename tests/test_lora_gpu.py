@@ -197,3 +197,93 @@ def test_adapter_abi_errors():
         assert E.num_adapters() == 0
     finally:
         E.close()
+
+
+def _oracle_scores(d, merged, prob, dims, pairs):
+    """VTG / TVG scores of `pairs` by the numpy oracle on `merged` weights."""
+    from oracle import blim_oracle as O
+    om = O.OracleModel(O.OracleConfig(**d), merged); om.set_tvg_prefix_length(prob.tvg_prefix_length)
+    ov = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+    ot = O.padding_ids(prob.tvg_ids, prob.tvg_labels, prob.tvg_masks, synth.PAD_ID)
+    v, t = [], []
+    for j, i in pairs:
+        mask, _, emb, lab = om.prepare_inputs_labels_for_multimodal(ov[0][[i]], ov[2][[i]], ov[1][[i]], [prob.video[j]])
+        v.append(om.label_logprobs(om.forward_hidden(emb, mask), lab)[0])
+        mask, _, emb, lab = om.prepare_inputs_labels_for_multimodal(ot[0][[i]], ot[2][[i]], ot[1][[i]], [prob.video[j]], tvg=True)
+        t.append(O._tvg_scores(om, om.forward_hidden(emb, mask), lab, prob.video_vocab, np.full((1, dims.num_clips), prob.tvg_video_labels[j]), dims.num_clips)[0])
+    return np.array(v), np.array(t)
+
+
+def _pair_scorer(model, prob, dims):
+    from blim_amd import retrieval_utils as RU
+    from blim_amd.modeling import DDPLike
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    return RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video], torch.from_numpy(prob.video_vocab),
+                         torch.from_numpy(prob.tvg_video_labels), dims.num_clips)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_rank_16_adapters_and_partial_adapter_sets(dtype):
+    """(1) lora_r = 16: q, k, v need 3 x 16 x (hi, lo) = 96 augmented K columns -> the 128-column form of every augmented operand; (2) a partial set (only layer 0's
+    q_proj, layer 1's v_proj and o_proj, lm_head, tvg_mlp Linear 2): the absent adapters of a q / k / v triple read an all-zero A operand.  Both against the numpy
+    oracle on weights merged in fp32."""
+    from blim_amd import lora
+    spec, g, dims, prob = LF.load_case("lora_tiny")
+    d = spec["dims"]
+    w = LF.base_weights_host(spec, dims)
+    pairs = np.array([[0, 0], [1, 2], [3, 1], [5, 4], [2, 2]])
+    model = BlimModel(dims, max_positions=1024, dtype=dtype)
+    E = model.engine
+    try:
+        E.load_weights(w)
+        model.set_tvg_prefix_length(prob.tvg_prefix_length)
+        for r, names in ((16, CK.expected_adapters(dims)), (8, ["layers.0.q_proj.w", "layers.1.v_proj.w", "layers.1.o_proj.w", "lm_head", "tvg_mlp.2.w"])):
+            tr = lora.synthetic_trainable(dims, r, 53, rel=LF.REL, alpha=LF.ALPHA)
+            E.clear_adapters()
+            merged = dict(w)
+            for n in names:
+                E.load_adapter(n, tr[n + ":A"], tr[n + ":B"], r, LF.ALPHA)
+                merged[n] = (w[n] + np.float32(LF.ALPHA / r) * (tr[n + ":B"] @ tr[n + ":A"])).astype(np.float32)
+            assert E.num_adapters() == len(names)
+            model.clear_cache()
+            sc = _pair_scorer(model, prob, dims)
+            got_v, got_t = sc.vtg(pairs), sc.tvg(pairs)
+            want_v, want_t = _oracle_scores(d, merged, prob, dims, pairs)
+            np.testing.assert_allclose(got_v, want_v, rtol=RTOL, err_msg=f"r = {r}, {len(names)} adapters, VTG")
+            np.testing.assert_allclose(got_t, want_t, rtol=RTOL, err_msg=f"r = {r}, {len(names)} adapters, TVG")
+            base_v, _ = _oracle_scores(d, w, prob, dims, pairs[:2])
+            assert np.max(np.abs(want_v[:2] - base_v) / np.abs(base_v)) > 1e-3            # the adapters are not a no-op
+    finally:
+        E.close()
+
+
+def test_adapters_apart_under_every_vtg_mode_and_on_an_fp8_engine(files, capsys):
+    """The compensated VTG modes route the QKV / o_proj inputs as plain, hi-only or hi + lo rows: with adapters apart every one of them carries the augmented columns.
+    28 layers (lora_deep), fp16, fused VTG passes, each mode against the reference golden; then the same checkpoint on an fp8 engine: the adapted projections run in
+    fp16 (the adapters survive), the MLP in e4m3 -- a reported mode, bounded like the other fp8 depth tests."""
+    t, g = _from_files("lora_deep", "f16", files, "apart")
+    res = {}
+    try:
+        for mode in (None, "qk", "qkx", "attn", "full"):
+            t.model.vtg_precise = mode
+            res[mode or "none"] = P._worst_rel(P._six_passes(t, False, names=("v2t_vtg", "t2v_vtg", "v2t_vtg_cpn")), g)
+    finally:
+        t.model.engine.close()
+    t8, g = _from_files("lora_deep", "f8", files, "apart")
+    try:
+        assert t8.model.engine.num_adapters() == len(CK.expected_adapters(t8.dims))
+        res["f8"] = P._worst_rel(P._six_passes(t8, False), g)
+    finally:
+        t8.model.engine.close()
+    with capsys.disabled():
+        for k, w in res.items():
+            print(f"\n[lora_deep adapters apart, vtg_precise / engine = {k}] " + ", ".join(f"{a} {b:.2e}" for a, b in w.items()))
+    for k, w in res.items():
+        if k == "f8":
+            assert max(v for a, v in w.items() if "tvg" not in a) < 0.08 and max(v for a, v in w.items() if "tvg" in a) < 0.18, w
+        else:
+            assert max(w.values()) < RTOL, (k, w)
+    assert max(res["full"].values()) < 1e-5 and max(res["attn"].values()) <= max(res["none"].values())
