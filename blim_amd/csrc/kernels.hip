@@ -184,11 +184,11 @@ int launch_gather_rows(void* dst, const void* src, const int32_t* rows, int64_t 
 template <int MAXV, int DT>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H,
                                                       const float* w, float eps, bf16_t* out_bf16, float* out_f32, int64_t n_src,
-                                                      int64_t ldo, bf16_t* out_lo) {
+                                                      int64_t ldo, bf16_t* out_lo, int saturate) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
-    if constexpr (DT == DT_F16) f16_saturate_on();
+    if constexpr (DT == DT_F16) { if (saturate) f16_saturate_on(); }
     const int64_t src = rows ? rows[r] : r;
     const int nv = H / 4;  // float4 per row
     if (src < 0 || src >= n_src) {   // a gather index outside the packed batch: poison the row (NaN score) instead of reading wild memory
@@ -232,11 +232,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
 // lanes' partial sums of squares are formed differs.
 template <int DT>
 __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
-                                                           bf16_t* out_bf16, float* out_f32, int64_t n_src, int64_t ldo, bf16_t* out_lo) {
+                                                           bf16_t* out_bf16, float* out_f32, int64_t n_src, int64_t ldo, bf16_t* out_lo, int saturate) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
-    if constexpr (DT == DT_F16) f16_saturate_on();
+    if constexpr (DT == DT_F16) { if (saturate) f16_saturate_on(); }
     const int64_t src = rows ? rows[r] : r;
     const int nc = H / 8;
     if (src < 0 || src >= n_src) {
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(const float* x, int64
 }
 static int g_rmsnorm_wide = getenv("BLIM_RMSNORM_WIDE") ? atoi(getenv("BLIM_RMSNORM_WIDE")) : 1;
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
-                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src, int64_t ldo, bf16_t* out_lo) {
+                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src, int64_t ldo, bf16_t* out_lo, bool saturate) {
+    const int sat = saturate ? 1 : 0;
     if (!rows) n_src = n_rows;
     if (ldo == 0) ldo = H;
     ARG_CHECK(ldo % 4 == 0 && (!out_lo || out_h16));
@@ -291,15 +292,15 @@ int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_r
     const int nv = H / 4;
     const dim3 grid((unsigned)((n_rows + 3) / 4));
     if (g_rmsnorm_wide && H % 8 == 0 && H <= 4096 && H > 256 && ldo % 8 == 0 && ldx % 4 == 0) {
-        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo);
-        else hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo);
+        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat);
+        else hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat);
         LAUNCH_CHECK("rmsnorm");
         return BLIM_OK;
     }
 #define RMS_LAUNCH(MV)                                                                                                              \
     do {                                                                                                                            \
-        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo); \
-        else hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo);                \
+        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat); \
+        else hipLaunchKernelGGL((rmsnorm_kernel<MV, DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat);                \
     } while (0)
     if (nv <= 64 * 4) RMS_LAUNCH(4);
     else if (nv <= 64 * 16) RMS_LAUNCH(16);

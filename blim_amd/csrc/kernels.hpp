@@ -20,7 +20,8 @@ int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s);
 // out[i, :] = bf16( w * x[rows ? rows[i] : i, :] * rsqrt(mean(x^2) + eps) ); optionally also f32 copy.
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
                    bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src = 0,    // n_src: valid source rows when `rows` gathers
-                   int64_t ldo = 0, bf16_t* out_lo = nullptr);   // ldo: row stride of out_h16 / out_lo (0 = H); out_lo: compensated mode, lo = 16-bit(x - f32(hi))
+                   int64_t ldo = 0, bf16_t* out_lo = nullptr,    // ldo: row stride of out_h16 / out_lo (0 = H); out_lo: compensated mode, lo = 16-bit(x - f32(hi))
+                   bool saturate = true);                        // fp16 stores saturate at +-65504 (scoring path); false: overflow to inf (the trainer: its loss scaler must see it)
 
 // mean over groups of `group` consecutive rows: out[i,:] = mean_j in[i*group + j, :]   (16-bit in/out, f32 accumulate)
 int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s, bool split = false);

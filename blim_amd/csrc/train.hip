@@ -24,6 +24,14 @@
 
 #define AUG 64   // extra K columns of an augmented weight / activation row
 
+// The trainer's GEMMs and norms do NOT saturate their fp16 stores (the scoring path's do: common.hpp f16_saturate_on): an activation beyond 65504 must become inf,
+// reach the loss and the gradients, and make the AMP scaler skip the step and halve the scale -- what the reference's autocast + GradScaler do (util/misc.py:232-259).
+static GemmParams gpt(int dt, const void* A, int64_t lda, const void* W, int64_t M, int N, int K, void* C, int64_t ldc) {
+    GemmParams p = gp(dt, A, lda, W, M, N, K, C, ldc);
+    p.f16_saturate = 0;
+    return p;
+}
+
 struct Adapter { int64_t offA = 0, offB = 0; int n_in = 0, n_out = 0; uint16_t* Bt16 = nullptr; int64_t ldb = 0; uint16_t* A16 = nullptr; };   // Bt16: 16-bit B^T [16, ldb] (launch_lora_du); A16: 16-bit A [16, n_in] (launch_lora_down)
 
 struct TrainLayerW { uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr; uint16_t* wqkvT = nullptr; uint16_t* woT = nullptr; uint16_t* wguT = nullptr; uint16_t* wdT = nullptr; };
@@ -289,7 +297,7 @@ static int projector_forward(blim_trainer* t, const blim_train_batch* b, int whi
     la.A16[0] = t->lay.mlp[which][0].A16;
     TRY(launch_lora_down(fa, Ma, F, M, la, r, t->s, t->p_drop, b->dropout_seed, 1000 + 2 * which, dt, s));
     {
-        GemmParams p = gp(dt, fa, Ma, t->w0_aug[which], F, H, Ma, pre, H);
+        GemmParams p = gpt(dt, fa, Ma, t->w0_aug[which], F, H, Ma, pre, H);
         p.bias = e->mlp_b0[which];
         TRY(launch_gemm(EPI_BF16, p, s));
     }
@@ -298,7 +306,7 @@ static int projector_forward(blim_trainer* t, const blim_train_batch* b, int whi
     TRY(launch_lora_down(h16, Ha, F, H, la, r, t->s, t->p_drop, b->dropout_seed, 1001 + 2 * which, dt, s));
     uint16_t* proj = which == 0 ? vid : (uint16_t*)t->proj16.p;
     {
-        GemmParams p = gp(dt, h16, Ha, t->w2_aug[which], F, H, Ha, proj, H);
+        GemmParams p = gpt(dt, h16, Ha, t->w2_aug[which], F, H, Ha, proj, H);
         p.bias = e->mlp_b2[which];
         TRY(launch_gemm(EPI_BF16, p, s));
     }
@@ -336,11 +344,11 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, hipStream_t
         float* x_in = res + (int64_t)li * T * H; float* x_mid = mid + (int64_t)li * T * H; float* x_out = res + (int64_t)(li + 1) * T * H;
         uint16_t* xn1 = (uint16_t*)t->sv_xn1.p + (int64_t)li * T * Ha; uint16_t* qkv = (uint16_t*)t->sv_qkv.p + (int64_t)li * T * qn;
         uint16_t* attn = (uint16_t*)t->sv_attn.p + (int64_t)li * T * Ha; uint16_t* gu = (uint16_t*)t->sv_gu.p + (int64_t)li * T * 2 * I;
-        TRY(launch_rmsnorm(x_in, H, nullptr, T, H, l.norm1, c.rms_eps, (bf16_t*)xn1, dt, nullptr, s, 0, Ha, nullptr));
+        TRY(launch_rmsnorm(x_in, H, nullptr, T, H, l.norm1, c.rms_eps, (bf16_t*)xn1, dt, nullptr, s, 0, Ha, nullptr, false));
         LoraDownArgs q3; q3.n = 3; for (int j = 0; j < 3; ++j) q3.A16[j] = ad[j].A16;
         TRY(launch_lora_down(xn1, Ha, T, H, q3, r, t->s, t->p_drop, b->dropout_seed, 8 * li, dt, s));
         {
-            GemmParams p = gp(dt, xn1, Ha, x.wqkv_aug, T, qn, Ha, qkv, qn);
+            GemmParams p = gpt(dt, xn1, Ha, x.wqkv_aug, T, qn, Ha, qkv, qn);
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = rope_stride;
             TRY(launch_gemm(EPI_QKV, p, s));
         }
@@ -356,18 +364,18 @@ static int train_forward(blim_trainer* t, const blim_train_batch* b, hipStream_t
         LoraDownArgs o1; o1.n = 1; o1.A16[0] = ad[3].A16; o1.A16[1] = o1.A16[2] = nullptr;
         TRY(launch_lora_down(attn, Ha, T, H, o1, r, t->s, t->p_drop, b->dropout_seed, 8 * li + 3, dt, s));
         {
-            GemmParams p = gp(dt, attn, Ha, x.wo_aug, T, H, Ha, x_mid, H);
+            GemmParams p = gpt(dt, attn, Ha, x.wo_aug, T, H, Ha, x_mid, H);
             p.resid_in = x_in;                                             // x_mid = x_in + o_proj(attn): the layer input stays intact for the backward
             TRY(launch_gemm(EPI_RESID, p, s));
         }
-        TRY(launch_rmsnorm(x_mid, H, nullptr, T, H, l.norm2, c.rms_eps, (bf16_t*)t->xn2.p, dt, nullptr, s, 0, 0, nullptr));
+        TRY(launch_rmsnorm(x_mid, H, nullptr, T, H, l.norm2, c.rms_eps, (bf16_t*)t->xn2.p, dt, nullptr, s, 0, 0, nullptr, false));
         {   // gate | up pre-activations kept for the backward; act = silu(gate) * up formed in the same epilogue
-            GemmParams p = gp(dt, t->xn2.p, H, l.wgu, T, 2 * I, H, gu, 2 * (int64_t)I);
+            GemmParams p = gpt(dt, t->xn2.p, H, l.wgu, T, 2 * I, H, gu, 2 * (int64_t)I);
             p.swiglu_act = (uint16_t*)t->act.p; p.swiglu_act_ld = I;
             TRY(launch_gemm(EPI_BF16, p, s));
         }
         {
-            GemmParams p = gp(dt, t->act.p, I, l.wd, T, H, I, x_out, H);
+            GemmParams p = gpt(dt, t->act.p, I, l.wd, T, H, I, x_out, H);
             p.resid_in = x_mid;
             TRY(launch_gemm(EPI_RESID, p, s));
         }
@@ -400,13 +408,13 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         uint16_t* attn = (uint16_t*)t->sv_attn.p + (int64_t)li * T * Ha; uint16_t* gu = (uint16_t*)t->sv_gu.p + (int64_t)li * T * 2 * I;
         // ---- MLP block: x_out = x_mid + down(silu(gate(n2)) * up(n2)), n2 = rmsnorm(x_mid); dy16 = 16-bit(dres) comes from the previous RMSNorm backward
         if (li == c.num_layers - 1) TRY(launch_f32_to_16(dy16, H, dres, H, T, H, 1.0f, dt, s));
-        { GemmParams p = gp(dt, dy16, H, x.wdT, T, I, H, t->act.p, I); p.swiglu_gu = gu; p.swiglu_ld = 2 * (int64_t)I; p.f16_saturate = 0; TRY(launch_gemm(EPI_BF16, p, s)); }   // d act = dy . Wd, and in the
+        { GemmParams p = gpt(dt, dy16, H, x.wdT, T, I, H, t->act.p, I); p.swiglu_gu = gu; p.swiglu_ld = 2 * (int64_t)I; TRY(launch_gemm(EPI_BF16, p, s)); }   // d act = dy . Wd, and in the
                                                                                                                          // epilogue gu <- [d gate | d up] (no d act round trip)
-        { GemmParams p = gp(dt, gu, 2 * (int64_t)I, x.wguT, T, H, 2 * I, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }    // d n2
+        { GemmParams p = gpt(dt, gu, 2 * (int64_t)I, x.wguT, T, H, 2 * I, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }    // d n2
         TRY(launch_rmsnorm_bwd(dres, dtmp, x_mid, nullptr, T, H, l.norm2, c.rms_eps, 1, dy16, dt, s));                   // dres = d x_mid (+ its 16-bit copy)
         // ---- attention block: x_mid = x_in + o_proj(attn), attn = Attention(rope(qkv(n1))), n1 = rmsnorm(x_in)
         TRY(lora_backward(t, ad[3], dy16, H, attn, Ha, H, 0, T, du, b->dropout_seed, 8 * li + 3, s));
-        { GemmParams p = gp(dt, dy16, H, x.woT, T, H, H, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }                    // d attn (base path)
+        { GemmParams p = gpt(dt, dy16, H, x.woT, T, H, H, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }                    // d attn (base path)
         {   // d attn = base path + the o_proj adapter's input gradient, written straight as the attention backward's 16-bit operand
             LoraDxArgs a1; a1.n = 1; a1.du[0] = du; a1.A[0] = t->params + ad[3].offA; a1.du[1] = a1.du[2] = nullptr; a1.A[1] = a1.A[2] = nullptr;
             TRY(launch_lora_dx(dtmp, H, a1, T, H, r, t->p_drop, b->dropout_seed, 8 * li + 3, s, dattn16, H, dt));
@@ -423,7 +431,7 @@ static int train_backward_layers(blim_trainer* t, const blim_train_batch* b, hip
         TRY(launch_rope_bwd(dqkv16, dqkv32, T, qn, (c.num_heads + c.num_kv_heads) * 128, b->batch->positions, e->rope_cos, e->rope_sin, c.max_positions, dt, s));
         for (int j = 0; j < 3; ++j)      // (a single pass over x for the three dA was tried: slower, 48 accumulators per lane)
             TRY(lora_backward(t, ad[j], dqkv16 + qcols[j], qn, xn1, Ha, H, j * r, T, du + (int64_t)j * T * r, b->dropout_seed, 8 * li + j, s));
-        { GemmParams p = gp(dt, dqkv16, qn, x.wqkvT, T, H, qn, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }              // d n1 (base path)
+        { GemmParams p = gpt(dt, dqkv16, qn, x.wqkvT, T, H, qn, dtmp, H); TRY(launch_gemm(EPI_F32, p, s)); }              // d n1 (base path)
         {   // dres = d x_in; the three adapters' input gradients join dtmp inside the RMSNorm backward
             LoraDxArgs a3; a3.n = 3;
             for (int j = 0; j < 3; ++j) { a3.du[j] = du + (int64_t)j * T * r; a3.A[j] = t->params + ad[j].offA; }
@@ -447,7 +455,7 @@ static int train_backward_projector(blim_trainer* t, const blim_train_batch* b, 
     uint16_t* dout = (uint16_t*)t->dout16[which].p; float* dh = (float*)t->dh32.p; float* du = (float*)t->du.p;
     const Adapter& a2 = t->lay.mlp[which][1]; const Adapter& a0 = t->lay.mlp[which][0];
     TRY(lora_backward(t, a2, dout, H, (const uint16_t*)t->h16[which].p, Ha, H, 0, F, du, b->dropout_seed, 1001 + 2 * which, s));
-    { GemmParams p = gp(dt, dout, H, t->w2T[which], F, H, H, dh, H); TRY(launch_gemm(EPI_F32, p, s)); }
+    { GemmParams p = gpt(dt, dout, H, t->w2T[which], F, H, H, dh, H); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(lora_dx1(dh, H, du, t->params + a2.offA, F, H, r, t->p_drop, b->dropout_seed, 1001 + 2 * which, s));
     TRY(launch_gelu_bwd(dout, dh, (const uint16_t*)t->pre16[which].p, F, H, dt, s));                                    // dout <- d pre-activation
     return lora_backward(t, a0, dout, H, (const uint16_t*)t->feats_aug[which].p, Ma, M, 0, F, du, b->dropout_seed, 1000 + 2 * which, s);
@@ -472,14 +480,14 @@ static int vtg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum,
     TRY(ensure_z(t->hsel, (size_t)R * Ha * 2, s)); TRY(ensure(t->logits, (size_t)R * Vp * 4)); TRY(ensure(t->dlog16, (size_t)R * Vp * 2)); TRY(ensure(t->dhsel, (size_t)R * H * 4));
     TRY(ensure(t->du, (size_t)std::max<int64_t>(R, T) * 3 * 16 * 4));
     uint16_t* hsel = (uint16_t*)t->hsel.p; float* logits = (float*)t->logits.p; uint16_t* dlog = (uint16_t*)t->dlog16.p; float* dhsel = (float*)t->dhsel.p; float* du = (float*)t->du.p;
-    TRY(launch_rmsnorm(x_final, H, b->rows, R, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, Ha, nullptr));
+    TRY(launch_rmsnorm(x_final, H, b->rows, R, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, Ha, nullptr, false));
     LoraDownArgs la; la.n = 1; la.A16[0] = t->lay.lm.A16; la.A16[1] = la.A16[2] = nullptr;
     TRY(launch_lora_down(hsel, Ha, R, H, la, r, t->s, t->p_drop, b->dropout_seed, 2000, dt, s));
-    { GemmParams p = gp(dt, hsel, Ha, t->lm_aug, R, V, Ha, logits, Vp); TRY(launch_gemm(EPI_F32, p, s)); }
+    { GemmParams p = gpt(dt, hsel, Ha, t->lm_aug, R, V, Ha, logits, Vp); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(ensure(t->red_scratch, (size_t)R * 4));
     TRY(launch_ce_fwd_bwd(logits, Vp, V, b->labels, 1, R, b->grad_scale / (float)R, dlog, nullptr, Vp, loss_sum, dt, (float*)t->red_scratch.p, s));
     TRY(lora_backward(t, t->lay.lm, dlog, Vp, hsel, Ha, H, 0, R, du, b->dropout_seed, 2000, s));
-    { GemmParams p = gp(dt, dlog, Vp, t->lmT, R, H, Vp, dhsel, H); TRY(launch_gemm(EPI_F32, p, s)); }
+    { GemmParams p = gpt(dt, dlog, Vp, t->lmT, R, H, Vp, dhsel, H); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(lora_dx1(dhsel, H, du, t->params + t->lay.lm.offA, R, H, r, t->p_drop, b->dropout_seed, 2000, s));
     return launch_rmsnorm_bwd((float*)t->dres.p, dhsel, x_final, b->rows, R, H, e->final_norm, c.rms_eps, 0, nullptr, dt, s);
 }
@@ -497,8 +505,8 @@ static int tvg_head(blim_trainer* t, const blim_train_batch* b, float* loss_sum,
     TRY(ensure(t->dl32, (size_t)BC * N * 4)); TRY(ensure(t->dvh, (size_t)BC * M * 4)); TRY(ensure(t->dhsel, (size_t)BC * H * 4));
     uint16_t* hsel = (uint16_t*)t->hsel_t.p; float* vh32 = (float*)t->vh32.p; uint16_t* vhb = (uint16_t*)t->vhb16.p; float* logits = (float*)t->logits.p;
     float* dl = (float*)t->dl32.p; float* dvh = (float*)t->dvh.p; float* dhsel = (float*)t->dhsel.p;
-    TRY(launch_rmsnorm(x_final, H, b->tvg_rows, BC, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, 0, nullptr));
-    { GemmParams p = gp(dt, hsel, H, t->vh16, BC, M, H, vh32, M); TRY(launch_gemm(EPI_F32, p, s)); }
+    TRY(launch_rmsnorm(x_final, H, b->tvg_rows, BC, H, e->final_norm, c.rms_eps, (bf16_t*)hsel, dt, nullptr, s, T, 0, nullptr, false));
+    { GemmParams p = gpt(dt, hsel, H, t->vh16, BC, M, H, vh32, M); TRY(launch_gemm(EPI_F32, p, s)); }
     TRY(launch_f32_to_16(vhb, M, vh32, M, BC, M, 1.0f, dt, s));
     TRY(blim_tvg_logits(e, vhb, b->vocab, N, B, logits, stream));
     TRY(ensure(t->red_scratch, (size_t)BC * 4));

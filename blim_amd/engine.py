@@ -206,6 +206,10 @@ class Engine:
         _check(self.lib.blim_create(C.byref(cfg), C.byref(h)), "blim_create")
         self.h = h
         self.device = torch.device("cuda", torch.cuda.current_device())
+        # blim_create honours BLIM_PRECISE_MLP / BLIM_PRECISE_ACT (A/B runs): the Python-side cache of those options starts from the same values, so that
+        # set_precise() neither clobbers an override nor believes in a default the engine does not have
+        self._precise_mlp = os.environ.get("BLIM_PRECISE_MLP", "1") != "0"
+        self._precise_act = os.environ.get("BLIM_PRECISE_ACT", "1") != "0"
 
     def close(self):
         if getattr(self, "h", None):
@@ -276,7 +280,7 @@ class Engine:
         if embeds != getattr(self, "_precise_embeds", False):
             self.set_option("precise_embeds", int(embeds))
             self._precise_embeds = embeds
-        mlp = bool(mlp)                                   # mlp=False: only the attention branch (QKV, attention, o_proj) is compensated
+        mlp = bool(mlp) and os.environ.get("BLIM_PRECISE_MLP", "1") != "0"      # mlp=False: only the attention branch (QKV, attention, o_proj) is compensated
         if on and mlp != getattr(self, "_precise_mlp", True):
             self.set_option("precise_mlp", int(mlp))
             self._precise_mlp = mlp
@@ -285,7 +289,7 @@ class Engine:
         # configuration (3.7e-5 with it), which made plain the fp16 default for a while -- but on weights with a trained checkpoint's dynamic ranges
         # (tests/golden/heavy7b.npz: residual channels at 1e4) the TVG prior moved by 2.5e-3 without it and 9e-5 with it, so the ~10 % on the TVG calls is
         # paid.  bf16 engines always needed it (8-bit mantissas: 2e-3 without).  DESIGN.md section 4.
-        act = True if act is None else bool(act)
+        act = (True if act is None else bool(act)) and os.environ.get("BLIM_PRECISE_ACT", "1") != "0"
         if on and act != getattr(self, "_precise_act", True):
             self.set_option("precise_act", int(act))
             self._precise_act = act

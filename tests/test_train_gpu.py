@@ -360,3 +360,35 @@ def test_training_shapes_against_the_oracle(heads, kv, layers, tok, text):
     assert abs(lv - ov) <= 1e-3 * abs(ov) and abs(lt - ot) <= 1e-3 * abs(ot)
     assert worst <= GRAD_RTOL["f16"]
     t.close(); eng.close()
+
+
+def test_an_fp16_overflow_in_the_training_forward_skips_the_step():
+    """the scoring path SATURATES its fp16 activation stores (finite scores where the reference's `.half()` forward returns NaN), but the trainer must
+    not: under the reference's autocast + GradScaler an activation beyond 65504 becomes inf, reaches the loss and the gradients, and the scaler skips the optimizer
+    step and halves the scale (util/misc.py:232-259).  `saturation.npz`'s weights (SwiGLU product ~7e6) make the training forward overflow: the step is reported as
+    skipped, no parameter moves, the loss scale is halved; the same batch on a bf16 engine (f32's range) steps normally."""
+    import torch
+    from blim_amd.modeling import BlimModel
+    from blim_amd.training import Trainer
+    from oracle.gen_golden_saturation import DIMS, N, PSEED, TEXT, TOK, scaled_weights
+    dims = synth.ModelDims(**DIMS)
+    w = scaled_weights(dims)
+    prob = synth.make_problem(PSEED, N, dims, tok_per_clip=TOK, text_len=TEXT)
+    out = {}
+    for dtype in ("f16", "bf16"):
+        model = BlimModel(dims, max_positions=512, dtype=dtype)
+        model.engine.load_weights(w)
+        tr = Trainer(model.engine, lora_r=8, lora_alpha=32.0, lora_dropout=0.0, seed=3)
+        try:
+            tr.set_video_vocab(torch.from_numpy(prob.video_vocab))
+            before = tr.params.clone()
+            scale0 = tr.scaler.scale
+            tr.zero_grad()
+            losses = tr.forward_backward(collate(prob, range(min(N, 4))))
+            st = tr.optimizer_step(1e-3)
+            out[dtype] = (losses, st, bool(torch.equal(tr.params, before)), tr.scaler.scale / scale0)
+        finally:
+            tr.close(); model.engine.close()
+    (l16, s16, same16, r16), (lb, sb, sameb, rb) = out["f16"], out["bf16"]
+    assert s16["skipped"] == 1.0 and same16 and r16 == 0.5 and not all(math.isfinite(x) for x in l16), out["f16"]
+    assert sb["skipped"] == 0.0 and not sameb and all(math.isfinite(x) for x in lb) and math.isfinite(sb["grad_norm"]), out["bf16"]
