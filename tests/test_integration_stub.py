@@ -65,3 +65,42 @@ def test_documented_stub_runs_against_the_golden_vectors(compute_dtype):
                     np.testing.assert_allclose(sc, g[f"fwd_vtg{tag}_score"], rtol=1e-3)
     finally:
         fwd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compute_dtype", [1, 0], ids=["f16", "bf16"])
+def test_documented_stub_with_lora_adapters_kept_apart(compute_dtype):
+    """The same stub with its `adapters=` argument (blim_load_adapter): forward() of an engine holding the lora_tiny case's base weights + adapters apart against the
+    numpy oracle on W + (alpha / r) B A merged in fp32 (which tests/golden/lora_tiny.npz pins to the reference's adapters-apart run)."""
+    import torch
+    import lora_fixture as LF
+    from blim_amd import checkpoint as CK
+    from oracle import blim_oracle as O
+    ns = _stub_namespace()
+    spec, g, dims, prob = LF.load_case("lora_tiny")
+    d = spec["dims"]
+    w = LF.base_weights_host(spec, dims)
+    tr = LF.trainable_of(spec, dims)
+    state = dict(w); state["visual_head"] = tr["visual_head"]
+    adapters = {n: (tr[n + ":A"], tr[n + ":B"]) for n in CK.expected_adapters(dims)}
+    cfg = dict(vocab_size=d["vocab_size"], hidden_size=d["hidden_size"], intermediate_size=d["intermediate_size"], num_hidden_layers=d["num_layers"],
+               num_attention_heads=d["num_heads"], num_key_value_heads=d["num_kv_heads"], mm_hidden_size=d["mm_hidden_size"], rms_norm_eps=1e-6, rope_theta=1e6)
+    fwd = ns["make_engine_forward"](eng.LIB_PATH, cfg, state, compute_dtype=compute_dtype, max_positions=512, adapters=adapters, lora_r=LF.R, lora_alpha=LF.ALPHA)
+    om = O.OracleModel(O.OracleConfig(**d), LF.merged_fp32(w, tr)); om.set_tvg_prefix_length(prob.tvg_prefix_length)
+    ov = O.padding_ids(prob.vtg_ids, prob.vtg_labels, prob.vtg_masks, synth.PAD_ID)
+    sel = [0, 1, 2]
+    mask, _, emb, lab = om.prepare_inputs_labels_for_multimodal(ov[0][sel], ov[2][sel], ov[1][sel], [prob.video[i] for i in sel])
+    want_h = om.forward_hidden(emb, mask)
+    want_s = om.label_logprobs(want_h, lab)
+    base_s = O.OracleModel(O.OracleConfig(**d), w).label_logprobs(O.OracleModel(O.OracleConfig(**d), w).forward_hidden(emb, mask), lab)
+    try:
+        from blim_amd import retrieval_utils as RU
+        out = fwd(inputs_embeds=torch.from_numpy(emb).cuda(), attention_mask=torch.from_numpy(mask).cuda())
+        valid = mask.astype(bool)
+        got = out.hidden_states.cpu().numpy()[valid]
+        assert np.abs(got - want_h[valid]).max() / np.abs(want_h[valid]).max() < (1e-2 if compute_dtype == 1 else 3e-2)
+        sc = RU.vtg_criterion(out.logits, torch.from_numpy(lab).cuda()).cpu().numpy()
+        np.testing.assert_allclose(sc, want_s, rtol=1e-3 if compute_dtype == 1 else 3e-3)        # (the stub's plain bf16 forward is the non-parity bf16 mode)
+        assert np.max(np.abs(want_s - base_s) / np.abs(base_s)) > 1e-4                            # the adapters are not a no-op
+    finally:
+        fwd.close()
