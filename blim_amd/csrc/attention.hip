@@ -12,6 +12,8 @@
 //                                          V: chunk c ^ ((r & 3) << 2)  (4 rows of a tr-read block on 4 bank quarters)
 #include "attention.hpp"
 
+#include <stdlib.h>
+
 #define HD 128
 #define KT 32  // keys per tile
 #define QB 32  // queries per block
@@ -32,12 +34,17 @@ __global__ __launch_bounds__((attn_bound<MAXC, SPLIT>::value)) void attn_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int G = p.num_heads / p.num_kv_heads;
-    const int kh = blockIdx.y;
-    // Waves beyond the G query heads of this KV head are HELPERS (compensated kernels with few heads per group, launch_attention): they take their share
+    // Head groups (launch_attention, plain kernels with G >= 5): the G query heads of a KV head are split over `ngrp` workgroups of <= 4 waves, so that TWO
+    // workgroups fit a CU (8 waves at ~200 VGPRs = 2 per SIMD) and one's barriers / load latency are covered by the other's work; each stages the K / V tiles itself.
+    const int ngrp = (int)gridDim.y / p.num_kv_heads;
+    const int kh = blockIdx.y / ngrp, hg = blockIdx.y - kh * ngrp;
+    const int hpg = (G + ngrp - 1) / ngrp;               // heads per group
+    const int wave_head = hg * hpg + wave;               // this wave's query head inside the KV group
+    // Waves beyond the query heads of this group are HELPERS (compensated kernels with few heads per group, launch_attention): they take their share
     // of every tile's staging -- 2,048 16-byte chunks in the compensated mode, which G <= 6 waves had to hold as 8 - 32 staging registers each (7 - 64
     // spilled VGPRs) -- and the barriers, and compute nothing.
-    const bool worker = wave < G;
-    const int head = kh * G + (worker ? wave : 0);
+    const bool worker = wave < hpg && wave_head < G;
+    const int head = kh * G + (worker ? wave_head : 0);
     const int blk = blockIdx.x;
     const int s = p.blk_seq[blk], q0 = p.blk_q0[blk];
     const int sstart = p.seq_start[s], slen = p.seq_len[s];
@@ -346,7 +353,14 @@ int launch_attention(const AttnParams& p, int use_tr_read, hipStream_t stream) {
         if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<TR, MC, DT_F16>), grid, block, 0, stream, p); \
         else hipLaunchKernelGGL((attn_kernel<TR, MC, DT_BF16>), grid, block, 0, stream, p);                \
     } while (0)
-    if (G >= 4) { if (use_tr_read) ATTN_LAUNCH(true, 4); else ATTN_LAUNCH(false, 4); }
+    static const int g_split = getenv("BLIM_ATTN_HEAD_GROUPS") ? atoi(getenv("BLIM_ATTN_HEAD_GROUPS")) : 2;
+    if (G >= 5 && g_split > 1 && use_tr_read && !p.out8) {
+        // two workgroups of ceil(G / 2) waves per (block, KV head): 1,024 chunks / 256 threads = four per thread
+        const int hpg = (G + 1) / 2;
+        const dim3 grid2(p.n_blocks, p.num_kv_heads * 2), block2(64 * hpg);
+        if (p.dtype == DT_F16) hipLaunchKernelGGL((attn_kernel<true, 4, DT_F16>), grid2, block2, 0, stream, p);
+        else hipLaunchKernelGGL((attn_kernel<true, 4, DT_BF16>), grid2, block2, 0, stream, p);
+    } else if (G >= 4) { if (use_tr_read) ATTN_LAUNCH(true, 4); else ATTN_LAUNCH(false, 4); }
     else if (G >= 2) { if (use_tr_read) ATTN_LAUNCH(true, 8); else ATTN_LAUNCH(false, 8); }
     else { if (use_tr_read) ATTN_LAUNCH(true, 16); else ATTN_LAUNCH(false, 16); }
 #undef ATTN_LAUNCH
