@@ -158,7 +158,7 @@ def tiny_config_evaluation():
     return {"pairs": 4 * n * topk, "oracle_s": round(t_cpu, 3), "engine_s": round(t_gpu, 4), "max_rel_diff": float(f"{worst:.2e}"), "agree_1e-3": worst < 1e-3}
 
 
-def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False):
+def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False, tvg_precise="auto"):
     """The fixed-size job north_star's scaling clause names: ONE complete evaluation of an MSRVTT-1kA-shaped test set (N = 1000 videos and
     texts, top-16 re-rank, all six passes of the fine-tuned + CPN flow = 96,000 (query, candidate) pairs, reference-shaped rows with
     4 x 64 = 256 video tokens, the full 7B model) through blim_amd.retrieval_utils.evaluation -- data handling, planning, pair ownership
@@ -185,6 +185,7 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
                                      iv2_scores={"v2t": torch.from_numpy(nz(prob.v2t_sims)), "t2v": torch.from_numpy(nz(prob.t2v_sims))},
                                      max_tokens=32768, dedup=True, shard=shard)
         model.clear_cache()
+        model.tvg_precise = tvg_precise if model.engine.can_precise else "full"   # "auto" (the driver's default): calibrated by every run, INSIDE its timed region
         if pg:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -216,6 +217,7 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
            "executed_tflop_job": round(st["executed_flops_job"] / 1e12, 1),
            "executed_tflops_per_gpu": round(st["executed_flops_job"] / dt / 1e12 / world, 1),
            "frac_mfma_peak": round(st["executed_flops_job"] / dt / (world * peak), 4),
+           "tvg_precise": f"{tvg_precise} -> {st['tvg_precise']}" if "tvg_precise" in st else getattr(model, "tvg_precise", "full"),
            "pairs_scored_rank0": st["pairs_scored"], "finite": bool(ok), "host_marks_rank0": st["host_marks"]}
     if world == 1 and emulate > 1:
         per_rank, per_rank_frac = [], []
@@ -283,6 +285,9 @@ def main():
     ap.add_argument("--vtg-precise", default="none", choices=["none", "qk", "qkx", "attn", "full"],
                     help="compensated (hi + lo) activations on the benched VTG calls: none (default; fp16 holds 1e-3 without), full = the bf16 PARITY mode "
                          "(2x GEMM flops; what `--dtype bf16` needs to hold 1e-3 at 7B depth: tests/test_gpu_parity.py::test_depth_*)")
+    ap.add_argument("--tvg-precise", default="auto", choices=["auto", "attn", "act0", "full"],
+                    help="strong-scaling leg only (the headline step is a VTG pass): how much of the TVG calls' MLP branch runs compensated; auto = measured on the "
+                         "job's own pairs inside the timed region, as main.py's default does (blim_amd/retrieval_utils.py: PairScorer.calibrate_tvg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed-size N = 1000 evaluation (strong-scaling leg)")
     ap.add_argument("--strong-only", action="store_true", help="only the strong-scaling leg (development aid; prints that object alone)")
@@ -317,7 +322,7 @@ def main():
     model.engine.init_synthetic_weights(0)                       # torch seed 0 of BASELINE.md -> engine seed 0
     model.vtg_precise = None if (a.vtg_precise == "none" or a.dtype == "f8") else a.vtg_precise
     if a.strong_only:
-        ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk, pg=pg)
+        ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk, pg=pg, tvg_precise=a.tvg_precise)
         if rank == 0:
             print(json.dumps({"strong_scaling": ss}), flush=True)
         if pg:
@@ -366,7 +371,7 @@ def main():
     ss, ss_failed = None, False
     if not a.no_strong:
         try:
-            ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk, pg=pg)
+            ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk, pg=pg, tvg_precise=a.tvg_precise)
         except Exception as e:                 # the headline line above is already measured: report the failure inside it instead of losing both
             import traceback
             ss = {"error": f"{type(e).__name__}: {e}", "traceback_tail": traceback.format_exc()[-1500:]}

@@ -949,7 +949,10 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     p.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : GROUP_M;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
     // round-robin map, the wide ones (gate|up 37888, lm_head) lose 4 % -- there the XCDs already walk the same W columns in step
-    p.tile_map = g_gemm_tile_map >= 0 ? g_gemm_tile_map : ((p.N + BN - 1) / BN <= 32 ? 1 : 0);
+    // ... but only with a chip's worth of tiles: the round-robin map hands each XCD 32 consecutive tiles, so a small call (M of 1-2 k rows x N = 3584:
+    // 56 tiles) ran on TWO of the eight XCDs and their share of the fabric -- down_proj 2.9 ms instead of 1.0 (round 4, rocprofv3 of the calibration calls)
+    const int64_t n_tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    p.tile_map = g_gemm_tile_map >= 0 ? g_gemm_tile_map : (((p.N + BN - 1) / BN <= 32 && n_tiles >= 256) ? 1 : 0);
     p.debug_stamps = ((g_stamp_epi < 0 || g_stamp_epi == (int)epi) && (g_stamp_k < 0 || g_stamp_k == p.K)) ? g_gemm_stamps : nullptr;
     ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0);
     ARG_CHECK(p.A && p.W);

@@ -75,6 +75,10 @@ def get_args_parser():
                         "has massive activations on sink tokens: tests/golden/sink.npz, where plain fp16 -- the reference's own numerics -- is ~3e-3 from the fp32 result); "
                         "qk = q / k / v and the attention as hi + lo (-2.5 %% speed); qkx = and the QKV GEMM's input (-8.4 %%); attn = the whole attention branch (-16 %%); "
                         "full = every activation (2x the GEMM flops: the mode in which a bf16 engine holds 1e-3 at 7B depth)")
+    p.add_argument("--tvg_precise", default="auto", choices=["auto", "attn", "act0", "full"],
+                   help="how much of the TVG calls' MLP branch runs compensated (their embeddings, QKV, attention, o_proj and head always do on a 16-bit engine).  auto (default): "
+                        "measured like --vtg_precise auto, on the TVG likelihood and prior of up to 256 pairs; attn = MLP plain (1.6x faster than full), act0 = MLP input compensated, "
+                        "SwiGLU output plain (1.1x), full = everything (what weights with massive residual channels need: tests/golden/heavy7b.npz)")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")
     p.add_argument("--no_dedup", action="store_false", dest="dedup", help="score the pairs both directions share twice, as the reference does")
@@ -178,6 +182,8 @@ def main(args):
         loader = load_data(args, tokenizer=tokenizer, split="test")
         if not args.eval:
             train_loader = load_data(args, tokenizer=tokenizer, split="train")
+    if model.engine.can_precise:
+        model.tvg_precise = args.tvg_precise
     if args.vtg_precise is not None and model.engine.can_precise:
         model.vtg_precise = None if args.vtg_precise == "none" else args.vtg_precise        # "auto": resolved by evaluation() on the loaded weights
     if model.engine.dtype == "f8":

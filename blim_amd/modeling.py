@@ -40,6 +40,8 @@ class BlimModel:
         self.vtg_precise = os.environ.get("BLIM_VTG_PRECISE") or ("full" if self.engine.dtype == "bf16" else None)
         if self.vtg_precise in ("none", "0", ""):
             self.vtg_precise = None
+        # How much of the TVG calls' MLP branch is compensated: "full" (library default) | "act0" | "attn" | "auto" (measured by evaluation(): PairScorer.calibrate_tvg)
+        self.tvg_precise = os.environ.get("BLIM_TVG_PRECISE") or "full"
 
     # ---- nn.Module-ish surface used by the eval loop
     def eval(self):
@@ -223,7 +225,8 @@ class BlimModel:
         # a forward over rows prepared with tvg=True runs in the compensated mode, like the fused TVG calls (engine.set_precise); VTG rows
         # follow self.vtg_precise
         if tvg_rows:
-            self.engine.set_precise(True, embeds=wide)
+            tm = self.tvg_precise if self.tvg_precise in ("attn", "act0") else "full"        # an unresolved "auto" runs fully compensated
+            self.engine.set_precise(True, embeds=wide, mlp=tm != "attn", act=tm == "full")
         else:
             on = self.vtg_precise in ("attn", "full")
             self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise == "full")

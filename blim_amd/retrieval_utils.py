@@ -17,6 +17,7 @@ Two layers:
 from __future__ import annotations
 
 import math
+import sys
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -195,13 +196,14 @@ def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_voc
     H, I = dims.hidden_size, dims.intermediate_size
     q = 2.0 * H * (dims.num_heads + 2 * dims.num_kv_heads) * dims.head_dim
     o, gu, d = 2.0 * H * H, 4.0 * H * I, 2.0 * H * I
-    fq = 2.0 if mode in ("qkx", "attn", "full") else 1.0
-    fo = 2.0 if mode in ("attn", "full") else 1.0
-    fm = 2.0 if mode == "full" else 1.0
-    per_tok = fq * q + fo * o + fm * (gu + d)
+    fq = 2.0 if mode in ("qkx", "attn", "act0", "full") else 1.0
+    fo = 2.0 if mode in ("attn", "act0", "full") else 1.0
+    fg = 2.0 if mode in ("act0", "full") else 1.0           # gate|up walks K twice; "act0": its output stays plain, so the down projection walks K once
+    fd = 2.0 if mode == "full" else 1.0
+    per_tok = fq * q + fo * o + fg * gu + fd * d
     total = dims.num_layers * per_tok * n_tokens
     if prune and n_rows <= n_tokens - n_tokens // 16:
-        total -= (fo * o + fm * (gu + d)) * (n_tokens - n_rows)
+        total -= (fo * o + fg * gu + fd * d) * (n_tokens - n_rows)
     if kind == "vtg":
         total += fo * 2.0 * H * dims.vocab_size * n_rows
     else:
@@ -209,6 +211,8 @@ def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_voc
     return total
 
 
+TVG_MODES = ("attn", "act0", "full")    # compensation of the TVG calls (always hi + lo embeddings, QKV, attention, o_proj, head), cheapest first: "attn" leaves the MLP branch plain
+                                        # (1.6x faster than full), "act0" compensates the MLP's input but not the SwiGLU output (1.1x), "full" everything
 VTG_MODES = ("none", "qk", "qkx", "attn", "full")       # compensation of the VTG calls, cheapest first (0 / -2.5 / -8.4 / -16.5 / -50 % on the headline step)
 
 
@@ -238,6 +242,8 @@ class PairScorer:
         self.vtg_mode = getattr(model.module if hasattr(model, "module") else model, "vtg_precise", None) if (eng_ is not None and getattr(eng_, "can_precise", False)) else None
         if self.vtg_mode == "auto":                                      # resolved by calibrate_vtg (evaluation() does it before the first pass)
             self.vtg_mode = None
+        tm = getattr(model.module if hasattr(model, "module") else model, "tvg_precise", None)
+        self.tvg_mode = tm if tm in TVG_MODES else "full"                # "auto" / None: full until calibrate_tvg says otherwise
         self.split_vtg = self.vtg_mode in ("attn", "full")               # "qk": plain activations, only q / k / v and the attention run as hi + lo (engine option precise_qk)
         self.m = model.module if hasattr(model, "module") else model
         self.engine = self.m.engine
@@ -543,11 +549,12 @@ class PairScorer:
                 self.engine.set_precise(False)
                 if mode in ("qk", "qkx"):
                     self.engine.set_option("precise_qk", 0)
-        self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", "full" if self.split_tvg else None,
+        self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode if self.split_tvg else None,
                                           n_vocab=self.n_vocab, prune=not f8)
         if self.vocab_cm is None and getattr(self.engine, "_vocab_key", None) != self._vocab_key:
             self.engine.set_video_vocab(self._vocab_src)                     # another scorer / the literal path registered its own vocabulary since
-        self.engine.set_precise(self.split_tvg, embeds=self.split_tvg)       # TVG calls: compensated fp16 (3-5 new tokens per pair: cheap)
+        # TVG calls: compensated (3-5 new tokens per pair: cheap); how much of the MLP branch is compensated follows tvg_mode (calibrate_tvg)
+        self.engine.set_precise(self.split_tvg, embeds=self.split_tvg, mlp=self.tvg_mode != "attn", act=self.tvg_mode == "full")
         try:
             embeds = self.engine.assemble(plan.src_index, plan.feats)
             return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)
@@ -623,6 +630,35 @@ class PairScorer:
                 chosen = mode
                 break                                                          # the dearer modes are not needed
         self.set_vtg_mode(chosen)
+        return chosen, table
+
+    def set_tvg_mode(self, mode) -> None:
+        if mode not in TVG_MODES:
+            raise ValueError(f"tvg mode {mode!r}: one of {TVG_MODES}")
+        self.tvg_mode = mode
+        self.m.tvg_precise = mode
+
+    def calibrate_tvg(self, pairs, bar: float = 1e-3, z: float = 4.5):
+        """The TVG calls' counterpart of calibrate_vtg (same criterion, same yardstick = the fully compensated mode).  Every TVG call of a 16-bit engine carries its
+        embeddings, QKV, attention, o_proj and head as hi + lo; what is decided here is the MLP branch (87 % of the flops): `attn` leaves it plain (1.6x faster than
+        `full`), `act0` compensates its input but not the SwiGLU output (1.1x).  Gaussian-like weights need neither more than `attn` since the TVG head is exact
+        (round 4); weights with massive residual channels need `full` (tests/golden/heavy7b.npz: the prior moved by 2.5e-3 with a plain SwiGLU output) -- measured per
+        checkpoint on the likelihood AND the prior (the prior's queries see one prefix token and their own segment: the most sensitive pass)."""
+        pairs = np.asarray(pairs, dtype=np.int64)
+        self.set_tvg_mode("full")
+        if not self.split_tvg:                                             # fp8 / fp32-less engines: nothing to choose
+            return "full", {}
+        ref = np.concatenate([self.tvg(pairs, False), self.tvg(pairs, True)]).astype(np.float64)
+        table, chosen = {}, "full"
+        for mode in TVG_MODES[:-1]:
+            self.set_tvg_mode(mode)
+            got = np.concatenate([self.tvg(pairs, False), self.tvg(pairs, True)]).astype(np.float64)
+            dev = np.abs(got - ref) / np.abs(ref)
+            table[mode] = {"max": float(np.max(dev)), "rms": float(np.sqrt(np.mean(dev * dev)))}
+            if np.all(np.isfinite(dev)) and table[mode]["max"] <= bar and z * table[mode]["rms"] <= bar:
+                chosen = mode
+                break
+        self.set_tvg_mode(chosen)
         return chosen, table
 
     def vtg(self, pairs, cpn=False) -> np.ndarray:
@@ -761,7 +797,19 @@ def evaluation(model, data_loader, device, tokenizer, args):
         stats["vtg_precise"] = chosen; stats["vtg_precise_table"] = table
         if rank == 0:
             print("vtg_precise auto: deviation from the fully compensated mode on the calibration pairs (max / rms): "
-                  + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in table.items()) + f" -> {chosen}")
+                  + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in table.items()) + f" -> {chosen}", file=sys.stderr, flush=True)
+    if getattr(model.module, "tvg_precise", None) == "auto" and finetuned:
+        # likewise for the TVG calls' MLP branch (PairScorer.calibrate_tvg); zero-shot evaluations run no TVG pass
+        cal = scorer if isinstance(scorer, PairScorer) else PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
+                                                                       tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
+        # a few TEXT queries and their top videos, as the t2v TVG passes score them: the text prefix is shared by a query's 16 videos, so a mode costs ~2k tokens
+        # (16 video queries x 16 texts would be 256 distinct text prefixes: 15k tokens per mode, 0.6 s of a 2.3 s rank share at 8 GPUs -- measured, round 4)
+        tp = calibration_pairs(t2v_iv2, args.topk, n_queries=8)          # 128 pairs x (likelihood, prior) = 256 entries: 0.13 s at 7B size, both modes
+        chosen, table = cal.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1))
+        stats["tvg_precise"] = chosen; stats["tvg_precise_table"] = table
+        if rank == 0:
+            print("tvg_precise auto: deviation from the fully compensated mode on the calibration pairs, likelihood + prior (max / rms): "
+                  + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in table.items()) + f" -> {chosen}", file=sys.stderr, flush=True)
     mark("setup")
 
     def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):

@@ -305,6 +305,28 @@ def _resolve_auto(t, prob=None, spec=None):
     return chosen, table
 
 
+def _resolve_tvg_auto(t, prob=None, spec=None):
+    """`--tvg_precise auto` as evaluation() resolves it (PairScorer.calibrate_tvg) -> (mode, table); t.model.tvg_precise is left at the chosen mode."""
+    prob = prob or t.prob
+    spec = spec or t.spec
+    t.model.set_tvg_prefix_length(prob.tvg_prefix_length)
+    tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+    Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+    vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+    tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+    t.model.tvg_precise = "auto"
+    sc = RU.PairScorer(DDPLike(t.model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video], torch.from_numpy(prob.video_vocab),
+                       torch.from_numpy(prob.tvg_video_labels), t.dims.num_clips)
+    assert sc.tvg_mode == "full"                                           # unresolved auto runs fully compensated
+    tp = RU.calibration_pairs(torch.from_numpy(prob.t2v_sims), spec["topk"], n_queries=8)
+    chosen, table = sc.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1))
+    assert t.model.tvg_precise == chosen
+    return chosen, table
+
+
+TVG_PASSES = ("t2v_tvg", "t2v_tvg_cpn", "v2t_tvg")
+
+
 def _worst_rel(got, g, prefix="S_"):
     """{pass: worst relative deviation over the computed entries}; the computed-entry pattern must equal the golden one."""
     worst = {}
@@ -456,6 +478,17 @@ def _depth_case(case, dtype, capsys, literal_too=True):
             with capsys.disabled():
                 print(f"\n[{case} f16] vtg_precise auto (max / rms vs the fully compensated mode): " + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in table.items()) + f" -> {chosen}")
             assert chosen == "none", (case, table)
+        # `--tvg_precise auto`: how much of the TVG calls' MLP branch needs compensating, measured; the TVG passes re-run in the chosen mode (both paths) against the golden
+        tchosen, ttable = _resolve_tvg_auto(t)
+        with capsys.disabled():
+            print(f"\n[{case} {dtype}] tvg_precise auto (max / rms vs the fully compensated mode): " + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in ttable.items()) + f" -> {tchosen}")
+        if tchosen != "full":
+            for literal in ([False, True] if literal_too else [False]):
+                res[("literal" if literal else "fused") + f"-tvg-{tchosen}"] = _worst_rel(_six_passes(t, literal, names=TVG_PASSES), g)
+        if dtype == "f16":
+            assert tchosen in ("attn", "act0"), (case, ttable)            # N(0, 0.02^2) weights: fp16 needs no fully compensated MLP branch (attn on the headline-shaped
+                                                                          # problem, 7e-5; act0 on the short ragged rows of the fixtures, where attn reads 6e-4 max / 2.4e-4 rms)
+        t.model.tvg_precise = "full"
     finally:
         t.model.engine.close()
     with capsys.disabled():
@@ -511,9 +544,19 @@ def test_heavy_tailed_weights_28_layers_vs_reference_golden(dtype, case, capsys)
             # the cheap compensated modes on this fixture, and every pass is then held to the same 1e-3 as everywhere else -- no carve-out.
             plain = {tag: _worst_rel(_six_passes(t, lit, names=("v2t_vtg", "t2v_vtg")), g) for tag, lit in (("fused", False), ("literal", True))}
             auto = _resolve_auto(t)
+        tauto = None
+        if dtype != "f8":
+            # `--tvg_precise auto`: measured too; massive residual channels need the MLP branch compensated -- the passes below run in what it chose
+            tauto = _resolve_tvg_auto(t)
         res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in ((("fused", False), ("literal", True)) if dtype != "f8" else (("fused", False),))}
     finally:
         model.engine.close()
+    if tauto is not None:
+        with capsys.disabled():
+            print(f"\n[{case} {dtype}] tvg_precise auto (max / rms vs the fully compensated mode): " + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in tauto[1].items())
+                  + f" -> {tauto[0]} (the TVG passes below ran in it)")
+        if dtype == "bf16":
+            assert tauto[0] == "full", tauto                                # 8-bit mantissas: a plain MLP branch leaves 2e-3
     if auto is not None:
         with capsys.disabled():
             print(f"\n[sink f16] plain fp16 VTG calls (library default), fused: " + ", ".join(f"{k} {v:.2e}" for k, v in plain["fused"].items())
@@ -595,6 +638,12 @@ def test_heavy_tailed_weights_full_7b_vs_reference_golden(dtype, case, capsys):
         model.set_tvg_prefix_length(prob.tvg_prefix_length)
         t = types.SimpleNamespace(spec=SPEC7B, dims=dims, model=model, prob=prob, dtype=dtype, case=case)
         res = {tag: _worst_rel(_six_passes(t, literal), g) for tag, literal in (("fused", False), ("literal", True))}
+        # `--tvg_precise auto` on these weights (massive residual channels at 7B width): measured, then the TVG passes re-run in the chosen mode against the golden
+        tauto = _resolve_tvg_auto(t)
+        if tauto[0] != "full":
+            for tag, literal in (("fused", False), ("literal", True)):
+                res[f"{tag}-tvg-{tauto[0]}"] = _worst_rel(_six_passes(t, literal, names=TVG_PASSES), g)
+        model.tvg_precise = "full"
         if sink and dtype == "f16":
             for mode in ("qkx", "attn"):
                 model.vtg_precise = mode
@@ -602,6 +651,7 @@ def test_heavy_tailed_weights_full_7b_vs_reference_golden(dtype, case, capsys):
     finally:
         model.engine.close()
     with capsys.disabled():
+        print(f"\n[{case} {dtype}] tvg_precise auto (max / rms vs the fully compensated mode): " + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e}" for k, v in tauto[1].items()) + f" -> {tauto[0]}")
         for tag, w in res.items():
             print(f"\n[{case} {dtype} {tag}] worst relative score deviation vs the fp32 reference, 28 layers of the 7B configuration, residual |max| "
                   f"{float(g['resid_absmax_per_layer'].max()):.0f} at rms {float(g['resid_rms_per_layer'].max()):.1f}: " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()))
