@@ -151,7 +151,12 @@ def numeric_checks(rep: Report, model, loader, tokenizer, args, n_pairs: int = 6
     chosen, table = scorer.calibrate_vtg(RU.calibration_pairs(sims, k))
     rep.add(True, "vtg_precise auto (PairScorer.calibrate_vtg) on this checkpoint",
             ", ".join(f"{m} max {v['max']:.1e} rms {v['rms']:.1e}" for m, v in table.items()) + f" -> {chosen}")
-    # ---- 5. fused vs literal on the same pairs
+    if args.resume and scorer.split_tvg:
+        tp = RU.calibration_pairs(sims.T, k, n_queries=8)
+        tchosen, ttable = scorer.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1))
+        rep.add(True, "tvg_precise auto (PairScorer.calibrate_tvg: how much of the TVG calls' MLP branch runs compensated)",
+                ", ".join(f"{m} max {v['max']:.1e} rms {v['rms']:.1e}" for m, v in ttable.items()) + f" -> {tchosen}")
+    # ---- 5. fused vs literal on the same pairs (the TVG pass in the mode just chosen, both paths)
     q = max(1, min(N, n_pairs // k))
     a = types.SimpleNamespace(topk=k, batch_size_eval=min(16, k), num_clips=args.num_clips)
     dev = model.device

@@ -191,8 +191,8 @@ def _split_prompt_response(ids: np.ndarray, labels: np.ndarray):
 def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_vocab: int = 0, prune: bool = True) -> float:
     """GEMM FLOPs one engine call EXECUTES (the per-token constants applied to the token counts actually launched; attention,
     < 1 - 3 %, excluded): decoder layers over n_tokens packed tokens + the head over n_rows scored rows.  `mode`: compensation of the call (None /
-    "qk": plain; "qkx": the QKV GEMM walks K twice; "attn": QKV, o_proj and the head; "full": every GEMM -- what every TVG call runs in on a 16-bit
-    engine).  prune: the last layer's o_proj / MLP run on the scored rows only (engine option prune_last) when they are < 15/16 of the tokens."""
+    "qk": plain; "qkx": the QKV GEMM walks K twice; "attn": QKV, o_proj and the head; "act0": gate|up as well; "full": every GEMM -- a TVG call of a
+    16-bit engine runs in one of the last three, TVG_MODES).  prune: the last layer's o_proj / MLP run on the scored rows only (engine option prune_last) when they are < 15/16 of the tokens."""
     H, I = dims.hidden_size, dims.intermediate_size
     q = 2.0 * H * (dims.num_heads + 2 * dims.num_kv_heads) * dims.head_dim
     o, gu, d = 2.0 * H * H, 4.0 * H * I, 2.0 * H * I
@@ -207,7 +207,8 @@ def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_voc
     if kind == "vtg":
         total += fo * 2.0 * H * dims.vocab_size * n_rows
     else:
-        total += fo * (2.0 * H * dims.mm_hidden_size + 2.0 * dims.mm_hidden_size * n_vocab) * n_rows
+        # the visual head and the product with the video vocabulary: three-term compensated products (one GEMM of depth 3 K each) on a compensated call
+        total += (3.0 if fo == 2.0 else 1.0) * (2.0 * H * dims.mm_hidden_size + 2.0 * dims.mm_hidden_size * n_vocab) * n_rows
     return total
 
 

@@ -414,7 +414,13 @@ def test_executed_flops_formula_and_calibration_pairs():
     assert RU.executed_flops(d, tok, rows, "vtg", "qkx", prune=False) == 28 * (F + qkv) * tok + head * rows
     assert RU.executed_flops(d, tok, rows, "vtg", "attn", prune=False) == 28 * (F + qkv + 2 * 3584 * 3584) * tok + 2 * head * rows
     assert RU.executed_flops(d, tok, rows, "vtg", "qk", prune=False) == RU.executed_flops(d, tok, rows, "vtg", None, prune=False)
-    assert RU.executed_flops(d, 1000, 400, "tvg", "full", n_vocab=1000, prune=False) == 2 * (28 * F * 1000 + (2 * 3584 * 1024 + 2 * 1024 * 1000) * 400)
+    tvg_head = (2 * 3584 * 1024 + 2 * 1024 * 1000) * 400                                               # visual head + vocabulary product: three-term when compensated
+    assert RU.executed_flops(d, 1000, 400, "tvg", "full", n_vocab=1000, prune=False) == 2 * 28 * F * 1000 + 3 * tvg_head
+    mlp_gu, mlp_d = 4 * 3584 * 18944, 2 * 3584 * 18944
+    assert RU.executed_flops(d, 1000, 400, "tvg", "act0", n_vocab=1000, prune=False) == 28 * (2 * F - mlp_d) * 1000 + 3 * tvg_head      # TVG_MODES: the down projection walks K once
+    assert RU.executed_flops(d, 1000, 400, "tvg", "attn", n_vocab=1000, prune=False) == 28 * (2 * F - mlp_d - mlp_gu) * 1000 + 3 * tvg_head
+    assert RU.executed_flops(d, 1000, 400, "tvg", None, n_vocab=1000, prune=False) == 28 * F * 1000 + tvg_head
+    assert RU.TVG_MODES == ("attn", "act0", "full")
     sims = torch.from_numpy(np.random.RandomState(0).randn(40, 50).astype(np.float32))
     p = RU.calibration_pairs(sims, topk=5)
     assert p.shape == (16 * 5, 2) and len(np.unique(p[:, 0])) == 16 and p[:, 0].min() == 0 and p[:, 0].max() == 39
