@@ -265,6 +265,7 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
     e->loaded[name] = true;
     e->f8_ready = false;
     e->aug_ready = false;          // the augmented copies of adapted weights are rebuilt from the placed base weights on the next call
+    if (name != "visual_head") e->lora_merged = false;       // the caller is (re)loading base weights: the mark of a merged update (blim_train_merge) goes with them
     return BLIM_OK;
 }
 
@@ -416,6 +417,11 @@ extern "C" int blim_load_adapter(blim_engine* e, const char* weight_name, const 
         blim_set_error("adapter '%s': r = %d, alpha / r = %g, but the engine's adapters have r = %d, alpha / r = %g (one LoraConfig per model, main.py:96-101)", weight_name, lora_r,
                        scale, e->lora_r, e->lora_scale);
         return BLIM_ERR_ARG;
+    }
+    if (e->lora_merged) {
+        blim_set_error("adapter '%s': the engine's base weights hold a merged LoRA update (blim_train_merge); adapters apart on top of it would apply the update twice -- "
+                       "load the base weights again first", weight_name);
+        return BLIM_ERR_STATE;
     }
     if (e->AD.empty()) e->AD.resize(e->c.num_layers);
     int n_out = 0, n_in = 0;

@@ -90,6 +90,7 @@ struct blim_engine {
     std::vector<LayerAd> AD; AdapterW ad_lm, ad_mlp[2][2];       // ad_mlp[mlp | tvg_mlp][Linear 0 | Linear 2]
     uint16_t* lm_aug = nullptr; uint16_t* w0_aug[2] = {nullptr, nullptr}; uint16_t* w2_aug[2] = {nullptr, nullptr};
     bool aug_ready = false;
+    bool lora_merged = false;                                    // blim_train_merge wrote W + (alpha / r) B A into the base weights: adapters apart on top would apply the update twice
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)
     std::vector<void*> ad_owned;                                 // the f32 A / B matrices
     DevBuf feats_aug, hid_aug;                                   // staging: caller-provided rows copied into augmented rows

@@ -229,6 +229,10 @@ extern "C" int blim_train_merge(blim_trainer* t, void* stream) {
     ARG_CHECK(t);
     hipStream_t s = (hipStream_t)stream;
     blim_engine* e = t->e;
+    if (e->aug) {
+        blim_set_error("blim_train_merge: the engine holds adapters apart (blim_load_adapter); merging into its base weights as well would apply the update twice -- blim_clear_adapters first");
+        return BLIM_ERR_STATE;
+    }
     const blim_config& c = e->c;
     const int H = c.hidden_size, M = c.mm_hidden_size, dt = c.compute_dtype, r = t->r;
     const int64_t qn = (int64_t)c.num_heads * 128, kn = (int64_t)c.num_kv_heads * 128;
@@ -249,6 +253,7 @@ extern "C" int blim_train_merge(blim_trainer* t, void* stream) {
     TRY(launch_f32_to_16(e->visual_head, H, P + t->lay.off_vh, H, M, H, 1.0f, dt, s));
     TRY(engine_set_visual_head3(e, P + t->lay.off_vh, BLIM_DTYPE_F32, s));      // the scoring path's hi + lo copy of the head
     e->f8_ready = false;
+    e->lora_merged = true;
     return BLIM_OK;
 }
 

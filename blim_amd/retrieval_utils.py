@@ -790,11 +790,24 @@ def evaluation(model, data_loader, device, tokenizer, args):
         scorer = PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
                             tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
     stats = {"pairs_requested": 0, "pairs_scored": 0}
+
+    def agree(chosen, modes, setter):
+        """One mode for the whole job: every rank measures the same pairs with deterministic kernels, so the choices agree -- this makes it a guarantee (ranks on
+        different devices, a future non-deterministic kernel): the most compensated choice of any rank, by one all-reduce(MAX) of the mode's index."""
+        if collective and dist_utils.is_dist_avail_and_initialized():
+            t = torch.tensor([modes.index(chosen)], dtype=torch.int32, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            if modes[int(t.item())] != chosen:
+                chosen = modes[int(t.item())]
+                setter(chosen)
+        return chosen
+
     if getattr(model.module, "vtg_precise", None) == "auto":
         # `--vtg_precise auto` (the driver's default): measure on this checkpoint which compensation the VTG calls need (PairScorer.calibrate_vtg)
         cal = scorer if isinstance(scorer, PairScorer) else PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
                                                                        tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
         chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk))
+        chosen = agree(chosen, VTG_MODES, cal.set_vtg_mode)
         stats["vtg_precise"] = chosen; stats["vtg_precise_table"] = table
         if rank == 0:
             print("vtg_precise auto: deviation from the fully compensated mode on the calibration pairs (max / rms): "
@@ -807,6 +820,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
         # (16 video queries x 16 texts would be 256 distinct text prefixes: 15k tokens per mode, 0.6 s of a 2.3 s rank share at 8 GPUs -- measured, round 4)
         tp = calibration_pairs(t2v_iv2, args.topk, n_queries=8)          # 128 pairs x (likelihood, prior) = 256 entries: 0.13 s at 7B size, both modes
         chosen, table = cal.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1))
+        chosen = agree(chosen, TVG_MODES, cal.set_tvg_mode)
         stats["tvg_precise"] = chosen; stats["tvg_precise_table"] = table
         if rank == 0:
             print("tvg_precise auto: deviation from the fully compensated mode on the calibration pairs, likelihood + prior (max / rms): "

@@ -111,7 +111,8 @@ int blim_weights_ready(const blim_engine* e);
  * main.py:96-101).  Base weights and adapters may be loaded in any order; the augmented weight copies are rebuilt on the next call after either
  * changes.  On an fp8 engine the adapted projections (q/k/v/o, lm_head) run in fp16 once adapters are loaded (the MLP, not adapted, stays e4m3).
  * The alternative -- folding W + (alpha / r) B A into the engine's 16-bit weight on the host before blim_load_weight (blim_amd/checkpoint.py,
- * lora_mode = "merge") -- needs no entry point; it rounds the sum to the engine's format. */
+ * lora_mode = "merge") -- needs no entry point; it rounds the sum to the engine's format.  An engine whose base weights
+ * received a merged update from blim_train_merge refuses adapters (BLIM_ERR_STATE: the update would apply twice) until base weights are loaded again. */
 int blim_load_adapter(blim_engine* e, const char* weight_name, const float* A, const float* B, int32_t lora_r, float lora_alpha);
 /* Drops every loaded adapter (the engine scores with the base weights again). */
 int blim_clear_adapters(blim_engine* e);
@@ -299,7 +300,8 @@ void blim_train_destroy(blim_trainer* t);
 /* after `params` changed (load, optimizer step): refresh the 16-bit copies the forward reads */
 int blim_train_sync_params(blim_trainer* t, void* stream);
 /* write W + alpha/r * B A (and visual_head) into the ENGINE's scoring weights: evaluation between epochs (main.py:166) sees the
- * fine-tuned model; always merged from the pristine base, so it can be called repeatedly */
+ * fine-tuned model; always merged from the pristine base, so it can be called repeatedly.  BLIM_ERR_STATE while the engine holds adapters apart
+ * (blim_load_adapter): one or the other. */
 int blim_train_merge(blim_trainer* t, void* stream);
 typedef struct blim_train_batch {
     const blim_batch* batch;      /* ONE packed batch holding the VTG rows and the TVG rows (either part may be absent), no shared prefixes */

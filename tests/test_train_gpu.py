@@ -183,6 +183,33 @@ def test_merge_equals_adapter_forward():
     t.close(); eng.close()
 
 
+def test_merged_and_apart_adapters_cannot_be_stacked():
+    """The two ways a fine-tuned model reaches the scoring engine -- blim_train_merge (W + alpha/r B A written into the base weights) and blim_load_adapter (adapters apart) --
+    exclude each other on one engine: both together would apply the update twice, silently.  Either order fails with BLIM_ERR_STATE; loading base weights again lifts the mark."""
+    from blim_amd.engine import Engine, BlimError
+    from blim_amd.training import Trainer
+    spec, dims, weights, prob, tr = _case("train_tiny")
+    eng = Engine(dims, max_positions=1024, dtype="f16")
+    eng.load_weights(weights)
+    t = Trainer(eng, lora_r=spec["r"], lora_alpha=spec["alpha"], lora_dropout=0.0, trainable=tr)
+    try:
+        t.adapters_into_engine()
+        assert eng.num_adapters() > 0
+        with pytest.raises(BlimError, match="twice"):
+            t.merge_into_engine()
+        eng.clear_adapters()
+        t.merge_into_engine()
+        with pytest.raises(BlimError, match="twice"):
+            t.adapters_into_engine()
+        assert eng.num_adapters() == 0
+        t.merge_into_engine()                                  # repeated merges stay fine (always from the pristine base)
+        eng.load_weights(weights)                              # base weights again: adapters apart are accepted
+        t.adapters_into_engine()
+        assert eng.num_adapters() > 0
+    finally:
+        t.close(); eng.close()
+
+
 def test_lora_dropout_mask_is_consistent_forward_and_backward():
     """lora_drop > 0 (main.py --lora_drop 0.05): the oracle applies the engine's counter-based mask (restated in oracle/train_oracle.py:
     drop_mult) to the adapters' inputs; losses and gradients must agree, i.e. forward and backward use the same mask at every site."""
