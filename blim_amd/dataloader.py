@@ -17,7 +17,7 @@ import copy
 import glob
 import json
 import os
-from typing import Callable, Dict, List, Optional
+from typing import List
 
 import torch
 

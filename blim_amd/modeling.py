@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import os
 from types import SimpleNamespace
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 

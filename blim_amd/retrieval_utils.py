@@ -16,7 +16,6 @@ Two layers:
 """
 from __future__ import annotations
 
-import math
 import sys
 import time
 from dataclasses import dataclass

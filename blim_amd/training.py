@@ -19,12 +19,12 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional
 
 import numpy as np
 
 from . import lora
-from .engine import Batch, BlimError, Engine, PackedBatch, _check, _ptr, _stream, load_library
+from .engine import Batch, BlimError, Engine, PackedBatch, _check, _stream, load_library
 from .synth import IGNORE_INDEX, IMAGE_TOKEN_INDEX
 
 IM_END = 151645          # videochat_flash/conversation.py:13 IMAGE_TOKEN_ID: the label that follows the <image> placeholder in a TVG row

@@ -14,7 +14,6 @@ All tensor work runs in HIP (csrc/vision.hip + the engine's GEMM); this module h
 from __future__ import annotations
 
 import ctypes as C
-import math
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
