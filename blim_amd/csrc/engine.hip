@@ -617,13 +617,6 @@ int engine_rope_rows(blim_engine* e, const blim_batch* b, hipStream_t s, float**
 // and the MLP run on those n_live rows only -- the same values, 1 / num_layers of the post-attention work saved on every row nobody reads
 // (the shared video + prompt prefix of a VTG query: 60 % of the tokens at the reference's shapes; the caption prompt of a TVG text).
 // *final_resid / *final_is_live tell the caller where the last layer's output sits.
-// outlier-channel experiment: lo halves kept in the k largest channels only (engine.hpp: oc_k_*)
-static int oc_mask(blim_engine* e, int k, bf16_t* rows, int64_t ld, int64_t lo_off, int64_t n, int cols, hipStream_t s) {
-    if (k < 0 || !e->precise) return BLIM_OK;
-    TRY(ensure(e->oc_scratch, (size_t)(std::max(e->c.intermediate_size, e->qkv_n) + 64) * 4));
-    return launch_mask_lo_topk(rows, rows + lo_off, ld, n, cols, k, e->c.compute_dtype, (uint32_t*)e->oc_scratch.p, s);
-}
-
 static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, hipStream_t s, const int32_t* live_rows, int64_t n_live, float** final_resid,
                       bool* final_is_live) {
     const blim_config& c = e->c;
@@ -672,7 +665,6 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             SpanGuard g(e, s, TC_NORM, 0);
             if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
             else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, (pqx ? 2 : pf) * Hq, (e->precise || pqx) ? xn + Hq : nullptr));
-            if (e->precise) TRY(oc_mask(e, e->oc_k_x, xn, 2 * Hq, Hq, T, H, s));
             if (G) TRY(adapter_u(e, xn, (pqx ? 2 : pf) * Hq, (e->precise || pqx) ? Hq : 0, T, H, &e->AD[li].ad[0], &e->AD[li].ad[1], &e->AD[li].ad[2], s));
         }
         {
@@ -682,7 +674,6 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (pq && !pqx) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
-            if (e->precise) TRY(oc_mask(e, e->oc_k_qkv, qkv, 2 * (int64_t)e->qkv_n, e->qkv_n, T, e->qkv_n, s));
         }
         {
             SpanGuard g(e, s, TC_ATTN, 0);
@@ -695,7 +686,6 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
             if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
-            if (e->precise) TRY(oc_mask(e, e->oc_k_attn, attn, 2 * Hq, Hq, T, H, s));
         }
         const bool fuse_o = o8 && e->f8_fuse;
         if (o8 && !fuse_o) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
@@ -714,12 +704,10 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
               GemmParams p = gp2(e, attn_live, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * Hq;   // pq: the hi halves of [hi | lo] rows
               TRY(launch_gemm(EPI_RESID, p, s)); }
             { SpanGuard g(e, s, TC_NORM, 0);
-              TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr));
-              if (pm) TRY(oc_mask(e, e->oc_k_x, xn, 2 * (int64_t)H, H, n_live, H, s)); }
+              TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
-              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; } TRY(launch_gemm(EPI_SWIGLU, p, s));
-              if (pa) TRY(oc_mask(e, e->oc_k_act, act, 2 * (int64_t)I, I, n_live, I, s)); }
+              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; } TRY(launch_gemm(EPI_SWIGLU, p, s)); }
             { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * (pa ? 2 : 1));
               GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pa); p.ldc = H; p.lo_off = 0; TRY(launch_gemm(EPI_RESID, p, s)); }
             *final_resid = rl; *final_is_live = true;
@@ -739,7 +727,6 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             SpanGuard g(e, s, TC_NORM, 0);
             if (g8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
             else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr));
-            if (pm) TRY(oc_mask(e, e->oc_k_x, xn, 2 * (int64_t)H, H, T, H, s));
         }
         const bool fuse = g8 && d8 && e->f8_fuse;      // fp8: the gate|up epilogue emits e4m3 + one E8M0 scale per (token, 128 outputs) itself
         {
@@ -748,7 +735,6 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (pm && !pa) { p.lo_off = 0; p.ldc = I; }                 // A = [hi | lo] (K walked twice), plain 16-bit output
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
-            if (pa) TRY(oc_mask(e, e->oc_k_act, act, 2 * (int64_t)I, I, T, I, s));
         }
         if (d8 && !fuse) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
         {
@@ -784,10 +770,8 @@ static int decode_impl(blim_engine* e, const blim_batch* b, const void* embeds, 
     const int H = e->c.hidden_size;
     if (W == 0) W = H;
     // (is_live: run_layers carried exactly the requested rows, in order, through the last layer: the final norm reads them straight)
-    TRY(launch_rmsnorm(fr, H, is_live ? nullptr : out_rows, n, H, e->final_norm, e->c.rms_eps, (bf16_t*)out_hidden_bf16, e->c.compute_dtype,
-                       out_hidden_f32, s, is_live ? n : b->n_tokens, split ? 2 * W : W, split && out_hidden_bf16 ? (bf16_t*)out_hidden_bf16 + W : nullptr));
-    if (split && out_hidden_bf16) TRY(oc_mask(e, e->oc_k_x, (bf16_t*)out_hidden_bf16, 2 * W, W, n, H, s));     // (experiment: the head's input rows too)
-    return BLIM_OK;
+    return launch_rmsnorm(fr, H, is_live ? nullptr : out_rows, n, H, e->final_norm, e->c.rms_eps, (bf16_t*)out_hidden_bf16, e->c.compute_dtype,
+                          out_hidden_f32, s, is_live ? n : b->n_tokens, split ? 2 * W : W, split && out_hidden_bf16 ? (bf16_t*)out_hidden_bf16 + W : nullptr);
 }
 extern "C" int blim_decode(blim_engine* e, const blim_batch* b, const void* embeds, const int32_t* out_rows, int64_t n_out,
                            void* out_hidden_bf16, float* out_hidden_f32, void* stream) {
@@ -1098,10 +1082,6 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
     if (!strcmp(key, "prune_last")) { e->prune_last = value != 0; return BLIM_OK; }
-    if (!strcmp(key, "oc_k_x")) { e->oc_k_x = value; return BLIM_OK; }
-    if (!strcmp(key, "oc_k_attn")) { e->oc_k_attn = value; return BLIM_OK; }
-    if (!strcmp(key, "oc_k_act")) { e->oc_k_act = value; return BLIM_OK; }
-    if (!strcmp(key, "oc_k_qkv")) { e->oc_k_qkv = value; return BLIM_OK; }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_act")) { e->precise_act = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_qk")) {

@@ -90,10 +90,6 @@ struct blim_engine {
     std::vector<LayerAd> AD; AdapterW ad_lm, ad_mlp[2][2];       // ad_mlp[mlp | tvg_mlp][Linear 0 | Linear 2]
     uint16_t* lm_aug = nullptr; uint16_t* w0_aug[2] = {nullptr, nullptr}; uint16_t* w2_aug[2] = {nullptr, nullptr};
     bool aug_ready = false;
-    // outlier-channel experiment (options "oc_k_x" / "oc_k_attn" / "oc_k_act" / "oc_k_qkv"; -1 = off): in the compensated mode, keep the lo halves of the
-    // normalised rows / attention output / SwiGLU output / q-k-v only in the k channels with the largest |hi| of the call (0: nowhere) -- kernels.hpp
-    int oc_k_x = -1, oc_k_attn = -1, oc_k_act = -1, oc_k_qkv = -1;
-    DevBuf oc_scratch;
     bool lora_merged = false;                                    // blim_train_merge wrote W + (alpha / r) B A into the base weights: adapters apart on top would apply the update twice
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)
     std::vector<void*> ad_owned;                                 // the f32 A / B matrices

@@ -563,53 +563,3 @@ int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const 
     LAUNCH_CHECK("rmsnorm_f8");
     return BLIM_OK;
 }
-
-// ---------------------------------------------------------------------------- outlier-channel experiment (kernels.hpp)
-template <int DT>
-__global__ void colmax_abs_kernel(const bf16_t* __restrict__ x, int64_t ld, int64_t rows, int cols, uint32_t* __restrict__ colmax) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(rows, r0 + 256);
-    float m = 0.f;
-    for (int64_t r = r0; r < r1; ++r) m = fmaxf(m, fabsf(from16<DT>(x[r * ld + c])));
-    if (!(m == m)) m = 3.0e38f;                                          // NaN: treat as the largest
-    atomicMax(colmax + c, __float_as_uint(m));                           // non-negative floats order like their bit patterns
-}
-// thr = the k-th largest entry of colmax (bit pattern); one workgroup, bisection on the bit pattern
-__global__ void kth_largest_kernel(const uint32_t* __restrict__ colmax, int cols, int k, uint32_t* __restrict__ thr) {
-    __shared__ int cnt;
-    uint32_t lo = 0, hi = 0x7f800000u;                                   // invariant: count(>= lo) >= k
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo + 1) / 2;
-        if (threadIdx.x == 0) cnt = 0;
-        __syncthreads();
-        int c = 0;
-        for (int i = threadIdx.x; i < cols; i += blockDim.x) c += colmax[i] >= mid;
-        if (c) atomicAdd(&cnt, c);
-        __syncthreads();
-        if (cnt >= k) lo = mid; else hi = mid - 1;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *thr = lo;
-}
-__global__ void mask_lo_kernel(bf16_t* __restrict__ lo, int64_t ld, int64_t rows, int cols, const uint32_t* __restrict__ colmax, const uint32_t* __restrict__ thr, int k) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    if (k > 0 && colmax[c] >= *thr) return;                               // an outlier channel: its lo part stays
-    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(rows, r0 + 256);
-    for (int64_t r = r0; r < r1; ++r) lo[r * ld + c] = 0;
-}
-int launch_mask_lo_topk(const bf16_t* hi, bf16_t* lo, int64_t ld, int64_t rows, int cols, int k, int dtype, uint32_t* scratch, hipStream_t s) {
-    if (k < 0 || rows <= 0) return BLIM_OK;
-    const dim3 grid((cols + 255) / 256, (unsigned)((rows + 255) / 256));
-    if (k > 0) {
-        HIP_TRY(hipMemsetAsync(scratch, 0, (size_t)(cols + 1) * 4, s));
-        if (dtype == DT_F16) hipLaunchKernelGGL(colmax_abs_kernel<DT_F16>, grid, dim3(256), 0, s, hi, ld, rows, cols, scratch);
-        else hipLaunchKernelGGL(colmax_abs_kernel<DT_BF16>, grid, dim3(256), 0, s, hi, ld, rows, cols, scratch);
-        hipLaunchKernelGGL(kth_largest_kernel, dim3(1), dim3(1024), 0, s, scratch, cols, k, scratch + cols);
-    }
-    hipLaunchKernelGGL(mask_lo_kernel, grid, dim3(256), 0, s, lo, ld, rows, cols, scratch, scratch + cols, k);
-    HIP_TRY(hipGetLastError());
-    return BLIM_OK;
-}
-

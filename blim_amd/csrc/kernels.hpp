@@ -43,9 +43,3 @@ int launch_tvg_score(const float* logits, int64_t ld, int n_vocab, const int32_t
 int launch_quant_rows(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, float* scale, hipStream_t s);
 // RMSNorm whose output is quantised per row (same arithmetic as launch_rmsnorm, then the rule above)
 int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const float* w, float eps, uint8_t* out8, float* scale, hipStream_t s);
-
-// ---- outlier-channel experiment (engine options "oc_k_*"): of the lo halves of [hi | lo] rows keep only the k columns whose hi half has the
-// largest |value| over the rows (k = 0: none), zero the rest -- what a plain 16-bit GEMM input with k compensated outlier channels would carry.
-// scratch: >= cols + 1 uint32 on the device.
-int launch_mask_lo_topk(const bf16_t* hi, bf16_t* lo, int64_t ld, int64_t rows, int cols, int k, int dtype, uint32_t* scratch, hipStream_t s);
-

@@ -148,14 +148,15 @@ def numeric_checks(rep: Report, model, loader, tokenizer, args, n_pairs: int = 6
     scorer = RU.PairScorer(ddp, vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], video, vocab, vlab, args.num_clips, max_tokens=args.max_tokens)
     # ---- 4. the numeric-mode table
     model.vtg_precise = "auto"
-    chosen, table = scorer.calibrate_vtg(RU.calibration_pairs(sims, k))
+    n_eval = 3 * N * k                                     # entries of each kind in a full evaluation of this set (the tail extrapolation's horizon)
+    chosen, table = scorer.calibrate_vtg(RU.calibration_pairs(sims, k, n_queries=32, per_query=8), n_eval=n_eval)
     rep.add(True, "vtg_precise auto (PairScorer.calibrate_vtg) on this checkpoint",
-            ", ".join(f"{m} max {v['max']:.1e} rms {v['rms']:.1e}" for m, v in table.items()) + f" -> {chosen}")
+            ", ".join(f"{m} max {v['max']:.1e} rms {v['rms']:.1e} predicted max {v['pred']:.1e}" for m, v in table.items()) + f" -> {chosen}")
     if args.resume and scorer.split_tvg:
-        tp = RU.calibration_pairs(sims.T, k, n_queries=8)
-        tchosen, ttable = scorer.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1))
+        tp = RU.calibration_pairs(sims.T, k, n_queries=64, per_query=4)
+        tchosen, ttable = scorer.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1), n_eval=n_eval)
         rep.add(True, "tvg_precise auto (PairScorer.calibrate_tvg: how much of the TVG calls' MLP branch runs compensated)",
-                ", ".join(f"{m} max {v['max']:.1e} rms {v['rms']:.1e}" for m, v in ttable.items()) + f" -> {tchosen}")
+                ", ".join(f"{m} max {v['max']:.1e} rms {v['rms']:.1e} predicted max {v['pred']:.1e}" for m, v in ttable.items()) + f" -> {tchosen}")
     # ---- 5. fused vs literal on the same pairs (the TVG pass in the mode just chosen, both paths)
     q = max(1, min(N, n_pairs // k))
     a = types.SimpleNamespace(topk=k, batch_size_eval=min(16, k), num_clips=args.num_clips)

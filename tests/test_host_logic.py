@@ -428,3 +428,31 @@ def test_executed_flops_formula_and_calibration_pairs():
     assert all(c in top[q] for q, c in p)
     assert np.array_equal(p, RU.calibration_pairs(sims, topk=5))                                        # deterministic: the same on every rank
     assert RU.calibration_pairs(sims[:3], topk=64).shape == (3 * 16, 2)                                 # at most 16 per query, at most Nt
+
+
+def test_predicted_max_deviation_extrapolates_the_samples_tail():
+    """retrieval_utils.predicted_max_deviation (`--vtg_precise` / `--tvg_precise auto`): a 256-entry sample of a log-normal law with the tail measured on weights with
+    massive activations (sigma_log 0.9) predicts the largest of 48,000 entries within its sampling spread, far above the sample's own maximum; Gaussian deviations are
+    over- not under-estimated; with no more entries than the sample the sample maximum is returned."""
+    import math
+    from statistics import NormalDist
+    from blim_amd import retrieval_utils as RU
+    rng = np.random.RandomState(0)
+    med, sig, N = 1e-4, 0.9, 48000
+    true_max = med * math.exp(sig * NormalDist().inv_cdf(1 - 1 / N))              # 3.9e-3
+    preds = []
+    for _ in range(40):
+        x = med * np.exp(sig * rng.randn(256))
+        p = RU.predicted_max_deviation(x, N)
+        assert p >= x.max()
+        preds.append(p)
+    assert 0.7 * true_max < np.median(preds) < 1.4 * true_max and min(preds) > 0.4 * true_max, (true_max, np.median(preds), min(preds))
+    for _ in range(20):
+        x = np.abs(rng.randn(256)) * 5e-5                                          # half-normal: the true largest of 48,000 is ~ 4.3 x rms = 2.1e-4
+        p = RU.predicted_max_deviation(x, N)
+        assert 2.1e-4 < p < 7e-4, p                                                # conservative (~ 8 x rms), still inside the bar
+    x = np.abs(rng.randn(256)) * 5e-5
+    assert RU.predicted_max_deviation(x, 256) == x.max() and RU.predicted_max_deviation(x, None) == x.max()
+    assert RU.predicted_max_deviation(np.array([0.0, np.nan]), N) == 0.0
+    assert RU.predicted_max_deviation(x[:10], N) == x[:10].max()                    # too small a sample to fit: its maximum
+
