@@ -282,7 +282,7 @@ def main():
                          "bf16 (same MFMA rate, ~3 %% faster under the power limit, but 1 - 2e-3 on the VTG scores at depth: a non-parity mode), "
                          "f8 (separate mode, deviations reported)")
     ap.add_argument("--topk", type=int, default=16)
-    ap.add_argument("--vtg-precise", default="none", choices=["none", "qk", "qkx", "attn", "full"],
+    ap.add_argument("--vtg-precise", default="none", choices=["none", "qk", "qkx", "attn", "act0", "full"],
                     help="compensated (hi + lo) activations on the benched VTG calls: none (default; fp16 holds 1e-3 without), full = the bf16 PARITY mode "
                          "(2x GEMM flops; what `--dtype bf16` needs to hold 1e-3 at 7B depth: tests/test_gpu_parity.py::test_depth_*)")
     ap.add_argument("--tvg-precise", default="auto", choices=["auto", "attn", "act0", "full"],

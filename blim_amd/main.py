@@ -67,7 +67,7 @@ def get_args_parser():
                    help="fp8 mode: which GEMMs take e4m3 operands (bit 0 qkv, 1 o_proj, 2 gate|up, 3 down, 4 lm_head).  Default 31 (all) on a base checkpoint, "
                         "12 (the MLP only) when --resume names a fine-tuned checkpoint: LoRA adapts q/k/v/o_proj and lm_head, whose merged rank-8 update is below one "
                         "e4m3 step of the base weight -- those GEMMs stay in fp16, the MLP (87 %% of a layer's flops, not adapted) runs in fp8")
-    p.add_argument("--vtg_precise", default="auto", choices=["auto", "none", "qk", "qkx", "attn", "full"],
+    p.add_argument("--vtg_precise", default="auto", choices=["auto", "none", "qk", "qkx", "attn", "act0", "full"],
                    help="compensated (hi + lo) activations on the VTG calls.  auto (default): measured on the loaded checkpoint before the first pass -- up to 256 pairs of the "
                         "evaluation are scored in every mode against the fully compensated one (which sits at 2e-6 .. 1e-5 of the fp32 reference) and the cheapest mode "
                         "whose largest deviation AND 4.5 x its RMS deviation are inside 1e-3 is kept (PairScorer.calibrate_vtg; the table is printed).  none = plain 16-bit (what auto picks on an fp16 engine unless the checkpoint "

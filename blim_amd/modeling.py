@@ -211,7 +211,7 @@ class BlimModel:
         tvg_rows = (kind == "tvg") if kind is not None else (self._tvg_rows or (inputs_embeds.dtype == torch.float32 and self.engine.dtype == "f16" and self.engine.can_precise))
         if self.vtg_precise == "auto" and not tvg_rows:
             raise RuntimeError("vtg_precise = 'auto' has not been resolved yet: evaluation() measures it on the loaded checkpoint before its first pass "
-                               "(PairScorer.calibrate_vtg); set BlimModel.vtg_precise to none / qk / qkx / attn / full to call forward() directly")
+                               "(PairScorer.calibrate_vtg); set BlimModel.vtg_precise to none / qk / qkx / attn / act0 / full to call forward() directly")
         wide = inputs_embeds.dtype == torch.float32 and self.engine.can_precise and (self.engine.dtype == "bf16" or tvg_rows)
         if wide:                                                          # float32 embeddings of prepare_inputs_labels_for_multimodal (bf16 engines; TVG rows on fp16 ones): back to [hi | lo]
             hi = inputs_embeds.to(self.dtype)
@@ -228,8 +228,8 @@ class BlimModel:
             tm = self.tvg_precise if self.tvg_precise in ("attn", "act0") else "full"        # an unresolved "auto" runs fully compensated
             self.engine.set_precise(True, embeds=wide, mlp=tm != "attn", act=tm == "full")
         else:
-            on = self.vtg_precise in ("attn", "full")
-            self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise == "full")
+            on = self.vtg_precise in ("attn", "act0", "full")
+            self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise in ("act0", "full"), act=self.vtg_precise == "full")
             if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none / qk): plain embeddings
                 emb = inputs_embeds.to(self.dtype).contiguous()
         qk = (not tvg_rows) and self.vtg_precise in ("qk", "qkx")          # plain activations, q / k / v and the attention as hi + lo (engine option precise_qk)
