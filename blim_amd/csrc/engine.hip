@@ -134,6 +134,9 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     if (getenv("BLIM_F8_FUSE")) e->f8_fuse = atoi(getenv("BLIM_F8_FUSE"));
     if (getenv("BLIM_PRECISE_MLP")) e->precise_mlp = atoi(getenv("BLIM_PRECISE_MLP")) != 0;
     if (getenv("BLIM_PRECISE_ACT")) e->precise_act = atoi(getenv("BLIM_PRECISE_ACT")) != 0;
+    // fp16 engines: the compensated modes' second pass over K runs in e4m3 (gemm.hip, phase 2) unless BLIM_PRECISE_LO8=0 / option "precise_lo8" = 0
+    e->lo8 = !e->f8 && cfg->compute_dtype == DT_F16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 && cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480;
+    if (getenv("BLIM_PRECISE_LO8") && atoi(getenv("BLIM_PRECISE_LO8")) == 0) e->lo8 = false;
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -179,7 +182,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     for (void* p : e->aug_owned) hipFree(p);
     for (void* p : e->ad_owned) hipFree(p);
     DevBuf* bufs[] = {&e->visual_head3, &e->hs3, &e->vocab3, &e->vocab1, &e->vh3, &e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale, &e->lo_mx};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -264,6 +267,7 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
     if (name == "visual_head") TRY(engine_set_visual_head3(e, dev_src, dtype, 0));
     e->loaded[name] = true;
     e->f8_ready = false;
+    e->lo8_ready = false;
     e->aug_ready = false;          // the augmented copies of adapted weights are rebuilt from the placed base weights on the next call
     if (name != "visual_head") e->lora_merged = false;       // the caller is (re)loading base weights: the mark of a merged update (blim_train_merge) goes with them
     return BLIM_OK;
@@ -352,6 +356,37 @@ static int finalize_f8(blim_engine* e) {
     return BLIM_OK;
 }
 
+static int build_aug(blim_engine* e);
+// option "precise_lo8": e4m3 copies of the decoder weights with E8M0 (power-of-two) row scales, for the second pass of the compensated GEMMs
+static int finalize_lo8(blim_engine* e) {
+    if (!e->lo8 || e->lo8_ready) return BLIM_OK;
+    TRY(blim_weights_ready(e));
+    const blim_config& c = e->c;
+    const int H = c.hidden_size, I = c.intermediate_size;
+    for (auto& l : e->L) {
+        if (!l.wqkv8) { TRY(dev_alloc(e, (void**)&l.wqkv8, (size_t)e->qkv_n * H)); TRY(dev_alloc(e, (void**)&l.wo8, (size_t)H * H));
+                        TRY(dev_alloc(e, (void**)&l.wgu8, (size_t)2 * I * H)); TRY(dev_alloc(e, (void**)&l.wd8, (size_t)H * I)); }
+        if (!l.eqkv) { TRY(dev_alloc(e, (void**)&l.eqkv, (size_t)e->qkv_n)); TRY(dev_alloc(e, (void**)&l.eo, (size_t)H)); TRY(dev_alloc(e, (void**)&l.egu, (size_t)2 * I)); TRY(dev_alloc(e, (void**)&l.ed, (size_t)H)); }
+        TRY(launch_quant_rows_e8(l.wqkv, H, e->qkv_n, H, c.compute_dtype, l.wqkv8, l.eqkv, 0));
+        TRY(launch_quant_rows_e8(l.wo, H, H, H, c.compute_dtype, l.wo8, l.eo, 0));
+        TRY(launch_quant_rows_e8(l.wgu, H, 2 * (int64_t)I, H, c.compute_dtype, l.wgu8, l.egu, 0));
+        TRY(launch_quant_rows_e8(l.wd, I, H, I, c.compute_dtype, l.wd8, l.ed, 0));
+    }
+    if (e->aug) {                         // adapters apart: the adapted projections' augmented weights [W | B_hi | B_lo | 0] (K = H + aug, a multiple of 128)
+        TRY(build_aug(e));
+        const int Hq = H + e->aug;
+        for (auto& d : e->AD) {
+            auto alloc8 = [&](uint8_t** q, size_t n) -> int { HIP_TRY(hipMalloc((void**)q, n)); e->aug_owned.push_back(*q); return BLIM_OK; };
+            if (!d.wqkv_aug8) { TRY(alloc8(&d.wqkv_aug8, (size_t)e->qkv_n * Hq)); TRY(alloc8(&d.wo_aug8, (size_t)H * Hq)); TRY(alloc8(&d.eqkv_aug, (size_t)e->qkv_n)); TRY(alloc8(&d.eo_aug, (size_t)H)); }
+            TRY(launch_quant_rows_e8(d.wqkv_aug, Hq, e->qkv_n, Hq, c.compute_dtype, d.wqkv_aug8, d.eqkv_aug, 0));
+            TRY(launch_quant_rows_e8(d.wo_aug, Hq, H, Hq, c.compute_dtype, d.wo_aug8, d.eo_aug, 0));
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    e->lo8_ready = true;
+    return BLIM_OK;
+}
+
 // ---------------------------------------------------------------------------- LoRA adapters kept apart (adapters.hpp)
 // main.py:96-105: peft LoRA on the projector MLPs' Linear "0" / "2", on every q/k/v/o_proj and on lm_head; main.py:125-128 loads the fine-tuned
 // A / B.  The reference evaluates with the adapters APART (y = W x + b + (alpha / r) B (A x)); so does this engine once adapters are loaded.
@@ -379,10 +414,11 @@ static AdapterW* find_adapter(blim_engine* e, const std::string& name, int* n_ou
 static void free_aug(blim_engine* e) {
     for (void* p : e->aug_owned) hipFree(p);
     e->aug_owned.clear();
-    for (auto& l : e->AD) { l.wqkv_aug = l.wo_aug = nullptr; for (auto& a : l.ad) a.A16 = nullptr; }
+    for (auto& l : e->AD) { l.wqkv_aug = l.wo_aug = nullptr; l.wqkv_aug8 = l.wo_aug8 = l.eqkv_aug = l.eo_aug = nullptr; for (auto& a : l.ad) a.A16 = nullptr; }
     e->lm_aug = nullptr; e->ad_lm.A16 = nullptr;
     for (int w = 0; w < 2; ++w) { e->w0_aug[w] = e->w2_aug[w] = nullptr; e->ad_mlp[w][0].A16 = e->ad_mlp[w][1].A16 = nullptr; }
     e->aug_ready = false;
+    e->lo8_ready = false;                 // (the e4m3 copies of the augmented weights went with them)
 }
 
 extern "C" int blim_clear_adapters(blim_engine* e) {
@@ -435,7 +471,10 @@ extern "C" int blim_load_adapter(blim_engine* e, const char* weight_name, const 
     HIP_TRY(hipMemcpy(a->A, A, (size_t)lora_r * n_in * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(a->B, B, (size_t)n_out * lora_r * 4, hipMemcpyHostToDevice));
     e->lora_r = lora_r; e->lora_scale = scale;
-    e->aug = 6 * lora_r <= 64 ? 64 : 128;        // three adapters (q, k, v) x r columns x (B_hi, B_lo)
+    // three adapters (q, k, v) x r columns x (B_hi, B_lo) need 6 r columns: 64 suffice up to r = 10.  fp16 engines take 128 whenever the e4m3 second pass of the
+    // compensated modes is possible (option "precise_lo8": its K-steps are 128 deep, so the augmented K must stay a multiple of 128)
+    const bool lo8_capable = !e->f8 && e->c.compute_dtype == DT_F16 && e->c.hidden_size % 128 == 0 && e->c.intermediate_size % 128 == 0;
+    e->aug = (6 * lora_r <= 64 && !lo8_capable) ? 64 : 128;
     e->aug_ready = false;
     return BLIM_OK;
 }
@@ -509,6 +548,13 @@ static int reserve_tokens(blim_engine* e, int64_t T) {
         TRY(ensure(e->rscale, (size_t)Tp * 4 * 4));      // [x | attn | act | label rows] scales
         TRY(ensure(e->act_mx, (size_t)Tp * (c.intermediate_size / 128)));
         TRY(ensure(e->attn_mx, (size_t)Tp * c.num_heads));
+    }
+    if (e->lo8) {                                      // e4m3 copies of the lo parts + their E8M0 tables (x8 doubles for both normalised inputs)
+        const int64_t T8 = round_up(T, 256);
+        TRY(ensure(e->x8, (size_t)T8 * (c.hidden_size + e->aug)));
+        TRY(ensure(e->a8, (size_t)T8 * (c.hidden_size + e->aug)));
+        TRY(ensure(e->act8, (size_t)T8 * c.intermediate_size));
+        TRY(ensure(e->lo_mx, (size_t)T8 * (std::max(c.intermediate_size, c.hidden_size + e->aug) / 128)));
     }
     const int64_t Hq = c.hidden_size + e->aug;        // adapters apart: the QKV / o_proj inputs carry `aug` extra columns (adapters.hpp)
     TRY(ensure(e->resid, (size_t)round_up(T, 256) * c.hidden_size * 4));
@@ -625,6 +671,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     TRY(build_aug(e));
     TRY(reserve_tokens(e, T));
     TRY(finalize_f8(e));
+    TRY(finalize_lo8(e));
     float* resid = (float*)e->resid.p;
     const bool prune = e->prune_last && live_rows && n_live > 0 && n_live <= T - T / 16 && !e->f8;
     if (prune) TRY(ensure(e->resid_live, (size_t)round_up(n_live, 256) * H * 4));
@@ -659,6 +706,16 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const bool pqx = pq && e->precise_qk > 1;                       // ... and a hi + lo input of the QKV GEMM (its K walked twice)
     const int pfq = (e->precise || pq) ? 2 : 1;                     // width factor of the qkv / attention-output rows
     if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
+    // option "precise_lo8": a compensated GEMM = its plain fp16 pass over the hi part + an e4m3 pass over the lo part, in one kernel (gemm.hip, phase 2).  `rows`
+    // are [hi | lo] rows (lo at +lo_elems, row stride ld); the lo halves are quantised into a8buf, their E8M0 bytes into lo_mx, and `p` -- set up as the
+    // PLAIN product of the hi halves -- gets the second pass attached.  With adapters apart the adapted projections use the augmented weights' e4m3 copies.
+    const bool lo8 = e->lo8 && e->precise;
+    const int64_t T8 = round_up(T, 256);
+    auto attach_lo8 = [&](GemmParams& p, const bf16_t* rows, int64_t ld, int64_t lo_elems, int64_t n, int K, uint8_t* a8buf, const uint8_t* w8, const uint8_t* we8) -> int {
+        TRY(launch_quant_lo_mx(rows + lo_elems, ld, n, K, c.compute_dtype, a8buf, K, (uint8_t*)e->lo_mx.p, T8, s));
+        p.A8 = a8buf; p.lda8 = K; p.W8 = w8; p.w_e8 = we8; p.K8 = K; p.a_mx = (const uint8_t*)e->lo_mx.p; p.mx_stride = T8;
+        return BLIM_OK;
+    };
     for (int li = 0; li < c.num_layers; ++li) {
         const LayerW& l = e->L[li];
         {
@@ -672,6 +729,10 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n)
                               : gp2(e, xn, Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise || pqx);
             if (pq && !pqx) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
+            if (lo8) {                                                                    // hi part in fp16, lo part in e4m3; [hi | lo] outputs as before
+                p = gp(c.compute_dtype, xn, 2 * Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, (int)Hq, qkv, 2 * (int64_t)e->qkv_n); p.lo_off = e->qkv_n;
+                TRY(attach_lo8(p, xn, 2 * Hq, Hq, T, (int)Hq, x8, G ? e->AD[li].wqkv_aug8 : l.wqkv8, G ? e->AD[li].eqkv_aug : l.eqkv));
+            }
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
         }
@@ -702,14 +763,20 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             const double tl = (double)n_live;
             { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * Hq * H * pf);
               GemmParams p = gp2(e, attn_live, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * Hq;   // pq: the hi halves of [hi | lo] rows
+              if (lo8) { p = gp(c.compute_dtype, attn_live, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, (int)Hq, rl, H);
+                         TRY(attach_lo8(p, attn_live, 2 * Hq, Hq, n_live, (int)Hq, a8, G ? e->AD[li].wo_aug8 : l.wo8, G ? e->AD[li].eo_aug : l.eo)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             { SpanGuard g(e, s, TC_NORM, 0);
               TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
-              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; } TRY(launch_gemm(EPI_SWIGLU, p, s)); }
+              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; }
+              if (lo8 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0; TRY(attach_lo8(p, xn, 2 * (int64_t)H, H, n_live, H, x8, l.wgu8, l.egu)); }
+              TRY(launch_gemm(EPI_SWIGLU, p, s)); }
             { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * (pa ? 2 : 1));
-              GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pa); p.ldc = H; p.lo_off = 0; TRY(launch_gemm(EPI_RESID, p, s)); }
+              GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pa); p.ldc = H; p.lo_off = 0;
+              if (lo8 && pa) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, n_live, H, I, rl, H); TRY(attach_lo8(p, act, 2 * (int64_t)I, I, n_live, I, act8, l.wd8, l.ed)); }
+              TRY(launch_gemm(EPI_RESID, p, s)); }
             *final_resid = rl; *final_is_live = true;
             break;
         }
@@ -721,6 +788,10 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (fuse_o) { p.a_mx = (const uint8_t*)e->attn_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             if (pq) p.lda = 2 * Hq;                                       // the hi halves of the attention output's [hi | lo] rows
+            if (lo8) {
+                p = gp(c.compute_dtype, attn, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, T, H, (int)Hq, resid, H);
+                TRY(attach_lo8(p, attn, 2 * Hq, Hq, T, (int)Hq, a8, G ? e->AD[li].wo_aug8 : l.wo8, G ? e->AD[li].eo_aug : l.eo));
+            }
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         {
@@ -734,6 +805,10 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I, pm);
             if (pm && !pa) { p.lo_off = 0; p.ldc = I; }                 // A = [hi | lo] (K walked twice), plain 16-bit output
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
+            if (lo8 && pm) {
+                p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, T, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0;
+                TRY(attach_lo8(p, xn, 2 * (int64_t)H, H, T, H, x8, l.wgu8, l.egu));
+            }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
         if (d8 && !fuse) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
@@ -742,6 +817,10 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0, pa);
             if (fuse) { p.a_mx = (const uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
+            if (lo8 && pa) {
+                p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, T, H, I, resid, H);
+                TRY(attach_lo8(p, act, 2 * (int64_t)I, I, T, I, act8, l.wd8, l.ed));
+            }
             TRY(launch_gemm(EPI_RESID, p, s));
         }
     }
@@ -1082,6 +1161,11 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
     if (!strcmp(key, "prune_last")) { e->prune_last = value != 0; return BLIM_OK; }
+    if (!strcmp(key, "precise_lo8")) {
+        if (value && (e->f8 || e->c.compute_dtype != DT_F16)) { blim_set_error("option 'precise_lo8' needs an fp16 engine"); return BLIM_ERR_ARG; }
+        if (value && (e->c.hidden_size % 128 || e->c.intermediate_size % 128)) { blim_set_error("option 'precise_lo8': hidden and intermediate sizes must be multiples of 128"); return BLIM_ERR_ARG; }
+        e->lo8 = value != 0; return BLIM_OK;
+    }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_act")) { e->precise_act = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_qk")) {

@@ -34,11 +34,13 @@ struct LayerW {
     // fp8 mode: e4m3 copies of the four matrices (same stored row order) + one f32 scale per stored row
     uint8_t* wqkv8 = nullptr; uint8_t* wo8 = nullptr; uint8_t* wgu8 = nullptr; uint8_t* wd8 = nullptr;
     float* sqkv = nullptr; float* so = nullptr; float* sgu = nullptr; float* sd = nullptr;
+    uint8_t* eqkv = nullptr; uint8_t* eo = nullptr; uint8_t* egu = nullptr; uint8_t* ed = nullptr;     // option "precise_lo8": E8M0 row scales of the e4m3 copies above (fp16 engines)
 };
 
 // LoRA adapters kept apart (adapters.hpp): the f32 matrices as loaded + their 16-bit MFMA operand
 struct AdapterW { float* A = nullptr; float* B = nullptr; uint16_t* A16 = nullptr; int n_in = 0, n_out = 0; };
-struct LayerAd { AdapterW ad[4]; uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr; };      // ad: q, k, v, o
+struct LayerAd { AdapterW ad[4]; uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr;           // ad: q, k, v, o
+                 uint8_t* wqkv_aug8 = nullptr; uint8_t* wo_aug8 = nullptr; uint8_t* eqkv_aug = nullptr; uint8_t* eo_aug = nullptr; };   // option "precise_lo8": e4m3 copies + E8M0 row scales
 
 struct blim_engine {
     blim_config c;
@@ -90,6 +92,10 @@ struct blim_engine {
     std::vector<LayerAd> AD; AdapterW ad_lm, ad_mlp[2][2];       // ad_mlp[mlp | tvg_mlp][Linear 0 | Linear 2]
     uint16_t* lm_aug = nullptr; uint16_t* w0_aug[2] = {nullptr, nullptr}; uint16_t* w2_aug[2] = {nullptr, nullptr};
     bool aug_ready = false;
+    // option "precise_lo8" (fp16 engines): in the compensated modes the second walk over K -- the product with the activations' LO parts -- runs on the e4m3
+    // MFMA at twice the rate (gemm.hip, phase 2): e4m3 copies of the decoder weights with power-of-two row scales, built lazily (finalize_lo8)
+    bool lo8 = false, lo8_ready = false;
+    DevBuf lo_mx;                                                // E8M0 bytes of the quantised lo parts: [K / 128][256-row tiles][256]
     bool lora_merged = false;                                    // blim_train_merge wrote W + (alpha / r) B A into the base weights: adapters apart on top would apply the update twice
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)
     std::vector<void*> ad_owned;                                 // the f32 A / B matrices

@@ -104,6 +104,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     // 16-bit forms (k = 8 fc .. and 32 + 8 fc ..), or the 32 e4m3 of one 128-deep fp8 MFMA (any k assignment works as long as the
     // A and W lanes use the same one).  Chunk c of row r sits at slot c ^ g(r): the second read is the first XOR 64 bytes.
     constexpr int ES = (DT == DT_F8) ? 1 : 2;            // operand element size
+    constexpr bool MX8 = MXA && DT == DT_F8;             // fp8 GEMM whose A operand carries E8M0 block scales (a_mx)
+    constexpr bool LO8 = MXA && DT != DT_F8;             // 16-bit GEMM followed, in the same accumulators, by an e4m3 pass over the A operand's LO part (see "phase 2")
     constexpr int ODT = out16<DT>::value;                // dtype of 16-bit outputs
     const int fr = lane & 15, fc = lane >> 4;
     const int fg = (fr >> 1) & 7;
@@ -157,13 +159,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         // MXA: this lane's eight A-side E8M0 bytes of the current K-step (one per 16-row fragment) and of the next one
         uint2 mx_cur = make_uint2(0x7f7f7f7fu, 0x7f7f7f7fu), mx_nxt = mx_cur;
         const uint8_t* mx_base = nullptr;
-        if constexpr (MXA) {
+        if constexpr (MX8) {
             int frm = fr;
             asm volatile("" : "+v"(frm));          // (per tile: the hoisted 64-bit lane address was spilled)
             mx_base = p.a_mx + (int64_t)tm * 256 + (wm * 16 + frm) * 8;
         }
         auto mx_request = [&](int kt) __attribute__((always_inline)) {
-            if constexpr (MXA) mx_nxt = *(const uint2*)(mx_base + (int64_t)min(kt, nk - 1) * p.mx_stride);
+            if constexpr (MX8) mx_nxt = *(const uint2*)(mx_base + (int64_t)min(kt, nk - 1) * p.mx_stride);
         };
         auto compute = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_s_setprio(1);
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 // in the epilogue).  A side: unit, or (MXA) byte mi & 3 of the lane's scale dword mi >> 2 -- opsel must be an immediate
 #define F8_ROW(MI)                                                                                                                                  \
                 _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                                                    \
-                    acc[MI][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni], fa8[MI], acc[MI][ni], 0, 0, 0, 0x7f7f7f7f, (MXA ? (MI & 3) : 0), \
-                                                                                  (int)(MXA ? ((MI) < 4 ? mx_cur.x : mx_cur.y) : 0x7f7f7f7fu));
+                    acc[MI][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni], fa8[MI], acc[MI][ni], 0, 0, 0, 0x7f7f7f7f, (MX8 ? (MI & 3) : 0), \
+                                                                                  (int)(MX8 ? ((MI) < 4 ? mx_cur.x : mx_cur.y) : 0x7f7f7f7fu));
                 F8_ROW(0) F8_ROW(1) F8_ROW(2) F8_ROW(3) F8_ROW(4) F8_ROW(5) F8_ROW(6) F8_ROW(7)
 #undef F8_ROW
             } else {
@@ -281,6 +283,74 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #endif
             }
         };
+        // ---- phase 2 (LO8): acc += (lo part of the A operand) . W^T on the block-scaled fp8 MFMA, at twice the 16-bit rate.  The compensated modes' second walk
+        // over K carries x_lo = x - f32(x_hi), 2^-11 of x in fp16: the product W . x_lo only needs a few percent of relative accuracy to remove > 95 % of the
+        // rounding noise of x_hi, which e4m3 x e4m3 delivers.  A8 = e4m3(x_lo) with one E8M0 scale per (row, 128-deep K-step) (a_mx: the MXA table layout),
+        // W8 = e4m3(W) with one E8M0 scale per row (w_e8); both scales enter through the MFMA's scale operands, so the products land in the SAME f32
+        // accumulators as phase 1 at their true magnitude and the epilogue is unchanged.  The loop is the fp8 kernel's (rotated: fragments read and consumed
+        // inside one iteration); every wave has passed phase 1's last barrier, so the ring is free.
+        const int nk8 = LO8 ? p.K8 / 128 : 0;
+        uint32_t off8b[8];
+        uint32_t wsc = 0;
+        uint32_t mxo = 0;                                            // this lane's byte offset inside a K-step's slice of the E8M0 table (32-bit: scalar base + voffset loads)
+        uint2 sc_cur = make_uint2(0, 0), sc_nxt = sc_cur;
+        // (formed AFTER phase 1, inside each wave group's own branch: computed up front these twelve registers would be live across the 16-bit loop)
+        const char* gbase8 = LO8 ? (grp == 1 ? (const char*)p.A8 : (const char*)p.W8) : nullptr;
+        auto init8 = [&]() __attribute__((always_inline)) {
+            int sr2 = sr, sc2 = sc;                                  // opaque copies: everything below is formed HERE, after phase 1, not hoisted above it
+            asm volatile("" : "+v"(sr2), "+v"(sc2));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b = wg + 4 * i;
+                if (grp == 1) off8b[i] = (uint32_t)((int64_t)min(row0 + 8 * b + sr2, p.M - 1) * p.lda8 + 16 * sc2);
+                else off8b[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr2, p.N - 1) * p.K8 + 16 * sc2);
+            }
+            // scales: W side, this lane's four fragment rows (one byte each, constant over K); A side, eight bytes per K-step (MXA table)
+            int frm = fr;
+            asm volatile("" : "+v"(frm));
+            wsc = 0;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wsc |= (uint32_t)p.w_e8[min(col0 + 64 * wn + 16 * ni + frm, p.N - 1)] << (8 * ni);
+            mxo = (uint32_t)(tm * 256 + (wm * 16 + frm) * 8);
+            sc_nxt = *(const uint2*)(p.a_mx + mxo);
+        };
+        auto stage8b = [&](int dst, int kt) __attribute__((always_inline)) {
+            const char* g = gbase8 + (int64_t)kt * 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint32_t o = off8b[i];
+                asm volatile("" : "+v"(o));
+                glds16(g + o, smem + dst + (wg + 4 * i) * 1024);
+            }
+        };
+        auto load_frags8 = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
+            const char* ba0 = smem + (offA_tile + a_off); const char* ba1 = smem + ((offA_tile + a_off) ^ 64);
+            const char* bb0 = smem + (offB_tile + b_off); const char* bb1 = smem + ((offB_tile + b_off) ^ 64);
+            auto rd = [](const char* q0, const char* q1) __attribute__((always_inline)) {
+                const i32x4 l = *(const i32x4*)q0, h = *(const i32x4*)q1;
+                return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+            };
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) fb8[ni] = rd(bb0 + ni * 2048, bb1 + ni * 2048);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) fa8[mi] = rd(ba0 + mi * 2048, ba1 + mi * 2048);
+        };
+        auto sc_request = [&](int kt) __attribute__((always_inline)) {
+            uint32_t o = mxo;
+            asm volatile("" : "+v"(o));
+            sc_nxt = *(const uint2*)(p.a_mx + (int64_t)min(kt, nk8 - 1) * p.mx_stride + o);
+        };
+        auto compute8 = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_s_setprio(1);
+#define L8_MMA(MI, NI)                                                                                                                         \
+            acc[MI][NI] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[NI], fa8[MI], acc[MI][NI], 0, 0, NI, (int)wsc, (MI & 3), \
+                                                                          (int)((MI) < 4 ? sc_cur.x : sc_cur.y));
+#define L8_ROW(MI) L8_MMA(MI, 0) L8_MMA(MI, 1) L8_MMA(MI, 2) L8_MMA(MI, 3)
+            L8_ROW(0) L8_ROW(1) L8_ROW(2) L8_ROW(3) L8_ROW(4) L8_ROW(5) L8_ROW(6) L8_ROW(7)
+#undef L8_ROW
+#undef L8_MMA
+            __builtin_amdgcn_s_setprio(0);
+        };
         int sa = 0;
         mx_request(0);
         if (grp == 0) {
@@ -289,7 +359,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();                                         // A0 W0 landed (every wave waited for its own DMA)
-            if constexpr (MXA) mx_cur = mx_nxt;                      // requested at tile entry, in front of every LDS-DMA
+            if constexpr (MX8) mx_cur = mx_nxt;                      // requested at tile entry, in front of every LDS-DMA
             if constexpr (DT == DT_F8) {
                 // same barrier sequence, loop rotated so that a step's fragments are read and consumed inside one iteration:
                 // the fp8 fragments are 8-register tuples assembled from two 16-B reads, and carried across the back edge the
@@ -302,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     PHASE_BARRIER();
                     compute();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my share of W(k+1) landed
-                    if constexpr (MXA) mx_cur = mx_nxt;
+                    if constexpr (MX8) mx_cur = mx_nxt;
                     PHASE_BARRIER();
                     sp = sa; sa = adv(sa, 2);
                 }
@@ -329,13 +399,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 sa = adv(sa, 2);
             }
             }
+            if constexpr (LO8) {
+                init8();
+                int s8 = 0;
+            stage8b(TILE_BYTES, 0);                                  // W0
+            if (nk8 > 1) stage8b(3 * TILE_BYTES, 1);                 // W1
+            if (nk8 > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PHASE_BARRIER();
+            sc_cur = sc_nxt;
+            int sp = 0;
+            for (int k = 0; k < nk8; ++k) {
+                sc_request(k + 1);
+                load_frags8(s8, adv(s8, 1));
+                if (k >= 1 && k + 1 < nk8) stage8b(sp, k + 1);       // W(k+1) into the slot A(k-1) left
+                PHASE_BARRIER();
+                compute8();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sc_cur = sc_nxt;
+                PHASE_BARRIER();
+                sp = s8; s8 = adv(s8, 2);
+            }
+            PHASE_BARRIER();
+            }
         } else {
             stage8(0, 0);                                            // A0
             if (nk > 1) stage8(2 * TILE_BYTES, 1);                   // A1
             if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();
-            if constexpr (MXA) mx_cur = mx_nxt;
+            if constexpr (MX8) mx_cur = mx_nxt;
             PHASE_BARRIER();
             for (int kt = 0; kt < nk; ++kt) {
                 WP_T(0);
@@ -354,12 +447,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 PHASE_BARRIER();
                 WP_T(3);
                 compute();
-                if constexpr (MXA) mx_cur = mx_nxt;                  // older than this iteration's LDS-DMA: landed by the vmcnt(8) above
+                if constexpr (MX8) mx_cur = mx_nxt;                  // older than this iteration's LDS-DMA: landed by the vmcnt(8) above
                 WP_T(4);
                 PHASE_BARRIER();
                 WP_T(5);
                 WP_ACC();
                 sa = adv(sa, 2);
+            }
+            if constexpr (LO8) {
+                init8();
+                int s8 = 0;
+            stage8b(0, 0);                                           // A0
+            if (nk8 > 1) stage8b(2 * TILE_BYTES, 1);                 // A1
+            if (nk8 > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PHASE_BARRIER();
+            sc_cur = sc_nxt;
+            PHASE_BARRIER();
+            for (int kt = 0; kt < nk8; ++kt) {
+                sc_request(kt + 1);
+                load_frags8(s8, adv(s8, 1));
+                if (kt + 2 < nk8) stage8b(adv(s8, 4), kt + 2);
+                if (kt + 2 < nk8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PHASE_BARRIER();
+                compute8();
+                sc_cur = sc_nxt;
+                PHASE_BARRIER();
+                s8 = adv(s8, 2);
+            }
             }
         }
 #undef PHASE_BARRIER
@@ -877,6 +993,17 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     }
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
+    if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU || EPI == EPI_RESID) {
+        if (p.A8) {            // fp16 main pass + e4m3 pass over the A operand's lo part (phase 2 of the kernel)
+            if constexpr (EPI == EPI_RESID) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
+            else if (p.lo_off != 0) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true, true>), grid, dim3(NTHREADS), 0, stream, p);
+            else if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
+            else { blim_set_error("lo8 QKV GEMM: hi | lo outputs only"); return BLIM_ERR_ARG; }
+            hipError_t e4 = hipGetLastError();
+            if (e4 != hipSuccess) { blim_set_error("gemm launch failed: %s", hipGetErrorString(e4)); return BLIM_ERR_HIP; }
+            return BLIM_OK;
+        }
+    }
     if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV || EPI == EPI_SWIGLU) {
         if (p.lo_off != 0) {   // compensated outputs: 16-bit engines (fp16: ~21 significant bits per activation, bf16: ~16)
             if (p.dtype == DT_F16) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true>), grid, dim3(NTHREADS), 0, stream, p);
@@ -929,6 +1056,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         if (p.row_scale) q.row_scale = p.row_scale + r0;
         if (p.rope_rows) q.rope_rows = p.rope_rows + r0 * 16;        // chunk-major table: the row offset inside every chunk (rope_stride unchanged)
         if (p.a_mx) q.a_mx = p.a_mx + r0;                         // r0 is a whole number of 256-row tiles: the table is tile-major inside a K-step
+        if (p.A8) q.A8 = p.A8 + r0 * p.lda8;
         if (p.out_mx) q.out_mx = p.out_mx + r0;
         if (p.labels) q.labels = p.labels + r0;
         if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
@@ -945,6 +1073,8 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
 static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
+    static const int dbg_k8 = getenv("BLIM_GEMM_LO8_K8") ? atoi(getenv("BLIM_GEMM_LO8_K8")) : 0;      // timing aid: shorten the e4m3 pass (wrong results)
+    if (p.A8 && dbg_k8 > 0 && dbg_k8 < p.K8) p.K8 = dbg_k8;
     if (!g_f16_saturate) p.f16_saturate = 0;
     p.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : GROUP_M;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
@@ -961,8 +1091,11 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK((int64_t)p.K * es % 128 == 0);                  // whole 128-byte K-steps
     ARG_CHECK(p.lda * es % 16 == 0);
     ARG_CHECK(p.dtype != DT_F8 || ((p.row_scale || p.a_mx) && p.col_scale));
-    ARG_CHECK((!p.a_mx && !p.out_mx) || (p.dtype == DT_F8 && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
-    ARG_CHECK(!p.a_mx || epi == EPI_RESID);                      // MX-scaled A operand: instantiated for the down projection
+    ARG_CHECK((!p.a_mx && !p.out_mx) || ((p.dtype == DT_F8 || p.A8) && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
+    ARG_CHECK(!p.a_mx || epi == EPI_RESID || p.A8);              // MX-scaled A operand: instantiated for the down projection (fp8) and for the lo8 pass
+    ARG_CHECK(!p.A8 || (p.dtype == DT_F16 && p.W8 && p.w_e8 && p.a_mx && p.w_wrap_k == 0 && p.K8 > 0 && p.K8 % 128 == 0 && p.lda8 % 16 == 0 &&
+                        p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU) &&
+                        (int64_t)p.M * p.lda8 < (1ll << 32) && (int64_t)p.N * p.K8 < (1ll << 32)));
     ARG_CHECK(!p.out_mx || (epi == EPI_SWIGLU && p.N % 256 == 0 && p.ldc % 16 == 0));
     ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice
     ARG_CHECK(p.lo_off == 0 || epi == EPI_BF16 || epi == EPI_QKV || epi == EPI_SWIGLU);

@@ -55,6 +55,14 @@ struct GemmParams {
     uint8_t* out_mx;
     const uint8_t* a_mx;
     int64_t mx_stride;
+    // fp16 engines, compensated modes with an e4m3 second pass ("lo8", gemm.hip phase 2): A / lda / K describe the plain 16-bit hi part (w_wrap_k = 0) and the
+    // A operand's LO part comes as A8 = e4m3 [M, lda8] with one E8M0 byte per (row, 128-deep K-step) in a_mx (table layout above; mx_stride), against
+    // W8 = e4m3 [N, K8] with one E8M0 byte per row (w_e8).  K8 % 128 == 0, lda8 % 16 == 0.  nullptr = off.
+    const uint8_t* A8;
+    int64_t lda8;
+    const uint8_t* W8;
+    const uint8_t* w_e8;
+    int K8;
     int f16_saturate;        // fp16 outputs: saturate to +-65504 instead of +-inf (common.hpp: f16_saturate_on).  engine.hip's gp() sets it; the one
                              // 16-bit GRADIENT store of the trainer clears it (the loss scaler must see an overflow as inf)
     int group_m;             // M-tiles per band of the tile order (8; BLIM_GEMM_GROUP_M)

@@ -563,3 +563,89 @@ int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const 
     LAUNCH_CHECK("rmsnorm_f8");
     return BLIM_OK;
 }
+
+static inline int64_t round_up256(int64_t x) { return (x + 255) / 256 * 256; }
+// ---------------------------------------------------------------------------- lo8 quantisers (kernels.hpp)
+__device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e with 2^e >= x (x > 0, finite)
+    int ex; const float m = frexpf(x, &ex);                      // x = m 2^ex, m in [0.5, 1)
+    return m == 0.5f ? ex - 1 : ex;
+}
+template <int DT>
+__global__ __launch_bounds__(256) void quant_rows_e8_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, uint8_t* e8) {
+    constexpr int MAXC = 10;
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const bf16_t* row = in + r * ld;
+    const int nchunk = K / 8;
+    uint4 v[MAXC];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nchunk) {
+            v[i] = *(const uint4*)(row + 8 * c);
+            const uint16_t* e = (const uint16_t*)&v[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(from16<DT>(e[j])));
+        }
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int ex = mx > 0.f && mx < 3.0e38f ? pow2_exp_ge(mx / FP8_MAX) : 0;
+    ex = max(-126, min(126, ex));
+    const float inv = ldexpf(1.0f, -ex);
+    if (threadIdx.x == 0) e8[r] = (uint8_t)(ex + 127);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nchunk) {
+            const uint16_t* e = (const uint16_t*)&v[i];
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = from16<DT>(e[j]) * inv;
+            *(uint2*)(out8 + r * K + 8 * c) = make_uint2(pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7]));
+        }
+    }
+}
+int launch_quant_rows_e8(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, uint8_t* e8, hipStream_t s) {
+    ARG_CHECK(in && out8 && e8 && n_rows > 0 && K > 0 && K % 8 == 0 && ld % 8 == 0 && K <= 256 * 8 * 10);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_e8_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8);
+    else hipLaunchKernelGGL((quant_rows_e8_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8);
+    LAUNCH_CHECK("quant_rows_e8");
+    return BLIM_OK;
+}
+// one thread per 8 columns, 16 consecutive lanes per 128-column block; 4 rows per 256-thread workgroup pass over the chunks
+template <int DT>
+__global__ __launch_bounds__(256) void quant_lo_mx_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride) {
+    const int64_t r = blockIdx.x;
+    const bf16_t* row = in + r * ld;
+    const int nchunk = K / 8;
+    const int rl = (int)(r & 255);
+    const int64_t mpos = (r >> 8) * 256 + ((rl >> 7) * 16 + (rl & 15)) * 8 + ((rl >> 4) & 7);
+    for (int c = threadIdx.x; c < nchunk; c += 256) {                 // nchunk % 16 == 0: the 16 lanes of a block are all in or all out
+        const uint4 v = *(const uint4*)(row + 8 * c);
+        const uint16_t* e = (const uint16_t*)&v;
+        float f[8], m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f[j] = from16<DT>(e[j]); m = fmaxf(m, fabsf(f[j])); }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+        int ex = m > 0.f && m < 3.0e38f ? pow2_exp_ge(m / FP8_MAX) : -127;
+        ex = max(-127, min(126, ex));
+        const float inv = ex > -127 ? ldexpf(1.0f, -ex) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= inv;
+        *(uint2*)(out8 + r * ld8 + 8 * c) = make_uint2(pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7]));
+        if ((threadIdx.x & 15) == 0) mx[(int64_t)(c >> 4) * mx_stride + mpos] = (uint8_t)(ex + 127);
+    }
+}
+int launch_quant_lo_mx(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride, hipStream_t s) {
+    ARG_CHECK(in && out8 && mx && n_rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld8 % 16 == 0 && ld8 >= K && mx_stride >= round_up256(n_rows));
+    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_lo_mx_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride);
+    else hipLaunchKernelGGL((quant_lo_mx_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride);
+    LAUNCH_CHECK("quant_lo_mx");
+    return BLIM_OK;
+}
+

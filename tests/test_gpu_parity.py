@@ -301,7 +301,8 @@ def _resolve_auto(t, prob=None, spec=None):
     t.model.vtg_precise = "auto"
     sc = RU.PairScorer(DDPLike(t.model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], [torch.from_numpy(v) for v in prob.video], torch.from_numpy(prob.video_vocab),
                        torch.from_numpy(prob.tvg_video_labels), t.dims.num_clips)
-    chosen, table = sc.calibrate_vtg(RU.calibration_pairs(torch.from_numpy(prob.v2t_sims), spec["topk"]))
+    cal = RU.calibration_pairs(torch.from_numpy(prob.v2t_sims), spec["topk"], n_queries=32, per_query=8)
+    chosen, table = sc.calibrate_vtg(cal, n_eval=3 * len(cal))          # as evaluation() does: the three VTG-type passes' entries (on these small fixtures the sample is one whole pass)
     assert (t.model.vtg_precise or "none") == chosen
     return chosen, table
 
@@ -320,7 +321,7 @@ def _resolve_tvg_auto(t, prob=None, spec=None):
                        torch.from_numpy(prob.tvg_video_labels), t.dims.num_clips)
     assert sc.tvg_mode == "full"                                           # unresolved auto runs fully compensated
     tp = RU.calibration_pairs(torch.from_numpy(prob.t2v_sims), spec["topk"], n_queries=64, per_query=4)
-    chosen, table = sc.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1))
+    chosen, table = sc.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1), n_eval=3 * len(tp))
     assert t.model.tvg_precise == chosen
     return chosen, table
 
