@@ -229,6 +229,11 @@ int blim_debug_gemm_stamps(void* device_buf);
  *   the 16-bit rounding of q and k (tests/golden/sink.npz: plain fp16 VTG 3.2e-3 off the fp32 reference, 1.2e-3 with this option at -2.5 % speed, 5.3e-4 with
  *   "precise" + "precise_mlp" = 0 at -16.5 %).  2: the QKV GEMM's input (the first norm's output) travels as hi + lo as well -- that GEMM walks K twice, nothing
  *   else changes: 6.6e-4 on the same fixture at -8.4 %, the cheapest setting inside the 1e-3 bar there;
+ * "precise_lo8" (0/1; fp16 engines with hidden / intermediate sizes that are multiples of 128: default 1, env BLIM_PRECISE_LO8=0 turns it off; other engines refuse 1):
+ *   in precise mode the decoder GEMMs' second walk over K -- the product of W with the activations' LO parts, 2^-11 of the values -- runs on the e4m3 MFMA at twice
+ *   the rate, inside the same kernel and into the same accumulators (e4m3 copies of the decoder weights with power-of-two row scales, +1 byte per weight, built on
+ *   the first compensated call; the lo parts quantised per (row, 128 columns)).  A fully compensated call costs 1.6x a plain one instead of 2x (1,648 against 1,336
+ *   pairs/s on the headline step) and stays within 4e-5 of the fp32 reference where the fp16 second pass reads 4e-6 (28 layers of the 7B configuration);
  * "prune_last" (0/1, default 1): calls that name the rows they read (blim_decode with out_rows, blim_score_*) run the LAST layer's o_proj / norm / MLP
  *   on those rows only (same values bit for bit; the other rows' K / V are still produced); after such a call the "resid" / "attn" / "act" workspaces of
  *   blim_debug_read hold the last layer's state of the live rows only -- bring-up code reads them after calls without out_rows, or sets 0;

@@ -766,6 +766,39 @@ def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
             e.close()
 
 
+@pytest.mark.parametrize("case", ["deep", "full7b"])
+def test_e4m3_second_pass_of_the_compensated_gemms(case, capsys):
+    """Engine option "precise_lo8" (default on fp16 engines; gemm.hip phase 2): in the compensated modes the product with the activations' LO parts -- 2^-11 of the
+    values -- runs on the e4m3 MFMA inside the same kernel instead of a second fp16 walk over K.  (a) With the option off the fp16 K-twice kernels still meet the
+    golden (the path every fp16 run took before round 4's end, and the one bf16 engines keep); (b) on / off differ in bits but by far less than the bar: the e4m3
+    pass removes > 95 % of what the lo pass removes at all; (c) both meet the golden on every pass with the VTG calls fully compensated."""
+    if not os.path.exists(os.path.join(GOLD, f"{case}.npz")):
+        pytest.skip(f"tests/golden/{case}.npz not generated")
+    t = _build(case, device_synth=True, dtype="f16")
+    g = np.load(os.path.join(GOLD, f"{case}.npz"))
+    res, got = {}, {}
+    try:
+        t.model.vtg_precise = "full"
+        for on in (1, 0):
+            t.model.engine.set_option("precise_lo8", on)
+            got[on] = _six_passes(t, False)
+            res[on] = _worst_rel(got[on], g)
+        t.model.engine.set_option("precise_lo8", 1)
+        lit = _worst_rel(_six_passes(t, True), g)
+    finally:
+        t.model.engine.close()
+    between = {}
+    for k in got[1]:
+        m = got[0][k] != -100.0
+        between[k] = float(np.max(np.abs(got[1][k][m].astype(np.float64) - got[0][k][m]) / np.abs(got[0][k][m])))
+    with capsys.disabled():
+        print(f"\n[{case} f16, every call fully compensated] vs the fp32 reference: e4m3 second pass " + ", ".join(f"{k} {v:.1e}" for k, v in res[1].items())
+              + "; fp16 second pass " + ", ".join(f"{k} {v:.1e}" for k, v in res[0].items()) + "; between the two " + ", ".join(f"{k} {v:.1e}" for k, v in between.items())
+              + "; literal path (e4m3) " + ", ".join(f"{k} {v:.1e}" for k, v in lit.items()))
+    assert max(res[0].values()) < 1e-4 and max(res[1].values()) < 2e-4 and max(lit.values()) < 2e-4, (res, lit)        # fully compensated calls sit far inside the bar either way
+    assert 0.0 < max(between.values()) < 1e-4, between
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_last_layer_pruning_changes_no_bit(dtype):
     """Engine option "prune_last" (default on): a call that names the rows it reads runs the last layer's o_proj / norm / MLP on those rows only.
