@@ -181,8 +181,10 @@ extern "C" void blim_destroy(blim_engine* e) {
     for (void* p : e->owned) hipFree(p);
     for (void* p : e->aug_owned) hipFree(p);
     for (void* p : e->ad_owned) hipFree(p);
+    if (e->lm8_lo) hipFree(e->lm8_lo);
+    if (e->e_lm) hipFree(e->e_lm);
     DevBuf* bufs[] = {&e->visual_head3, &e->hs3, &e->vocab3, &e->vocab1, &e->vh3, &e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale, &e->lo_mx};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale, &e->lo_mx, &e->h8_lo, &e->h_mx};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -381,6 +383,16 @@ static int finalize_lo8(blim_engine* e) {
             TRY(launch_quant_rows_e8(d.wqkv_aug, Hq, e->qkv_n, Hq, c.compute_dtype, d.wqkv_aug8, d.eqkv_aug, 0));
             TRY(launch_quant_rows_e8(d.wo_aug, Hq, H, Hq, c.compute_dtype, d.wo_aug8, d.eo_aug, 0));
         }
+    }
+    {   // lm_head: the augmented copy when adapters are apart (rebuilt with them), the base matrix otherwise
+        const int Hl = H + e->aug;
+        if (e->lm8_k != Hl) {
+            if (e->lm8_lo) { hipFree(e->lm8_lo); e->lm8_lo = nullptr; }
+            HIP_TRY(hipMalloc((void**)&e->lm8_lo, (size_t)c.vocab_size * Hl));
+            if (!e->e_lm) HIP_TRY(hipMalloc((void**)&e->e_lm, (size_t)c.vocab_size));
+            e->lm8_k = Hl;
+        }
+        TRY(launch_quant_rows_e8(e->aug ? (const bf16_t*)e->lm_aug : e->lm_head, Hl, c.vocab_size, Hl, c.compute_dtype, e->lm8_lo, e->e_lm, 0));
     }
     HIP_TRY(hipDeviceSynchronize());
     e->lo8_ready = true;
@@ -903,6 +915,15 @@ static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split
         GemmParams p = l8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0)
                           : gp(e->c.compute_dtype, A, Hl, e->aug ? (const void*)e->lm_aug : (const void*)e->lm_head, n_rows, V, (int)Hl, nullptr, 0);
         if (split) { ARG_CHECK(!l8); p.lda = 2 * Hl; p.K = (int)(2 * Hl); p.w_wrap_k = (int)Hl; }
+        if (split && e->lo8 && V % 256 == 0 && Hl % 128 == 0) {           // lo8: the rows' lo parts against the head in e4m3 (gemm.hip phase 2), as in the decoder GEMMs
+            TRY(finalize_lo8(e));
+            const int64_t R8 = round_up(n_rows, 256);
+            TRY(ensure(e->h8_lo, (size_t)R8 * Hl));
+            TRY(ensure(e->h_mx, (size_t)R8 * (Hl / 128)));
+            TRY(launch_quant_lo_mx((const bf16_t*)A + Hl, 2 * Hl, n_rows, (int)Hl, e->c.compute_dtype, (uint8_t*)e->h8_lo.p, Hl, (uint8_t*)e->h_mx.p, R8, s));
+            p.K = (int)Hl; p.w_wrap_k = 0;
+            p.A8 = (const uint8_t*)e->h8_lo.p; p.lda8 = Hl; p.W8 = e->lm8_lo; p.w_e8 = e->e_lm; p.K8 = (int)Hl; p.a_mx = (const uint8_t*)e->h_mx.p; p.mx_stride = R8;
+        }
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
     }

@@ -95,6 +95,9 @@ struct blim_engine {
     // option "precise_lo8" (fp16 engines): in the compensated modes the second walk over K -- the product with the activations' LO parts -- runs on the e4m3
     // MFMA at twice the rate (gemm.hip, phase 2): e4m3 copies of the decoder weights with power-of-two row scales, built lazily (finalize_lo8)
     bool lo8 = false, lo8_ready = false;
+    uint8_t* lm8_lo = nullptr; uint8_t* e_lm = nullptr;          // lm_head (or its augmented copy) in e4m3 + E8M0 row scales; width lm8_k
+    int lm8_k = 0;
+    DevBuf h8_lo, h_mx;                                          // the scored rows' lo parts in e4m3 + their E8M0 table
     DevBuf lo_mx;                                                // E8M0 bytes of the quantised lo parts: [K / 128][256-row tiles][256]
     bool lora_merged = false;                                    // blim_train_merge wrote W + (alpha / r) B A into the base weights: adapters apart on top would apply the update twice
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)

@@ -993,9 +993,9 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     }
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
-    if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU || EPI == EPI_RESID) {
+    if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU || EPI == EPI_RESID || EPI == EPI_LSE) {
         if (p.A8) {            // fp16 main pass + e4m3 pass over the A operand's lo part (phase 2 of the kernel)
-            if constexpr (EPI == EPI_RESID) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
+            if constexpr (EPI == EPI_RESID || EPI == EPI_LSE) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
             else if (p.lo_off != 0) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true, true>), grid, dim3(NTHREADS), 0, stream, p);
             else if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
             else { blim_set_error("lo8 QKV GEMM: hi | lo outputs only"); return BLIM_ERR_ARG; }
@@ -1094,7 +1094,7 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK((!p.a_mx && !p.out_mx) || ((p.dtype == DT_F8 || p.A8) && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
     ARG_CHECK(!p.a_mx || epi == EPI_RESID || p.A8);              // MX-scaled A operand: instantiated for the down projection (fp8) and for the lo8 pass
     ARG_CHECK(!p.A8 || (p.dtype == DT_F16 && p.W8 && p.w_e8 && p.a_mx && p.w_wrap_k == 0 && p.K8 > 0 && p.K8 % 128 == 0 && p.lda8 % 16 == 0 &&
-                        p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU) &&
+                        p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE) &&
                         (int64_t)p.M * p.lda8 < (1ll << 32) && (int64_t)p.N * p.K8 < (1ll << 32)));
     ARG_CHECK(!p.out_mx || (epi == EPI_SWIGLU && p.N % 256 == 0 && p.ldc % 16 == 0));
     ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice

@@ -232,7 +232,7 @@ int blim_debug_gemm_stamps(void* device_buf);
  * "precise_lo8" (0/1; fp16 engines with hidden / intermediate sizes that are multiples of 128: default 1, env BLIM_PRECISE_LO8=0 turns it off; other engines refuse 1):
  *   in precise mode the decoder GEMMs' second walk over K -- the product of W with the activations' LO parts, 2^-11 of the values -- runs on the e4m3 MFMA at twice
  *   the rate, inside the same kernel and into the same accumulators (e4m3 copies of the decoder weights with power-of-two row scales, +1 byte per weight, built on
- *   the first compensated call; the lo parts quantised per (row, 128 columns)).  A fully compensated call costs 1.6x a plain one instead of 2x (1,648 against 1,336
+ *   the first compensated call; the lo parts quantised per (row, 128 columns)).  A fully compensated call costs 1.6x a plain one instead of 2x (1,677 against 1,336
  *   pairs/s on the headline step) and stays within 4e-5 of the fp32 reference where the fp16 second pass reads 4e-6 (28 layers of the 7B configuration);
  * "prune_last" (0/1, default 1): calls that name the rows they read (blim_decode with out_rows, blim_score_*) run the LAST layer's o_proj / norm / MLP
  *   on those rows only (same values bit for bit; the other rows' K / V are still produced); after such a call the "resid" / "attn" / "act" workspaces of

@@ -48,11 +48,15 @@ def run(mode):
     torch.cuda.synchronize()
     return out, time.time() - t0
 
-ref, t_ref = run("full")
-print(f"[{a.weights}] N = {a.n}: {len(pairs)} v2t VTG pairs, relative deviation from the fully compensated mode ({t_ref:.1f} s = {len(pairs) / t_ref:.0f} pairs/s)", flush=True)
-print("| mode | pairs/s | max | rms | median | 99 % | 99.9 % | entries > 1e-3 | predicted max from the 256-pair sample (n_eval = 48,000) |\n|---|---|---|---|---|---|---|---|---|")
+lo8_default = model.engine.dtype == "f16"
+model.engine.set_option("precise_lo8", 0) if lo8_default else None
+ref, t_ref = run("full")                                           # the yardstick: both walks over K in fp16
+if lo8_default:
+    model.engine.set_option("precise_lo8", 1)
+print(f"[{a.weights}] N = {a.n}: {len(pairs)} v2t VTG pairs, relative deviation from the fully compensated mode with a 16-bit second pass ({t_ref:.1f} s = {len(pairs) / t_ref:.0f} pairs/s)", flush=True)
+print("| mode (e4m3 second pass where compensated: the default) | pairs/s | max | rms | median | 99 % | 99.9 % | entries > 1e-3 | predicted max from the 256-pair sample (n_eval = 48,000) |\n|---|---|---|---|---|---|---|---|---|")
 rows = []
-for mode in (() if os.environ.get("ONLY_LO8") else RU.VTG_MODES[:-1]):
+for mode in RU.VTG_MODES:
     got, dt = run(mode)
     dev = np.abs(got - ref) / np.abs(ref)
     q = np.quantile(dev, [0.5, 0.99, 0.999])
@@ -61,18 +65,4 @@ for mode in (() if os.environ.get("ONLY_LO8") else RU.VTG_MODES[:-1]):
                  "p99.9": float(q[2]), "over_1e-3": int((dev > 1e-3).sum()), "pred_from_sample": pred})
     r = rows[-1]
     print(f"| {mode} | {r['pairs_per_s']:.0f} | {r['max']:.2e} | {r['rms']:.2e} | {r['p50']:.2e} | {r['p99']:.2e} | {r['p99.9']:.2e} | {r['over_1e-3']} | {pred:.2e} |", flush=True)
-if os.environ.get("LO8", "1") != "0":
-    for mode in (("full",) if os.environ.get("ONLY_LO8") else ("full", "act0", "attn")):
-        model.engine.set_option("precise_lo8", 1)
-        try:
-            got, dt = run(mode)
-        finally:
-            model.engine.set_option("precise_lo8", 0)
-        dev = np.abs(got - ref) / np.abs(ref)
-        q = np.quantile(dev, [0.5, 0.99, 0.999])
-        pred = RU.predicted_max_deviation(dev[sel], 48000)
-        rows.append({"mode": mode + " + lo8", "pairs_per_s": round(len(pairs) / dt, 1), "max": float(dev.max()), "rms": float(np.sqrt(np.mean(dev ** 2))), "p50": float(q[0]), "p99": float(q[1]),
-                     "p99.9": float(q[2]), "over_1e-3": int((dev > 1e-3).sum()), "pred_from_sample": pred})
-        r = rows[-1]
-        print(f"| {mode} + lo8 | {r['pairs_per_s']:.0f} | {r['max']:.2e} | {r['rms']:.2e} | {r['p50']:.2e} | {r['p99']:.2e} | {r['p99.9']:.2e} | {r['over_1e-3']} | {pred:.2e} |", flush=True)
 print(json.dumps({"weights": a.weights, "n": a.n, "pairs": len(pairs), "full_pairs_per_s": round(len(pairs) / t_ref, 1), "rows": rows}))
