@@ -208,6 +208,9 @@ class Engine:
         self.device = torch.device("cuda", torch.cuda.current_device())
         # blim_create honours BLIM_PRECISE_MLP / BLIM_PRECISE_ACT (A/B runs): the Python-side cache of those options starts from the same values, so that
         # set_precise() neither clobbers an override nor believes in a default the engine does not have
+        # mirrors the engine's default of option "precise_lo8" (include/blim.h): the compensated modes' second pass over K in e4m3 on fp16 engines
+        self.lo8 = (dtype == "f16" and dims.hidden_size % 128 == 0 and dims.intermediate_size % 128 == 0 and max(dims.hidden_size, dims.intermediate_size) <= 20480
+                    and os.environ.get("BLIM_PRECISE_LO8", "1") != "0")
         self._precise_mlp = os.environ.get("BLIM_PRECISE_MLP", "1") != "0"
         self._precise_act = os.environ.get("BLIM_PRECISE_ACT", "1") != "0"
 
@@ -261,6 +264,8 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         _check(self.lib.blim_set_option(self.h, key.encode(), value), "blim_set_option")
+        if key == "precise_lo8":
+            self.lo8 = bool(value)
 
     @property
     def can_precise(self) -> bool:

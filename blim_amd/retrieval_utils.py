@@ -212,6 +212,25 @@ def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_voc
     return total
 
 
+def e4m3_pass_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, prune: bool = True) -> float:
+    """The part of executed_flops() that runs on the e4m3 MFMA when the engine's option "precise_lo8" is on (fp16 engines, default): the second walk over K of the
+    decoder GEMMs and of lm_head in the compensated modes (attn / act0 / full; `qkx`'s doubled QKV GEMM is a plain-mode kernel and stays 16-bit, and the TVG head's
+    three-term products are 16-bit GEMMs of depth 3 K).  A roofline for such a call prices these flops at the fp8 peak and the rest at the 16-bit one."""
+    if mode not in ("attn", "act0", "full"):
+        return 0.0
+    H, I = dims.hidden_size, dims.intermediate_size
+    q = 2.0 * H * (dims.num_heads + 2 * dims.num_kv_heads) * dims.head_dim
+    o, gu, d = 2.0 * H * H, 4.0 * H * I, 2.0 * H * I
+    g2 = gu if mode in ("act0", "full") else 0.0
+    d2 = d if mode == "full" else 0.0
+    total = dims.num_layers * (q + o + g2 + d2) * n_tokens
+    if prune and n_rows <= n_tokens - n_tokens // 16:
+        total -= (o + g2 + d2) * (n_tokens - n_rows)
+    if kind == "vtg":
+        total += 2.0 * H * dims.vocab_size * n_rows
+    return total
+
+
 TVG_MODES = ("attn", "act0", "full")    # compensation of the TVG calls (always hi + lo embeddings, QKV, attention, o_proj, head), cheapest first: "attn" leaves the MLP branch plain
                                         # (1.6x faster than full), "act0" compensates the MLP's input but not the SwiGLU output (1.1x), "full" everything
 VTG_MODES = ("none", "qk", "qkx", "attn", "act0", "full")   # compensation of the VTG calls, cheapest first (0 / -2.5 / -8.4 / -16.5 / -41 / -50 % on the headline step); "act0" = everything
@@ -297,6 +316,7 @@ class PairScorer:
             else:
                 self.vocab_cm = _clip_major_vocab(video_vocab, self.device, self.m.dtype)
         self.exec_flops = 0.0            # GEMM FLOPs of the engine calls run so far (executed_flops; bench.py's roofline fractions)
+        self.exec_flops_e4m3 = 0.0       # ... of which on the e4m3 MFMA (e4m3_pass_flops: the compensated modes' second pass under the engine's "precise_lo8")
         self.exec_tokens = 0
         self._vfeat: Dict[Tuple[int, bool], object] = {}
         self._upcoming: Dict[bool, List[int]] = {}; self._upcoming_pos: Dict[bool, int] = {}
@@ -565,6 +585,8 @@ class PairScorer:
         if plan.kind == "vtg":
             mode = self.vtg_mode                                             # None (fp16 engines) | "qk" | "attn" | "full" (bf16 engines: modeling.py)
             self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "vtg", mode, prune=not f8)
+            if getattr(self.engine, "lo8", False):
+                self.exec_flops_e4m3 += e4m3_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "vtg", mode, prune=not f8)
             comp = mode in VTG_SPLIT_MODES
             self.engine.set_precise(comp, embeds=comp, mlp=mode in ("act0", "full"), act=mode == "full")
             if mode in ("qk", "qkx"):
@@ -578,6 +600,8 @@ class PairScorer:
                     self.engine.set_option("precise_qk", 0)
         self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode if self.split_tvg else None,
                                           n_vocab=self.n_vocab, prune=not f8)
+        if getattr(self.engine, "lo8", False) and self.split_tvg:
+            self.exec_flops_e4m3 += e4m3_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode, prune=not f8)
         if self.vocab_cm is None and getattr(self.engine, "_vocab_key", None) != self._vocab_key:
             self.engine.set_video_vocab(self._vocab_src)                     # another scorer / the literal path registered its own vocabulary since
         # TVG calls: compensated (3-5 new tokens per pair: cheap); how much of the MLP branch is compensated follows tvg_mode (calibrate_tvg)
@@ -1036,6 +1060,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
     mark("done")
     if isinstance(scorer, PairScorer):
         stats["executed_flops"] = scorer.exec_flops; stats["executed_tokens"] = scorer.exec_tokens
+        stats["executed_flops_e4m3"] = getattr(scorer, "exec_flops_e4m3", 0.0)
     args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank, host_marks=marks)
     t2v_dict["internvideo2"] = t2v_iv2.cpu().numpy()
     v2t_dict["internvideo2"] = v2t_iv2.cpu().numpy()
