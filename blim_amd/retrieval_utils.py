@@ -655,7 +655,34 @@ class PairScorer:
         self.vtg_mode, self.split_vtg = mode, split
         self.m.vtg_precise = mode
 
-    def calibrate_vtg(self, pairs, bar: float = 1e-3, z: float = 4.5, n_eval: Optional[int] = None, tail_margin: float = 0.8):
+    # what a cheaper VTG mode's largest deviation is expected to be, relative to the plain mode's, on weights where plain fails (15 mode x weight-set populations,
+    # profiles/r04_vtg_modes_population.md): used ONLY to skip measuring modes that cannot make it -- a mode is never accepted unmeasured
+    _VTG_GAIN = {"qk": 0.85, "qkx": 0.65, "attn": 0.30, "act0": 0.18}
+
+    def _gather_dev(self, dev: np.ndarray, share) -> np.ndarray:
+        """Multi-rank calibration: every rank scored its own block of the sample; all ranks get all deviations (one all-gather of <= 256 floats)."""
+        if share is None or share[0] <= 1:
+            return dev
+        import torch
+        W = int(share[0])
+        n = int(share[2])                                                   # the largest block
+        buf = torch.full((n,), float("nan"), dtype=torch.float64, device=self.device)
+        buf[: len(dev)] = torch.from_numpy(np.ascontiguousarray(dev, dtype=np.float64)).to(self.device)
+        parts = [torch.empty_like(buf) for _ in range(W)]
+        torch.distributed.all_gather(parts, buf)
+        out = torch.cat(parts).cpu().numpy()
+        return out[~np.isnan(out)]
+
+    @staticmethod
+    def _my_block(pairs: np.ndarray, share):
+        """share = (world, rank): this rank's contiguous block of the sample (whole queries stay together: their prefix is computed once) -> (block, share + largest block)."""
+        if share is None or share[0] <= 1:
+            return pairs, None
+        W, r = int(share[0]), int(share[1])
+        blocks = np.array_split(np.arange(len(pairs)), W)
+        return pairs[blocks[r]], (W, r, max(len(b) for b in blocks))
+
+    def calibrate_vtg(self, pairs, bar: float = 1e-3, z: float = 4.5, n_eval: Optional[int] = None, tail_margin: float = 0.8, share=None):
         """The reference has ONE numeric mode (training_utils.py:142: autocast fp16) and no decision to make; this engine's plain 16-bit VTG
         calls are the fastest of five modes, and whether they hold the 1e-3 bar depends on the checkpoint's statistics (attention sinks,
         massive activations: tests/golden/sink.npz).  So the decision is MEASURED on the loaded weights: `pairs` (up to 256 (video, text)
@@ -673,15 +700,21 @@ class PairScorer:
         pairs = np.asarray(pairs, dtype=np.int64)
         if not bool(getattr(self.engine, "can_precise", False)):              # fp8 engines have no compensated modes
             return "none", {}
+        n_all = len(pairs)
+        pairs, share = self._my_block(pairs, share)                           # share = (world, rank): each rank scores its block, the deviations are all-gathered
         self.set_vtg_mode("full")
-        ref = self.vtg(pairs).astype(np.float64)
+        ref = self.vtg(pairs).astype(np.float64) if len(pairs) else np.zeros(0)
         table = {}
         chosen = "full"
+        limit = tail_margin * bar if (n_eval or 0) > n_all else bar
         for mode in VTG_MODES[:-1]:
+            if "none" in table and mode in self._VTG_GAIN and table["none"]["pred"] * self._VTG_GAIN[mode] > 2.0 * limit:
+                continue                                                       # cannot make it (expected at > 2 x the limit): not worth a pass over the sample
             self.set_vtg_mode(mode)
-            dev = np.abs(self.vtg(pairs).astype(np.float64) - ref) / np.abs(ref)
+            dev = np.abs(self.vtg(pairs).astype(np.float64) - ref) / np.abs(ref) if len(pairs) else np.zeros(0)
+            dev = self._gather_dev(dev, share)
             table[mode] = {"max": float(np.max(dev)), "rms": float(np.sqrt(np.mean(dev * dev))), "pred": predicted_max_deviation(dev, n_eval)}
-            if np.all(np.isfinite(dev)) and table[mode]["max"] <= bar and z * table[mode]["rms"] <= bar and table[mode]["pred"] <= (tail_margin * bar if (n_eval or 0) > len(dev) else bar):
+            if np.all(np.isfinite(dev)) and table[mode]["max"] <= bar and z * table[mode]["rms"] <= bar and table[mode]["pred"] <= limit:
                 chosen = mode
                 break                                                          # the dearer modes are not needed
         self.set_vtg_mode(chosen)
@@ -693,7 +726,7 @@ class PairScorer:
         self.tvg_mode = mode
         self.m.tvg_precise = mode
 
-    def calibrate_tvg(self, pairs, bar: float = 1e-3, z: float = 4.5, n_eval: Optional[int] = None, tail_margin: float = 0.8):
+    def calibrate_tvg(self, pairs, bar: float = 1e-3, z: float = 4.5, n_eval: Optional[int] = None, tail_margin: float = 0.8, share=None):
         """The TVG calls' counterpart of calibrate_vtg (same criterion, same yardstick = the fully compensated mode).  Every TVG call of a 16-bit engine carries its
         embeddings, QKV, attention, o_proj and head as hi + lo; what is decided here is the MLP branch (87 % of the flops): `attn` leaves it plain (1.6x faster than
         `full`), `act0` compensates its input but not the SwiGLU output (1.1x).  Gaussian-like weights need neither more than `attn` since the TVG head is exact
@@ -703,14 +736,19 @@ class PairScorer:
         self.set_tvg_mode("full")
         if not self.split_tvg:                                             # fp8 / fp32-less engines: nothing to choose
             return "full", {}
-        ref = np.concatenate([self.tvg(pairs, False), self.tvg(pairs, True)]).astype(np.float64)
+        n_all = len(pairs)
+        pairs, share = self._my_block(pairs, share)
+        both = lambda: (np.concatenate([self.tvg(pairs, False), self.tvg(pairs, True)]).astype(np.float64) if len(pairs) else np.zeros(0))
+        ref = both()
         table, chosen = {}, "full"
         for mode in TVG_MODES[:-1]:
             self.set_tvg_mode(mode)
-            got = np.concatenate([self.tvg(pairs, False), self.tvg(pairs, True)]).astype(np.float64)
-            dev = np.abs(got - ref) / np.abs(ref)
-            half = len(dev) // 2                                           # likelihood entries, then prior entries: two laws, each extrapolated on its own
-            pred = max(predicted_max_deviation(dev[:half], n_eval), predicted_max_deviation(dev[half:], n_eval))
+            got = both()
+            d_ = np.abs(got - ref) / np.abs(ref) if len(pairs) else np.zeros(0)
+            h_ = len(d_) // 2
+            dl, dp = self._gather_dev(d_[:h_], share), self._gather_dev(d_[h_:], share)      # likelihood entries, prior entries: two laws, each extrapolated on its own
+            dev, half = np.concatenate([dl, dp]), n_all
+            pred = max(predicted_max_deviation(dl, n_eval), predicted_max_deviation(dp, n_eval))
             table[mode] = {"max": float(np.max(dev)), "rms": float(np.sqrt(np.mean(dev * dev))), "pred": pred}
             if np.all(np.isfinite(dev)) and table[mode]["max"] <= bar and z * table[mode]["rms"] <= bar and pred <= (tail_margin * bar if (n_eval or 0) > half else bar):
                 chosen = mode
@@ -864,7 +902,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
                                                                        tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
         kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
         n_eval_vtg = num_videos * kt_ * (2 if args.cpn else 1) + num_texts * kv_                 # VTG-type entries of the whole evaluation (every rank's)
-        chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk, n_queries=32, per_query=8), n_eval=n_eval_vtg)      # 256 pairs, 32 distinct prefixes
+        cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None      # every rank scores its block of the sample; deviations all-gathered
+        chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk, n_queries=32, per_query=8), n_eval=n_eval_vtg, share=cal_share)      # 256 pairs, 32 distinct prefixes
         chosen = agree(chosen, VTG_MODES, cal.set_vtg_mode)
         stats["vtg_precise"] = chosen; stats["vtg_precise_table"] = table
         if rank == 0:
@@ -880,7 +919,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
         # (heavy7b weights, N = 1,000: sample rms 2.7e-5 against 5.0e-5 over the whole evaluation, and `attn` was let through with 5 of 48,000 entries above the bar)
         tp = calibration_pairs(t2v_iv2, args.topk, n_queries=64, per_query=4)      # 256 pairs x (likelihood, prior) = 512 entries, 64 distinct text prefixes
         kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
-        chosen, table = cal.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1), n_eval=num_videos * kt_ + num_texts * kv_ * (2 if args.cpn else 1))
+        cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None
+        chosen, table = cal.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1), n_eval=num_videos * kt_ + num_texts * kv_ * (2 if args.cpn else 1), share=cal_share)
         chosen = agree(chosen, TVG_MODES, cal.set_tvg_mode)
         stats["tvg_precise"] = chosen; stats["tvg_precise_table"] = table
         if rank == 0:

@@ -19,6 +19,7 @@ ap.add_argument("--n", type=int, default=1000)
 ap.add_argument("--topk", type=int, default=16)
 ap.add_argument("--weights", default="gaussian", choices=["gaussian", "sink7b", "heavy7b"])
 ap.add_argument("--dtype", default="f16")
+ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic problem (videos, texts, similarity matrices)")
 ap.add_argument("--vtg", action="store_true", help="validate `--vtg_precise auto` the same way (the yardstick run then has its VTG calls fully compensated too: 2x the time)")
 a = ap.parse_args()
 
@@ -33,7 +34,7 @@ model.engine.init_synthetic_weights(wseed)
 if a.weights != "gaussian":
     for name, arr in heavy_items(dims, wseed, only_changed=True, sink=bool(spec.get("sink", False))):
         model.engine.load_weight(name, arr)
-prob = synth.make_problem(1, a.n, dims, tok_per_clip=64, fast_video=True)
+prob = synth.make_problem(a.seed, a.n, dims, tok_per_clip=64, fast_video=True)
 loader = synth.ProblemLoader(prob, 64, video_dtype=torch.float16)
 tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
 nz = lambda x: np.where(x == 0, np.float32(1e-6), x)
@@ -50,7 +51,7 @@ for mode in ("full", "auto"):
     st = args._eval_stats
     out[mode] = (t2v, v2t, time.time() - t0, st.get("tvg_precise", mode), st.get("tvg_precise_table", {}), st.get("vtg_precise"), st.get("vtg_precise_table"))
 (t2v_f, v2t_f, s_f, _, _, _, _), (t2v_a, v2t_a, s_a, chosen, table, vchosen, vtable) = out["full"], out["auto"]
-rep = {"weights": a.weights, "dtype": a.dtype, "n": a.n, "chosen": chosen, "sample_table": table, "vtg_chosen": vchosen, "vtg_sample_table": vtable,
+rep = {"weights": a.weights, "dtype": a.dtype, "n": a.n, "seed": a.seed, "chosen": chosen, "sample_table": table, "vtg_chosen": vchosen, "vtg_sample_table": vtable,
        "seconds_full": round(s_f, 2), "seconds_auto": round(s_a, 2)}
 for name, F, A in (("t2v candidate_likelihood (TVG)", t2v_f["candidate_likelihood"], t2v_a["candidate_likelihood"]),
                    ("t2v candidate_prior (TVG, CPN)", t2v_f["candidate_prior"], t2v_a["candidate_prior"]),
