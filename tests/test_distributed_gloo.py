@@ -273,3 +273,37 @@ def test_forced_collectives_at_world_size_one_change_no_bit():
         assert np.array_equal(t2v[k], ref_t2v[k]), ("t2v", k)
     for k in ref_v2t:
         assert np.array_equal(v2t[k], ref_v2t[k]), ("v2t", k)
+
+
+# ----------------------------------------------------------------------------- sharded calibration sample (`--vtg_precise` / `--tvg_precise auto` at W > 1)
+def _cal_worker(rank, world, port, out_q):
+    import types
+    from blim_amd import retrieval_utils as RU
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D.init_distributed_mode(backend="gloo")
+    pairs = np.stack([np.repeat(np.arange(9), 5), np.arange(45) % 7], axis=1)           # 9 queries x 5 candidates
+    mine, share = RU.PairScorer._my_block(pairs, (world, rank))
+    dev_all = np.abs(np.random.RandomState(3).randn(len(pairs))) * 1e-4                  # the deviation "of pair k" (what a rank would measure on its block)
+    k0 = int(np.nonzero((pairs == mine[0]).all(axis=1))[0][0])
+    got = RU.PairScorer._gather_dev(types.SimpleNamespace(device=torch.device("cpu")), dev_all[k0:k0 + len(mine)], share)
+    out_q.put((rank, len(mine), sorted(got.tolist()) == sorted(dev_all.tolist()), RU.predicted_max_deviation(got, 48000)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_calibration_sample_is_split_over_the_ranks_and_gathered():
+    """PairScorer.calibrate_*'s `share`: each rank scores one contiguous block of the sample; every rank then holds ALL deviations (same decision everywhere)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [23, 22] and all(r[2] for r in res) and res[0][3] == res[1][3]
+    from blim_amd import retrieval_utils as RU
+    pairs = np.zeros((5, 2), np.int64)
+    assert RU.PairScorer._my_block(pairs, None)[1] is None and RU.PairScorer._my_block(pairs, (1, 0))[1] is None      # no process group: the whole sample, no gather
