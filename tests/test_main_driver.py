@@ -182,6 +182,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert d["metric"].startswith("candidate-pairs/sec") and d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f16"
     assert "workload" in d["config"] and "model" not in d["config"]
+    cm = d["compensated_mode"]              # the same step with fully compensated VTG calls, reported beside the headline (never as `value`)
+    assert cm["vtg_compensated"] == "full" and cm["finite"] is True and 0.4 * d["value"] < cm["value"] < 0.9 * d["value"] and cm["second_pass"].startswith("e4m3")
+    assert 0 < cm["frac_mfma_peak_whole_step"] < 1
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
