@@ -253,6 +253,7 @@ extern "C" int blim_train_merge(blim_trainer* t, void* stream) {
     TRY(launch_f32_to_16(e->visual_head, H, P + t->lay.off_vh, H, M, H, 1.0f, dt, s));
     TRY(engine_set_visual_head3(e, P + t->lay.off_vh, BLIM_DTYPE_F32, s));      // the scoring path's hi + lo copy of the head
     e->f8_ready = false;
+    e->lo8_ready = false;          // the e4m3 copies of the compensated modes' second pass follow the merged weights
     e->lora_merged = true;
     return BLIM_OK;
 }
