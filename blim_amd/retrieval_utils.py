@@ -661,7 +661,7 @@ class PairScorer:
 
     def _gather_dev(self, dev: np.ndarray, share) -> np.ndarray:
         """Multi-rank calibration: every rank scored its own block of the sample; all ranks get all deviations (one all-gather of <= 256 floats)."""
-        if share is None or share[0] <= 1:
+        if share is None:
             return dev
         import torch
         W = int(share[0])
@@ -676,7 +676,7 @@ class PairScorer:
     @staticmethod
     def _my_block(pairs: np.ndarray, share):
         """share = (world, rank): this rank's contiguous block of the sample (whole queries stay together: their prefix is computed once) -> (block, share + largest block)."""
-        if share is None or share[0] <= 1:
+        if share is None or (share[0] <= 1 and not dist_utils.force_collective()):       # (world size 1 with BLIM_FORCE_COLLECTIVE=1: the gather runs, through RCCL, on one block)
             return pairs, None
         W, r = int(share[0]), int(share[1])
         blocks = np.array_split(np.arange(len(pairs)), W)
