@@ -799,6 +799,45 @@ def test_e4m3_second_pass_of_the_compensated_gemms(case, capsys):
     assert 0.0 < max(between.values()) < 1e-4, between
 
 
+def test_e4m3_weight_copies_follow_the_weights():
+    """The e4m3 copies the compensated modes' second pass reads (option "precise_lo8") are derived state: replacing weights in a live engine must rebuild them.  A stale
+    copy would be a SILENT error of ~2^-11 of the weight change -- so: an engine that has already run compensated calls gets another weight set loaded over the first
+    (all tensors, then a single decoder matrix) and must score bit for bit like a fresh engine loaded with the same tensors."""
+    spec = CASES["tiny"]
+    dims = synth.ModelDims(**spec["dims"])
+    prob = synth.make_problem(spec["pseed"], spec["n"], dims, tok_per_clip=spec["tok_per_clip"], text_len=spec["text_len"])
+    w1, w2 = synth.synthetic_weights(dims, 11), synth.synthetic_weights(dims, 12)
+    w3 = dict(w2); w3["layers.1.down_proj.w"] = w1["layers.1.down_proj.w"]
+
+    def scores(model):
+        t = types.SimpleNamespace(spec=spec, dims=dims, model=model, prob=prob, dtype="f16", case="tiny")
+        model.set_tvg_prefix_length(prob.tvg_prefix_length)
+        model.vtg_precise = "full"
+        return _six_passes(t, False)
+
+    live = BlimModel(dims, max_positions=1024, dtype="f16")
+    try:
+        assert live.engine.lo8
+        live.engine.load_weights(w1)
+        s1 = scores(live)                                              # builds the copies of w1
+        live.engine.load_weights(w2)
+        s2 = scores(live)
+        live.engine.load_weight("layers.1.down_proj.w", w3["layers.1.down_proj.w"])
+        s3 = scores(live)
+    finally:
+        live.engine.close()
+    for w, got in ((w2, s2), (w3, s3)):
+        fresh = BlimModel(dims, max_positions=1024, dtype="f16")
+        try:
+            fresh.engine.load_weights(w)
+            want = scores(fresh)
+        finally:
+            fresh.engine.close()
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+    assert not np.array_equal(s1["v2t_vtg"], s2["v2t_vtg"]) and not np.array_equal(s2["v2t_vtg"], s3["v2t_vtg"])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_last_layer_pruning_changes_no_bit(dtype):
     """Engine option "prune_last" (default on): a call that names the rows it reads runs the last layer's o_proj / norm / MLP on those rows only.
