@@ -666,12 +666,13 @@ class PairScorer:
         import torch
         W = int(share[0])
         n = int(share[2])                                                   # the largest block
-        buf = torch.full((n,), float("nan"), dtype=torch.float64, device=self.device)
+        buf = torch.full((n,), -1.0, dtype=torch.float64, device=self.device)            # padding: -1 (a deviation is >= 0; a non-finite one travels as +inf and rejects the mode)
+        dev = np.where(np.isfinite(dev), dev, np.inf)
         buf[: len(dev)] = torch.from_numpy(np.ascontiguousarray(dev, dtype=np.float64)).to(self.device)
         parts = [torch.empty_like(buf) for _ in range(W)]
         torch.distributed.all_gather(parts, buf)
         out = torch.cat(parts).cpu().numpy()
-        return out[~np.isnan(out)]
+        return out[out >= 0.0]
 
     @staticmethod
     def _my_block(pairs: np.ndarray, share):
