@@ -1,5 +1,6 @@
 // HBM-bound helper kernels (see kernels.hpp).  All loads/stores are 8-16 B per lane.
 #include "kernels.hpp"
+#include <stdlib.h>
 
 #define LAUNCH_CHECK(name)                                                           \
     do {                                                                             \
@@ -570,8 +571,31 @@ __device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e w
     int ex; const float m = frexpf(x, &ex);                      // x = m 2^ex, m in [0.5, 1)
     return m == 0.5f ? ex - 1 : ex;
 }
+// EXPERIMENT (round 5, tools/lo_format_probe.py): round the scaled values of a 32-element block onto the grid a narrower MX format would keep -- e2m3 (emu = 1)
+// or e2m1 (emu = 2) times the block's own power-of-two scale -- before they are stored as e4m3 (which holds every such value exactly while the block's maximum is
+// within 2^12 of the 128-block's).  The four consecutive lanes that own a 32-block share its maximum.  Emulates the NUMERICS of an fp6 / fp4 second pass exactly.
+__device__ __forceinline__ void emulate_narrow(float (&f)[8], int emu) {
+    if (emu == 0) return;
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[j]));
+    m = fmaxf(m, __shfl_xor(m, 1, 4)); m = fmaxf(m, __shfl_xor(m, 2, 4));
+    if (!(m > 0.f) || !(m < 3.0e38f)) return;
+    const float top = emu == 1 ? 7.5f : 6.0f;
+    int ex; const float mant = frexpf(m / top, &ex);
+    if (mant == 0.5f) ex -= 1;
+    const float up = ldexpf(1.0f, ex), dn = ldexpf(1.0f, -ex);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = fabsf(f[j]) * dn;
+        const float step = emu == 1 ? (a < 2.f ? 0.125f : a < 4.f ? 0.25f : 0.5f) : (a < 2.f ? 0.5f : a < 4.f ? 1.0f : 2.0f);
+        const float q = fminf(rintf(a / step) * step, top);
+        f[j] = copysignf(q * up, f[j]);
+    }
+}
+static int lo_emulate(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
 template <int DT>
-__global__ __launch_bounds__(256) void quant_rows_e8_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, uint8_t* e8) {
+__global__ __launch_bounds__(256) void quant_rows_e8_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, uint8_t* e8, int emu) {
     constexpr int MAXC = 10;
     __shared__ float red[4];
     const int64_t r = blockIdx.x;
@@ -605,20 +629,21 @@ __global__ __launch_bounds__(256) void quant_rows_e8_kernel(const bf16_t* in, in
             float f[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = from16<DT>(e[j]) * inv;
+            emulate_narrow(f, emu);
             *(uint2*)(out8 + r * K + 8 * c) = make_uint2(pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7]));
         }
     }
 }
 int launch_quant_rows_e8(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, uint8_t* e8, hipStream_t s) {
     ARG_CHECK(in && out8 && e8 && n_rows > 0 && K > 0 && K % 8 == 0 && ld % 8 == 0 && K <= 256 * 8 * 10);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_e8_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8);
-    else hipLaunchKernelGGL((quant_rows_e8_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_e8_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8, lo_emulate("BLIM_LO_EMULATE_W"));
+    else hipLaunchKernelGGL((quant_rows_e8_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8, lo_emulate("BLIM_LO_EMULATE_W"));
     LAUNCH_CHECK("quant_rows_e8");
     return BLIM_OK;
 }
 // one thread per 8 columns, 16 consecutive lanes per 128-column block; 4 rows per 256-thread workgroup pass over the chunks
 template <int DT>
-__global__ __launch_bounds__(256) void quant_lo_mx_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride) {
+__global__ __launch_bounds__(256) void quant_lo_mx_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride, int emu) {
     const int64_t r = blockIdx.x;
     const bf16_t* row = in + r * ld;
     const int nchunk = K / 8;
@@ -637,14 +662,15 @@ __global__ __launch_bounds__(256) void quant_lo_mx_kernel(const bf16_t* in, int6
         const float inv = ex > -127 ? ldexpf(1.0f, -ex) : 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] *= inv;
+        emulate_narrow(f, emu);
         *(uint2*)(out8 + r * ld8 + 8 * c) = make_uint2(pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7]));
         if ((threadIdx.x & 15) == 0) mx[(int64_t)(c >> 4) * mx_stride + mpos] = (uint8_t)(ex + 127);
     }
 }
 int launch_quant_lo_mx(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride, hipStream_t s) {
     ARG_CHECK(in && out8 && mx && n_rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld8 % 16 == 0 && ld8 >= K && mx_stride >= round_up256(n_rows));
-    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_lo_mx_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride);
-    else hipLaunchKernelGGL((quant_lo_mx_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_lo_mx_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride, lo_emulate("BLIM_LO_EMULATE_A"));
+    else hipLaunchKernelGGL((quant_lo_mx_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride, lo_emulate("BLIM_LO_EMULATE_A"));
     LAUNCH_CHECK("quant_lo_mx");
     return BLIM_OK;
 }

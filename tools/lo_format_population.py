@@ -1,0 +1,74 @@
+"""The second pass's operand format over a WHOLE pass (companion of tools/lo_format_probe.py): the 16 N v2t VTG pairs of an N x top-16 evaluation (real 7B
+configuration, reference-shaped rows), every call fully compensated, scored with the lo pass (a) in fp16 (the yardstick: <= 4e-6 from the fp32 reference),
+(b) in e4m3 (round 4's kernels), (c) with the quantisers emulating narrower MX formats on the e4m3 kernels (BLIM_LO_EMULATE_A / _W: 1 = e2m3, 2 = e2m1 per 32-block).
+
+    python tools/lo_format_population.py [--weights gaussian|sink7b|heavy7b] [--n 1000] [--formats e4m3,e2m3,...]
+"""
+import argparse, json, os, sys, time, types
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from blim_amd import retrieval_utils as RU, synth
+from blim_amd.modeling import BlimModel, DDPLike
+
+FORMATS = {"fp16": None, "e4m3": (0, 0), "e2m3": (1, 1), "e2m3_a_only": (1, 0), "e2m3_w_only": (0, 1), "e2m1": (2, 2), "e2m1_a_e2m3_w": (2, 1)}
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1000)
+ap.add_argument("--weights", default="heavy7b", choices=["gaussian", "sink7b", "heavy7b"])
+ap.add_argument("--formats", default="fp16,e4m3,e2m3,e2m3_a_only,e2m3_w_only,e2m1")
+a = ap.parse_args()
+dims = synth.ModelDims()
+prob = synth.make_problem(1, a.n, dims, tok_per_clip=64, fast_video=True)
+tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+Tt = lambda rows: [torch.from_numpy(r) for r in rows]
+vtg = RU.padding_ids(Tt(prob.vtg_ids), Tt(prob.vtg_labels), Tt(prob.vtg_masks), tok)
+tvg = RU.padding_ids(Tt(prob.tvg_ids), Tt(prob.tvg_labels), Tt(prob.tvg_masks), tok)
+video = [torch.from_numpy(v).half() for v in prob.video]
+pairs = RU._topk_pairs(torch.from_numpy(prob.v2t_sims), 0, 16, True)
+
+
+def run(fmt):
+    model = BlimModel(dims, max_positions=1024, dtype="f16")
+    try:
+        wseed = 0
+        if a.weights != "gaussian":
+            from oracle.gen_golden_heavy import CASES, heavy_items          # (development aid: the reshaped tensors of the trained-like fixtures)
+            spec = CASES[a.weights]; wseed = spec["wseed"]
+        model.engine.init_synthetic_weights(wseed)
+        if a.weights != "gaussian":
+            for name, arr in heavy_items(dims, wseed, only_changed=True, sink=bool(spec.get("sink", False))):
+                model.engine.load_weight(name, arr)
+        model.set_tvg_prefix_length(prob.tvg_prefix_length)
+        model.vtg_precise = "full"
+        if FORMATS[fmt] is None:
+            model.engine.set_option("precise_lo8", 0)
+        else:
+            os.environ["BLIM_LO_EMULATE_A"], os.environ["BLIM_LO_EMULATE_W"] = str(FORMATS[fmt][0]), str(FORMATS[fmt][1])
+        sc = RU.PairScorer(DDPLike(model), vtg[0], vtg[2], vtg[1], tvg[0], tvg[2], tvg[1], video, torch.from_numpy(prob.video_vocab), torch.from_numpy(prob.tvg_video_labels),
+                           dims.num_clips, max_tokens=32768)
+        sc.set_vtg_mode("full")
+        sc.vtg(pairs[:256])
+        torch.cuda.synchronize(); t0 = time.time()
+        out = sc.vtg(pairs).astype(np.float64)
+        torch.cuda.synchronize()
+        return out, time.time() - t0
+    finally:
+        model.engine.close()
+
+
+ref, t_ref = run("fp16")
+print(f"[{a.weights}] N = {a.n}: {len(pairs)} v2t VTG pairs, every call fully compensated; relative deviation from the fp16 second pass ({len(pairs) / t_ref:.0f} pairs/s)", flush=True)
+print("| second-pass operands (A = x_lo, W) | max | rms | median | 99 % | 99.9 % | entries > 1e-4 | entries > 1e-3 |\n|---|---|---|---|---|---|---|---|")
+rows = []
+for fmt in a.formats.split(","):
+    if fmt == "fp16":
+        continue
+    got, dt = run(fmt)
+    dev = np.abs(got - ref) / np.abs(ref)
+    q = np.quantile(dev, [0.5, 0.99, 0.999])
+    rows.append({"format": fmt, "max": float(dev.max()), "rms": float(np.sqrt(np.mean(dev ** 2))), "p50": float(q[0]), "p99": float(q[1]), "p99.9": float(q[2]),
+                 "over_1e-4": int((dev > 1e-4).sum()), "over_1e-3": int((dev > 1e-3).sum())})
+    r = rows[-1]
+    print(f"| {fmt} | {r['max']:.2e} | {r['rms']:.2e} | {r['p50']:.2e} | {r['p99']:.2e} | {r['p99.9']:.2e} | {r['over_1e-4']} | {r['over_1e-3']} |", flush=True)
+print(json.dumps({"weights": a.weights, "n": a.n, "pairs": len(pairs), "rows": rows}))
