@@ -205,7 +205,7 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
             st["executed_flops_job"], st["executed_flops_e4m3_job"] = float(f[0].item()), float(f[1].item())
         return dt, st, (t2v, v2t)
 
-    # seconds the executed FLOPs would take at the dense peaks: the e4m3 second pass of compensated calls (engine option "precise_lo8") at the fp8 peak, the rest
+    # seconds the executed FLOPs would take at the dense peaks: the e4m3 second pass of compensated calls (engine option "precise_lo6") at the fp8 peak, the rest
     # at this engine's own (16-bit or fp8) peak
     at_peak = lambda total, f8: ((total - f8) / peak + f8 / (PEAK_FP8_TFLOPS * 1e12))
     run((4 * max(world, emulate), rank))                                      # warm-up: workspaces, allocator, first-call costs (a small share)
@@ -397,9 +397,9 @@ def main():
                 out_c = sc_c.run(pl_c)
             torch.cuda.synchronize(); dtc = (time.perf_counter() - tc) / 3
             fl = RU.executed_flops(dims, pl_c.n_tokens, pl_c.n_rows, "vtg", "full")
-            f8 = RU.e4m3_pass_flops(dims, pl_c.n_tokens, pl_c.n_rows, "vtg", "full") if getattr(model.engine, "lo8", False) else 0.0
+            f8 = RU.e4m3_pass_flops(dims, pl_c.n_tokens, pl_c.n_rows, "vtg", "full") if getattr(model.engine, "lo6", False) else 0.0
             comp = {"vtg_compensated": "full", "value": round(pl_c.n_pairs / dtc, 2), "unit": "pairs/s", "ms_per_step": round(dtc * 1e3, 3), "finite": bool(torch.isfinite(out_c).all()),
-                    "second_pass": "e4m3 (engine option precise_lo8)" if f8 else "16-bit",
+                    "second_pass": "e4m3 (engine option precise_lo6)" if f8 else "16-bit",
                     "frac_mfma_peak_whole_step": round(((fl - f8) / (PEAK_BF16_TFLOPS * 1e12) + f8 / (PEAK_FP8_TFLOPS * 1e12)) / dtc, 4),
                     "note": "same batch, every activation hi + lo; <= 4e-5 from the fp32 reference at 7B depth (tests/test_gpu_parity.py::test_e4m3_second_pass_of_the_compensated_gemms)"}
         except Exception as e:
@@ -419,9 +419,9 @@ def main():
         d = rep[dom]
         ach = d["flops"] / d["calls"] / (d["ms"] / d["calls"] * 1e-3) / 1e12
         peak = PEAK_FP8_TFLOPS if model.engine.dtype == "f8" else PEAK_BF16_TFLOPS
-        # compensated modes on an fp16 engine (option "precise_lo8", default): the second walk over K runs on the e4m3 MFMA -- those flops are priced at the fp8
+        # compensated modes on an fp16 engine (option "precise_lo6", default): the second walk over K runs on the e4m3 MFMA -- those flops are priced at the fp8
         # peak, the rest at the 16-bit one: peak_mixed = flops / (flops16 / P16 + flops8 / P8).  Plain modes (the headline): share 0, nothing changes.
-        lo8 = bool(getattr(model.engine, "lo8", False))
+        lo8 = bool(getattr(model.engine, "lo6", False))
         e4m3_step = RU.e4m3_pass_flops(dims, n_tok, n_rows, "vtg", model.vtg_precise, prune=True) if lo8 else 0.0
         mixed = lambda total, f8: total / ((total - f8) / PEAK_BF16_TFLOPS + f8 / PEAK_FP8_TFLOPS) if total > 0 else PEAK_BF16_TFLOPS
         peak_step = mixed(exec_flops_step, e4m3_step) if model.engine.dtype != "f8" else peak

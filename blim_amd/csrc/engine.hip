@@ -134,9 +134,9 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     if (getenv("BLIM_F8_FUSE")) e->f8_fuse = atoi(getenv("BLIM_F8_FUSE"));
     if (getenv("BLIM_PRECISE_MLP")) e->precise_mlp = atoi(getenv("BLIM_PRECISE_MLP")) != 0;
     if (getenv("BLIM_PRECISE_ACT")) e->precise_act = atoi(getenv("BLIM_PRECISE_ACT")) != 0;
-    // fp16 engines: the compensated modes' second pass over K runs in e4m3 (gemm.hip, phase 2) unless BLIM_PRECISE_LO8=0 / option "precise_lo8" = 0
-    e->lo8 = !e->f8 && cfg->compute_dtype == DT_F16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 && cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480;
-    if (getenv("BLIM_PRECISE_LO8") && atoi(getenv("BLIM_PRECISE_LO8")) == 0) e->lo8 = false;
+    // fp16 engines: the compensated modes' second pass over K runs in e2m3 (gemm.hip, phase 2) unless BLIM_PRECISE_LO6=0 / option "precise_lo6" = 0
+    e->lo6 = !e->f8 && cfg->compute_dtype == DT_F16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 && cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480;
+    if (getenv("BLIM_PRECISE_LO6") && atoi(getenv("BLIM_PRECISE_LO6")) == 0) e->lo6 = false;
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -181,10 +181,9 @@ extern "C" void blim_destroy(blim_engine* e) {
     for (void* p : e->owned) hipFree(p);
     for (void* p : e->aug_owned) hipFree(p);
     for (void* p : e->ad_owned) hipFree(p);
-    if (e->lm8_lo) hipFree(e->lm8_lo);
-    if (e->e_lm) hipFree(e->e_lm);
+    if (e->lm_c6) hipFree(e->lm_c6);
     DevBuf* bufs[] = {&e->visual_head3, &e->hs3, &e->vocab3, &e->vocab1, &e->vh3, &e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale, &e->lo_mx, &e->h8_lo, &e->h_mx};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -269,9 +268,13 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
     if (name == "visual_head") TRY(engine_set_visual_head3(e, dev_src, dtype, 0));
     e->loaded[name] = true;
     e->f8_ready = false;
-    e->lo8_ready = false;
+    e->lo6_ready = false;
+    if (s.kind == 0) e->c6_dirty.insert(s.dst);              // (finalize_lo6 re-derives the combined copy of THIS matrix only)
     e->aug_ready = false;          // the augmented copies of adapted weights are rebuilt from the placed base weights on the next call
-    if (name != "visual_head") e->lora_merged = false;       // the caller is (re)loading base weights: the mark of a merged update (blim_train_merge) goes with them
+    // A merged update (blim_train_merge) stays marked until EVERY adapted matrix has been re-placed: reloading one tensor -- a norm, a bias, one projection -- must
+    // not lift the "update would apply twice" guard of blim_load_adapter while the other projections still hold W + s B A.
+    e->merged_pending.erase(name);
+    if (e->merged_pending.empty()) e->lora_merged = false;
     return BLIM_OK;
 }
 
@@ -359,43 +362,63 @@ static int finalize_f8(blim_engine* e) {
 }
 
 static int build_aug(blim_engine* e);
-// option "precise_lo8": e4m3 copies of the decoder weights with E8M0 (power-of-two) row scales, for the second pass of the compensated GEMMs
-static int finalize_lo8(blim_engine* e) {
-    if (!e->lo8 || e->lo8_ready) return BLIM_OK;
+// option "precise_lo6": the combined copies [W16 | e2m3 image] the compensated GEMMs read (kernels.hpp: launch_combine_w_f6).  Derived state, kept per matrix: a
+// copy is rebuilt when its source matrix was (re)placed since (c6_dirty), the augmented matrices' copies when the augmented matrices were rebuilt -- loading new
+// adapters every epoch (training.py: adapters_into_engine) does not touch the 0.6 GB per layer of the MLP's copies.  Allocation failures say what was being built.
+static int c6_alloc(blim_engine* e, uint8_t** q, size_t bytes, bool aug, const char* what) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        blim_set_error("option 'precise_lo6': out of device memory for the combined 16-bit | e2m3 copy of %s (%zu MB; the copies take 3 bytes per decoder / head weight: "
+                       "set option 'precise_lo6' = 0 to run the second pass on the 16-bit weights instead)", what, bytes >> 20);
+        return BLIM_ERR_NOMEM;
+    }
+    (aug ? e->aug_owned : e->owned).push_back(p);
+    *q = (uint8_t*)p;
+    return BLIM_OK;
+}
+static int finalize_lo6(blim_engine* e) {
+    if (!e->lo6 || e->lo6_ready) return BLIM_OK;
     TRY(blim_weights_ready(e));
     const blim_config& c = e->c;
-    const int H = c.hidden_size, I = c.intermediate_size;
+    const int H = c.hidden_size, I = c.intermediate_size, dt = c.compute_dtype;
+    auto base = [&](uint8_t** copy, const bf16_t* w, int64_t n, int K, const char* what) -> int {
+        if (*copy && !e->c6_dirty.count((const void*)w)) return BLIM_OK;
+        if (!*copy) TRY(c6_alloc(e, copy, (size_t)n * K * 3, false, what));
+        return launch_combine_w_f6(w, K, n, K, dt, *copy, 0);
+    };
     for (auto& l : e->L) {
-        if (!l.wqkv8) { TRY(dev_alloc(e, (void**)&l.wqkv8, (size_t)e->qkv_n * H)); TRY(dev_alloc(e, (void**)&l.wo8, (size_t)H * H));
-                        TRY(dev_alloc(e, (void**)&l.wgu8, (size_t)2 * I * H)); TRY(dev_alloc(e, (void**)&l.wd8, (size_t)H * I)); }
-        if (!l.eqkv) { TRY(dev_alloc(e, (void**)&l.eqkv, (size_t)e->qkv_n)); TRY(dev_alloc(e, (void**)&l.eo, (size_t)H)); TRY(dev_alloc(e, (void**)&l.egu, (size_t)2 * I)); TRY(dev_alloc(e, (void**)&l.ed, (size_t)H)); }
-        TRY(launch_quant_rows_e8(l.wqkv, H, e->qkv_n, H, c.compute_dtype, l.wqkv8, l.eqkv, 0));
-        TRY(launch_quant_rows_e8(l.wo, H, H, H, c.compute_dtype, l.wo8, l.eo, 0));
-        TRY(launch_quant_rows_e8(l.wgu, H, 2 * (int64_t)I, H, c.compute_dtype, l.wgu8, l.egu, 0));
-        TRY(launch_quant_rows_e8(l.wd, I, H, I, c.compute_dtype, l.wd8, l.ed, 0));
+        TRY(base(&l.wqkv_c6, l.wqkv, e->qkv_n, H, "q/k/v_proj")); TRY(base(&l.wo_c6, l.wo, H, H, "o_proj"));
+        TRY(base(&l.wgu_c6, l.wgu, 2 * (int64_t)I, H, "gate/up_proj")); TRY(base(&l.wd_c6, l.wd, H, I, "down_proj"));
     }
     if (e->aug) {                         // adapters apart: the adapted projections' augmented weights [W | B_hi | B_lo | 0] (K = H + aug, a multiple of 128)
         TRY(build_aug(e));
         const int Hq = H + e->aug;
         for (auto& d : e->AD) {
-            auto alloc8 = [&](uint8_t** q, size_t n) -> int { HIP_TRY(hipMalloc((void**)q, n)); e->aug_owned.push_back(*q); return BLIM_OK; };
-            if (!d.wqkv_aug8) { TRY(alloc8(&d.wqkv_aug8, (size_t)e->qkv_n * Hq)); TRY(alloc8(&d.wo_aug8, (size_t)H * Hq)); TRY(alloc8(&d.eqkv_aug, (size_t)e->qkv_n)); TRY(alloc8(&d.eo_aug, (size_t)H)); }
-            TRY(launch_quant_rows_e8(d.wqkv_aug, Hq, e->qkv_n, Hq, c.compute_dtype, d.wqkv_aug8, d.eqkv_aug, 0));
-            TRY(launch_quant_rows_e8(d.wo_aug, Hq, H, Hq, c.compute_dtype, d.wo_aug8, d.eo_aug, 0));
+            if (d.wqkv_aug_c6) continue;                                  // built since the augmented matrices were (free_aug clears the pointers)
+            TRY(c6_alloc(e, &d.wqkv_aug_c6, (size_t)e->qkv_n * Hq * 3, true, "q/k/v_proj + adapters")); TRY(c6_alloc(e, &d.wo_aug_c6, (size_t)H * Hq * 3, true, "o_proj + adapters"));
+            TRY(launch_combine_w_f6(d.wqkv_aug, Hq, e->qkv_n, Hq, dt, d.wqkv_aug_c6, 0));
+            TRY(launch_combine_w_f6(d.wo_aug, Hq, H, Hq, dt, d.wo_aug_c6, 0));
         }
     }
     {   // lm_head: the augmented copy when adapters are apart (rebuilt with them), the base matrix otherwise
         const int Hl = H + e->aug;
-        if (e->lm8_k != Hl) {
-            if (e->lm8_lo) { hipFree(e->lm8_lo); e->lm8_lo = nullptr; }
-            HIP_TRY(hipMalloc((void**)&e->lm8_lo, (size_t)c.vocab_size * Hl));
-            if (!e->e_lm) HIP_TRY(hipMalloc((void**)&e->e_lm, (size_t)c.vocab_size));
-            e->lm8_k = Hl;
+        const bf16_t* src = e->aug ? (const bf16_t*)e->lm_aug : e->lm_head;
+        if (e->lm_c6_k != Hl) {
+            if (e->lm_c6) { hipFree(e->lm_c6); e->lm_c6 = nullptr; }
+            if (hipMalloc((void**)&e->lm_c6, (size_t)c.vocab_size * Hl * 3) != hipSuccess) {
+                (void)hipGetLastError(); e->lm_c6 = nullptr; e->lm_c6_k = 0;
+                blim_set_error("option 'precise_lo6': out of device memory for the combined copy of lm_head (%zu MB)", ((size_t)c.vocab_size * Hl * 3) >> 20);
+                return BLIM_ERR_NOMEM;
+            }
+            e->lm_c6_k = Hl; e->lm_c6_src = nullptr;
         }
-        TRY(launch_quant_rows_e8(e->aug ? (const bf16_t*)e->lm_aug : e->lm_head, Hl, c.vocab_size, Hl, c.compute_dtype, e->lm8_lo, e->e_lm, 0));
+        if (e->lm_c6_src != (const void*)src || e->aug || e->c6_dirty.count((const void*)e->lm_head)) TRY(launch_combine_w_f6(src, Hl, c.vocab_size, Hl, dt, e->lm_c6, 0));
+        e->lm_c6_src = (const void*)src;
     }
     HIP_TRY(hipDeviceSynchronize());
-    e->lo8_ready = true;
+    e->c6_dirty.clear();
+    e->lo6_ready = true;
     return BLIM_OK;
 }
 
@@ -426,11 +449,11 @@ static AdapterW* find_adapter(blim_engine* e, const std::string& name, int* n_ou
 static void free_aug(blim_engine* e) {
     for (void* p : e->aug_owned) hipFree(p);
     e->aug_owned.clear();
-    for (auto& l : e->AD) { l.wqkv_aug = l.wo_aug = nullptr; l.wqkv_aug8 = l.wo_aug8 = l.eqkv_aug = l.eo_aug = nullptr; for (auto& a : l.ad) a.A16 = nullptr; }
+    for (auto& l : e->AD) { l.wqkv_aug = l.wo_aug = nullptr; l.wqkv_aug_c6 = l.wo_aug_c6 = nullptr; for (auto& a : l.ad) a.A16 = nullptr; }
     e->lm_aug = nullptr; e->ad_lm.A16 = nullptr;
     for (int w = 0; w < 2; ++w) { e->w0_aug[w] = e->w2_aug[w] = nullptr; e->ad_mlp[w][0].A16 = e->ad_mlp[w][1].A16 = nullptr; }
     e->aug_ready = false;
-    e->lo8_ready = false;                 // (the e4m3 copies of the augmented weights went with them)
+    e->lo6_ready = false;                 // (the combined copies of the augmented weights went with them; the base matrices' copies stay)
 }
 
 extern "C" int blim_clear_adapters(blim_engine* e) {
@@ -484,9 +507,9 @@ extern "C" int blim_load_adapter(blim_engine* e, const char* weight_name, const 
     HIP_TRY(hipMemcpy(a->B, B, (size_t)n_out * lora_r * 4, hipMemcpyHostToDevice));
     e->lora_r = lora_r; e->lora_scale = scale;
     // three adapters (q, k, v) x r columns x (B_hi, B_lo) need 6 r columns: 64 suffice up to r = 10.  fp16 engines take 128 whenever the e4m3 second pass of the
-    // compensated modes is possible (option "precise_lo8": its K-steps are 128 deep, so the augmented K must stay a multiple of 128)
-    const bool lo8_capable = !e->f8 && e->c.compute_dtype == DT_F16 && e->c.hidden_size % 128 == 0 && e->c.intermediate_size % 128 == 0;
-    e->aug = (6 * lora_r <= 64 && !lo8_capable) ? 64 : 128;
+    // compensated modes is possible (option "precise_lo6": its K-steps are 128 deep, so the augmented K must stay a multiple of 128)
+    const bool lo6_capable = !e->f8 && e->c.compute_dtype == DT_F16 && e->c.hidden_size % 128 == 0 && e->c.intermediate_size % 128 == 0;
+    e->aug = (6 * lora_r <= 64 && !lo6_capable) ? 64 : 128;
     e->aug_ready = false;
     return BLIM_OK;
 }
@@ -560,13 +583,6 @@ static int reserve_tokens(blim_engine* e, int64_t T) {
         TRY(ensure(e->rscale, (size_t)Tp * 4 * 4));      // [x | attn | act | label rows] scales
         TRY(ensure(e->act_mx, (size_t)Tp * (c.intermediate_size / 128)));
         TRY(ensure(e->attn_mx, (size_t)Tp * c.num_heads));
-    }
-    if (e->lo8) {                                      // e4m3 copies of the lo parts + their E8M0 tables (x8 doubles for both normalised inputs)
-        const int64_t T8 = round_up(T, 256);
-        TRY(ensure(e->x8, (size_t)T8 * (c.hidden_size + e->aug)));
-        TRY(ensure(e->a8, (size_t)T8 * (c.hidden_size + e->aug)));
-        TRY(ensure(e->act8, (size_t)T8 * c.intermediate_size));
-        TRY(ensure(e->lo_mx, (size_t)T8 * (std::max(c.intermediate_size, c.hidden_size + e->aug) / 128)));
     }
     const int64_t Hq = c.hidden_size + e->aug;        // adapters apart: the QKV / o_proj inputs carry `aug` extra columns (adapters.hpp)
     TRY(ensure(e->resid, (size_t)round_up(T, 256) * c.hidden_size * 4));
@@ -683,7 +699,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     TRY(build_aug(e));
     TRY(reserve_tokens(e, T));
     TRY(finalize_f8(e));
-    TRY(finalize_lo8(e));
+    TRY(finalize_lo6(e));
     float* resid = (float*)e->resid.p;
     const bool prune = e->prune_last && live_rows && n_live > 0 && n_live <= T - T / 16 && !e->f8;
     if (prune) TRY(ensure(e->resid_live, (size_t)round_up(n_live, 256) * H * 4));
@@ -718,14 +734,14 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const bool pqx = pq && e->precise_qk > 1;                       // ... and a hi + lo input of the QKV GEMM (its K walked twice)
     const int pfq = (e->precise || pq) ? 2 : 1;                     // width factor of the qkv / attention-output rows
     if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
-    // option "precise_lo8": a compensated GEMM = its plain fp16 pass over the hi part + an e4m3 pass over the lo part, in one kernel (gemm.hip, phase 2).  `rows`
-    // are [hi | lo] rows (lo at +lo_elems, row stride ld); the lo halves are quantised into a8buf, their E8M0 bytes into lo_mx, and `p` -- set up as the
-    // PLAIN product of the hi halves -- gets the second pass attached.  With adapters apart the adapted projections use the augmented weights' e4m3 copies.
-    const bool lo8 = e->lo8 && e->precise;
-    const int64_t T8 = round_up(T, 256);
-    auto attach_lo8 = [&](GemmParams& p, const bf16_t* rows, int64_t ld, int64_t lo_elems, int64_t n, int K, uint8_t* a8buf, const uint8_t* w8, const uint8_t* we8) -> int {
-        TRY(launch_quant_lo_mx(rows + lo_elems, ld, n, K, c.compute_dtype, a8buf, K, (uint8_t*)e->lo_mx.p, T8, s));
-        p.A8 = a8buf; p.lda8 = K; p.W8 = w8; p.w_e8 = we8; p.K8 = K; p.a_mx = (const uint8_t*)e->lo_mx.p; p.mx_stride = T8;
+    // option "precise_lo6": a compensated GEMM = its plain fp16 pass over the hi part + an e2m3 pass over the lo part, in one kernel and one K loop's worth of
+    // staging (gemm.hip, phase 2).  `rows` are [hi | lo] rows (lo at +K elements, row stride ld >= 2 K): the lo halves are quantised IN PLACE into the e2m3 image
+    // (kernels.hpp: launch_quant_lo_f6) and `p` -- set up as the PLAIN product of the hi halves -- is told that rows and weights continue with K6 = K such values;
+    // w_c6 is the matrix's combined copy [W16 | e2m3 image].  With adapters apart the adapted projections use the augmented weights' copies.
+    const bool lo6 = e->lo6 && e->precise;
+    auto attach_lo6 = [&](GemmParams& p, bf16_t* rows, int64_t ld, int64_t n, int K, const uint8_t* w_c6) -> int {
+        { SpanGuard gq(e, s, TC_QUANT, 0); TRY(launch_quant_lo_f6(rows + K, ld, n, K, c.compute_dtype, s)); }
+        p.W = (const bf16_t*)w_c6; p.ldw = 3 * (int64_t)K / 2; p.K6 = K;
         return BLIM_OK;
     };
     for (int li = 0; li < c.num_layers; ++li) {
@@ -741,9 +757,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n)
                               : gp2(e, xn, Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise || pqx);
             if (pq && !pqx) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
-            if (lo8) {                                                                    // hi part in fp16, lo part in e4m3; [hi | lo] outputs as before
-                p = gp(c.compute_dtype, xn, 2 * Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, (int)Hq, qkv, 2 * (int64_t)e->qkv_n); p.lo_off = e->qkv_n;
-                TRY(attach_lo8(p, xn, 2 * Hq, Hq, T, (int)Hq, x8, G ? e->AD[li].wqkv_aug8 : l.wqkv8, G ? e->AD[li].eqkv_aug : l.eqkv));
+            if (lo6) {                                                                    // hi part in fp16, lo part in e2m3; [hi | lo] outputs as before
+                p = gp(c.compute_dtype, xn, 2 * Hq, nullptr, T, e->qkv_n, (int)Hq, qkv, 2 * (int64_t)e->qkv_n); p.lo_off = e->qkv_n;
+                TRY(attach_lo6(p, xn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wqkv_aug_c6 : l.wqkv_c6));
             }
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -775,19 +791,19 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             const double tl = (double)n_live;
             { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * Hq * H * pf);
               GemmParams p = gp2(e, attn_live, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * Hq;   // pq: the hi halves of [hi | lo] rows
-              if (lo8) { p = gp(c.compute_dtype, attn_live, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, (int)Hq, rl, H);
-                         TRY(attach_lo8(p, attn_live, 2 * Hq, Hq, n_live, (int)Hq, a8, G ? e->AD[li].wo_aug8 : l.wo8, G ? e->AD[li].eo_aug : l.eo)); }
+              if (lo6) { p = gp(c.compute_dtype, attn_live, 2 * Hq, nullptr, n_live, H, (int)Hq, rl, H);
+                         TRY(attach_lo6(p, attn_live, 2 * Hq, n_live, (int)Hq, G ? e->AD[li].wo_aug_c6 : l.wo_c6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             { SpanGuard g(e, s, TC_NORM, 0);
               TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
               GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; }
-              if (lo8 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0; TRY(attach_lo8(p, xn, 2 * (int64_t)H, H, n_live, H, x8, l.wgu8, l.egu)); }
+              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, nullptr, n_live, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu_c6)); }
               TRY(launch_gemm(EPI_SWIGLU, p, s)); }
             { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * (pa ? 2 : 1));
               GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pa); p.ldc = H; p.lo_off = 0;
-              if (lo8 && pa) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, n_live, H, I, rl, H); TRY(attach_lo8(p, act, 2 * (int64_t)I, I, n_live, I, act8, l.wd8, l.ed)); }
+              if (lo6 && pa) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, nullptr, n_live, H, I, rl, H); TRY(attach_lo6(p, act, 2 * (int64_t)I, n_live, I, l.wd_c6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             *final_resid = rl; *final_is_live = true;
             break;
@@ -800,9 +816,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (fuse_o) { p.a_mx = (const uint8_t*)e->attn_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             if (pq) p.lda = 2 * Hq;                                       // the hi halves of the attention output's [hi | lo] rows
-            if (lo8) {
-                p = gp(c.compute_dtype, attn, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, T, H, (int)Hq, resid, H);
-                TRY(attach_lo8(p, attn, 2 * Hq, Hq, T, (int)Hq, a8, G ? e->AD[li].wo_aug8 : l.wo8, G ? e->AD[li].eo_aug : l.eo));
+            if (lo6) {
+                p = gp(c.compute_dtype, attn, 2 * Hq, nullptr, T, H, (int)Hq, resid, H);
+                TRY(attach_lo6(p, attn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wo_aug_c6 : l.wo_c6));
             }
             TRY(launch_gemm(EPI_RESID, p, s));
         }
@@ -817,9 +833,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I, pm);
             if (pm && !pa) { p.lo_off = 0; p.ldc = I; }                 // A = [hi | lo] (K walked twice), plain 16-bit output
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
-            if (lo8 && pm) {
-                p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, T, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0;
-                TRY(attach_lo8(p, xn, 2 * (int64_t)H, H, T, H, x8, l.wgu8, l.egu));
+            if (lo6 && pm) {
+                p = gp(c.compute_dtype, xn, 2 * (int64_t)H, nullptr, T, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0;
+                TRY(attach_lo6(p, xn, 2 * (int64_t)H, T, H, l.wgu_c6));
             }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
@@ -829,9 +845,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0, pa);
             if (fuse) { p.a_mx = (const uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
-            if (lo8 && pa) {
-                p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, T, H, I, resid, H);
-                TRY(attach_lo8(p, act, 2 * (int64_t)I, I, T, I, act8, l.wd8, l.ed));
+            if (lo6 && pa) {
+                p = gp(c.compute_dtype, act, 2 * (int64_t)I, nullptr, T, H, I, resid, H);
+                TRY(attach_lo6(p, act, 2 * (int64_t)I, T, I, l.wd_c6));
             }
             TRY(launch_gemm(EPI_RESID, p, s));
         }
@@ -915,14 +931,16 @@ static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split
         GemmParams p = l8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0)
                           : gp(e->c.compute_dtype, A, Hl, e->aug ? (const void*)e->lm_aug : (const void*)e->lm_head, n_rows, V, (int)Hl, nullptr, 0);
         if (split) { ARG_CHECK(!l8); p.lda = 2 * Hl; p.K = (int)(2 * Hl); p.w_wrap_k = (int)Hl; }
-        if (split && e->lo8 && V % 256 == 0 && Hl % 128 == 0) {           // lo8: the rows' lo parts against the head in e4m3 (gemm.hip phase 2), as in the decoder GEMMs
-            TRY(finalize_lo8(e));
-            const int64_t R8 = round_up(n_rows, 256);
-            TRY(ensure(e->h8_lo, (size_t)R8 * Hl));
-            TRY(ensure(e->h_mx, (size_t)R8 * (Hl / 128)));
-            TRY(launch_quant_lo_mx((const bf16_t*)A + Hl, 2 * Hl, n_rows, (int)Hl, e->c.compute_dtype, (uint8_t*)e->h8_lo.p, Hl, (uint8_t*)e->h_mx.p, R8, s));
+        if (split && e->lo6 && V % 256 == 0 && Hl % 128 == 0) {           // lo6: the rows' lo parts against the head in e2m3 (gemm.hip phase 2), as in the decoder GEMMs
+            TRY(finalize_lo6(e));
+            if (A == hidden_bf16 && !wide) {                               // a caller's buffer: the in-place quantisation of the lo halves works on a copy
+                TRY(ensure(e->hid_aug, (size_t)round_up(n_rows, 256) * 2 * Hl * 2));
+                TRY(launch_copy_rows16((uint16_t*)e->hid_aug.p, 2 * Hl, (const uint16_t*)hidden_bf16, 2 * Hl, n_rows, (int)(2 * Hl), s));
+                A = e->hid_aug.p; p.A = (const bf16_t*)A;
+            }
+            TRY(launch_quant_lo_f6((bf16_t*)A + Hl, 2 * Hl, n_rows, (int)Hl, e->c.compute_dtype, s));
             p.K = (int)Hl; p.w_wrap_k = 0;
-            p.A8 = (const uint8_t*)e->h8_lo.p; p.lda8 = Hl; p.W8 = e->lm8_lo; p.w_e8 = e->e_lm; p.K8 = (int)Hl; p.a_mx = (const uint8_t*)e->h_mx.p; p.mx_stride = R8;
+            p.W = (const bf16_t*)e->lm_c6; p.ldw = 3 * Hl / 2; p.K6 = (int)Hl;
         }
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
@@ -1126,6 +1144,18 @@ extern "C" int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t 
     GemmParams p = gp(DT_F16, A, lda, W, M, N, K, C, ldc);
     return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
 }
+// The compensated GEMM as a building block (tests): A_hilo [M, 2 K] fp16 rows [hi | lo], W [N, K] fp16 -> C f32 [M, N] = hi . W^T + e2m3(lo) . e2m3(W)^T.  The lo halves
+// of A_hilo are replaced by their e2m3 image (in place, as in the engine); w_c6 [N, 3 K bytes] receives the combined copy of W.
+extern "C" int blim_gemm_f16_lo6(void* A_hilo, const void* W, int32_t M, int32_t N, int32_t K, void* w_c6, float* C, void* stream) {
+    ARG_CHECK(A_hilo && W && w_c6 && C && K % 128 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    TRY(launch_combine_w_f6((const bf16_t*)W, K, N, K, DT_F16, (uint8_t*)w_c6, s));
+    TRY(launch_quant_lo_f6((bf16_t*)A_hilo + K, 2 * (int64_t)K, M, K, DT_F16, s));
+    HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * 4, s));
+    GemmParams p = gp(DT_F16, A_hilo, 2 * (int64_t)K, w_c6, M, N, K, C, N);
+    p.ldw = 3 * (int64_t)K / 2; p.K6 = K;
+    return launch_gemm(EPI_RESID, p, s);
+}
 extern "C" int blim_quant_rows(const void* in16, int64_t ld, int64_t n_rows, int32_t K, int32_t dtype16, void* out8, float* scale, void* stream) {
     ARG_CHECK(dtype16 == BLIM_COMPUTE_BF16 || dtype16 == BLIM_COMPUTE_F16);
     return launch_quant_rows((const bf16_t*)in16, ld, n_rows, K, dtype16, (uint8_t*)out8, scale, (hipStream_t)stream);
@@ -1182,10 +1212,10 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
     if (!strcmp(key, "prune_last")) { e->prune_last = value != 0; return BLIM_OK; }
-    if (!strcmp(key, "precise_lo8")) {
-        if (value && (e->f8 || e->c.compute_dtype != DT_F16)) { blim_set_error("option 'precise_lo8' needs an fp16 engine"); return BLIM_ERR_ARG; }
-        if (value && (e->c.hidden_size % 128 || e->c.intermediate_size % 128)) { blim_set_error("option 'precise_lo8': hidden and intermediate sizes must be multiples of 128"); return BLIM_ERR_ARG; }
-        e->lo8 = value != 0; return BLIM_OK;
+    if (!strcmp(key, "precise_lo6")) {
+        if (value && (e->f8 || e->c.compute_dtype != DT_F16)) { blim_set_error("option 'precise_lo6' needs an fp16 engine"); return BLIM_ERR_ARG; }
+        if (value && (e->c.hidden_size % 128 || e->c.intermediate_size % 128)) { blim_set_error("option 'precise_lo6': hidden and intermediate sizes must be multiples of 128"); return BLIM_ERR_ARG; }
+        e->lo6 = value != 0; return BLIM_OK;
     }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_act")) { e->precise_act = value != 0; return BLIM_OK; }

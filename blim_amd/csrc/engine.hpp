@@ -1,6 +1,7 @@
 // Engine state shared by engine.hip (scoring path) and train.hip (fine-tuning step).
 #pragma once
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -34,13 +35,15 @@ struct LayerW {
     // fp8 mode: e4m3 copies of the four matrices (same stored row order) + one f32 scale per stored row
     uint8_t* wqkv8 = nullptr; uint8_t* wo8 = nullptr; uint8_t* wgu8 = nullptr; uint8_t* wd8 = nullptr;
     float* sqkv = nullptr; float* so = nullptr; float* sgu = nullptr; float* sd = nullptr;
-    uint8_t* eqkv = nullptr; uint8_t* eo = nullptr; uint8_t* egu = nullptr; uint8_t* ed = nullptr;     // option "precise_lo8": E8M0 row scales of the e4m3 copies above (fp16 engines)
+    // option "precise_lo6" (fp16 engines): combined copies [W16 | e2m3 image of W] of the four matrices, row stride 3 K bytes (kernels.hpp: launch_combine_w_f6) --
+    // what the compensated GEMMs read in BOTH their passes (gemm.hpp: K6, ldw)
+    uint8_t* wqkv_c6 = nullptr; uint8_t* wo_c6 = nullptr; uint8_t* wgu_c6 = nullptr; uint8_t* wd_c6 = nullptr;
 };
 
 // LoRA adapters kept apart (adapters.hpp): the f32 matrices as loaded + their 16-bit MFMA operand
 struct AdapterW { float* A = nullptr; float* B = nullptr; uint16_t* A16 = nullptr; int n_in = 0, n_out = 0; };
 struct LayerAd { AdapterW ad[4]; uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr;           // ad: q, k, v, o
-                 uint8_t* wqkv_aug8 = nullptr; uint8_t* wo_aug8 = nullptr; uint8_t* eqkv_aug = nullptr; uint8_t* eo_aug = nullptr; };   // option "precise_lo8": e4m3 copies + E8M0 row scales
+                 uint8_t* wqkv_aug_c6 = nullptr; uint8_t* wo_aug_c6 = nullptr; };   // option "precise_lo6": combined copies [W_aug 16-bit | e2m3 image]
 
 struct blim_engine {
     blim_config c;
@@ -92,13 +95,15 @@ struct blim_engine {
     std::vector<LayerAd> AD; AdapterW ad_lm, ad_mlp[2][2];       // ad_mlp[mlp | tvg_mlp][Linear 0 | Linear 2]
     uint16_t* lm_aug = nullptr; uint16_t* w0_aug[2] = {nullptr, nullptr}; uint16_t* w2_aug[2] = {nullptr, nullptr};
     bool aug_ready = false;
-    // option "precise_lo8" (fp16 engines): in the compensated modes the second walk over K -- the product with the activations' LO parts -- runs on the e4m3
-    // MFMA at twice the rate (gemm.hip, phase 2): e4m3 copies of the decoder weights with power-of-two row scales, built lazily (finalize_lo8)
-    bool lo8 = false, lo8_ready = false;
-    uint8_t* lm8_lo = nullptr; uint8_t* e_lm = nullptr;          // lm_head (or its augmented copy) in e4m3 + E8M0 row scales; width lm8_k
-    int lm8_k = 0;
-    DevBuf h8_lo, h_mx;                                          // the scored rows' lo parts in e4m3 + their E8M0 table
-    DevBuf lo_mx;                                                // E8M0 bytes of the quantised lo parts: [K / 128][256-row tiles][256]
+    // option "precise_lo6" (fp16 engines): in the compensated modes the second walk over K -- the product with the activations' LO parts -- runs on the block-scaled
+    // MFMA with e2m3 operands at four times the 16-bit rate (gemm.hip, phase 2), on combined copies [W16 | e2m3(W)] of the decoder weights and the head, built
+    // lazily (finalize_lo6: + 3 bytes per decoder / head weight, 21 GB at 7B)
+    bool lo6 = false, lo6_ready = false;
+    uint8_t* lm_c6 = nullptr;                                    // lm_head (or its augmented copy), combined; K = lm_c6_k
+    int lm_c6_k = 0;
+    const void* lm_c6_src = nullptr;                             // the matrix lm_c6 was derived from
+    std::set<const void*> c6_dirty;                              // base matrices (re)placed since their combined copy was built
+    std::set<std::string> merged_pending;                        // after blim_train_merge: the adapted weights that still hold W + s B A (lora_merged stays set until all are re-placed)
     bool lora_merged = false;                                    // blim_train_merge wrote W + (alpha / r) B A into the base weights: adapters apart on top would apply the update twice
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)
     std::vector<void*> ad_owned;                                 // the f32 A / B matrices

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     // A and W lanes use the same one).  Chunk c of row r sits at slot c ^ g(r): the second read is the first XOR 64 bytes.
     constexpr int ES = (DT == DT_F8) ? 1 : 2;            // operand element size
     constexpr bool MX8 = MXA && DT == DT_F8;             // fp8 GEMM whose A operand carries E8M0 block scales (a_mx)
-    constexpr bool LO8 = MXA && DT != DT_F8;             // 16-bit GEMM followed, in the same accumulators, by an e4m3 pass over the A operand's LO part (see "phase 2")
+    constexpr bool LO6 = MXA && DT != DT_F8;             // 16-bit GEMM followed, in the same accumulators, by an e2m3 pass over the A operand's LO part (see "phase 2")
     constexpr int ODT = out16<DT>::value;                // dtype of 16-bit outputs
     const int fr = lane & 15, fc = lane >> 4;
     const int fg = (fr >> 1) & 7;
@@ -120,6 +120,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K * ES / (BK * 2);   // K-steps of 128 bytes per row
+    const int nk6 = LO6 ? p.K6 / 128 : 0; // ... of the second pass (phase 2), which follow in the same rows
+    const int nkt = nk + nk6;
     // fp8: this thread's dequantisation scale (threads 0-255: the tile's rows, 256-511: its columns), requested before the K loop
     // so that its latency is not exposed in front of the epilogue
     float f8_scale = 0.f;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < 8; ++i) {
             const int b = wg + 4 * i;   // 1-KiB block (8 rows) of the operand tile
             if (grp == 1) off8[i] = (uint32_t)((int64_t)min(row0 + 8 * b + sr, p.M - 1) * p.lda * ES + 16 * sc);
-            else off8[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr, p.N - 1) * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * ES + 16 * sc);   // W row stride
+            else off8[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr, p.N - 1) * (p.ldw > 0 ? p.ldw : p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * ES + 16 * sc);   // W row stride
         }
         const char* gbase = grp == 1 ? baseA : baseW;
         // compensated mode: A is [hi | lo] along K and W is used twice -- the W group's K-step index wraps (scalar select)
@@ -283,47 +285,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #endif
             }
         };
-        // ---- phase 2 (LO8): acc += (lo part of the A operand) . W^T on the block-scaled fp8 MFMA, at twice the 16-bit rate.  The compensated modes' second walk
-        // over K carries x_lo = x - f32(x_hi), 2^-11 of x in fp16: the product W . x_lo only needs a few percent of relative accuracy to remove > 95 % of the
-        // rounding noise of x_hi, which e4m3 x e4m3 delivers.  A8 = e4m3(x_lo) with one E8M0 scale per (row, 128-deep K-step) (a_mx: the MXA table layout),
-        // W8 = e4m3(W) with one E8M0 scale per row (w_e8); both scales enter through the MFMA's scale operands, so the products land in the SAME f32
-        // accumulators as phase 1 at their true magnitude and the epilogue is unchanged.  The loop is the fp8 kernel's (rotated: fragments read and consumed
-        // inside one iteration); every wave has passed phase 1's last barrier, so the ring is free.
-        const int nk8 = LO8 ? p.K8 / 128 : 0;
-        uint32_t off8b[8];
-        uint32_t wsc = 0;
-        uint32_t mxo = 0;                                            // this lane's byte offset inside a K-step's slice of the E8M0 table (32-bit: scalar base + voffset loads)
-        uint2 sc_cur = make_uint2(0, 0), sc_nxt = sc_cur;
-        // (formed AFTER phase 1, inside each wave group's own branch: computed up front these twelve registers would be live across the 16-bit loop)
-        const char* gbase8 = LO8 ? (grp == 1 ? (const char*)p.A8 : (const char*)p.W8) : nullptr;
-        auto init8 = [&]() __attribute__((always_inline)) {
-            int sr2 = sr, sc2 = sc;                                  // opaque copies: everything below is formed HERE, after phase 1, not hoisted above it
-            asm volatile("" : "+v"(sr2), "+v"(sc2));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int b = wg + 4 * i;
-                if (grp == 1) off8b[i] = (uint32_t)((int64_t)min(row0 + 8 * b + sr2, p.M - 1) * p.lda8 + 16 * sc2);
-                else off8b[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr2, p.N - 1) * p.K8 + 16 * sc2);
-            }
-            // scales: W side, this lane's four fragment rows (one byte each, constant over K); A side, eight bytes per K-step (MXA table)
-            int frm = fr;
-            asm volatile("" : "+v"(frm));
-            wsc = 0;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wsc |= (uint32_t)p.w_e8[min(col0 + 64 * wn + 16 * ni + frm, p.N - 1)] << (8 * ni);
-            mxo = (uint32_t)(tm * 256 + (wm * 16 + frm) * 8);
-            sc_nxt = *(const uint2*)(p.a_mx + mxo);
-        };
-        auto stage8b = [&](int dst, int kt) __attribute__((always_inline)) {
-            const char* g = gbase8 + (int64_t)kt * 128;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                uint32_t o = off8b[i];
-                asm volatile("" : "+v"(o));
-                glds16(g + o, smem + dst + (wg + 4 * i) * 1024);
-            }
-        };
-        auto load_frags8 = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
+        // ---- phase 2 (LO6): acc += (lo part of the A operand) . W^T on the block-scaled MFMA with e2m3 operands, at FOUR times the 16-bit rate (gfx950 issues fp6
+        // at the fp4 rate: tools/mfma_f6_probe.hip, 7.5 against 4.1 PFLOP/s for e4m3 on random operands).  The compensated modes' second walk over K carries
+        // x_lo = x - f32(x_hi), 2^-11 of x in fp16: the product W . x_lo only needs a few percent of relative accuracy to remove > 95 % of the rounding noise of x_hi,
+        // and e2m3 with one E8M0 scale per 32 values delivers what e4m3 did (profiles/r05_lo_format_emulation.txt: 16,000-entry populations on the trained-like
+        // weight sets, e2m3 within 20 % of e4m3).  Both operands' rows CONTINUE behind their 16-bit part with the e2m3 image of gemm.hpp (K6), 128 bytes per K-step
+        // like the 16-bit steps: the LDS-DMA of the 16-bit loop simply runs on into the second pass's tiles (same lane offsets, same ring order), so the second
+        // pass starts with its first two K-steps staged -- round 4's separate e4m3 operands cost a drained ring, twelve more address registers and ~7 us per tile.
+        // A lane's two 16-byte fragment reads bring the six operand registers of a 16-row fragment and, in register 6, the block's scale byte: no scale tables.
+        // The loop is the fp8 kernel's (rotated: fragments read and consumed inside one iteration).
+        auto load_frags6 = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
             const char* ba0 = smem + (offA_tile + a_off); const char* ba1 = smem + ((offA_tile + a_off) ^ 64);
             const char* bb0 = smem + (offB_tile + b_off); const char* bb1 = smem + ((offB_tile + b_off) ^ 64);
             auto rd = [](const char* q0, const char* q1) __attribute__((always_inline)) {
@@ -335,28 +306,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) fa8[mi] = rd(ba0 + mi * 2048, ba1 + mi * 2048);
         };
-        auto sc_request = [&](int kt) __attribute__((always_inline)) {
-            uint32_t o = mxo;
-            asm volatile("" : "+v"(o));
-            sc_nxt = *(const uint2*)(p.a_mx + (int64_t)min(kt, nk8 - 1) * p.mx_stride + o);
-        };
-        auto compute8 = [&]() __attribute__((always_inline)) {
+        auto compute6 = [&]() __attribute__((always_inline)) {
             __builtin_amdgcn_s_setprio(1);
-#define L8_MMA(MI, NI)                                                                                                                         \
-            acc[MI][NI] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[NI], fa8[MI], acc[MI][NI], 0, 0, NI, (int)wsc, (MI & 3), \
-                                                                          (int)((MI) < 4 ? sc_cur.x : sc_cur.y));
-#define L8_ROW(MI) L8_MMA(MI, 0) L8_MMA(MI, 1) L8_MMA(MI, 2) L8_MMA(MI, 3)
-            L8_ROW(0) L8_ROW(1) L8_ROW(2) L8_ROW(3) L8_ROW(4) L8_ROW(5) L8_ROW(6) L8_ROW(7)
-#undef L8_ROW
-#undef L8_MMA
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni], fa8[mi], acc[mi][ni], 2, 2, 0, fb8[ni][6], 0, fa8[mi][6]);   // cbsz = blgp = 2: e2m3
             __builtin_amdgcn_s_setprio(0);
         };
         int sa = 0;
         mx_request(0);
         if (grp == 0) {
             stage8(TILE_BYTES, 0);                                   // W0
-            if (nk > 1) stage8(3 * TILE_BYTES, 1);                   // W1
-            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (nkt > 1) stage8(3 * TILE_BYTES, 1);                  // W1
+            if (nkt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();                                         // A0 W0 landed (every wave waited for its own DMA)
             if constexpr (MX8) mx_cur = mx_nxt;                      // requested at tile entry, in front of every LDS-DMA
@@ -388,7 +352,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_T(2);
                 PHASE_BARRIER();
                 WP_T(3);
-                if (kt + 1 < nk) frags_and_dma(adv(sa, 2), adv(sa, 3), sa, kt + 2, kt + 2 < nk);   // fragments of kt+1, W(kt+2)
+                if (kt + 1 < nk) frags_and_dma(adv(sa, 2), adv(sa, 3), sa, kt + 2, kt + 2 < nkt);  // fragments of kt+1, W(kt+2) (LO6: on into the second pass's tiles)
+                else if (LO6 && kt + 2 < nkt) stage8(sa, kt + 2);                                  // last 16-bit step: the second pass reads its own fragments, W(nk+1) is still staged here
 #ifdef GEMM_WAIT_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -399,33 +364,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 sa = adv(sa, 2);
             }
             }
-            if constexpr (LO8) {
-                init8();
-                int s8 = 0;
-            stage8b(TILE_BYTES, 0);                                  // W0
-            if (nk8 > 1) stage8b(3 * TILE_BYTES, 1);                 // W1
-            if (nk8 > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PHASE_BARRIER();
-            sc_cur = sc_nxt;
-            int sp = 0;
-            for (int k = 0; k < nk8; ++k) {
-                sc_request(k + 1);
-                load_frags8(s8, adv(s8, 1));
-                if (k >= 1 && k + 1 < nk8) stage8b(sp, k + 1);       // W(k+1) into the slot A(k-1) left
-                PHASE_BARRIER();
-                compute8();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                sc_cur = sc_nxt;
-                PHASE_BARRIER();
-                sp = s8; s8 = adv(s8, 2);
-            }
-            PHASE_BARRIER();
+            if constexpr (LO6) {
+                // phase 2, W group: A(nk) W(nk) are complete (every wave waited for its share before the last 16-bit step's first barrier), A(nk+1) W(nk+1) in flight
+                int sp = sa;
+                for (int k = 0; k < nk6; ++k) {
+                    load_frags6(sa, adv(sa, 1));
+                    if (k >= 1 && k + 1 < nk6) stage8(sp, nk + k + 1);   // W(k+1) into the slot A(k-1) left
+                    PHASE_BARRIER();
+                    compute6();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of W(k+1) landed
+                    PHASE_BARRIER();
+                    sp = sa; sa = adv(sa, 2);
+                }
             }
         } else {
             stage8(0, 0);                                            // A0
-            if (nk > 1) stage8(2 * TILE_BYTES, 1);                   // A1
-            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (nkt > 1) stage8(2 * TILE_BYTES, 1);                  // A1
+            if (nkt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();
             if constexpr (MX8) mx_cur = mx_nxt;
@@ -436,12 +391,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     mx_request(kt + 1);
                     load_frags(sa, adv(sa, 1));
                     if (kt + 2 < nk) stage8(adv(sa, 4), kt + 2);
-                } else frags_and_dma(sa, adv(sa, 1), adv(sa, 4), kt + 2, kt + 2 < nk);          // fragments of kt, A(kt+2)
+                } else frags_and_dma(sa, adv(sa, 1), adv(sa, 4), kt + 2, kt + 2 < nkt);         // fragments of kt, A(kt+2) (LO6: on into the second pass's tiles)
 #ifdef GEMM_WAIT_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
                 WP_T(1);
-                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // my share of A(kt+1) landed
+                if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // my share of A(kt+1) landed
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 WP_T(2);
                 PHASE_BARRIER();
@@ -454,28 +409,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_ACC();
                 sa = adv(sa, 2);
             }
-            if constexpr (LO8) {
-                init8();
-                int s8 = 0;
-            stage8b(0, 0);                                           // A0
-            if (nk8 > 1) stage8b(2 * TILE_BYTES, 1);                 // A1
-            if (nk8 > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PHASE_BARRIER();
-            sc_cur = sc_nxt;
-            PHASE_BARRIER();
-            for (int kt = 0; kt < nk8; ++kt) {
-                sc_request(kt + 1);
-                load_frags8(s8, adv(s8, 1));
-                if (kt + 2 < nk8) stage8b(adv(s8, 4), kt + 2);
-                if (kt + 2 < nk8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                PHASE_BARRIER();
-                compute8();
-                sc_cur = sc_nxt;
-                PHASE_BARRIER();
-                s8 = adv(s8, 2);
-            }
+            if constexpr (LO6) {
+                for (int k = 0; k < nk6; ++k) {                          // phase 2, A group
+                    load_frags6(sa, adv(sa, 1));
+                    if (k + 2 < nk6) stage8(adv(sa, 4), nk + k + 2);
+                    if (k + 2 < nk6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // my share of A(k+1) landed
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PHASE_BARRIER();
+                    compute6();
+                    PHASE_BARRIER();
+                    sa = adv(sa, 2);
+                }
             }
         }
 #undef PHASE_BARRIER
@@ -994,11 +938,11 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
     if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU || EPI == EPI_RESID || EPI == EPI_LSE) {
-        if (p.A8) {            // fp16 main pass + e4m3 pass over the A operand's lo part (phase 2 of the kernel)
+        if (p.K6 > 0) {        // fp16 main pass + e2m3 pass over the A operand's lo part (phase 2 of the kernel)
             if constexpr (EPI == EPI_RESID || EPI == EPI_LSE) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
             else if (p.lo_off != 0) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true, true>), grid, dim3(NTHREADS), 0, stream, p);
             else if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
-            else { blim_set_error("lo8 QKV GEMM: hi | lo outputs only"); return BLIM_ERR_ARG; }
+            else { blim_set_error("lo6 QKV GEMM: hi | lo outputs only"); return BLIM_ERR_ARG; }
             hipError_t e4 = hipGetLastError();
             if (e4 != hipSuccess) { blim_set_error("gemm launch failed: %s", hipGetErrorString(e4)); return BLIM_ERR_HIP; }
             return BLIM_OK;
@@ -1056,7 +1000,6 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         if (p.row_scale) q.row_scale = p.row_scale + r0;
         if (p.rope_rows) q.rope_rows = p.rope_rows + r0 * 16;        // chunk-major table: the row offset inside every chunk (rope_stride unchanged)
         if (p.a_mx) q.a_mx = p.a_mx + r0;                         // r0 is a whole number of 256-row tiles: the table is tile-major inside a K-step
-        if (p.A8) q.A8 = p.A8 + r0 * p.lda8;
         if (p.out_mx) q.out_mx = p.out_mx + r0;
         if (p.labels) q.labels = p.labels + r0;
         if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
@@ -1073,8 +1016,8 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
 static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
-    static const int dbg_k8 = getenv("BLIM_GEMM_LO8_K8") ? atoi(getenv("BLIM_GEMM_LO8_K8")) : 0;      // timing aid: shorten the e4m3 pass (wrong results)
-    if (p.A8 && dbg_k8 > 0 && dbg_k8 < p.K8) p.K8 = dbg_k8;
+    static const int dbg_k6 = getenv("BLIM_GEMM_LO6_K6") ? atoi(getenv("BLIM_GEMM_LO6_K6")) : 0;      // timing aid: shorten the e2m3 pass (wrong results)
+    if (p.K6 > 0 && dbg_k6 > 0 && dbg_k6 < p.K6) p.K6 = dbg_k6;
     if (!g_f16_saturate) p.f16_saturate = 0;
     p.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : GROUP_M;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
@@ -1091,15 +1034,16 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK((int64_t)p.K * es % 128 == 0);                  // whole 128-byte K-steps
     ARG_CHECK(p.lda * es % 16 == 0);
     ARG_CHECK(p.dtype != DT_F8 || ((p.row_scale || p.a_mx) && p.col_scale));
-    ARG_CHECK((!p.a_mx && !p.out_mx) || ((p.dtype == DT_F8 || p.A8) && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
-    ARG_CHECK(!p.a_mx || epi == EPI_RESID || p.A8);              // MX-scaled A operand: instantiated for the down projection (fp8) and for the lo8 pass
-    ARG_CHECK(!p.A8 || (p.dtype == DT_F16 && p.W8 && p.w_e8 && p.a_mx && p.w_wrap_k == 0 && p.K8 > 0 && p.K8 % 128 == 0 && p.lda8 % 16 == 0 &&
-                        p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE) &&
-                        (int64_t)p.M * p.lda8 < (1ll << 32) && (int64_t)p.N * p.K8 < (1ll << 32)));
+    ARG_CHECK((!p.a_mx && !p.out_mx) || (p.dtype == DT_F8 && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
+    ARG_CHECK(!p.a_mx || epi == EPI_RESID);                      // MX-scaled A operand: instantiated for the down projection (fp8)
+    // lo6: both operands' rows hold K 16-bit values and then K6 bytes of e2m3 image (gemm.hpp)
+    ARG_CHECK(p.K6 == 0 || (p.dtype == DT_F16 && p.w_wrap_k == 0 && p.K6 > 0 && p.K6 % 128 == 0 && p.lda * 2 >= (int64_t)p.K * 2 + p.K6 && p.ldw * 2 >= (int64_t)p.K * 2 + p.K6 &&
+                            (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE) && (int64_t)p.N * p.ldw * 2 < (1ll << 32)));
+    ARG_CHECK(p.ldw == 0 || (p.ldw >= (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) && p.ldw * es % 16 == 0));
     ARG_CHECK(!p.out_mx || (epi == EPI_SWIGLU && p.N % 256 == 0 && p.ldc % 16 == 0));
     ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice
     ARG_CHECK(p.lo_off == 0 || epi == EPI_BF16 || epi == EPI_QKV || epi == EPI_SWIGLU);
-    ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets
+    ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.ldw > 0 ? p.ldw : p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
         case EPI_BF16:
             ARG_CHECK(p.C && p.ldc % 4 == 0);

@@ -55,14 +55,16 @@ struct GemmParams {
     uint8_t* out_mx;
     const uint8_t* a_mx;
     int64_t mx_stride;
-    // fp16 engines, compensated modes with an e4m3 second pass ("lo8", gemm.hip phase 2): A / lda / K describe the plain 16-bit hi part (w_wrap_k = 0) and the
-    // A operand's LO part comes as A8 = e4m3 [M, lda8] with one E8M0 byte per (row, 128-deep K-step) in a_mx (table layout above; mx_stride), against
-    // W8 = e4m3 [N, K8] with one E8M0 byte per row (w_e8).  K8 % 128 == 0, lda8 % 16 == 0.  nullptr = off.
-    const uint8_t* A8;
-    int64_t lda8;
-    const uint8_t* W8;
-    const uint8_t* w_e8;
-    int K8;
+    // fp16 engines, compensated modes with an fp6 second pass ("lo6", gemm.hip phase 2; round 5, replaces round 4's e4m3 pass).  A / lda / K describe the plain
+    // 16-bit hi part (w_wrap_k = 0); K6 > 0 says that BOTH operands' rows continue, right behind their K 16-bit values (byte offset 2 K), with K6 e2m3 values in
+    // the MX image below (128 bytes per 128 values: the second pass's K-steps are the same 128 bytes per row as the first's, so the ring, the LDS-DMA and the
+    // fragment reads simply run on from K-step K / 64 to K / 64 + K6 / 128 with no hand-over).  A: the lo parts, quantised in place over the first K6 bytes of the
+    // rows' 16-bit lo halves (kernels.hpp: launch_quant_lo_f6); W: the combined copy [W16 | W6] with row stride ldw (launch_combine_w_f6).  K6 % 128 == 0.
+    // Image of one 128-value K-step of a row: the 32 values k = 32 g .. 32 g + 31 (g = 0..3; what the MFMA's lane group g holds) are 24 bytes of packed e2m3
+    // (value j at bits [6 j, 6 j + 6)): bytes 0-15 at [16 g, 16 g + 16), bytes 16-23 at [64 + 16 g, 64 + 16 g + 8), then the block's E8M0 scale byte at
+    // 64 + 16 g + 8 and 7 bytes of padding -- a lane's two 16-byte fragment reads (chunks g and g + 4) bring its 6 operand registers AND its scale register.
+    int K6;
+    int64_t ldw;             // row stride of W in elements (0: K, or w_wrap_k when that is set)
     int f16_saturate;        // fp16 outputs: saturate to +-65504 instead of +-inf (common.hpp: f16_saturate_on).  engine.hip's gp() sets it; the one
                              // 16-bit GRADIENT store of the trainer clears it (the loss scaler must see an overflow as inf)
     int group_m;             // M-tiles per band of the tile order (8; BLIM_GEMM_GROUP_M)

@@ -565,113 +565,104 @@ int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const 
     return BLIM_OK;
 }
 
-static inline int64_t round_up256(int64_t x) { return (x + 255) / 256 * 256; }
-// ---------------------------------------------------------------------------- lo8 quantisers (kernels.hpp)
+// ---------------------------------------------------------------------------- lo6 quantisers (kernels.hpp; image: gemm.hpp K6)
 __device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e with 2^e >= x (x > 0, finite)
     int ex; const float m = frexpf(x, &ex);                      // x = m 2^ex, m in [0.5, 1)
     return m == 0.5f ? ex - 1 : ex;
 }
-// EXPERIMENT (round 5, tools/lo_format_probe.py): round the scaled values of a 32-element block onto the grid a narrower MX format would keep -- e2m3 (emu = 1)
-// or e2m1 (emu = 2) times the block's own power-of-two scale -- before they are stored as e4m3 (which holds every such value exactly while the block's maximum is
-// within 2^12 of the 128-block's).  The four consecutive lanes that own a 32-block share its maximum.  Emulates the NUMERICS of an fp6 / fp4 second pass exactly.
-__device__ __forceinline__ void emulate_narrow(float (&f)[8], int emu) {
-    if (emu == 0) return;
+// 32 values -> their e2m3 block: six dwords of packed 6-bit codes (value j at bits [6 j, 6 j + 6): sign | 2-bit exponent | 3-bit mantissa, OCP MX: magnitudes
+// m / 8 (exponent 0) and (1 + m / 8) 2^(e - 1), largest 7.5; round to nearest even on that grid) and the E8M0 byte of the block's power-of-two scale -- the smallest
+// 2^s with max|x| 2^-s <= 7.5.  A block that is all zero, or holds an inf / NaN, is stored as zeros (the hi part carries non-finite values through the first pass).
+struct F6Block { uint32_t d[6]; uint32_t e8; };
+__device__ __forceinline__ F6Block e2m3_block(const float (&f)[32]) {
     float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[j]));
-    m = fmaxf(m, __shfl_xor(m, 1, 4)); m = fmaxf(m, __shfl_xor(m, 2, 4));
-    if (!(m > 0.f) || !(m < 3.0e38f)) return;
-    const float top = emu == 1 ? 7.5f : 6.0f;
-    int ex; const float mant = frexpf(m / top, &ex);
-    if (mant == 0.5f) ex -= 1;
-    const float up = ldexpf(1.0f, ex), dn = ldexpf(1.0f, -ex);
+    for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(f[j]));
+    F6Block b;
+    const bool live = m > 0.f && m < 3.0e38f;
+    int ex = live ? pow2_exp_ge(m * (1.0f / 7.5f)) : -127;
+    ex = max(-127, min(127, ex));
+    const float inv = live ? ldexpf(1.0f, -ex) : 0.f;
+    b.e8 = (uint32_t)(ex + 127);
+    uint32_t c[32];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float a = fabsf(f[j]) * dn;
-        const float step = emu == 1 ? (a < 2.f ? 0.125f : a < 4.f ? 0.25f : 0.5f) : (a < 2.f ? 0.5f : a < 4.f ? 1.0f : 2.0f);
-        const float q = fminf(rintf(a / step) * step, top);
-        f[j] = copysignf(q * up, f[j]);
+    for (int j = 0; j < 32; ++j) {
+        const float a = fminf(fabsf(f[j]) * inv, 7.5f);
+        const int bin = a < 2.f ? 0 : a < 4.f ? 1 : 2;                   // step 1/8 below 2 (subnormals and the first binade share it), 1/4 below 4, 1/2 above
+        const int q = (int)rintf(a * (bin == 0 ? 8.f : bin == 1 ? 4.f : 2.f));
+        const int code = min(q + 8 * bin, 31);                             // [0, 16] | 8 + [8, 16] | 16 + [8, 15]: continuous across the binades
+        c[j] = (uint32_t)code | (f[j] < 0.f ? 32u : 0u);
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                          // 16 codes = 96 bits = three dwords
+        const uint32_t* k = c + 16 * h;
+        b.d[3 * h + 0] = k[0] | k[1] << 6 | k[2] << 12 | k[3] << 18 | k[4] << 24 | k[5] << 30;
+        b.d[3 * h + 1] = k[5] >> 2 | k[6] << 4 | k[7] << 10 | k[8] << 16 | k[9] << 22 | k[10] << 28;
+        b.d[3 * h + 2] = k[10] >> 4 | k[11] << 2 | k[12] << 8 | k[13] << 14 | k[14] << 20 | k[15] << 26;
+    }
+    return b;
 }
-static int lo_emulate(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+// block g of K-step `step` of a row image at `img`: bytes 0-15 at chunk g, bytes 16-23 + the scale byte at chunk g + 4
+__device__ __forceinline__ void store_f6_block(uint8_t* img, int blk, const F6Block& b) {
+    uint8_t* stp = img + (int64_t)(blk >> 2) * 128 + 16 * (blk & 3);
+    *(uint4*)stp = make_uint4(b.d[0], b.d[1], b.d[2], b.d[3]);
+    *(uint4*)(stp + 64) = make_uint4(b.d[4], b.d[5], b.e8, 0u);
+}
 template <int DT>
-__global__ __launch_bounds__(256) void quant_rows_e8_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, uint8_t* e8, int emu) {
-    constexpr int MAXC = 10;
-    __shared__ float red[4];
-    const int64_t r = blockIdx.x;
-    const bf16_t* row = in + r * ld;
-    const int nchunk = K / 8;
-    uint4 v[MAXC];
-    float mx = 0.f;
+__device__ __forceinline__ void load32(const bf16_t* src, float (&f)[32]) {
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = threadIdx.x + 256 * i;
-        if (c < nchunk) {
-            v[i] = *(const uint4*)(row + 8 * c);
-            const uint16_t* e = (const uint16_t*)&v[i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(from16<DT>(e[j])));
-        }
-    }
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    int ex = mx > 0.f && mx < 3.0e38f ? pow2_exp_ge(mx / FP8_MAX) : 0;
-    ex = max(-126, min(126, ex));
-    const float inv = ldexpf(1.0f, -ex);
-    if (threadIdx.x == 0) e8[r] = (uint8_t)(ex + 127);
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = threadIdx.x + 256 * i;
-        if (c < nchunk) {
-            const uint16_t* e = (const uint16_t*)&v[i];
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = from16<DT>(e[j]) * inv;
-            emulate_narrow(f, emu);
-            *(uint2*)(out8 + r * K + 8 * c) = make_uint2(pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7]));
-        }
-    }
-}
-int launch_quant_rows_e8(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, uint8_t* e8, hipStream_t s) {
-    ARG_CHECK(in && out8 && e8 && n_rows > 0 && K > 0 && K % 8 == 0 && ld % 8 == 0 && K <= 256 * 8 * 10);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_rows_e8_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8, lo_emulate("BLIM_LO_EMULATE_W"));
-    else hipLaunchKernelGGL((quant_rows_e8_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, e8, lo_emulate("BLIM_LO_EMULATE_W"));
-    LAUNCH_CHECK("quant_rows_e8");
-    return BLIM_OK;
-}
-// one thread per 8 columns, 16 consecutive lanes per 128-column block; 4 rows per 256-thread workgroup pass over the chunks
-template <int DT>
-__global__ __launch_bounds__(256) void quant_lo_mx_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride, int emu) {
-    const int64_t r = blockIdx.x;
-    const bf16_t* row = in + r * ld;
-    const int nchunk = K / 8;
-    const int rl = (int)(r & 255);
-    const int64_t mpos = (r >> 8) * 256 + ((rl >> 7) * 16 + (rl & 15)) * 8 + ((rl >> 4) & 7);
-    for (int c = threadIdx.x; c < nchunk; c += 256) {                 // nchunk % 16 == 0: the 16 lanes of a block are all in or all out
-        const uint4 v = *(const uint4*)(row + 8 * c);
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = *(const uint4*)(src + 8 * q);
         const uint16_t* e = (const uint16_t*)&v;
-        float f[8], m = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { f[j] = from16<DT>(e[j]); m = fmaxf(m, fabsf(f[j])); }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
-        int ex = m > 0.f && m < 3.0e38f ? pow2_exp_ge(m / FP8_MAX) : -127;
-        ex = max(-127, min(126, ex));
-        const float inv = ex > -127 ? ldexpf(1.0f, -ex) : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] *= inv;
-        emulate_narrow(f, emu);
-        *(uint2*)(out8 + r * ld8 + 8 * c) = make_uint2(pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7]));
-        if ((threadIdx.x & 15) == 0) mx[(int64_t)(c >> 4) * mx_stride + mpos] = (uint8_t)(ex + 127);
+        for (int j = 0; j < 8; ++j) f[8 * q + j] = from16<DT>(e[j]);
     }
 }
-int launch_quant_lo_mx(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride, hipStream_t s) {
-    ARG_CHECK(in && out8 && mx && n_rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld8 % 16 == 0 && ld8 >= K && mx_stride >= round_up256(n_rows));
-    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_lo_mx_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride, lo_emulate("BLIM_LO_EMULATE_A"));
-    else hipLaunchKernelGGL((quant_lo_mx_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, in, ld, n_rows, K, out8, ld8, mx, mx_stride, lo_emulate("BLIM_LO_EMULATE_A"));
-    LAUNCH_CHECK("quant_lo_mx");
+// The lo halves of [hi | lo] rows, IN PLACE: row r's K 16-bit lo values at rows + r * ld become K bytes of e2m3 image at the same address (the GEMM's second pass
+// reads them as the row's K-steps K / 64 ...; the second half of the lo region is dead afterwards).  One workgroup per row; every block is read and quantised
+// into registers, then -- behind a barrier, the image of K-step s overlaps the 16-bit values of step s / 2 -- written.
+#define F6_MAXB 3
+template <int DT>
+__global__ __launch_bounds__(256) void quant_lo_f6_kernel(bf16_t* rows, int64_t ld, int64_t n_rows, int K) {
+    bf16_t* row = rows + (int64_t)blockIdx.x * ld;
+    const int nblk = K / 32;
+    F6Block b[F6_MAXB];
+#pragma unroll
+    for (int i = 0; i < F6_MAXB; ++i) {
+        const int blk = threadIdx.x + 256 * i;
+        if (blk < nblk) { float f[32]; load32<DT>(row + 32 * blk, f); b[i] = e2m3_block(f); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < F6_MAXB; ++i) {
+        const int blk = threadIdx.x + 256 * i;
+        if (blk < nblk) store_f6_block((uint8_t*)row, blk, b[i]);
+    }
+}
+int launch_quant_lo_f6(bf16_t* rows, int64_t ld, int64_t n_rows, int K, int dtype, hipStream_t s) {
+    ARG_CHECK(rows && n_rows > 0 && K > 0 && K % 128 == 0 && K <= 256 * 32 * F6_MAXB && ld % 8 == 0 && ld >= K);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_lo_f6_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, rows, ld, n_rows, K);
+    else hipLaunchKernelGGL((quant_lo_f6_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, rows, ld, n_rows, K);
+    LAUNCH_CHECK("quant_lo_f6");
     return BLIM_OK;
 }
-
+// The combined weight copy the compensated GEMMs read: row n = [the K 16-bit values of W's row n | K bytes of their e2m3 image], row stride 3 K bytes
+template <int DT>
+__global__ __launch_bounds__(256) void combine_w_f6_kernel(const bf16_t* w, int64_t ld, int K, uint8_t* out) {
+    const bf16_t* row = w + (int64_t)blockIdx.x * ld;
+    uint8_t* orow = out + (int64_t)blockIdx.x * K * 3;
+    for (int blk = threadIdx.x; blk < K / 32; blk += 256) {
+        float f[32];
+        load32<DT>(row + 32 * blk, f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(uint4*)(orow + 64 * blk + 16 * q) = *(const uint4*)(row + 32 * blk + 8 * q);
+        store_f6_block(orow + 2 * (int64_t)K, blk, e2m3_block(f));
+    }
+}
+int launch_combine_w_f6(const bf16_t* w, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out, hipStream_t s) {
+    ARG_CHECK(w && out && n_rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld >= K);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((combine_w_f6_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, w, ld, K, out);
+    else hipLaunchKernelGGL((combine_w_f6_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, w, ld, K, out);
+    LAUNCH_CHECK("combine_w_f6");
+    return BLIM_OK;
+}

@@ -44,10 +44,9 @@ int launch_quant_rows(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int d
 // RMSNorm whose output is quantised per row (same arithmetic as launch_rmsnorm, then the rule above)
 int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const float* w, float eps, uint8_t* out8, float* scale, hipStream_t s);
 
-// ---- "lo8" (gemm.hpp: A8 / W8): e4m3 operands with POWER-OF-TWO scales that the block-scaled MFMA applies itself (E8M0 bytes, value 2^(byte - 127))
-// W side: out8 [n_rows, K] = e4m3(in / 2^e_row), e8[n_rows] = e_row + 127 with 2^e_row the smallest power of two >= absmax / 448
-int launch_quant_rows_e8(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, uint8_t* e8, hipStream_t s);
-// A side: in = the LO halves of [hi | lo] rows (row stride ld); out8 [n_rows, ld8] e4m3 and one E8M0 byte per (row, 128 columns) into the MXA table
-// mx[(k / 128) * mx_stride + (row / 256) * 256 + ((rl >> 7) * 16 + (rl & 15)) * 8 + ((rl >> 4) & 7)], rl = row % 256 (gemm.hpp: a_mx).  K % 128 == 0.
-int launch_quant_lo_mx(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out8, int64_t ld8, uint8_t* mx, int64_t mx_stride, hipStream_t s);
-
+// ---- "lo6" (gemm.hpp: K6): the operands of the compensated GEMMs' second pass, e2m3 with one E8M0 (power-of-two) scale per 32 values that the block-scaled MFMA
+// applies itself, in the 128-bytes-per-128-values image the GEMM reads as further K-steps of the same rows.
+// The lo halves of [hi | lo] rows, quantised IN PLACE: the K 16-bit values at rows + r * ld (r < n_rows) become K bytes of image at the same address.  K % 128 == 0.
+int launch_quant_lo_f6(bf16_t* rows, int64_t ld, int64_t n_rows, int K, int dtype, hipStream_t s);
+// out[n] = [the K 16-bit values of w's row n | K bytes of their e2m3 image], row stride 3 K bytes (GemmParams.ldw = 3 K / 2 elements)
+int launch_combine_w_f6(const bf16_t* w, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out, hipStream_t s);

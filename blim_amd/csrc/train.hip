@@ -94,12 +94,12 @@ static int talloc(blim_trainer* t, void** p, size_t bytes) {
 }
 
 extern "C" int64_t blim_train_flat_size(const blim_engine* e, int32_t lora_r) {
-    if (!e || lora_r <= 0) return -1;
+    if (!e || lora_r <= 0 || lora_r > 16) return -1;          // (blim_train_create / blim_load_adapter refuse r > 16: no layout for it either)
     return make_layout(e->c, lora_r).total;
 }
 
 extern "C" int blim_train_param_offset(const blim_engine* e, int32_t lora_r, const char* name, int64_t* offset, int64_t* rows, int64_t* cols) {
-    ARG_CHECK(e && name && offset && rows && cols && lora_r > 0);
+    ARG_CHECK(e && name && offset && rows && cols && lora_r > 0 && lora_r <= 16);
     const Layout L = make_layout(e->c, lora_r);
     const std::string n(name);
     if (n == "visual_head") { *offset = L.off_vh; *rows = e->c.mm_hidden_size; *cols = e->c.hidden_size; return BLIM_OK; }
@@ -253,7 +253,14 @@ extern "C" int blim_train_merge(blim_trainer* t, void* stream) {
     TRY(launch_f32_to_16(e->visual_head, H, P + t->lay.off_vh, H, M, H, 1.0f, dt, s));
     TRY(engine_set_visual_head3(e, P + t->lay.off_vh, BLIM_DTYPE_F32, s));      // the scoring path's hi + lo copy of the head
     e->f8_ready = false;
-    e->lo8_ready = false;          // the e4m3 copies of the compensated modes' second pass follow the merged weights
+    e->lo6_ready = false;          // the combined 16-bit | e2m3 copies of the compensated modes' second pass follow the merged weights
+    e->merged_pending.clear();
+    for (int l = 0; l < c.num_layers; ++l) {
+        e->c6_dirty.insert(e->L[l].wqkv); e->c6_dirty.insert(e->L[l].wo);
+        for (const char* n : {"q_proj.w", "k_proj.w", "v_proj.w", "o_proj.w"}) e->merged_pending.insert("layers." + std::to_string(l) + "." + n);
+    }
+    e->c6_dirty.insert(e->lm_head);
+    for (const char* n : {"lm_head", "mlp.0.w", "mlp.2.w", "tvg_mlp.0.w", "tvg_mlp.2.w"}) e->merged_pending.insert(n);
     e->lora_merged = true;
     return BLIM_OK;
 }

@@ -103,6 +103,7 @@ def load_library(path: str = LIB_PATH):
         "blim_fill_bell_f32": ([vp, i64, u64, C.c_char_p, f32, f32, i32, vp], C.c_int),
         "blim_gemm_bf16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
         "blim_gemm_f16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
+        "blim_gemm_f16_lo6": ([vp, vp, i32, i32, i32, vp, vp, vp], C.c_int),
         "blim_quant_rows": ([vp, i64, i64, i32, i32, vp, vp, vp], C.c_int),
         "blim_gemm_f8": ([vp, i64, vp, vp, vp, i32, i32, i32, vp, i64, vp], C.c_int),
         "blim_timing_enable": ([vp, i32], C.c_int),
@@ -208,9 +209,9 @@ class Engine:
         self.device = torch.device("cuda", torch.cuda.current_device())
         # blim_create honours BLIM_PRECISE_MLP / BLIM_PRECISE_ACT (A/B runs): the Python-side cache of those options starts from the same values, so that
         # set_precise() neither clobbers an override nor believes in a default the engine does not have
-        # mirrors the engine's default of option "precise_lo8" (include/blim.h): the compensated modes' second pass over K in e4m3 on fp16 engines
-        self.lo8 = (dtype == "f16" and dims.hidden_size % 128 == 0 and dims.intermediate_size % 128 == 0 and max(dims.hidden_size, dims.intermediate_size) <= 20480
-                    and os.environ.get("BLIM_PRECISE_LO8", "1") != "0")
+        # mirrors the engine's default of option "precise_lo6" (include/blim.h): the compensated modes' second pass over K in e4m3 on fp16 engines
+        self.lo6 = (dtype == "f16" and dims.hidden_size % 128 == 0 and dims.intermediate_size % 128 == 0 and max(dims.hidden_size, dims.intermediate_size) <= 20480
+                    and os.environ.get("BLIM_PRECISE_LO6", "1") != "0")
         self._precise_mlp = os.environ.get("BLIM_PRECISE_MLP", "1") != "0"
         self._precise_act = os.environ.get("BLIM_PRECISE_ACT", "1") != "0"
 
@@ -264,8 +265,8 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         _check(self.lib.blim_set_option(self.h, key.encode(), value), "blim_set_option")
-        if key == "precise_lo8":
-            self.lo8 = bool(value)
+        if key == "precise_lo6":
+            self.lo6 = bool(value)
 
     @property
     def can_precise(self) -> bool:
@@ -488,6 +489,21 @@ def gemm_f8(a8, a_scale, w8, w_scale):
     out = torch.empty((M, N), dtype=torch.float16, device=a8.device)
     _check(lib.blim_gemm_f8(_ptr(a8), K, _ptr(a_scale), _ptr(w8), _ptr(w_scale), M, N, K, _ptr(out), N, _stream()), "blim_gemm_f8")
     return out
+
+
+def gemm_f16_lo6(a_hilo, w):
+    """The compensated GEMM of fp16 engines (option "precise_lo6"): a_hilo [M, 2K] f16 rows [hi | lo], w [N, K] f16 -> (C f32 [M, N] = hi . w^T + e2m3(lo) . e2m3(w)^T,
+    the rows as the kernel read them -- lo halves replaced by their e2m3 image --, the combined weight copy uint8 [N, 3K])."""
+    import torch
+    lib = load_library()
+    M, K2 = a_hilo.shape
+    N, K = w.shape
+    assert K2 == 2 * K and a_hilo.dtype == torch.float16 and w.dtype == torch.float16 and a_hilo.is_contiguous() and w.is_contiguous()
+    rows = a_hilo.clone()
+    wc = torch.empty((N, 3 * K), dtype=torch.uint8, device=w.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=w.device)
+    _check(lib.blim_gemm_f16_lo6(_ptr(rows), _ptr(w), M, N, K, _ptr(wc), _ptr(out), _stream()), "blim_gemm_f16_lo6")
+    return out, rows, wc
 
 
 def gemm_bf16(a, w):

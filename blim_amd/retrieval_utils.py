@@ -213,7 +213,7 @@ def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_voc
 
 
 def e4m3_pass_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, prune: bool = True) -> float:
-    """The part of executed_flops() that runs on the e4m3 MFMA when the engine's option "precise_lo8" is on (fp16 engines, default): the second walk over K of the
+    """The part of executed_flops() that runs on the e4m3 MFMA when the engine's option "precise_lo6" is on (fp16 engines, default): the second walk over K of the
     decoder GEMMs and of lm_head in the compensated modes (attn / act0 / full; `qkx`'s doubled QKV GEMM is a plain-mode kernel and stays 16-bit, and the TVG head's
     three-term products are 16-bit GEMMs of depth 3 K).  A roofline for such a call prices these flops at the fp8 peak and the rest at the 16-bit one."""
     if mode not in ("attn", "act0", "full"):
@@ -316,7 +316,7 @@ class PairScorer:
             else:
                 self.vocab_cm = _clip_major_vocab(video_vocab, self.device, self.m.dtype)
         self.exec_flops = 0.0            # GEMM FLOPs of the engine calls run so far (executed_flops; bench.py's roofline fractions)
-        self.exec_flops_e4m3 = 0.0       # ... of which on the e4m3 MFMA (e4m3_pass_flops: the compensated modes' second pass under the engine's "precise_lo8")
+        self.exec_flops_e4m3 = 0.0       # ... of which on the e4m3 MFMA (e4m3_pass_flops: the compensated modes' second pass under the engine's "precise_lo6")
         self.exec_tokens = 0
         self._vfeat: Dict[Tuple[int, bool], object] = {}
         self._upcoming: Dict[bool, List[int]] = {}; self._upcoming_pos: Dict[bool, int] = {}
@@ -585,7 +585,7 @@ class PairScorer:
         if plan.kind == "vtg":
             mode = self.vtg_mode                                             # None (fp16 engines) | "qk" | "attn" | "full" (bf16 engines: modeling.py)
             self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "vtg", mode, prune=not f8)
-            if getattr(self.engine, "lo8", False):
+            if getattr(self.engine, "lo6", False):
                 self.exec_flops_e4m3 += e4m3_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "vtg", mode, prune=not f8)
             comp = mode in VTG_SPLIT_MODES
             self.engine.set_precise(comp, embeds=comp, mlp=mode in ("act0", "full"), act=mode == "full")
@@ -600,7 +600,7 @@ class PairScorer:
                     self.engine.set_option("precise_qk", 0)
         self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode if self.split_tvg else None,
                                           n_vocab=self.n_vocab, prune=not f8)
-        if getattr(self.engine, "lo8", False) and self.split_tvg:
+        if getattr(self.engine, "lo6", False) and self.split_tvg:
             self.exec_flops_e4m3 += e4m3_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode, prune=not f8)
         if self.vocab_cm is None and getattr(self.engine, "_vocab_key", None) != self._vocab_key:
             self.engine.set_video_vocab(self._vocab_src)                     # another scorer / the literal path registered its own vocabulary since

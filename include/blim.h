@@ -191,6 +191,10 @@ int blim_fill_bell_f32(float* out, int64_t n, uint64_t seed, const char* name, f
 /* C [M, ldc] = A [M, lda] . W [N, K]^T, all bf16 (resp. f16) */
 int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
 int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
+/* The compensated GEMM of fp16 engines as a building block (tests; option "precise_lo6"): A_hilo [M, 2 K] fp16 rows [hi | lo], W [N, K] fp16 ->
+ * C f32 [M, N] = hi . W^T (fp16 MFMA) + e2m3(lo) . e2m3(W)^T (block-scaled MFMA, one power-of-two scale per 32 values), one kernel.  The lo halves of A_hilo are
+ * REPLACED by their e2m3 image (the engine quantises in place); w_c6 [N, 3 K bytes] receives the combined copy [W | e2m3 image of W].  K % 128 == 0. */
+int blim_gemm_f16_lo6(void* A_hilo, const void* W, int32_t M, int32_t N, int32_t K, void* w_c6, float* C, void* stream);
 /* fp8 building blocks (tests / bench): per-row e4m3 quantisation of a 16-bit matrix (dtype16 = BLIM_COMPUTE_BF16 / _F16;
  * out8 [n_rows, K] bytes, scale [n_rows] = absmax / 448, 1 for an all-zero row), and
  * C f16 [M, ldc] = (A8 [M, lda] . W8 [N, K]^T) * a_scale[m] * w_scale[n] on the block-scaled fp8 MFMA.  K % 128 == 0. */
@@ -229,7 +233,7 @@ int blim_debug_gemm_stamps(void* device_buf);
  *   the 16-bit rounding of q and k (tests/golden/sink.npz: plain fp16 VTG 3.2e-3 off the fp32 reference, 1.2e-3 with this option at -2.5 % speed, 5.3e-4 with
  *   "precise" + "precise_mlp" = 0 at -16.5 %).  2: the QKV GEMM's input (the first norm's output) travels as hi + lo as well -- that GEMM walks K twice, nothing
  *   else changes: 6.6e-4 on the same fixture at -8.4 %, the cheapest setting inside the 1e-3 bar there;
- * "precise_lo8" (0/1; fp16 engines with hidden / intermediate sizes that are multiples of 128: default 1, env BLIM_PRECISE_LO8=0 turns it off; other engines refuse 1):
+ * "precise_lo6" (0/1; fp16 engines with hidden / intermediate sizes that are multiples of 128: default 1, env BLIM_PRECISE_LO6=0 turns it off; other engines refuse 1):
  *   in precise mode the decoder GEMMs' second walk over K -- the product of W with the activations' LO parts, 2^-11 of the values -- runs on the e4m3 MFMA at twice
  *   the rate, inside the same kernel and into the same accumulators (e4m3 copies of the decoder weights with power-of-two row scales, +1 byte per weight, built on
  *   the first compensated call; the lo parts quantised per (row, 128 columns)).  A fully compensated call costs 1.6x a plain one instead of 2x (1,677 against 1,336

@@ -768,7 +768,7 @@ def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
 
 @pytest.mark.parametrize("case", ["deep", "full7b"])
 def test_e4m3_second_pass_of_the_compensated_gemms(case, capsys):
-    """Engine option "precise_lo8" (default on fp16 engines; gemm.hip phase 2): in the compensated modes the product with the activations' LO parts -- 2^-11 of the
+    """Engine option "precise_lo6" (default on fp16 engines; gemm.hip phase 2): in the compensated modes the product with the activations' LO parts -- 2^-11 of the
     values -- runs on the e4m3 MFMA inside the same kernel instead of a second fp16 walk over K.  (a) With the option off the fp16 K-twice kernels still meet the
     golden (the path every fp16 run took before round 4's end, and the one bf16 engines keep); (b) on / off differ in bits but by far less than the bar: the e4m3
     pass removes > 95 % of what the lo pass removes at all; (c) both meet the golden on every pass with the VTG calls fully compensated."""
@@ -780,10 +780,10 @@ def test_e4m3_second_pass_of_the_compensated_gemms(case, capsys):
     try:
         t.model.vtg_precise = "full"
         for on in (1, 0):
-            t.model.engine.set_option("precise_lo8", on)
+            t.model.engine.set_option("precise_lo6", on)
             got[on] = _six_passes(t, False)
             res[on] = _worst_rel(got[on], g)
-        t.model.engine.set_option("precise_lo8", 1)
+        t.model.engine.set_option("precise_lo6", 1)
         lit = _worst_rel(_six_passes(t, True), g)
     finally:
         t.model.engine.close()
@@ -800,7 +800,7 @@ def test_e4m3_second_pass_of_the_compensated_gemms(case, capsys):
 
 
 def test_e4m3_weight_copies_follow_the_weights():
-    """The e4m3 copies the compensated modes' second pass reads (option "precise_lo8") are derived state: replacing weights in a live engine must rebuild them.  A stale
+    """The e4m3 copies the compensated modes' second pass reads (option "precise_lo6") are derived state: replacing weights in a live engine must rebuild them.  A stale
     copy would be a SILENT error of ~2^-11 of the weight change -- so: an engine that has already run compensated calls gets another weight set loaded over the first
     (all tensors, then a single decoder matrix) and must score bit for bit like a fresh engine loaded with the same tensors."""
     spec = CASES["tiny"]
@@ -817,7 +817,7 @@ def test_e4m3_weight_copies_follow_the_weights():
 
     live = BlimModel(dims, max_positions=1024, dtype="f16")
     try:
-        assert live.engine.lo8
+        assert live.engine.lo6
         live.engine.load_weights(w1)
         s1 = scores(live)                                              # builds the copies of w1
         live.engine.load_weights(w2)
@@ -1055,6 +1055,69 @@ def test_fp8_gemm_is_exact_on_integer_data(M, N, K):
     ref = (a.double() @ w.double().T) * sa.double().unsqueeze(1) * sw.double().unsqueeze(0)
     assert float(ref.abs().max()) < 60000                        # inside fp16 range, integers * powers of two: exactly representable?
     assert torch.equal(out.double(), ref.to(torch.float16).double())
+
+
+# ----------------------------------------------------------------------------- the compensated GEMM's e2m3 second pass (option "precise_lo6", gemm.hip phase 2)
+E2M3_VALUES = np.array([m / 8.0 for m in range(8)] + [(1 + m / 8.0) * 2.0 ** (e - 1) for e in (1, 2, 3) for m in range(8)])        # magnitude of code 0..31
+
+
+def _e2m3_quant(x):
+    """numpy statement of kernels.hip: e2m3_block -- x [..., K] (K % 32 == 0) -> (codes uint8 [..., K] incl. the sign bit, E8M0 bytes [..., K / 32], dequantised values)."""
+    x = np.asarray(x, np.float64)
+    b = x.reshape(x.shape[:-1] + (-1, 32))
+    amax = np.abs(b).max(axis=-1, keepdims=True)
+    mant, ex = np.frexp(amax / 7.5)                                   # amax / 7.5 = mant 2^ex, mant in [0.5, 1): smallest s with 2^s >= it
+    s_ = np.where(mant == 0.5, ex - 1, ex)
+    s_ = np.where(amax > 0, np.clip(s_, -127, 127), -127)
+    a = np.minimum(np.abs(b) * np.where(amax > 0, 2.0 ** (-s_.astype(np.float64)), 0.0), 7.5)
+    bin_ = np.where(a < 2, 0, np.where(a < 4, 1, 2))
+    q = np.rint(a * np.choose(bin_, [8.0, 4.0, 2.0])).astype(np.int64)
+    code = np.minimum(q + 8 * bin_, 31)
+    val = np.sign(b) * E2M3_VALUES[code] * 2.0 ** s_.astype(np.float64)
+    return (code | np.where(b < 0, 32, 0)).astype(np.uint8).reshape(x.shape), (s_[..., 0] + 127).astype(np.uint8), val.reshape(x.shape)
+
+
+def _e2m3_image_decode(img, K):
+    """img uint8 [rows, K] (the 128-bytes-per-128-values image of gemm.hpp) -> (codes [rows, K], E8M0 bytes [rows, K / 32])."""
+    rows = img.shape[0]
+    st = img.reshape(rows, K // 128, 128)
+    codes = np.zeros((rows, K // 128, 4, 32), np.uint8); e8 = np.zeros((rows, K // 128, 4), np.uint8)
+    for g in range(4):
+        data = np.concatenate([st[:, :, 16 * g:16 * g + 16], st[:, :, 64 + 16 * g:64 + 16 * g + 8]], axis=-1)          # 24 bytes = 32 x 6 bits, little endian
+        bits = np.unpackbits(data, axis=-1, bitorder="little").reshape(rows, K // 128, 32, 6)
+        codes[:, :, g] = (bits * (1 << np.arange(6))).sum(-1)
+        e8[:, :, g] = st[:, :, 64 + 16 * g + 8]
+        assert not st[:, :, 64 + 16 * g + 9:64 + 16 * g + 16].any()                                                 # padding
+    return codes.reshape(rows, K), e8.reshape(rows, K // 32)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (700, 512, 3584), (512, 256, 18944)])
+def test_lo6_gemm_quantisers_and_kernel_vs_numpy(M, N, K):
+    """blim_gemm_f16_lo6 = the engine's compensated GEMM: C = hi . W^T on the fp16 MFMA + e2m3(lo) . e2m3(W)^T on the block-scaled MFMA, one kernel, both operands'
+    rows continuing into their e2m3 image.  (a) the two quantisers write exactly the image numpy's statement of the rule gives (codes, scale bytes, padding, the 16-bit
+    half of the combined weight copy); (b) the kernel's result equals hi . W^T + dequantised(lo) . dequantised(W)^T in float64 to f32 summation accuracy -- a wrong K
+    assignment, scale block or pairing of the second pass shows at 1e-3 of the second term; (c) the second term is really there."""
+    g = np.random.RandomState(M + N + K)
+    hi = (g.randn(M, K) * 0.5).astype(np.float16)
+    lo = (g.randn(M, K) * 2.0 ** -11 * np.exp(g.randn(M, 1)) * (1 + 50 * (g.rand(M, K) < 0.002))).astype(np.float16)        # ragged magnitudes, a few outliers per row
+    lo[:, 32:64] = 0                                                                                                       # an all-zero block
+    w = (g.randn(N, K) * 0.02 * (1 + 30 * (g.rand(N, K) < 0.001))).astype(np.float16)
+    out, rows, wc = eng.gemm_f16_lo6(torch.from_numpy(np.concatenate([hi, lo], axis=1)).cuda(), torch.from_numpy(w).cuda())
+    rows = rows.cpu().numpy(); wc = wc.cpu().numpy(); out = out.cpu().numpy().astype(np.float64)
+    assert np.array_equal(rows[:, :K], hi)
+    assert np.array_equal(wc[:, :2 * K].copy().view(np.float16), w)
+    c_lo, e_lo, v_lo = _e2m3_quant(lo.astype(np.float64))
+    c_w, e_w, v_w = _e2m3_quant(w.astype(np.float64))
+    got_c, got_e = _e2m3_image_decode(rows[:, K:].copy().view(np.uint8)[:, :K], K)
+    live = np.repeat(e_lo != 0, 32, axis=1)                                        # (the sign bit of a value in an all-zero block is free)
+    assert np.array_equal(got_e, e_lo) and np.array_equal(got_c[live], c_lo[live]) and not (got_c[~live] & 31).any()
+    got_c, got_e = _e2m3_image_decode(wc[:, 2 * K:], K)
+    assert np.array_equal(got_e, e_w) and np.array_equal(got_c, c_w)
+    first = hi.astype(np.float64) @ w.astype(np.float64).T
+    second = v_lo @ v_w.T
+    scale = np.abs(hi.astype(np.float64)) @ np.abs(w.astype(np.float64)).T
+    assert np.abs(out - (first + second)).max() < 2e-6 * scale.max()
+    assert np.abs(second).max() > 1e-4 * np.abs(first).max() and np.abs(out - first).max() > 0.5 * np.abs(second).max()
 
 
 @pytest.fixture(scope="module")

@@ -421,7 +421,7 @@ def test_executed_flops_formula_and_calibration_pairs():
     assert RU.executed_flops(d, 1000, 400, "tvg", "attn", n_vocab=1000, prune=False) == 28 * (2 * F - mlp_d - mlp_gu) * 1000 + 3 * tvg_head
     assert RU.executed_flops(d, 1000, 400, "tvg", None, n_vocab=1000, prune=False) == 28 * F * 1000 + tvg_head
     assert RU.TVG_MODES == ("attn", "act0", "full")
-    # the e4m3 share (engine option "precise_lo8"): the second walk over K of the compensated decoder GEMMs and of lm_head; never in the plain modes, nor qkx's doubled QKV
+    # the e4m3 share (engine option "precise_lo6"): the second walk over K of the compensated decoder GEMMs and of lm_head; never in the plain modes, nor qkx's doubled QKV
     assert RU.e4m3_pass_flops(d, tok, rows, "vtg", None) == 0 and RU.e4m3_pass_flops(d, tok, rows, "vtg", "qkx") == 0
     assert RU.e4m3_pass_flops(d, tok, rows, "vtg", "full", prune=False) == RU.executed_flops(d, tok, rows, "vtg", "full", prune=False) / 2
     assert RU.e4m3_pass_flops(d, tok, rows, "vtg", "attn", prune=False) == 28 * (qkv + 2 * 3584 * 3584) * tok + head * rows

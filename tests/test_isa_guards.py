@@ -103,7 +103,7 @@ def test_fp16_saturation_window_excludes_every_mfma(gemm_kernels):
         assert len(_reachable_before(body, off[0], ON, r"v_mfma")) == len(mfma), (name, "every MFMA sits inside the cleared window")
         assert _reachable_before(body, on[0], OFF, CVT), (name, "the conversions sit inside the set window")
         checked += 1
-    assert checked >= 9           # EPI_BF16 / QKV / SWIGLU x {plain, split} in fp16 (+ the fp8 kernels' fp16 outputs, + the two-phase lo8 kernels)
+    assert checked >= 9           # EPI_BF16 / QKV / SWIGLU x {plain, split} in fp16 (+ the fp8 kernels' fp16 outputs, + the two-phase lo6 kernels)
 
 
 @pytest.mark.parametrize("src,pattern", [("gemm.hip", r"gemm_kernelILi\dELi[01]E"), ("attention.hip", r"attn_kernel"), ("adapters.hip", r"adapter_down_kernel")])
@@ -115,9 +115,10 @@ def test_no_spills_in_the_16_bit_kernels(src, pattern, gemm_kernels, tmp_path):
             continue
         seen += 1
         if src == "gemm.hip" and re.search(r"gemm_kernelILi\dELi1ELb[01]ELb1E", name):
-            # the two-phase "lo8" kernels (fp16 pass + e4m3 pass over the lo part in one accumulator set, gemm.hip phase 2): 14 - 17 VGPRs spilled around the
-            # hand-over between the two loops and in the tile prologue -- tolerated as long as NO basic block that issues MFMAs touches scratch
-            assert meta["vgpr_spills"] <= 24, (name, meta)
+            # the two-phase "lo6" kernels (fp16 pass + e2m3 pass over the lo part in one accumulator set, gemm.hip phase 2).  Round 4's e4m3 form spilled 14 - 17 VGPRs around
+            # the hand-over between its two loops; round 5's rows continue into the second pass's operands and nothing is handed over: <= 3 spilled VGPRs, all of them
+            # kernel-invariant values stored once per kernel and reloaded in the tile prologue / epilogue -- and NO basic block of a K loop touches scratch
+            assert meta["vgpr_spills"] <= 4, (name, meta)
             body = ks[name][0]
             # basic blocks and their successors
             heads = [0] + [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
