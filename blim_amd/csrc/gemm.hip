@@ -294,7 +294,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         // pass starts with its first two K-steps staged -- round 4's separate e4m3 operands cost a drained ring, twelve more address registers and ~7 us per tile.
         // A lane's two 16-byte fragment reads bring the six operand registers of a 16-row fragment and, in register 6, the block's scale byte: no scale tables.
         // The loop is the fp8 kernel's (rotated: fragments read and consumed inside one iteration).
+        int p2_first = -1;                                           // (ablation builds: ring slot of the second pass's first A tile)
         auto load_frags6 = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 2   // ablation builds only (make ablate_p2; timing, wrong results): 1 = no MFMAs in phase 2, 2 = fragments read in its first
+            if (offA_tile != p2_first) return;       // step only, 3 = no LDS-DMA issued by phase 2
+#endif
             const char* ba0 = smem + (offA_tile + a_off); const char* ba1 = smem + ((offA_tile + a_off) ^ 64);
             const char* bb0 = smem + (offB_tile + b_off); const char* bb1 = smem + ((offB_tile + b_off) ^ 64);
             auto rd = [](const char* q0, const char* q1) __attribute__((always_inline)) {
@@ -307,6 +311,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             for (int mi = 0; mi < 8; ++mi) fa8[mi] = rd(ba0 + mi * 2048, ba1 + mi * 2048);
         };
         auto compute6 = [&]() __attribute__((always_inline)) {
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 1
+            return;
+#endif
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
@@ -366,16 +373,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }
             if constexpr (LO6) {
                 // phase 2, W group: A(nk) W(nk) are complete (every wave waited for its share before the last 16-bit step's first barrier), A(nk+1) W(nk+1) in flight
-                int sp = sa;
+                // Ping-pong like the 16-bit loop, but with BOTH groups reading and consuming a step's fragments inside one iteration (fragments carried over a back
+                // edge cost this kernel its registers: the fp8 loops) -- the A group runs half a step behind:
+                //   interval 2k:     W group reads the fragments of step k, stages W(k+1)  | A group computes step k-1
+                //   interval 2k + 1: W group computes step k                             | A group reads the fragments of step k, stages A(k+2)
+                // As ONE lock-step loop (both groups reading, then both computing) a step took 1.5 us: 0.6 us of fragment reads with the matrix pipe idle, then
+                // 0.7 us of MFMAs with the LDS idle (ablation builds, make ablate_p2).
+                p2_first = sa;
+                int sp = sa;                                             // slot of A(k-1): free since the A group finished reading step k-1 (end of interval 2k-1)
                 for (int k = 0; k < nk6; ++k) {
                     load_frags6(sa, adv(sa, 1));
-                    if (k >= 1 && k + 1 < nk6) stage8(sp, nk + k + 1);   // W(k+1) into the slot A(k-1) left
-                    PHASE_BARRIER();
+#if !defined(GEMM_ABLATE_P2) || GEMM_ABLATE_P2 != 3
+                    if (k >= 1 && k + 1 < nk6) stage8(sp, nk + k + 1);   // W(k+1) into the slot A(k-1) left (W(nk+1): staged by the last 16-bit step)
+#endif
+                    PHASE_BARRIER();                                     // end of interval 2k
                     compute6();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of W(k+1) landed
-                    PHASE_BARRIER();
+                    PHASE_BARRIER();                                     // end of interval 2k + 1
                     sp = sa; sa = adv(sa, 2);
                 }
+                PHASE_BARRIER();                                         // end of interval 2 nk6 (the A group's last compute)
             }
         } else {
             stage8(0, 0);                                            // A0
@@ -410,14 +427,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 sa = adv(sa, 2);
             }
             if constexpr (LO6) {
-                for (int k = 0; k < nk6; ++k) {                          // phase 2, A group
+                p2_first = sa;
+                PHASE_BARRIER();                                         // end of interval 0 (the W group's first fragment reads)
+                for (int k = 0; k < nk6; ++k) {                          // phase 2, A group (half a step behind the W group: above)
                     load_frags6(sa, adv(sa, 1));
-                    if (k + 2 < nk6) stage8(adv(sa, 4), nk + k + 2);
+#if !defined(GEMM_ABLATE_P2) || GEMM_ABLATE_P2 != 3
+                    if (k + 2 < nk6) stage8(adv(sa, 4), nk + k + 2);     // A(k+2) into the slot W(k-1) left
+#endif
                     if (k + 2 < nk6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // my share of A(k+1) landed
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    PHASE_BARRIER();
+                    PHASE_BARRIER();                                     // end of interval 2k + 1
                     compute6();
-                    PHASE_BARRIER();
+                    PHASE_BARRIER();                                     // end of interval 2k + 2
                     sa = adv(sa, 2);
                 }
             }
