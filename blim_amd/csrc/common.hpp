@@ -36,6 +36,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // sides, MX block scales fixed at 1) on the block-scaled MFMA; everything 16-bit around them is fp16.
 #define DT_F8 2
 #define FP8_MAX 448.0f
+#define F6_TILE_BYTES 25600   // "lo6" operand tiles (gemm.hpp: A6 / W6): 24 KiB of packed e2m3 + 1 KiB of E8M0 scale bytes per (256-row tile, 128-value K-step)
 template <int DT> struct out16 { static constexpr int value = DT == DT_F8 ? DT_F16 : DT; };
 
 // two floats -> two e4m3 bytes in the low (hi = false) or high half of `old` (round to nearest even, v_cvt_pk_fp8_f32)

@@ -181,9 +181,9 @@ extern "C" void blim_destroy(blim_engine* e) {
     for (void* p : e->owned) hipFree(p);
     for (void* p : e->aug_owned) hipFree(p);
     for (void* p : e->ad_owned) hipFree(p);
-    if (e->lm_c6) hipFree(e->lm_c6);
+    if (e->lm6) hipFree(e->lm6);
     DevBuf* bufs[] = {&e->visual_head3, &e->hs3, &e->vocab3, &e->vocab1, &e->vh3, &e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale, &e->a6, &e->h6};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -269,7 +269,7 @@ static int place_weight(blim_engine* e, const std::string& name, const void* dev
     e->loaded[name] = true;
     e->f8_ready = false;
     e->lo6_ready = false;
-    if (s.kind == 0) e->c6_dirty.insert(s.dst);              // (finalize_lo6 re-derives the combined copy of THIS matrix only)
+    if (s.kind == 0) e->c6_dirty.insert(s.dst);              // (finalize_lo6 re-derives the e2m3 image of THIS matrix only)
     e->aug_ready = false;          // the augmented copies of adapted weights are rebuilt from the placed base weights on the next call
     // A merged update (blim_train_merge) stays marked until EVERY adapted matrix has been re-placed: reloading one tensor -- a norm, a bias, one projection -- must
     // not lift the "update would apply twice" guard of blim_load_adapter while the other projections still hold W + s B A.
@@ -362,14 +362,14 @@ static int finalize_f8(blim_engine* e) {
 }
 
 static int build_aug(blim_engine* e);
-// option "precise_lo6": the combined copies [W16 | e2m3 image] the compensated GEMMs read (kernels.hpp: launch_combine_w_f6).  Derived state, kept per matrix: a
-// copy is rebuilt when its source matrix was (re)placed since (c6_dirty), the augmented matrices' copies when the augmented matrices were rebuilt -- loading new
-// adapters every epoch (training.py: adapters_into_engine) does not touch the 0.6 GB per layer of the MLP's copies.  Allocation failures say what was being built.
+// option "precise_lo6": the e2m3 tile images of the weights the compensated GEMMs' second pass reads (kernels.hpp: launch_f6_tiles).  Derived state, kept per matrix:
+// an image is rebuilt when its source matrix was (re)placed since (c6_dirty), the augmented matrices' images when the augmented matrices were rebuilt -- loading new
+// adapters every epoch (training.py: adapters_into_engine) does not touch the MLP's images.  Allocation failures say what was being built.
 static int c6_alloc(blim_engine* e, uint8_t** q, size_t bytes, bool aug, const char* what) {
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
-        blim_set_error("option 'precise_lo6': out of device memory for the combined 16-bit | e2m3 copy of %s (%zu MB; the copies take 3 bytes per decoder / head weight: "
+        blim_set_error("option 'precise_lo6': out of device memory for the e2m3 image of %s (%zu MB; the images take 0.78 byte per decoder / head weight: "
                        "set option 'precise_lo6' = 0 to run the second pass on the 16-bit weights instead)", what, bytes >> 20);
         return BLIM_ERR_NOMEM;
     }
@@ -382,39 +382,39 @@ static int finalize_lo6(blim_engine* e) {
     TRY(blim_weights_ready(e));
     const blim_config& c = e->c;
     const int H = c.hidden_size, I = c.intermediate_size, dt = c.compute_dtype;
-    auto base = [&](uint8_t** copy, const bf16_t* w, int64_t n, int K, const char* what) -> int {
-        if (*copy && !e->c6_dirty.count((const void*)w)) return BLIM_OK;
-        if (!*copy) TRY(c6_alloc(e, copy, (size_t)n * K * 3, false, what));
-        return launch_combine_w_f6(w, K, n, K, dt, *copy, 0);
+    auto base = [&](uint8_t** img, const bf16_t* w, int64_t n, int K, const char* what) -> int {
+        if (*img && !e->c6_dirty.count((const void*)w)) return BLIM_OK;
+        if (!*img) TRY(c6_alloc(e, img, f6_tiles_bytes(n, K), false, what));
+        return launch_f6_tiles(w, K, n, K, dt, true, *img, 0);
     };
     for (auto& l : e->L) {
-        TRY(base(&l.wqkv_c6, l.wqkv, e->qkv_n, H, "q/k/v_proj")); TRY(base(&l.wo_c6, l.wo, H, H, "o_proj"));
-        TRY(base(&l.wgu_c6, l.wgu, 2 * (int64_t)I, H, "gate/up_proj")); TRY(base(&l.wd_c6, l.wd, H, I, "down_proj"));
+        TRY(base(&l.wqkv6, l.wqkv, e->qkv_n, H, "q/k/v_proj")); TRY(base(&l.wo6, l.wo, H, H, "o_proj"));
+        TRY(base(&l.wgu6, l.wgu, 2 * (int64_t)I, H, "gate/up_proj")); TRY(base(&l.wd6, l.wd, H, I, "down_proj"));
     }
     if (e->aug) {                         // adapters apart: the adapted projections' augmented weights [W | B_hi | B_lo | 0] (K = H + aug, a multiple of 128)
         TRY(build_aug(e));
         const int Hq = H + e->aug;
         for (auto& d : e->AD) {
-            if (d.wqkv_aug_c6) continue;                                  // built since the augmented matrices were (free_aug clears the pointers)
-            TRY(c6_alloc(e, &d.wqkv_aug_c6, (size_t)e->qkv_n * Hq * 3, true, "q/k/v_proj + adapters")); TRY(c6_alloc(e, &d.wo_aug_c6, (size_t)H * Hq * 3, true, "o_proj + adapters"));
-            TRY(launch_combine_w_f6(d.wqkv_aug, Hq, e->qkv_n, Hq, dt, d.wqkv_aug_c6, 0));
-            TRY(launch_combine_w_f6(d.wo_aug, Hq, H, Hq, dt, d.wo_aug_c6, 0));
+            if (d.wqkv_aug6) continue;                                    // built since the augmented matrices were (free_aug clears the pointers)
+            TRY(c6_alloc(e, &d.wqkv_aug6, f6_tiles_bytes(e->qkv_n, Hq), true, "q/k/v_proj + adapters")); TRY(c6_alloc(e, &d.wo_aug6, f6_tiles_bytes(H, Hq), true, "o_proj + adapters"));
+            TRY(launch_f6_tiles(d.wqkv_aug, Hq, e->qkv_n, Hq, dt, true, d.wqkv_aug6, 0));
+            TRY(launch_f6_tiles(d.wo_aug, Hq, H, Hq, dt, true, d.wo_aug6, 0));
         }
     }
     {   // lm_head: the augmented copy when adapters are apart (rebuilt with them), the base matrix otherwise
         const int Hl = H + e->aug;
         const bf16_t* src = e->aug ? (const bf16_t*)e->lm_aug : e->lm_head;
-        if (e->lm_c6_k != Hl) {
-            if (e->lm_c6) { hipFree(e->lm_c6); e->lm_c6 = nullptr; }
-            if (hipMalloc((void**)&e->lm_c6, (size_t)c.vocab_size * Hl * 3) != hipSuccess) {
-                (void)hipGetLastError(); e->lm_c6 = nullptr; e->lm_c6_k = 0;
-                blim_set_error("option 'precise_lo6': out of device memory for the combined copy of lm_head (%zu MB)", ((size_t)c.vocab_size * Hl * 3) >> 20);
+        if (e->lm6_k != Hl) {
+            if (e->lm6) { hipFree(e->lm6); e->lm6 = nullptr; }
+            if (hipMalloc((void**)&e->lm6, f6_tiles_bytes(c.vocab_size, Hl)) != hipSuccess) {
+                (void)hipGetLastError(); e->lm6 = nullptr; e->lm6_k = 0;
+                blim_set_error("option 'precise_lo6': out of device memory for the e2m3 image of lm_head (%zu MB)", f6_tiles_bytes(c.vocab_size, Hl) >> 20);
                 return BLIM_ERR_NOMEM;
             }
-            e->lm_c6_k = Hl; e->lm_c6_src = nullptr;
+            e->lm6_k = Hl; e->lm6_src = nullptr;
         }
-        if (e->lm_c6_src != (const void*)src || e->aug || e->c6_dirty.count((const void*)e->lm_head)) TRY(launch_combine_w_f6(src, Hl, c.vocab_size, Hl, dt, e->lm_c6, 0));
-        e->lm_c6_src = (const void*)src;
+        if (e->lm6_src != (const void*)src || e->aug || e->c6_dirty.count((const void*)e->lm_head)) TRY(launch_f6_tiles(src, Hl, c.vocab_size, Hl, dt, true, e->lm6, 0));
+        e->lm6_src = (const void*)src;
     }
     HIP_TRY(hipDeviceSynchronize());
     e->c6_dirty.clear();
@@ -449,11 +449,11 @@ static AdapterW* find_adapter(blim_engine* e, const std::string& name, int* n_ou
 static void free_aug(blim_engine* e) {
     for (void* p : e->aug_owned) hipFree(p);
     e->aug_owned.clear();
-    for (auto& l : e->AD) { l.wqkv_aug = l.wo_aug = nullptr; l.wqkv_aug_c6 = l.wo_aug_c6 = nullptr; for (auto& a : l.ad) a.A16 = nullptr; }
+    for (auto& l : e->AD) { l.wqkv_aug = l.wo_aug = nullptr; l.wqkv_aug6 = l.wo_aug6 = nullptr; for (auto& a : l.ad) a.A16 = nullptr; }
     e->lm_aug = nullptr; e->ad_lm.A16 = nullptr;
     for (int w = 0; w < 2; ++w) { e->w0_aug[w] = e->w2_aug[w] = nullptr; e->ad_mlp[w][0].A16 = e->ad_mlp[w][1].A16 = nullptr; }
     e->aug_ready = false;
-    e->lo6_ready = false;                 // (the combined copies of the augmented weights went with them; the base matrices' copies stay)
+    e->lo6_ready = false;                 // (the e2m3 images of the augmented weights went with them; the base matrices' images stay)
 }
 
 extern "C" int blim_clear_adapters(blim_engine* e) {
@@ -734,14 +734,15 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const bool pqx = pq && e->precise_qk > 1;                       // ... and a hi + lo input of the QKV GEMM (its K walked twice)
     const int pfq = (e->precise || pq) ? 2 : 1;                     // width factor of the qkv / attention-output rows
     if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
-    // option "precise_lo6": a compensated GEMM = its plain fp16 pass over the hi part + an e2m3 pass over the lo part, in one kernel and one K loop's worth of
-    // staging (gemm.hip, phase 2).  `rows` are [hi | lo] rows (lo at +K elements, row stride ld >= 2 K): the lo halves are quantised IN PLACE into the e2m3 image
-    // (kernels.hpp: launch_quant_lo_f6) and `p` -- set up as the PLAIN product of the hi halves -- is told that rows and weights continue with K6 = K such values;
-    // w_c6 is the matrix's combined copy [W16 | e2m3 image].  With adapters apart the adapted projections use the augmented weights' copies.
+    // option "precise_lo6": a compensated GEMM = its plain fp16 pass over the hi part + an e2m3 pass over the lo part, in one kernel and into the same accumulators
+    // (gemm.hip, phase 2).  `rows` are [hi | lo] rows (lo at +K elements, row stride ld): the lo halves are written as e2m3 operand tiles into the a6 workspace
+    // (kernels.hpp: launch_f6_tiles) and `p` -- set up as the PLAIN product of the hi halves -- gets the second pass attached; w6 is the matrix's e2m3 image.  With
+    // adapters apart the adapted projections use the augmented weights' images.
     const bool lo6 = e->lo6 && e->precise;
-    auto attach_lo6 = [&](GemmParams& p, bf16_t* rows, int64_t ld, int64_t n, int K, const uint8_t* w_c6) -> int {
-        { SpanGuard gq(e, s, TC_QUANT, 0); TRY(launch_quant_lo_f6(rows + K, ld, n, K, c.compute_dtype, s)); }
-        p.W = (const bf16_t*)w_c6; p.ldw = 3 * (int64_t)K / 2; p.K6 = K;
+    if (lo6) TRY(ensure(e->a6, f6_tiles_bytes(T, (int)std::max<int64_t>(I, Hq))));
+    auto attach_lo6 = [&](GemmParams& p, const bf16_t* rows, int64_t ld, int64_t n, int K, const uint8_t* w6) -> int {
+        { SpanGuard gq(e, s, TC_QUANT, 0); TRY(launch_f6_tiles(rows + K, ld, n, K, c.compute_dtype, false, (uint8_t*)e->a6.p, s)); }
+        p.A6 = (const uint8_t*)e->a6.p; p.W6 = w6; p.K6 = K;
         return BLIM_OK;
     };
     for (int li = 0; li < c.num_layers; ++li) {
@@ -758,8 +759,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
                               : gp2(e, xn, Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise || pqx);
             if (pq && !pqx) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
             if (lo6) {                                                                    // hi part in fp16, lo part in e2m3; [hi | lo] outputs as before
-                p = gp(c.compute_dtype, xn, 2 * Hq, nullptr, T, e->qkv_n, (int)Hq, qkv, 2 * (int64_t)e->qkv_n); p.lo_off = e->qkv_n;
-                TRY(attach_lo6(p, xn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wqkv_aug_c6 : l.wqkv_c6));
+                p = gp(c.compute_dtype, xn, 2 * Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, (int)Hq, qkv, 2 * (int64_t)e->qkv_n); p.lo_off = e->qkv_n;
+                TRY(attach_lo6(p, xn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wqkv_aug6 : l.wqkv6));
             }
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -791,19 +792,19 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             const double tl = (double)n_live;
             { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * Hq * H * pf);
               GemmParams p = gp2(e, attn_live, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * Hq;   // pq: the hi halves of [hi | lo] rows
-              if (lo6) { p = gp(c.compute_dtype, attn_live, 2 * Hq, nullptr, n_live, H, (int)Hq, rl, H);
-                         TRY(attach_lo6(p, attn_live, 2 * Hq, n_live, (int)Hq, G ? e->AD[li].wo_aug_c6 : l.wo_c6)); }
+              if (lo6) { p = gp(c.compute_dtype, attn_live, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, (int)Hq, rl, H);
+                         TRY(attach_lo6(p, attn_live, 2 * Hq, n_live, (int)Hq, G ? e->AD[li].wo_aug6 : l.wo6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             { SpanGuard g(e, s, TC_NORM, 0);
               TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
               GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; }
-              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, nullptr, n_live, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu_c6)); }
+              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu6)); }
               TRY(launch_gemm(EPI_SWIGLU, p, s)); }
             { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * (pa ? 2 : 1));
               GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pa); p.ldc = H; p.lo_off = 0;
-              if (lo6 && pa) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, nullptr, n_live, H, I, rl, H); TRY(attach_lo6(p, act, 2 * (int64_t)I, n_live, I, l.wd_c6)); }
+              if (lo6 && pa) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, n_live, H, I, rl, H); TRY(attach_lo6(p, act, 2 * (int64_t)I, n_live, I, l.wd6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             *final_resid = rl; *final_is_live = true;
             break;
@@ -817,8 +818,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             p.ldc = H; p.lo_off = 0;
             if (pq) p.lda = 2 * Hq;                                       // the hi halves of the attention output's [hi | lo] rows
             if (lo6) {
-                p = gp(c.compute_dtype, attn, 2 * Hq, nullptr, T, H, (int)Hq, resid, H);
-                TRY(attach_lo6(p, attn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wo_aug_c6 : l.wo_c6));
+                p = gp(c.compute_dtype, attn, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, T, H, (int)Hq, resid, H);
+                TRY(attach_lo6(p, attn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wo_aug6 : l.wo6));
             }
             TRY(launch_gemm(EPI_RESID, p, s));
         }
@@ -834,8 +835,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (pm && !pa) { p.lo_off = 0; p.ldc = I; }                 // A = [hi | lo] (K walked twice), plain 16-bit output
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             if (lo6 && pm) {
-                p = gp(c.compute_dtype, xn, 2 * (int64_t)H, nullptr, T, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0;
-                TRY(attach_lo6(p, xn, 2 * (int64_t)H, T, H, l.wgu_c6));
+                p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, T, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0;
+                TRY(attach_lo6(p, xn, 2 * (int64_t)H, T, H, l.wgu6));
             }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
@@ -846,8 +847,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (fuse) { p.a_mx = (const uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
             if (lo6 && pa) {
-                p = gp(c.compute_dtype, act, 2 * (int64_t)I, nullptr, T, H, I, resid, H);
-                TRY(attach_lo6(p, act, 2 * (int64_t)I, T, I, l.wd_c6));
+                p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, T, H, I, resid, H);
+                TRY(attach_lo6(p, act, 2 * (int64_t)I, T, I, l.wd6));
             }
             TRY(launch_gemm(EPI_RESID, p, s));
         }
@@ -931,16 +932,12 @@ static int vtg_logprobs_impl(blim_engine* e, const void* hidden_bf16, bool split
         GemmParams p = l8 ? gp8(h8, H, hs, e->lm_head8, e->s_lm, n_rows, V, H, nullptr, 0)
                           : gp(e->c.compute_dtype, A, Hl, e->aug ? (const void*)e->lm_aug : (const void*)e->lm_head, n_rows, V, (int)Hl, nullptr, 0);
         if (split) { ARG_CHECK(!l8); p.lda = 2 * Hl; p.K = (int)(2 * Hl); p.w_wrap_k = (int)Hl; }
-        if (split && e->lo6 && V % 256 == 0 && Hl % 128 == 0) {           // lo6: the rows' lo parts against the head in e2m3 (gemm.hip phase 2), as in the decoder GEMMs
+        if (split && e->lo6 && Hl % 128 == 0) {                          // lo6: the rows' lo parts against the head in e2m3 (gemm.hip phase 2), as in the decoder GEMMs
             TRY(finalize_lo6(e));
-            if (A == hidden_bf16 && !wide) {                               // a caller's buffer: the in-place quantisation of the lo halves works on a copy
-                TRY(ensure(e->hid_aug, (size_t)round_up(n_rows, 256) * 2 * Hl * 2));
-                TRY(launch_copy_rows16((uint16_t*)e->hid_aug.p, 2 * Hl, (const uint16_t*)hidden_bf16, 2 * Hl, n_rows, (int)(2 * Hl), s));
-                A = e->hid_aug.p; p.A = (const bf16_t*)A;
-            }
-            TRY(launch_quant_lo_f6((bf16_t*)A + Hl, 2 * Hl, n_rows, (int)Hl, e->c.compute_dtype, s));
+            TRY(ensure(e->h6, f6_tiles_bytes(n_rows, (int)Hl)));
+            TRY(launch_f6_tiles((const bf16_t*)A + Hl, 2 * Hl, n_rows, (int)Hl, e->c.compute_dtype, false, (uint8_t*)e->h6.p, s));
             p.K = (int)Hl; p.w_wrap_k = 0;
-            p.W = (const bf16_t*)e->lm_c6; p.ldw = 3 * Hl / 2; p.K6 = (int)Hl;
+            p.A6 = (const uint8_t*)e->h6.p; p.W6 = e->lm6; p.K6 = (int)Hl;
         }
         p.labels = labels; p.lse_part = (float2*)e->lse_part.p; p.label_logit = (float*)e->lab_logit.p;
         TRY(launch_gemm(EPI_LSE, p, s));
@@ -1144,16 +1141,17 @@ extern "C" int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t 
     GemmParams p = gp(DT_F16, A, lda, W, M, N, K, C, ldc);
     return launch_gemm(EPI_BF16, p, (hipStream_t)stream);
 }
-// The compensated GEMM as a building block (tests): A_hilo [M, 2 K] fp16 rows [hi | lo], W [N, K] fp16 -> C f32 [M, N] = hi . W^T + e2m3(lo) . e2m3(W)^T.  The lo halves
-// of A_hilo are replaced by their e2m3 image (in place, as in the engine); w_c6 [N, 3 K bytes] receives the combined copy of W.
-extern "C" int blim_gemm_f16_lo6(void* A_hilo, const void* W, int32_t M, int32_t N, int32_t K, void* w_c6, float* C, void* stream) {
-    ARG_CHECK(A_hilo && W && w_c6 && C && K % 128 == 0);
+// The compensated GEMM as a building block (tests): A_hilo [M, 2 K] fp16 rows [hi | lo], W [N, K] fp16 -> C f32 [M, N] = hi . W^T + e2m3(lo) . e2m3(W)^T.  a6 / w6
+// receive the e2m3 tile images of the lo part and of W (gemm.hpp; blim_f6_tiles_bytes(M | N, K) bytes each).
+extern "C" int64_t blim_f6_tiles_bytes(int64_t n_rows, int32_t K) { return (n_rows > 0 && K > 0 && K % 128 == 0) ? (int64_t)f6_tiles_bytes(n_rows, K) : -1; }
+extern "C" int blim_gemm_f16_lo6(const void* A_hilo, const void* W, int32_t M, int32_t N, int32_t K, void* a6, void* w6, float* C, void* stream) {
+    ARG_CHECK(A_hilo && W && a6 && w6 && C && K % 128 == 0);
     hipStream_t s = (hipStream_t)stream;
-    TRY(launch_combine_w_f6((const bf16_t*)W, K, N, K, DT_F16, (uint8_t*)w_c6, s));
-    TRY(launch_quant_lo_f6((bf16_t*)A_hilo + K, 2 * (int64_t)K, M, K, DT_F16, s));
+    TRY(launch_f6_tiles((const bf16_t*)W, K, N, K, DT_F16, true, (uint8_t*)w6, s));
+    TRY(launch_f6_tiles((const bf16_t*)A_hilo + K, 2 * (int64_t)K, M, K, DT_F16, false, (uint8_t*)a6, s));
     HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * 4, s));
-    GemmParams p = gp(DT_F16, A_hilo, 2 * (int64_t)K, w_c6, M, N, K, C, N);
-    p.ldw = 3 * (int64_t)K / 2; p.K6 = K;
+    GemmParams p = gp(DT_F16, A_hilo, 2 * (int64_t)K, W, M, N, K, C, N);
+    p.A6 = (const uint8_t*)a6; p.W6 = (const uint8_t*)w6; p.K6 = K;
     return launch_gemm(EPI_RESID, p, s);
 }
 extern "C" int blim_quant_rows(const void* in16, int64_t ld, int64_t n_rows, int32_t K, int32_t dtype16, void* out8, float* scale, void* stream) {

@@ -35,15 +35,15 @@ struct LayerW {
     // fp8 mode: e4m3 copies of the four matrices (same stored row order) + one f32 scale per stored row
     uint8_t* wqkv8 = nullptr; uint8_t* wo8 = nullptr; uint8_t* wgu8 = nullptr; uint8_t* wd8 = nullptr;
     float* sqkv = nullptr; float* so = nullptr; float* sgu = nullptr; float* sd = nullptr;
-    // option "precise_lo6" (fp16 engines): combined copies [W16 | e2m3 image of W] of the four matrices, row stride 3 K bytes (kernels.hpp: launch_combine_w_f6) --
-    // what the compensated GEMMs read in BOTH their passes (gemm.hpp: K6, ldw)
-    uint8_t* wqkv_c6 = nullptr; uint8_t* wo_c6 = nullptr; uint8_t* wgu_c6 = nullptr; uint8_t* wd_c6 = nullptr;
+    // option "precise_lo6" (fp16 engines): e2m3 tile images of the four matrices (kernels.hpp: launch_f6_tiles, W side) -- the W operand of the compensated GEMMs'
+    // second pass (gemm.hpp: W6)
+    uint8_t* wqkv6 = nullptr; uint8_t* wo6 = nullptr; uint8_t* wgu6 = nullptr; uint8_t* wd6 = nullptr;
 };
 
 // LoRA adapters kept apart (adapters.hpp): the f32 matrices as loaded + their 16-bit MFMA operand
 struct AdapterW { float* A = nullptr; float* B = nullptr; uint16_t* A16 = nullptr; int n_in = 0, n_out = 0; };
 struct LayerAd { AdapterW ad[4]; uint16_t* wqkv_aug = nullptr; uint16_t* wo_aug = nullptr;           // ad: q, k, v, o
-                 uint8_t* wqkv_aug_c6 = nullptr; uint8_t* wo_aug_c6 = nullptr; };   // option "precise_lo6": combined copies [W_aug 16-bit | e2m3 image]
+                 uint8_t* wqkv_aug6 = nullptr; uint8_t* wo_aug6 = nullptr; };   // option "precise_lo6": e2m3 tile images of the augmented matrices
 
 struct blim_engine {
     blim_config c;
@@ -96,13 +96,14 @@ struct blim_engine {
     uint16_t* lm_aug = nullptr; uint16_t* w0_aug[2] = {nullptr, nullptr}; uint16_t* w2_aug[2] = {nullptr, nullptr};
     bool aug_ready = false;
     // option "precise_lo6" (fp16 engines): in the compensated modes the second walk over K -- the product with the activations' LO parts -- runs on the block-scaled
-    // MFMA with e2m3 operands at four times the 16-bit rate (gemm.hip, phase 2), on combined copies [W16 | e2m3(W)] of the decoder weights and the head, built
-    // lazily (finalize_lo6: + 3 bytes per decoder / head weight, 21 GB at 7B)
+    // MFMA with e2m3 operands at four times the 16-bit rate (gemm.hip, phase 2), against e2m3 tile images of the decoder weights and the head, built lazily
+    // (finalize_lo6: + 0.78 byte per decoder / head weight, 5.9 GB at 7B)
     bool lo6 = false, lo6_ready = false;
-    uint8_t* lm_c6 = nullptr;                                    // lm_head (or its augmented copy), combined; K = lm_c6_k
-    int lm_c6_k = 0;
-    const void* lm_c6_src = nullptr;                             // the matrix lm_c6 was derived from
-    std::set<const void*> c6_dirty;                              // base matrices (re)placed since their combined copy was built
+    uint8_t* lm6 = nullptr;                                      // lm_head (or its augmented copy) as e2m3 tiles; K = lm6_k
+    int lm6_k = 0;
+    const void* lm6_src = nullptr;                               // the matrix lm6 was derived from
+    std::set<const void*> c6_dirty;                              // base matrices (re)placed since their e2m3 image was built
+    DevBuf a6, h6;                                               // e2m3 tile images of the current GEMM input's lo part / of the scored rows' lo parts
     std::set<std::string> merged_pending;                        // after blim_train_merge: the adapted weights that still hold W + s B A (lora_merged stays set until all are re-placed)
     bool lora_merged = false;                                    // blim_train_merge wrote W + (alpha / r) B A into the base weights: adapters apart on top would apply the update twice
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)

@@ -120,8 +120,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K * ES / (BK * 2);   // K-steps of 128 bytes per row
-    const int nk6 = LO6 ? p.K6 / 128 : 0; // ... of the second pass (phase 2), which follow in the same rows
-    const int nkt = nk + nk6;
+    const int nk6 = LO6 ? p.K6 / 128 : 0; // ... of the second pass (phase 2)
     // fp8: this thread's dequantisation scale (threads 0-255: the tile's rows, 256-511: its columns), requested before the K loop
     // so that its latency is not exposed in front of the epilogue
     float f8_scale = 0.f;
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < 8; ++i) {
             const int b = wg + 4 * i;   // 1-KiB block (8 rows) of the operand tile
             if (grp == 1) off8[i] = (uint32_t)((int64_t)min(row0 + 8 * b + sr, p.M - 1) * p.lda * ES + 16 * sc);
-            else off8[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr, p.N - 1) * (p.ldw > 0 ? p.ldw : p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * ES + 16 * sc);   // W row stride
+            else off8[i] = (uint32_t)((int64_t)min(col0 + 8 * b + sr, p.N - 1) * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * ES + 16 * sc);   // W row stride
         }
         const char* gbase = grp == 1 ? baseA : baseW;
         // compensated mode: A is [hi | lo] along K and W is used twice -- the W group's K-step index wraps (scalar select)
@@ -288,46 +287,109 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         // ---- phase 2 (LO6): acc += (lo part of the A operand) . W^T on the block-scaled MFMA with e2m3 operands, at FOUR times the 16-bit rate (gfx950 issues fp6
         // at the fp4 rate: tools/mfma_f6_probe.hip, 7.5 against 4.1 PFLOP/s for e4m3 on random operands).  The compensated modes' second walk over K carries
         // x_lo = x - f32(x_hi), 2^-11 of x in fp16: the product W . x_lo only needs a few percent of relative accuracy to remove > 95 % of the rounding noise of x_hi,
-        // and e2m3 with one E8M0 scale per 32 values delivers what e4m3 did (profiles/r05_lo_format_emulation.txt: 16,000-entry populations on the trained-like
-        // weight sets, e2m3 within 20 % of e4m3).  Both operands' rows CONTINUE behind their 16-bit part with the e2m3 image of gemm.hpp (K6), 128 bytes per K-step
-        // like the 16-bit steps: the LDS-DMA of the 16-bit loop simply runs on into the second pass's tiles (same lane offsets, same ring order), so the second
-        // pass starts with its first two K-steps staged -- round 4's separate e4m3 operands cost a drained ring, twelve more address registers and ~7 us per tile.
-        // A lane's two 16-byte fragment reads bring the six operand registers of a 16-row fragment and, in register 6, the block's scale byte: no scale tables.
-        // The loop is the fp8 kernel's (rotated: fragments read and consumed inside one iteration).
-        int p2_first = -1;                                           // (ablation builds: ring slot of the second pass's first A tile)
-        auto load_frags6 = [&](int offA_tile, int offB_tile) __attribute__((always_inline)) {
-#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 2   // ablation builds only (make ablate_p2; timing, wrong results): 1 = no MFMAs in phase 2, 2 = fragments read in its first
-            if (offA_tile != p2_first) return;       // step only, 3 = no LDS-DMA issued by phase 2
+        // and e2m3 with one E8M0 scale per 32 values delivers what round 4's e4m3 did (profiles/r05_lo_format_emulation.txt: 16,000-entry populations on the
+        // trained-like weight sets).  With the MFMAs at a quarter of the 16-bit time the pass is bound by what it moves, so it moves as little as the format allows:
+        // the operands come as ready-made LDS images of dense tiles (gemm.hpp: 25 KiB per 256 rows x 128 values instead of the 32 KiB of a byte per value), staged by
+        // lane-linear LDS-DMA copies into a ring of SIX slots (three per operand: every tile is requested two K-steps before its first read), read as one
+        // ds_read_b128 + one ds_read_b64 per fragment plus one scale read per operand and step.
+        // Schedule: a ping-pong of two ROTATED loops (a group reads and consumes a step's fragments inside one iteration: fragments carried over a back edge cost
+        // this kernel its registers), the A group half a step behind the W group:
+        //   interval 2k:     W group reads the fragments of step k, stages W(k+2)  | A group computes step k-1
+        //   interval 2k + 1: W group computes step k                             | A group reads the fragments of step k, stages A(k+2)
+        // (As one lock-step loop -- both groups reading, then both computing -- a step of the padded 32-KiB form took 1.5 us: 0.6 us of fragment reads with the
+        // matrix pipe idle, then 0.7 us of MFMAs with the LDS idle; make ablate_p2.)
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        const char* g6A = LO6 ? (const char*)p.A6 + (int64_t)tm * nk6 * F6_TILE_BYTES : nullptr;
+        const char* g6W = LO6 ? (const char*)p.W6 + (int64_t)tn * nk6 * F6_TILE_BYTES : nullptr;
+        // one operand tile of K-step k into ring slot `slot` (0-5): this wave's 6 KiB-blocks of e2m3 and its quarter of the scale KiB (7 LDS-DMA per wave)
+        auto stage6 = [&](int slot, int k, bool isW) __attribute__((always_inline)) {
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 3   // ablation build: phase 2 stages its first two steps only, then runs on stale tiles
+            if (k >= 2) return;
 #endif
-            const char* ba0 = smem + (offA_tile + a_off); const char* ba1 = smem + ((offA_tile + a_off) ^ 64);
-            const char* bb0 = smem + (offB_tile + b_off); const char* bb1 = smem + ((offB_tile + b_off) ^ 64);
-            auto rd = [](const char* q0, const char* q1) __attribute__((always_inline)) {
-                const i32x4 l = *(const i32x4*)q0, h = *(const i32x4*)q1;
-                return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
-            };
+            const char* g = (isW ? g6W : g6A) + (int64_t)k * F6_TILE_BYTES;
+            char* d = smem + slot * F6_TILE_BYTES;
+            uint32_t l16 = (uint32_t)lane * 16u;                     // (unsigned 32-bit lane offset + scalar base: the saddr + voffset form of the LDS-DMA, as in the 16-bit loop)
+            asm volatile("" : "+v"(l16));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) fb8[ni] = rd(bb0 + ni * 2048, bb1 + ni * 2048);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) fa8[mi] = rd(ba0 + mi * 2048, ba1 + mi * 2048);
+            for (int i = 0; i < 6; ++i) glds16(g + (wg + 4 * i) * 1024 + l16, d + (wg + 4 * i) * 1024);
+            // (the scale KiB as 16-byte pieces of the first 16 lanes, 256 B per wave: with the 4-byte form of the LDS-DMA the compiler's wait-count pass put an
+            // s_waitcnt vmcnt(0) in front of the NEXT step's fragment reads -- it tracks that form as an LDS store any LDS read may alias -- and every K-step
+            // waited for the tiles just requested: 1.2 us per step whatever the layout)
+            if (lane < 16) glds16(g + 24576 + wg * 256 + l16, d + 24576 + wg * 256);
         };
-        auto compute6 = [&]() __attribute__((always_inline)) {
-#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 1
+        uint2 sc6a = make_uint2(0, 0);                                // this lane's eight A-side scale bytes of the step (one per 16-row fragment)
+        uint32_t sc6w = 0;                                            // ... and its four W-side ones
+        // a step's 26 fragment / scale reads with the 7 LDS-DMA of one operand tile (K-step kd into ring slot `dslot`; on = false: none) between them, one after
+        // every fourth read: the wave's LDS-DMA issue (~70 cycles each: the CU's 64 B / clk path into LDS is shared by the four staging waves) overlaps the
+        // LDS's answers to its reads.  (Requested in a block -- before the reads, after them, or in front of the computing group's MFMAs -- the seven cost the
+        // interval ~500 cycles on top: tools/gemm_waits_lo6.py.)
+        // piece q (0-6) of this wave's share of one operand tile (K-step kd into ring slot `dslot`): six KiB-blocks of e2m3 and a quarter of the scale KiB
+        auto dma6 = [&](int q, int dslot, int kd, bool isW, bool on) __attribute__((always_inline)) {
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 3
+            on = false;
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (on) {
+                const char* g = (isW ? g6W : g6A) + (int64_t)kd * F6_TILE_BYTES;
+                char* d = smem + dslot * F6_TILE_BYTES;
+                uint32_t o16 = (uint32_t)lane * 16u;
+                asm volatile("" : "+v"(o16));
+                if (q < 6) glds16(g + (wg + 4 * q) * 1024 + o16, d + (wg + 4 * q) * 1024);
+                else if (lane < 16) glds16(g + 24576 + wg * 256 + o16, d + 24576 + wg * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int DMA_IN_READS = 4;                               // pieces 0-3 between the fragment reads, 4-6 between the MFMAs: both intervals of a step the same length
+        auto load_frags6 = [&](int slotA, int slotB, int dslot, int kd, bool isW, bool on) __attribute__((always_inline)) {
+            const char* ta = smem + slotA * F6_TILE_BYTES;
+            const char* tb = smem + slotB * F6_TILE_BYTES;
+            int l16 = lane * 16;
+            asm volatile("" : "+v"(l16));
+            auto dma = [&](int q) __attribute__((always_inline)) { if (q < DMA_IN_READS) dma6(q, dslot, kd, isW, on); };
+            auto rd = [&](const char* blk) __attribute__((always_inline)) {
+                const i32x4 l = *(const i32x4*)(blk + l16);
+                const i32x2 h = *(const i32x2*)(blk + 1024 + (l16 >> 1));
+                return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], 0, 0};
+            };
+            // (scales read through ext-vector types like the fragments: behind loads typed uint32_t / uint2 the compiler's wait-count pass put an s_waitcnt vmcnt(0) --
+            // every outstanding LDS-DMA -- in front of each step's fragment reads)
+            typedef int i32x1 __attribute__((ext_vector_type(1)));
+            const i32x1 sw_ = *(const i32x1*)(tb + 24576 + wn * 256 + (l16 >> 2));             // ((wn * 4 + g) * 16 + r) * 4 = wn * 256 + lane * 4
+            const i32x2 sa_ = *(const i32x2*)(ta + 24576 + wm * 512 + (l16 >> 1));             // ((wm * 4 + g) * 16 + r) * 8 = wm * 512 + lane * 8
+            sc6w = (uint32_t)sw_[0]; sc6a = make_uint2((uint32_t)sa_[0], (uint32_t)sa_[1]);
+            dma(0);
+            fb8[0] = rd(tb + (4 * wn + 0) * 1536); fb8[1] = rd(tb + (4 * wn + 1) * 1536); fb8[2] = rd(tb + (4 * wn + 2) * 1536);
+            dma(1);
+            fb8[3] = rd(tb + (4 * wn + 3) * 1536); fa8[0] = rd(ta + (8 * wm + 0) * 1536); fa8[1] = rd(ta + (8 * wm + 1) * 1536);
+            dma(2);
+            fa8[2] = rd(ta + (8 * wm + 2) * 1536); fa8[3] = rd(ta + (8 * wm + 3) * 1536); fa8[4] = rd(ta + (8 * wm + 4) * 1536);
+            dma(3);
+            fa8[5] = rd(ta + (8 * wm + 5) * 1536); fa8[6] = rd(ta + (8 * wm + 6) * 1536); fa8[7] = rd(ta + (8 * wm + 7) * 1536);
+        };
+        auto compute6 = [&](int dslot, int kd, bool isW, bool on) __attribute__((always_inline)) {
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 1   // ablation build (make ablate_p2; timing only, wrong results): no MFMAs in phase 2
             return;
 #endif
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[ni], fa8[mi], acc[mi][ni], 2, 2, 0, fb8[ni][6], 0, fa8[mi][6]);   // cbsz = blgp = 2: e2m3
+#define L6_MMA(MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[NI], fa8[MI], acc[MI][NI], 2, 2, NI, (int)sc6w, (MI & 3), (int)((MI) < 4 ? sc6a.x : sc6a.y));   // cbsz = blgp = 2: e2m3
+#define L6_ROW(MI) L6_MMA(MI, 0) L6_MMA(MI, 1) L6_MMA(MI, 2) L6_MMA(MI, 3)
+            L6_ROW(0) L6_ROW(1)
+            dma6(4, dslot, kd, isW, on);
+            L6_ROW(2) L6_ROW(3)
+            dma6(5, dslot, kd, isW, on);
+            L6_ROW(4) L6_ROW(5)
+            dma6(6, dslot, kd, isW, on);
+            L6_ROW(6) L6_ROW(7)
+#undef L6_ROW
+#undef L6_MMA
             __builtin_amdgcn_s_setprio(0);
         };
         int sa = 0;
         mx_request(0);
         if (grp == 0) {
             stage8(TILE_BYTES, 0);                                   // W0
-            if (nkt > 1) stage8(3 * TILE_BYTES, 1);                  // W1
-            if (nkt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (nk > 1) stage8(3 * TILE_BYTES, 1);                  // W1
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();                                         // A0 W0 landed (every wave waited for its own DMA)
             if constexpr (MX8) mx_cur = mx_nxt;                      // requested at tile entry, in front of every LDS-DMA
@@ -359,8 +421,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_T(2);
                 PHASE_BARRIER();
                 WP_T(3);
-                if (kt + 1 < nk) frags_and_dma(adv(sa, 2), adv(sa, 3), sa, kt + 2, kt + 2 < nkt);  // fragments of kt+1, W(kt+2) (LO6: on into the second pass's tiles)
-                else if (LO6 && kt + 2 < nkt) stage8(sa, kt + 2);                                  // last 16-bit step: the second pass reads its own fragments, W(nk+1) is still staged here
+                if (kt + 1 < nk) frags_and_dma(adv(sa, 2), adv(sa, 3), sa, kt + 2, kt + 2 < nk);   // fragments of kt+1, W(kt+2)
+                else if constexpr (LO6) {
+                    // last 16-bit step: this group has nothing left to read while the A group computes from registers, and no wave reads LDS any more -- the
+                    // second pass's first two K-steps (both operands) are requested HERE, under the A group's last 64 MFMAs
+                    stage6(0, 0, false); stage6(1, 0, true);
+                    if (nk6 > 1) { stage6(2, 1, false); stage6(3, 1, true); }
+                    if (nk6 > 2) stage6(4, 2, false);
+                }
 #ifdef GEMM_WAIT_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -372,32 +440,41 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }
             }
             if constexpr (LO6) {
-                // phase 2, W group: A(nk) W(nk) are complete (every wave waited for its share before the last 16-bit step's first barrier), A(nk+1) W(nk+1) in flight
-                // Ping-pong like the 16-bit loop, but with BOTH groups reading and consuming a step's fragments inside one iteration (fragments carried over a back
-                // edge cost this kernel its registers: the fp8 loops) -- the A group runs half a step behind:
-                //   interval 2k:     W group reads the fragments of step k, stages W(k+1)  | A group computes step k-1
-                //   interval 2k + 1: W group computes step k                             | A group reads the fragments of step k, stages A(k+2)
-                // As ONE lock-step loop (both groups reading, then both computing) a step took 1.5 us: 0.6 us of fragment reads with the matrix pipe idle, then
-                // 0.7 us of MFMAs with the LDS idle (ablation builds, make ablate_p2).
-                p2_first = sa;
-                int sp = sa;                                             // slot of A(k-1): free since the A group finished reading step k-1 (end of interval 2k-1)
-                for (int k = 0; k < nk6; ++k) {
-                    load_frags6(sa, adv(sa, 1));
-#if !defined(GEMM_ABLATE_P2) || GEMM_ABLATE_P2 != 3
-                    if (k >= 1 && k + 1 < nk6) stage8(sp, nk + k + 1);   // W(k+1) into the slot A(k-1) left (W(nk+1): staged by the last 16-bit step)
+                // phase 2, W group.  Ring slot of A(k): 2 (k % 3), of W(k): 2 (k % 3) + 1.  Requested so far (by this group, above): both operands of steps 0 and 1.
+                if (nk6 > 2) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");          // my shares of A(0) W(0) landed
+                else if (nk6 > 1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PHASE_BARRIER();
+                int s3 = 0;                                              // k % 3
+#ifdef GEMM_WAIT_PROF   // (instrumented build: the sums below are phase 2's alone -- reads | barrier | dma + mfma | vmcnt | barrier)
+                for (int q_ = 0; q_ < 5; ++q_) wp_acc[q_] = 0;
 #endif
+                for (int k = 0; k < nk6; ++k) {
+                    const int s3n = s3 == 0 ? 2 : s3 - 1;                // (k + 2) % 3 = (k - 1) % 3: the slot pair step k-1 left (both groups have read it)
+                    WP_T(0);
+                    load_frags6(2 * s3, 2 * s3 + 1, 2 * s3n + 1, k + 2, true, k + 2 < nk6);     // ... and W(k+2) into the slot W(k-1) left
+#ifdef GEMM_WAIT_PROF
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    WP_T(1);
                     PHASE_BARRIER();                                     // end of interval 2k
-                    compute6();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of W(k+1) landed
+                    WP_T(2);
+                    compute6(2 * s3n + 1, k + 2, true, k + 2 < nk6);
+                    WP_T(3);
+                    if (k + 2 < nk6) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");    // my share of W(k+1) (and, k = 0, of A(1), A(2)) landed
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    WP_T(4);
                     PHASE_BARRIER();                                     // end of interval 2k + 1
-                    sp = sa; sa = adv(sa, 2);
+                    WP_T(5);
+                    WP_ACC();
+                    s3 = s3 == 2 ? 0 : s3 + 1;
                 }
                 PHASE_BARRIER();                                         // end of interval 2 nk6 (the A group's last compute)
             }
         } else {
             stage8(0, 0);                                            // A0
-            if (nkt > 1) stage8(2 * TILE_BYTES, 1);                  // A1
-            if (nkt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (nk > 1) stage8(2 * TILE_BYTES, 1);                  // A1
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PHASE_BARRIER();
             if constexpr (MX8) mx_cur = mx_nxt;
@@ -408,12 +485,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     mx_request(kt + 1);
                     load_frags(sa, adv(sa, 1));
                     if (kt + 2 < nk) stage8(adv(sa, 4), kt + 2);
-                } else frags_and_dma(sa, adv(sa, 1), adv(sa, 4), kt + 2, kt + 2 < nkt);         // fragments of kt, A(kt+2) (LO6: on into the second pass's tiles)
+                } else frags_and_dma(sa, adv(sa, 1), adv(sa, 4), kt + 2, kt + 2 < nk);          // fragments of kt, A(kt+2)
 #ifdef GEMM_WAIT_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
                 WP_T(1);
-                if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // my share of A(kt+1) landed
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // my share of A(kt+1) landed
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 WP_T(2);
                 PHASE_BARRIER();
@@ -427,19 +504,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 sa = adv(sa, 2);
             }
             if constexpr (LO6) {
-                p2_first = sa;
+                PHASE_BARRIER();                                         // (the W group has waited for A(0) W(0))
                 PHASE_BARRIER();                                         // end of interval 0 (the W group's first fragment reads)
-                for (int k = 0; k < nk6; ++k) {                          // phase 2, A group (half a step behind the W group: above)
-                    load_frags6(sa, adv(sa, 1));
-#if !defined(GEMM_ABLATE_P2) || GEMM_ABLATE_P2 != 3
-                    if (k + 2 < nk6) stage8(adv(sa, 4), nk + k + 2);     // A(k+2) into the slot W(k-1) left
+                int s3 = 0;
+#ifdef GEMM_WAIT_PROF
+                for (int q_ = 0; q_ < 5; ++q_) wp_acc[q_] = 0;
 #endif
-                    if (k + 2 < nk6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // my share of A(k+1) landed
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int k = 0; k < nk6; ++k) {                          // phase 2, A group (half a step behind the W group: above)
+                    const int s3n = s3 == 0 ? 2 : s3 - 1;
+                    WP_T(0);
+                    load_frags6(2 * s3, 2 * s3 + 1, 2 * s3n, k + 2, false, k >= 1 && k + 2 < nk6);  // ... and A(k+2) into the slot A(k-1) left (A(0..2): requested and awaited by the W group)
+                    // A(k+1) is read by the W group in the NEXT interval: my share of it has to be there before this interval's barrier
+                    if (k >= 1 && k + 2 < nk6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (only the four pieces of A(k+2) just requested may be outstanding)
+                    else if (k >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GEMM_WAIT_PROF
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    WP_T(1);
                     PHASE_BARRIER();                                     // end of interval 2k + 1
-                    compute6();
+                    WP_T(2);
+                    compute6(2 * s3n, k + 2, false, k >= 1 && k + 2 < nk6);
+                    WP_T(3);
+                    WP_T(4);
                     PHASE_BARRIER();                                     // end of interval 2k + 2
-                    sa = adv(sa, 2);
+                    WP_T(5);
+                    WP_ACC();
+                    s3 = s3 == 2 ? 0 : s3 + 1;
                 }
             }
         }
@@ -959,7 +1049,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
     if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU || EPI == EPI_RESID || EPI == EPI_LSE) {
-        if (p.K6 > 0) {        // fp16 main pass + e2m3 pass over the A operand's lo part (phase 2 of the kernel)
+        if (p.A6) {            // fp16 main pass + e2m3 pass over the A operand's lo part (phase 2 of the kernel)
             if constexpr (EPI == EPI_RESID || EPI == EPI_LSE) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
             else if (p.lo_off != 0) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true, true>), grid, dim3(NTHREADS), 0, stream, p);
             else if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
@@ -1022,6 +1112,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         if (p.rope_rows) q.rope_rows = p.rope_rows + r0 * 16;        // chunk-major table: the row offset inside every chunk (rope_stride unchanged)
         if (p.a_mx) q.a_mx = p.a_mx + r0;                         // r0 is a whole number of 256-row tiles: the table is tile-major inside a K-step
         if (p.out_mx) q.out_mx = p.out_mx + r0;
+        if (p.A6) q.A6 = p.A6 + (r0 / BM) * (int64_t)(p.K6 / 128) * F6_TILE_BYTES;     // tile-major: a chunk is a whole number of 256-row tiles
         if (p.labels) q.labels = p.labels + r0;
         if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
         if (p.label_logit) q.label_logit = p.label_logit + r0;
@@ -1038,7 +1129,7 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug_skip_epilogue = g_gemm_skip_epi;
     static const int dbg_k6 = getenv("BLIM_GEMM_LO6_K6") ? atoi(getenv("BLIM_GEMM_LO6_K6")) : 0;      // timing aid: shorten the e2m3 pass (wrong results)
-    if (p.K6 > 0 && dbg_k6 > 0 && dbg_k6 < p.K6) p.K6 = dbg_k6;
+    if (p.A6 && dbg_k6 > 0 && dbg_k6 < p.K6) p.K6 = dbg_k6;     // (wrong tiles too: the images are [tile][K6 / 128 steps])
     if (!g_f16_saturate) p.f16_saturate = 0;
     p.group_m = g_gemm_group_m > 0 ? g_gemm_group_m : GROUP_M;
     // measured (one MI355X, A/B in one process): narrow outputs (N = 3584 / 4608: o_proj, down_proj, qkv) gain 3-5 % from the
@@ -1057,14 +1148,12 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK(p.dtype != DT_F8 || ((p.row_scale || p.a_mx) && p.col_scale));
     ARG_CHECK((!p.a_mx && !p.out_mx) || (p.dtype == DT_F8 && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
     ARG_CHECK(!p.a_mx || epi == EPI_RESID);                      // MX-scaled A operand: instantiated for the down projection (fp8)
-    // lo6: both operands' rows hold K 16-bit values and then K6 bytes of e2m3 image (gemm.hpp)
-    ARG_CHECK(p.K6 == 0 || (p.dtype == DT_F16 && p.w_wrap_k == 0 && p.K6 > 0 && p.K6 % 128 == 0 && p.lda * 2 >= (int64_t)p.K * 2 + p.K6 && p.ldw * 2 >= (int64_t)p.K * 2 + p.K6 &&
-                            (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE) && (int64_t)p.N * p.ldw * 2 < (1ll << 32)));
-    ARG_CHECK(p.ldw == 0 || (p.ldw >= (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) && p.ldw * es % 16 == 0));
+    // lo6: the A operand's lo part and W as e2m3 tile images (gemm.hpp)
+    ARG_CHECK(!p.A6 || (p.dtype == DT_F16 && p.W6 && p.w_wrap_k == 0 && p.K6 > 0 && p.K6 % 128 == 0 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE)));
     ARG_CHECK(!p.out_mx || (epi == EPI_SWIGLU && p.N % 256 == 0 && p.ldc % 16 == 0));
     ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice
     ARG_CHECK(p.lo_off == 0 || epi == EPI_BF16 || epi == EPI_QKV || epi == EPI_SWIGLU);
-    ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.ldw > 0 ? p.ldw : p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets
+    ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets
     switch (epi) {
         case EPI_BF16:
             ARG_CHECK(p.C && p.ldc % 4 == 0);

@@ -55,16 +55,20 @@ struct GemmParams {
     uint8_t* out_mx;
     const uint8_t* a_mx;
     int64_t mx_stride;
-    // fp16 engines, compensated modes with an fp6 second pass ("lo6", gemm.hip phase 2; round 5, replaces round 4's e4m3 pass).  A / lda / K describe the plain
-    // 16-bit hi part (w_wrap_k = 0); K6 > 0 says that BOTH operands' rows continue, right behind their K 16-bit values (byte offset 2 K), with K6 e2m3 values in
-    // the MX image below (128 bytes per 128 values: the second pass's K-steps are the same 128 bytes per row as the first's, so the ring, the LDS-DMA and the
-    // fragment reads simply run on from K-step K / 64 to K / 64 + K6 / 128 with no hand-over).  A: the lo parts, quantised in place over the first K6 bytes of the
-    // rows' 16-bit lo halves (kernels.hpp: launch_quant_lo_f6); W: the combined copy [W16 | W6] with row stride ldw (launch_combine_w_f6).  K6 % 128 == 0.
-    // Image of one 128-value K-step of a row: the 32 values k = 32 g .. 32 g + 31 (g = 0..3; what the MFMA's lane group g holds) are 24 bytes of packed e2m3
-    // (value j at bits [6 j, 6 j + 6)): bytes 0-15 at [16 g, 16 g + 16), bytes 16-23 at [64 + 16 g, 64 + 16 g + 8), then the block's E8M0 scale byte at
-    // 64 + 16 g + 8 and 7 bytes of padding -- a lane's two 16-byte fragment reads (chunks g and g + 4) bring its 6 operand registers AND its scale register.
+    // fp16 engines, compensated modes with an e2m3 second pass ("lo6", gemm.hip phase 2; round 5, replaces round 4's e4m3 pass).  A / lda / K / W describe the plain
+    // 16-bit product of the hi parts (w_wrap_k = 0); A6 / W6 are the e2m3 forms of the A operand's LO part and of W (kernels.hpp: launch_f6_tiles), K6 values per
+    // row (K6 % 128 == 0), stored as the LDS IMAGE of the second pass's operand tiles: one block of F6_TILE_BYTES per (256-row tile, 128-value K-step), tile-major
+    // ([row tile][K-step]), so that a tile is staged by a lane-linear LDS-DMA copy of 25 KiB.  Inside a block, for each 16-row fragment group fb (16 of them):
+    //   [fb * 1536 + lane * 16, + 16)          bytes 0-15 of the 24 packed e2m3 bytes of (row lane & 15, values 32 g .. 32 g + 31 of the step, g = lane >> 4)
+    //   [fb * 1536 + 1024 + lane * 8, + 8)     bytes 16-23 of the same 32 values
+    // -- exactly what MFMA lane `lane` of that fragment needs, so a fragment is one ds_read_b128 + one ds_read_b64 of consecutive lanes (no bank conflict by
+    // construction) -- and at byte 24576 the E8M0 scale bytes of the tile's 256 x 4 blocks, ordered so that a lane reads the scales of all its fragments at once:
+    //   A side: [((row >> 7) * 4 + g) * 128 + (row & 15) * 8 + ((row >> 4) & 7)]     (8 bytes per lane: its eight 16-row fragments of a wave's 128 rows)
+    //   W side: [((row >> 6) * 4 + g) * 64 + (row & 15) * 4 + ((row >> 4) & 3)]      (4 bytes per lane: its four fragments of a wave's 64 columns)
+    // Value j of a 32-value block sits at bits [6 j, 6 j + 6) of its 24 bytes; a block's scale is the smallest power of two with max|x| / scale <= 7.5.
+    const uint8_t* A6;
+    const uint8_t* W6;
     int K6;
-    int64_t ldw;             // row stride of W in elements (0: K, or w_wrap_k when that is set)
     int f16_saturate;        // fp16 outputs: saturate to +-65504 instead of +-inf (common.hpp: f16_saturate_on).  engine.hip's gp() sets it; the one
                              // 16-bit GRADIENT store of the trainer clears it (the loss scaler must see an overflow as inf)
     int group_m;             // M-tiles per band of the tile order (8; BLIM_GEMM_GROUP_M)

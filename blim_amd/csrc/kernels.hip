@@ -565,7 +565,7 @@ int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const 
     return BLIM_OK;
 }
 
-// ---------------------------------------------------------------------------- lo6 quantisers (kernels.hpp; image: gemm.hpp K6)
+// ---------------------------------------------------------------------------- lo6 quantiser (kernels.hpp; image: gemm.hpp A6 / W6)
 __device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e with 2^e >= x (x > 0, finite)
     int ex; const float m = frexpf(x, &ex);                      // x = m 2^ex, m in [0.5, 1)
     return m == 0.5f ? ex - 1 : ex;
@@ -602,12 +602,6 @@ __device__ __forceinline__ F6Block e2m3_block(const float (&f)[32]) {
     }
     return b;
 }
-// block g of K-step `step` of a row image at `img`: bytes 0-15 at chunk g, bytes 16-23 + the scale byte at chunk g + 4
-__device__ __forceinline__ void store_f6_block(uint8_t* img, int blk, const F6Block& b) {
-    uint8_t* stp = img + (int64_t)(blk >> 2) * 128 + 16 * (blk & 3);
-    *(uint4*)stp = make_uint4(b.d[0], b.d[1], b.d[2], b.d[3]);
-    *(uint4*)(stp + 64) = make_uint4(b.d[4], b.d[5], b.e8, 0u);
-}
 template <int DT>
 __device__ __forceinline__ void load32(const bf16_t* src, float (&f)[32]) {
 #pragma unroll
@@ -618,51 +612,32 @@ __device__ __forceinline__ void load32(const bf16_t* src, float (&f)[32]) {
         for (int j = 0; j < 8; ++j) f[8 * q + j] = from16<DT>(e[j]);
     }
 }
-// The lo halves of [hi | lo] rows, IN PLACE: row r's K 16-bit lo values at rows + r * ld become K bytes of e2m3 image at the same address (the GEMM's second pass
-// reads them as the row's K-steps K / 64 ...; the second half of the lo region is dead afterwards).  One workgroup per row; every block is read and quantised
-// into registers, then -- behind a barrier, the image of K-step s overlaps the 16-bit values of step s / 2 -- written.
-#define F6_MAXB 3
-template <int DT>
-__global__ __launch_bounds__(256) void quant_lo_f6_kernel(bf16_t* rows, int64_t ld, int64_t n_rows, int K) {
-    bf16_t* row = rows + (int64_t)blockIdx.x * ld;
-    const int nblk = K / 32;
-    F6Block b[F6_MAXB];
-#pragma unroll
-    for (int i = 0; i < F6_MAXB; ++i) {
-        const int blk = threadIdx.x + 256 * i;
-        if (blk < nblk) { float f[32]; load32<DT>(row + 32 * blk, f); b[i] = e2m3_block(f); }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < F6_MAXB; ++i) {
-        const int blk = threadIdx.x + 256 * i;
-        if (blk < nblk) store_f6_block((uint8_t*)row, blk, b[i]);
-    }
-}
-int launch_quant_lo_f6(bf16_t* rows, int64_t ld, int64_t n_rows, int K, int dtype, hipStream_t s) {
-    ARG_CHECK(rows && n_rows > 0 && K > 0 && K % 128 == 0 && K <= 256 * 32 * F6_MAXB && ld % 8 == 0 && ld >= K);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((quant_lo_f6_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, rows, ld, n_rows, K);
-    else hipLaunchKernelGGL((quant_lo_f6_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, rows, ld, n_rows, K);
-    LAUNCH_CHECK("quant_lo_f6");
-    return BLIM_OK;
-}
-// The combined weight copy the compensated GEMMs read: row n = [the K 16-bit values of W's row n | K bytes of their e2m3 image], row stride 3 K bytes
-template <int DT>
-__global__ __launch_bounds__(256) void combine_w_f6_kernel(const bf16_t* w, int64_t ld, int K, uint8_t* out) {
-    const bf16_t* row = w + (int64_t)blockIdx.x * ld;
-    uint8_t* orow = out + (int64_t)blockIdx.x * K * 3;
-    for (int blk = threadIdx.x; blk < K / 32; blk += 256) {
-        float f[32];
-        load32<DT>(row + 32 * blk, f);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *(uint4*)(orow + 64 * blk + 16 * q) = *(const uint4*)(row + 32 * blk + 8 * q);
-        store_f6_block(orow + 2 * (int64_t)K, blk, e2m3_block(f));
+// One workgroup = one 16-row fragment group; thread = (row r of the group, one of 16 consecutive 32-value blocks), looping over K: the 16 lanes of a block write 256
+// (resp. 128) consecutive bytes of the tile image.
+template <int DT, bool W_SIDE>
+__global__ __launch_bounds__(256) void f6_tiles_kernel(const bf16_t* in, int64_t ld, int64_t n_rows, int K, uint8_t* out) {
+    const int r = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    const int64_t fbg = blockIdx.x, row = fbg * 16 + r, tile = fbg >> 4;
+    const int fb = (int)(fbg & 15), rl = fb * 16 + r, nk6 = K / 128, nblk = K / 32;
+    for (int b0 = 0; b0 < nblk; b0 += 16) {
+        const int blk = b0 + bl;
+        if (blk >= nblk) break;
+        F6Block q;
+        if (row < n_rows) { float f[32]; load32<DT>(in + row * ld + 32 * blk, f); q = e2m3_block(f); }
+        else { q.d[0] = q.d[1] = q.d[2] = q.d[3] = q.d[4] = q.d[5] = 0u; q.e8 = 0u; }
+        const int st = blk >> 2, g = blk & 3;
+        uint8_t* t = out + ((int64_t)tile * nk6 + st) * F6_TILE_BYTES;
+        *(uint4*)(t + fb * 1536 + g * 256 + r * 16) = make_uint4(q.d[0], q.d[1], q.d[2], q.d[3]);
+        *(uint2*)(t + fb * 1536 + 1024 + g * 128 + r * 8) = make_uint2(q.d[4], q.d[5]);
+        const int sidx = W_SIDE ? ((rl >> 6) * 4 + g) * 64 + (rl & 15) * 4 + ((rl >> 4) & 3) : ((rl >> 7) * 4 + g) * 128 + (rl & 15) * 8 + ((rl >> 4) & 7);
+        t[24576 + sidx] = (uint8_t)q.e8;
     }
 }
-int launch_combine_w_f6(const bf16_t* w, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out, hipStream_t s) {
-    ARG_CHECK(w && out && n_rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld >= K);
-    if (dtype == DT_BF16) hipLaunchKernelGGL((combine_w_f6_kernel<DT_BF16>), dim3((unsigned)n_rows), dim3(256), 0, s, w, ld, K, out);
-    else hipLaunchKernelGGL((combine_w_f6_kernel<DT_F16>), dim3((unsigned)n_rows), dim3(256), 0, s, w, ld, K, out);
-    LAUNCH_CHECK("combine_w_f6");
+int launch_f6_tiles(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, bool w_side, uint8_t* out, hipStream_t s) {
+    ARG_CHECK(in && out && n_rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld >= K);
+    const dim3 grid((unsigned)((n_rows + 255) / 256 * 16));
+    if (dtype == DT_BF16) { if (w_side) hipLaunchKernelGGL((f6_tiles_kernel<DT_BF16, true>), grid, dim3(256), 0, s, in, ld, n_rows, K, out); else hipLaunchKernelGGL((f6_tiles_kernel<DT_BF16, false>), grid, dim3(256), 0, s, in, ld, n_rows, K, out); }
+    else { if (w_side) hipLaunchKernelGGL((f6_tiles_kernel<DT_F16, true>), grid, dim3(256), 0, s, in, ld, n_rows, K, out); else hipLaunchKernelGGL((f6_tiles_kernel<DT_F16, false>), grid, dim3(256), 0, s, in, ld, n_rows, K, out); }
+    LAUNCH_CHECK("f6_tiles");
     return BLIM_OK;
 }

@@ -44,9 +44,9 @@ int launch_quant_rows(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int d
 // RMSNorm whose output is quantised per row (same arithmetic as launch_rmsnorm, then the rule above)
 int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const float* w, float eps, uint8_t* out8, float* scale, hipStream_t s);
 
-// ---- "lo6" (gemm.hpp: K6): the operands of the compensated GEMMs' second pass, e2m3 with one E8M0 (power-of-two) scale per 32 values that the block-scaled MFMA
-// applies itself, in the 128-bytes-per-128-values image the GEMM reads as further K-steps of the same rows.
-// The lo halves of [hi | lo] rows, quantised IN PLACE: the K 16-bit values at rows + r * ld (r < n_rows) become K bytes of image at the same address.  K % 128 == 0.
-int launch_quant_lo_f6(bf16_t* rows, int64_t ld, int64_t n_rows, int K, int dtype, hipStream_t s);
-// out[n] = [the K 16-bit values of w's row n | K bytes of their e2m3 image], row stride 3 K bytes (GemmParams.ldw = 3 K / 2 elements)
-int launch_combine_w_f6(const bf16_t* w, int64_t ld, int64_t n_rows, int K, int dtype, uint8_t* out, hipStream_t s);
+// ---- "lo6" (gemm.hpp: A6 / W6 / K6): the operands of the compensated GEMMs' second pass, e2m3 with one E8M0 (power-of-two) scale per 32 values that the block-scaled
+// MFMA applies itself, written as the LDS image of the pass's operand tiles (layout: gemm.hpp).
+// in: 16-bit [n_rows, K] (row stride ld) -> out: f6_tiles_bytes(n_rows, K) bytes; rows n_rows .. the next multiple of 256 are written as zeros.  K % 128 == 0.
+// w_side: the scale table of a W operand (4 fragments per lane) instead of an A operand's (8).
+int launch_f6_tiles(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, bool w_side, uint8_t* out, hipStream_t s);
+static inline size_t f6_tiles_bytes(int64_t n_rows, int K) { return (size_t)((n_rows + 255) / 256) * (K / 128) * 25600; }

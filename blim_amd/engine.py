@@ -103,7 +103,8 @@ def load_library(path: str = LIB_PATH):
         "blim_fill_bell_f32": ([vp, i64, u64, C.c_char_p, f32, f32, i32, vp], C.c_int),
         "blim_gemm_bf16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
         "blim_gemm_f16": ([vp, i64, vp, i32, i32, i32, vp, i64, vp], C.c_int),
-        "blim_gemm_f16_lo6": ([vp, vp, i32, i32, i32, vp, vp, vp], C.c_int),
+        "blim_f6_tiles_bytes": ([i64, i32], C.c_int64),
+        "blim_gemm_f16_lo6": ([vp, vp, i32, i32, i32, vp, vp, vp, vp], C.c_int),
         "blim_quant_rows": ([vp, i64, i64, i32, i32, vp, vp, vp], C.c_int),
         "blim_gemm_f8": ([vp, i64, vp, vp, vp, i32, i32, i32, vp, i64, vp], C.c_int),
         "blim_timing_enable": ([vp, i32], C.c_int),
@@ -493,17 +494,17 @@ def gemm_f8(a8, a_scale, w8, w_scale):
 
 def gemm_f16_lo6(a_hilo, w):
     """The compensated GEMM of fp16 engines (option "precise_lo6"): a_hilo [M, 2K] f16 rows [hi | lo], w [N, K] f16 -> (C f32 [M, N] = hi . w^T + e2m3(lo) . e2m3(w)^T,
-    the rows as the kernel read them -- lo halves replaced by their e2m3 image --, the combined weight copy uint8 [N, 3K])."""
+    the e2m3 operand tiles of lo and of w as uint8 [row tiles, K / 128, 25600] -- layout: csrc/gemm.hpp)."""
     import torch
     lib = load_library()
     M, K2 = a_hilo.shape
     N, K = w.shape
     assert K2 == 2 * K and a_hilo.dtype == torch.float16 and w.dtype == torch.float16 and a_hilo.is_contiguous() and w.is_contiguous()
-    rows = a_hilo.clone()
-    wc = torch.empty((N, 3 * K), dtype=torch.uint8, device=w.device)
+    a6 = torch.empty(lib.blim_f6_tiles_bytes(M, K), dtype=torch.uint8, device=w.device)
+    w6 = torch.empty(lib.blim_f6_tiles_bytes(N, K), dtype=torch.uint8, device=w.device)
     out = torch.empty((M, N), dtype=torch.float32, device=w.device)
-    _check(lib.blim_gemm_f16_lo6(_ptr(rows), _ptr(w), M, N, K, _ptr(wc), _ptr(out), _stream()), "blim_gemm_f16_lo6")
-    return out, rows, wc
+    _check(lib.blim_gemm_f16_lo6(_ptr(a_hilo), _ptr(w), M, N, K, _ptr(a6), _ptr(w6), _ptr(out), _stream()), "blim_gemm_f16_lo6")
+    return out, a6.view(-1, K // 128, 25600), w6.view(-1, K // 128, 25600)
 
 
 def gemm_bf16(a, w):

@@ -192,9 +192,11 @@ int blim_fill_bell_f32(float* out, int64_t n, uint64_t seed, const char* name, f
 int blim_gemm_f16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
 int blim_gemm_bf16(const void* A, int64_t lda, const void* W, int32_t M, int32_t N, int32_t K, void* C, int64_t ldc, void* stream);
 /* The compensated GEMM of fp16 engines as a building block (tests; option "precise_lo6"): A_hilo [M, 2 K] fp16 rows [hi | lo], W [N, K] fp16 ->
- * C f32 [M, N] = hi . W^T (fp16 MFMA) + e2m3(lo) . e2m3(W)^T (block-scaled MFMA, one power-of-two scale per 32 values), one kernel.  The lo halves of A_hilo are
- * REPLACED by their e2m3 image (the engine quantises in place); w_c6 [N, 3 K bytes] receives the combined copy [W | e2m3 image of W].  K % 128 == 0. */
-int blim_gemm_f16_lo6(void* A_hilo, const void* W, int32_t M, int32_t N, int32_t K, void* w_c6, float* C, void* stream);
+ * C f32 [M, N] = hi . W^T (fp16 MFMA) + e2m3(lo) . e2m3(W)^T (block-scaled MFMA: e2m3 values with one power-of-two scale per 32), one kernel, one set of
+ * accumulators.  a6 / w6 (blim_f6_tiles_bytes(M, K) / (N, K) bytes) receive the e2m3 operand tiles of the lo part and of W in the layout the kernel stages:
+ * per (256-row tile, 128-value K-step) 24 KiB of packed 6-bit values in MFMA-lane order + 1 KiB of E8M0 scale bytes (csrc/gemm.hpp).  K % 128 == 0. */
+int64_t blim_f6_tiles_bytes(int64_t n_rows, int32_t K);
+int blim_gemm_f16_lo6(const void* A_hilo, const void* W, int32_t M, int32_t N, int32_t K, void* a6, void* w6, float* C, void* stream);
 /* fp8 building blocks (tests / bench): per-row e4m3 quantisation of a 16-bit matrix (dtype16 = BLIM_COMPUTE_BF16 / _F16;
  * out8 [n_rows, K] bytes, scale [n_rows] = absmax / 448, 1 for an all-zero row), and
  * C f16 [M, ldc] = (A8 [M, lda] . W8 [N, K]^T) * a_scale[m] * w_scale[n] on the block-scaled fp8 MFMA.  K % 128 == 0. */

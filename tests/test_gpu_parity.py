@@ -1077,41 +1077,47 @@ def _e2m3_quant(x):
     return (code | np.where(b < 0, 32, 0)).astype(np.uint8).reshape(x.shape), (s_[..., 0] + 127).astype(np.uint8), val.reshape(x.shape)
 
 
-def _e2m3_image_decode(img, K):
-    """img uint8 [rows, K] (the 128-bytes-per-128-values image of gemm.hpp) -> (codes [rows, K], E8M0 bytes [rows, K / 32])."""
-    rows = img.shape[0]
-    st = img.reshape(rows, K // 128, 128)
-    codes = np.zeros((rows, K // 128, 4, 32), np.uint8); e8 = np.zeros((rows, K // 128, 4), np.uint8)
+def _e2m3_tiles_decode(tiles, n_rows, K, w_side):
+    """tiles uint8 [row tiles, K / 128, 25600] (the operand-tile image of csrc/gemm.hpp) -> (codes [n_rows, K], E8M0 bytes [n_rows, K / 32]); rows beyond n_rows must be zero."""
+    nt, nk = tiles.shape[0], K // 128
+    assert tiles.shape == (nt, nk, 25600) and nt == (n_rows + 255) // 256
+    data = tiles[:, :, :24576].reshape(nt, nk, 16, 1536)                                       # [tile][step][fragment group][1024 B of 16-byte parts | 512 B of 8-byte parts]
+    p16 = data[..., :1024].reshape(nt, nk, 16, 4, 16, 16)                                      # [..][g][row r][16 bytes]
+    p8 = data[..., 1024:].reshape(nt, nk, 16, 4, 16, 8)
+    packed = np.concatenate([p16, p8], axis=-1)                                                # 24 bytes = 32 x 6 bits, little endian
+    bits = np.unpackbits(packed, axis=-1, bitorder="little").reshape(nt, nk, 16, 4, 16, 32, 6)
+    codes = (bits * (1 << np.arange(6))).sum(-1).astype(np.uint8)                              # [tile][step][fb][g][r][j]
+    codes = codes.transpose(0, 2, 4, 1, 3, 5).reshape(nt * 256, K)                             # row = tile * 256 + fb * 16 + r; k = step * 128 + g * 32 + j
+    sc = tiles[:, :, 24576:]
+    rl = np.arange(256)
+    e8 = np.zeros((nt, 256, nk, 4), np.uint8)
     for g in range(4):
-        data = np.concatenate([st[:, :, 16 * g:16 * g + 16], st[:, :, 64 + 16 * g:64 + 16 * g + 8]], axis=-1)          # 24 bytes = 32 x 6 bits, little endian
-        bits = np.unpackbits(data, axis=-1, bitorder="little").reshape(rows, K // 128, 32, 6)
-        codes[:, :, g] = (bits * (1 << np.arange(6))).sum(-1)
-        e8[:, :, g] = st[:, :, 64 + 16 * g + 8]
-        assert not st[:, :, 64 + 16 * g + 9:64 + 16 * g + 16].any()                                                 # padding
-    return codes.reshape(rows, K), e8.reshape(rows, K // 32)
+        idx = ((rl >> 6) * 4 + g) * 64 + (rl & 15) * 4 + ((rl >> 4) & 3) if w_side else ((rl >> 7) * 4 + g) * 128 + (rl & 15) * 8 + ((rl >> 4) & 7)
+        e8[:, :, :, g] = sc[:, :, idx].transpose(0, 2, 1)
+    e8 = e8.reshape(nt * 256, K // 32)
+    assert not codes[n_rows:].any() and not e8[n_rows:].any()                                  # the padding rows of the last tile are zeros
+    return codes[:n_rows], e8[:n_rows]
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (700, 512, 3584), (512, 256, 18944)])
-def test_lo6_gemm_quantisers_and_kernel_vs_numpy(M, N, K):
-    """blim_gemm_f16_lo6 = the engine's compensated GEMM: C = hi . W^T on the fp16 MFMA + e2m3(lo) . e2m3(W)^T on the block-scaled MFMA, one kernel, both operands'
-    rows continuing into their e2m3 image.  (a) the two quantisers write exactly the image numpy's statement of the rule gives (codes, scale bytes, padding, the 16-bit
-    half of the combined weight copy); (b) the kernel's result equals hi . W^T + dequantised(lo) . dequantised(W)^T in float64 to f32 summation accuracy -- a wrong K
-    assignment, scale block or pairing of the second pass shows at 1e-3 of the second term; (c) the second term is really there."""
+def test_lo6_gemm_quantiser_and_kernel_vs_numpy(M, N, K):
+    """blim_gemm_f16_lo6 = the engine's compensated GEMM: C = hi . W^T on the fp16 MFMA + e2m3(lo) . e2m3(W)^T on the block-scaled MFMA, one kernel, one set of
+    accumulators.  (a) the quantiser writes exactly the operand tiles numpy's statement of the rule gives (codes, scale bytes, lane order, zero padding rows), for
+    both operand sides; (b) the kernel's result equals hi . W^T + dequantised(lo) . dequantised(W)^T in float64 to f32 summation accuracy -- a wrong K assignment, scale
+    block, ring slot or pairing of the second pass shows at 1e-3 of the second term; (c) the second term is really there."""
     g = np.random.RandomState(M + N + K)
     hi = (g.randn(M, K) * 0.5).astype(np.float16)
     lo = (g.randn(M, K) * 2.0 ** -11 * np.exp(g.randn(M, 1)) * (1 + 50 * (g.rand(M, K) < 0.002))).astype(np.float16)        # ragged magnitudes, a few outliers per row
     lo[:, 32:64] = 0                                                                                                       # an all-zero block
     w = (g.randn(N, K) * 0.02 * (1 + 30 * (g.rand(N, K) < 0.001))).astype(np.float16)
-    out, rows, wc = eng.gemm_f16_lo6(torch.from_numpy(np.concatenate([hi, lo], axis=1)).cuda(), torch.from_numpy(w).cuda())
-    rows = rows.cpu().numpy(); wc = wc.cpu().numpy(); out = out.cpu().numpy().astype(np.float64)
-    assert np.array_equal(rows[:, :K], hi)
-    assert np.array_equal(wc[:, :2 * K].copy().view(np.float16), w)
+    out, a6, w6 = eng.gemm_f16_lo6(torch.from_numpy(np.concatenate([hi, lo], axis=1)).cuda(), torch.from_numpy(w).cuda())
+    out = out.cpu().numpy().astype(np.float64)
     c_lo, e_lo, v_lo = _e2m3_quant(lo.astype(np.float64))
     c_w, e_w, v_w = _e2m3_quant(w.astype(np.float64))
-    got_c, got_e = _e2m3_image_decode(rows[:, K:].copy().view(np.uint8)[:, :K], K)
+    got_c, got_e = _e2m3_tiles_decode(a6.cpu().numpy(), M, K, w_side=False)
     live = np.repeat(e_lo != 0, 32, axis=1)                                        # (the sign bit of a value in an all-zero block is free)
     assert np.array_equal(got_e, e_lo) and np.array_equal(got_c[live], c_lo[live]) and not (got_c[~live] & 31).any()
-    got_c, got_e = _e2m3_image_decode(wc[:, 2 * K:], K)
+    got_c, got_e = _e2m3_tiles_decode(w6.cpu().numpy(), N, K, w_side=True)
     assert np.array_equal(got_e, e_w) and np.array_equal(got_c, c_w)
     first = hi.astype(np.float64) @ w.astype(np.float64).T
     second = v_lo @ v_w.T

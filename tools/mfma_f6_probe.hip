@@ -116,8 +116,8 @@ int main() {
             printf("\n");
         }
     }
-    // (4) rate
-    {
+    // (4) rate: two waves per SIMD (512 threads) and ONE wave per SIMD (256 threads: what a ping-pong of wave groups gives the matrix pipe)
+    for (int threads : {512, 256}) {
         int* src; float* out; hipMalloc(&src, 8192 * 4); hipMalloc(&out, 256 * 512 * 4);
         static int h[8192]; uint32_t x = 12345;
         for (int zero = 0; zero < 2; ++zero) {
@@ -126,14 +126,14 @@ int main() {
             for (int fmt = 0; fmt < 2; ++fmt) {
                 const int iters = 20000;
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-                if (fmt) hipLaunchKernelGGL(rate<FMT_F6>, dim3(256), dim3(512), 0, 0, src, out, 100); else hipLaunchKernelGGL(rate<0>, dim3(256), dim3(512), 0, 0, src, out, 100);
+                if (fmt) hipLaunchKernelGGL(rate<FMT_F6>, dim3(256), dim3(threads), 0, 0, src, out, 100); else hipLaunchKernelGGL(rate<0>, dim3(256), dim3(threads), 0, 0, src, out, 100);
                 hipDeviceSynchronize();
                 hipEventRecord(e0);
-                if (fmt) hipLaunchKernelGGL(rate<FMT_F6>, dim3(256), dim3(512), 0, 0, src, out, iters); else hipLaunchKernelGGL(rate<0>, dim3(256), dim3(512), 0, 0, src, out, iters);
+                if (fmt) hipLaunchKernelGGL(rate<FMT_F6>, dim3(256), dim3(threads), 0, 0, src, out, iters); else hipLaunchKernelGGL(rate<0>, dim3(256), dim3(threads), 0, 0, src, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
-                const double flops = 256.0 * 8 * iters * 32 * 2.0 * 16 * 16 * 128;
-                printf("(4) %s operands, %s 16x16x128: %.2f ms  %.0f TFLOP/s\n", zero ? "zero" : "random", fmt ? "mx-fp6 (e2m3)" : "mx-fp8 (e4m3)", ms, flops / ms / 1e9);
+                const double flops = 256.0 * (threads / 64) * iters * 32 * 2.0 * 16 * 16 * 128;
+                printf("(4) %d waves per SIMD, %s operands, %s 16x16x128: %.2f ms  %.0f TFLOP/s\n", threads / 256, zero ? "zero" : "random", fmt ? "mx-fp6 (e2m3)" : "mx-fp8 (e4m3)", ms, flops / ms / 1e9);
             }
         }
     }
