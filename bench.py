@@ -25,6 +25,7 @@ FLOP_TOKEN_LAYER = 2 * H * (H + 2 * 512) + 2 * H * H + 6 * H * I      # 466,092,
 FLOP_HEAD_ROW = 2 * H * V                                           # 1,089,994,752
 PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0                                            # dense fp8 (block-scaled MFMA), same table
+PEAK_FP6_TFLOPS = 10000.0                                           # dense fp6 / fp4 (block-scaled MFMA; gfx950 issues fp6 at the fp4 rate), same table
 
 
 def f_pair(L, t_lab):
@@ -32,22 +33,21 @@ def f_pair(L, t_lab):
     return LAYERS * (FLOP_TOKEN_LAYER * L + 2 * H * L * L) + FLOP_HEAD_ROW * t_lab
 
 
-def measured_traffic(kernel_class, dtype):
-    """HBM-side bytes per launch of a kernel class from the newest committed PMC summary (profiles/*_traffic.json, made by
-    tools/collect_profiles.sh + tools/parse_profiles.py with separate --pmc FETCH_SIZE / WRITE_SIZE passes); None if absent."""
-    import glob
+def measured_traffic(kernel_class, dtype, compensated=False):
+    """HBM-side bytes per launch of a kernel class from the committed PMC summary that profiles/CURRENT.json names for this kind of run ("plain" / "full": written by
+    tools/collect_profiles.sh next to the bench command it profiled; made by tools/parse_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes); None if absent."""
     epi = {"gemm_qkv_rope": 3, "gemm_o_resid": 2, "gemm_down_resid": 2, "gemm_gateup_swiglu": 4, "lm_head_lse": 5}.get(kernel_class)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if epi is None or not files:
-        return None
-    dt = dict(bf16=0, f16=1, f8=2)[dtype]
-    names = (f"void gemm_kernel<{epi}, {dt}, false, false>(GemmParams)", f"void gemm_kernel<{epi}, {dt}, false>(GemmParams)", f"void gemm_kernel<{epi}, {dt}>(GemmParams)")
     try:
-        for f in reversed(files):                                   # newest summary that profiled this kernel
-            d = json.load(open(f))
-            for name in names:
-                if name in d:
-                    return d[name]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+        cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json")))
+        f = cur.get("traffic", {}).get(("full" if compensated else "plain") + "_" + dtype)
+        if epi is None or not f:
+            return None
+        d = json.load(open(os.path.join(ROOT, "profiles", f)))
+        dt = dict(bf16=0, f16=1, f8=2)[dtype]
+        split = "true" if (compensated and epi in (3, 4)) else "false"
+        for name in (f"void gemm_kernel<{epi}, {dt}, {split}, {'true' if compensated and dtype == 'f16' else 'false'}>(GemmParams)",):
+            if name in d:
+                return d[name]["hbm_bytes_per_launch"], os.path.join("profiles", f)
         return None
     except Exception:
         return None
@@ -195,19 +195,19 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
         dt = time.perf_counter() - t0
         st = args._eval_stats
         st["executed_flops_job"] = st.get("executed_flops", 0.0)
-        st["executed_flops_e4m3_job"] = st.get("executed_flops_e4m3", 0.0)
+        st["executed_flops_lo6_job"] = st.get("executed_flops_lo6", 0.0)
         if pg:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
-            f = torch.tensor([st.get("executed_flops", 0.0), st.get("executed_flops_e4m3", 0.0)], dtype=torch.float64, device=dev)
+            f = torch.tensor([st.get("executed_flops", 0.0), st.get("executed_flops_lo6", 0.0)], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.SUM)      # the whole job's executed FLOPs (every rank's own calls)
-            st["executed_flops_job"], st["executed_flops_e4m3_job"] = float(f[0].item()), float(f[1].item())
+            st["executed_flops_job"], st["executed_flops_lo6_job"] = float(f[0].item()), float(f[1].item())
         return dt, st, (t2v, v2t)
 
-    # seconds the executed FLOPs would take at the dense peaks: the e4m3 second pass of compensated calls (engine option "precise_lo6") at the fp8 peak, the rest
+    # seconds the executed FLOPs would take at the dense peaks: the e2m3 second pass of compensated calls (engine option "precise_lo6") at the fp6 peak, the rest
     # at this engine's own (16-bit or fp8) peak
-    at_peak = lambda total, f8: ((total - f8) / peak + f8 / (PEAK_FP8_TFLOPS * 1e12))
+    at_peak = lambda total, f6: ((total - f6) / peak + f6 / (PEAK_FP6_TFLOPS * 1e12))
     run((4 * max(world, emulate), rank))                                      # warm-up: workspaces, allocator, first-call costs (a small share)
     dt, st, (t2v, v2t) = run(None)
     ok = all(np.isfinite(m).all() for d in (t2v, v2t) for m in d.values())
@@ -220,8 +220,8 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
            # counts launched, compensated TVG calls counted twice, last-layer pruning subtracted) / wall time of the job / (world x dense peak)
            "executed_tflop_job": round(st["executed_flops_job"] / 1e12, 1),
            "executed_tflops_per_gpu": round(st["executed_flops_job"] / dt / 1e12 / world, 1),
-           "executed_tflop_job_e4m3_pass": round(st["executed_flops_e4m3_job"] / 1e12, 1),
-           "frac_mfma_peak": round(at_peak(st["executed_flops_job"], st["executed_flops_e4m3_job"]) / (dt * world), 4),
+           "executed_tflop_job_e2m3_pass": round(st["executed_flops_lo6_job"] / 1e12, 1),
+           "frac_mfma_peak": round(at_peak(st["executed_flops_job"], st["executed_flops_lo6_job"]) / (dt * world), 4),
            "tvg_precise": f"{tvg_precise} -> {st['tvg_precise']}" if "tvg_precise" in st else getattr(model, "tvg_precise", "full"),
            "pairs_scored_rank0": st["pairs_scored"], "finite": bool(ok), "host_marks_rank0": st["host_marks"]}
     if world == 1 and emulate > 1:
@@ -229,7 +229,7 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
         for r in range(emulate):
             d_r, st_r, _ = run((emulate, r))
             per_rank.append(round(d_r, 3))
-            per_rank_frac.append(round(at_peak(st_r.get("executed_flops", 0.0), st_r.get("executed_flops_e4m3", 0.0)) / d_r, 4))
+            per_rank_frac.append(round(at_peak(st_r.get("executed_flops", 0.0), st_r.get("executed_flops_lo6", 0.0)) / d_r, 4))
             if r == 0:
                 out["emulated_rank0_host_marks"] = st_r["host_marks"]
         out.update({"emulated_world": emulate, "emulated_rank_seconds": per_rank, "predicted_seconds": max(per_rank),
@@ -287,10 +287,11 @@ def main():
                          "bf16 (same MFMA rate, ~3 %% faster under the power limit, but 1 - 2e-3 on the VTG scores at depth: a non-parity mode), "
                          "f8 (separate mode, deviations reported)")
     ap.add_argument("--topk", type=int, default=16)
-    ap.add_argument("--vtg-precise", default="none", choices=["none", "qk", "qkx", "attn", "act0", "full"],
-                    help="compensated (hi + lo) activations on the benched VTG calls: none (default; fp16 holds 1e-3 without), full = the bf16 PARITY mode "
-                         "(2x GEMM flops; what `--dtype bf16` needs to hold 1e-3 at 7B depth: tests/test_gpu_parity.py::test_depth_*)")
-    ap.add_argument("--tvg-precise", default="auto", choices=["auto", "attn", "act0", "full"],
+    ap.add_argument("--vtg-precise", default="none", choices=["none", "full"],
+                    help="compensated (hi + lo) activations on the benched VTG calls: none (default; fp16 holds 1e-3 without on these weights), full = what weights with a "
+                         "trained checkpoint's massive activations need (fp16: second pass on the e2m3 MFMA) and the bf16 PARITY mode (2x GEMM flops; what "
+                         "`--dtype bf16` needs to hold 1e-3 at 7B depth: tests/test_gpu_parity.py::test_depth_*)")
+    ap.add_argument("--tvg-precise", default="auto", choices=["auto", "attn", "full"],
                     help="strong-scaling leg only (the headline step is a VTG pass): how much of the TVG calls' MLP branch runs compensated; auto = measured on the "
                          "job's own pairs inside the timed region, as main.py's default does (blim_amd/retrieval_utils.py: PairScorer.calibrate_tvg)")
     ap.add_argument("--no-compensated", action="store_true", help="skip the extra timing of the same step with fully compensated VTG calls (reported as `compensated_mode`)")
@@ -391,17 +392,19 @@ def main():
         try:
             model.vtg_precise = "full"
             (sc_c, pl_c, _, _), = build_step_plans(model, rank, 1, Q, K)
-            sc_c.run(pl_c)                                        # warm-up: feature rows in the [hi | lo] layout, the e4m3 weight copies
+            sc_c.run(pl_c)                                        # warm-up: feature rows in the [hi | lo] layout, the e2m3 weight images
             torch.cuda.synchronize(); tc = time.perf_counter()
             for _ in range(3):
                 out_c = sc_c.run(pl_c)
             torch.cuda.synchronize(); dtc = (time.perf_counter() - tc) / 3
             fl = RU.executed_flops(dims, pl_c.n_tokens, pl_c.n_rows, "vtg", "full")
-            f8 = RU.e4m3_pass_flops(dims, pl_c.n_tokens, pl_c.n_rows, "vtg", "full") if getattr(model.engine, "lo6", False) else 0.0
+            f6 = RU.lo6_pass_flops(dims, pl_c.n_tokens, pl_c.n_rows, "vtg", "full") if getattr(model.engine, "lo6", False) else 0.0
             comp = {"vtg_compensated": "full", "value": round(pl_c.n_pairs / dtc, 2), "unit": "pairs/s", "ms_per_step": round(dtc * 1e3, 3), "finite": bool(torch.isfinite(out_c).all()),
-                    "second_pass": "e4m3 (engine option precise_lo6)" if f8 else "16-bit",
-                    "frac_mfma_peak_whole_step": round(((fl - f8) / (PEAK_BF16_TFLOPS * 1e12) + f8 / (PEAK_FP8_TFLOPS * 1e12)) / dtc, 4),
-                    "note": "same batch, every activation hi + lo; <= 4e-5 from the fp32 reference at 7B depth (tests/test_gpu_parity.py::test_e4m3_second_pass_of_the_compensated_gemms)"}
+                    "second_pass": "e2m3 (engine option precise_lo6)" if f6 else "16-bit",
+                    "frac_mfma_peak_whole_step": round(((fl - f6) / (PEAK_BF16_TFLOPS * 1e12) + f6 / (PEAK_FP6_TFLOPS * 1e12)) / dtc, 4),
+                    "frac_mfma_peak_note": "the second pass's half of the executed flops priced at the fp6 peak (10 PFLOP/s), the rest at the 16-bit one: the pass is bound by what it "
+                                           "moves (25 KiB per operand tile and 128-deep K-step through LDS-DMA and LDS), not by the e2m3 MFMAs -- DESIGN.md section 3",
+                    "note": "same batch, every activation hi + lo; <= 4e-5 from the fp32 reference at 7B depth (tests/test_gpu_parity.py::test_e2m3_second_pass_of_the_compensated_gemms)"}
         except Exception as e:
             comp = {"error": f"{type(e).__name__}: {e}"}
         finally:
@@ -419,17 +422,16 @@ def main():
         d = rep[dom]
         ach = d["flops"] / d["calls"] / (d["ms"] / d["calls"] * 1e-3) / 1e12
         peak = PEAK_FP8_TFLOPS if model.engine.dtype == "f8" else PEAK_BF16_TFLOPS
-        # compensated modes on an fp16 engine (option "precise_lo6", default): the second walk over K runs on the e4m3 MFMA -- those flops are priced at the fp8
-        # peak, the rest at the 16-bit one: peak_mixed = flops / (flops16 / P16 + flops8 / P8).  Plain modes (the headline): share 0, nothing changes.
-        lo8 = bool(getattr(model.engine, "lo6", False))
-        e4m3_step = RU.e4m3_pass_flops(dims, n_tok, n_rows, "vtg", model.vtg_precise, prune=True) if lo8 else 0.0
-        mixed = lambda total, f8: total / ((total - f8) / PEAK_BF16_TFLOPS + f8 / PEAK_FP8_TFLOPS) if total > 0 else PEAK_BF16_TFLOPS
-        peak_step = mixed(exec_flops_step, e4m3_step) if model.engine.dtype != "f8" else peak
-        dom_e4m3 = 0.5 if (e4m3_step > 0 and (dom in ("gemm_qkv_rope", "gemm_o_resid", "lm_head_lse") or (dom == "gemm_gateup_swiglu" and model.vtg_precise in ("act0", "full"))
-                                              or (dom == "gemm_down_resid" and model.vtg_precise == "full"))) else 0.0
+        # compensated mode on an fp16 engine (option "precise_lo6", default): the second walk over K runs on the e2m3 MFMA -- those flops are priced at the fp6
+        # peak, the rest at the 16-bit one: peak_mixed = flops / (flops16 / P16 + flops6 / P6).  Plain mode (the headline): share 0, nothing changes.
+        lo6 = bool(getattr(model.engine, "lo6", False))
+        lo6_step = RU.lo6_pass_flops(dims, n_tok, n_rows, "vtg", model.vtg_precise, prune=True) if lo6 else 0.0
+        mixed = lambda total, f6: total / ((total - f6) / PEAK_BF16_TFLOPS + f6 / PEAK_FP6_TFLOPS) if total > 0 else PEAK_BF16_TFLOPS
+        peak_step = mixed(exec_flops_step, lo6_step) if model.engine.dtype != "f8" else peak
+        dom_lo6 = 0.5 if (lo6_step > 0 and rep[dom]["flops"] > 0 and dom != "attention") else 0.0       # fully compensated: half of every GEMM's flops are its second pass
         if model.engine.dtype != "f8":
-            peak = mixed(1.0, dom_e4m3)
-        tr = measured_traffic(dom, model.engine.dtype)
+            peak = mixed(1.0, dom_lo6)
+        tr = measured_traffic(dom, model.engine.dtype, compensated=model.vtg_precise == "full")
         es = 1 if model.engine.dtype == "f8" else 2
         alg_bytes = {"gemm_gateup_swiglu": n_tok * H * es + 2 * I * H * es + n_tok * I * 2, "gemm_down_resid": n_tok * I * es + H * I * es + 2 * n_tok * H * 4,
                      "gemm_qkv_rope": n_tok * H * es + 4608 * H * es + n_tok * 4608 * 2, "gemm_o_resid": n_tok * H * es + H * H * es + 2 * n_tok * H * 4,
@@ -445,10 +447,10 @@ def main():
             "algorithmic_gflop_per_pair": round(f_pair(128, 32) / 1e9, 1),
             "executed_gflop_per_pair": round(exec_flops_step / n_pairs / 1e9, 1),
             "executed_tflops_per_gpu": round(exec_flops_step * a.steps / dt / 1e12, 1),
-            "executed_gflop_per_pair_e4m3": round(e4m3_step / n_pairs / 1e9, 1),
+            "executed_gflop_per_pair_e2m3": round(lo6_step / n_pairs / 1e9, 1),
             "frac_mfma_peak_whole_step": round(exec_flops_step * a.steps / dt / 1e12 / peak_step, 4),
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "peak_note": None if dom_e4m3 == 0.0 else "half of this kernel's flops are the e4m3 second pass of the compensated mode: peak = 2 / (1 / 2500 + 1 / 5000)",
+                         "peak_note": None if dom_lo6 == 0.0 else "half of this kernel's flops are the e2m3 second pass of the compensated mode: peak = 2 / (1 / 2500 + 1 / 10000)",
                          "frac": round(ach / peak, 4), "traffic": tr[0] if tr else None,
                          "traffic_source": (f"{tr[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 x FETCH_SIZE + WRITE_SIZE, "
                                             "fabric side of L2, Infinity-Cache hits included); looked up, not re-measured in this run") if tr else None,

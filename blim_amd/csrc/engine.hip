@@ -133,7 +133,6 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     if (cfg->compute_dtype == BLIM_COMPUTE_F8) { e->f8 = true; e->c.compute_dtype = BLIM_COMPUTE_F16; }
     if (getenv("BLIM_F8_FUSE")) e->f8_fuse = atoi(getenv("BLIM_F8_FUSE"));
     if (getenv("BLIM_PRECISE_MLP")) e->precise_mlp = atoi(getenv("BLIM_PRECISE_MLP")) != 0;
-    if (getenv("BLIM_PRECISE_ACT")) e->precise_act = atoi(getenv("BLIM_PRECISE_ACT")) != 0;
     // fp16 engines: the compensated modes' second pass over K runs in e2m3 (gemm.hip, phase 2) unless BLIM_PRECISE_LO6=0 / option "precise_lo6" = 0
     e->lo6 = !e->f8 && cfg->compute_dtype == DT_F16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 && cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480;
     if (getenv("BLIM_PRECISE_LO6") && atoi(getenv("BLIM_PRECISE_LO6")) == 0) e->lo6 = false;
@@ -575,7 +574,7 @@ static int adapter_u(blim_engine* e, void* x16, int64_t ldx, int64_t lo_off, int
 // ---------------------------------------------------------------------------- workspaces
 static int reserve_tokens(blim_engine* e, int64_t T) {
     const blim_config& c = e->c;
-    const int64_t Tp = round_up(T, 256) * ((e->precise || e->precise_qk > 0) ? 2 : 1);      // precise modes: [hi | lo] rows of twice the width
+    const int64_t Tp = round_up(T, 256) * (e->precise ? 2 : 1);      // precise mode: [hi | lo] rows of twice the width
     if (e->f8) {
         TRY(ensure(e->x8, (size_t)Tp * c.hidden_size));
         TRY(ensure(e->a8, (size_t)Tp * c.hidden_size));
@@ -729,10 +728,6 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     const int pf = e->precise ? 2 : 1;                              // attention branch
     const bool pm = e->precise && e->precise_mlp;                   // MLP branch (option "precise_mlp")
     const int pfm = pm ? 2 : 1;
-    const bool pa = pm && e->precise_act;                           // ... including the SwiGLU output / down-proj input (option "precise_act")
-    const bool pq = !e->precise && e->precise_qk > 0 && !e->f8;     // plain mode with hi + lo q / k / v and attention output (option "precise_qk")
-    const bool pqx = pq && e->precise_qk > 1;                       // ... and a hi + lo input of the QKV GEMM (its K walked twice)
-    const int pfq = (e->precise || pq) ? 2 : 1;                     // width factor of the qkv / attention-output rows
     if (e->precise && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_STATE; }
     // option "precise_lo6": a compensated GEMM = its plain fp16 pass over the hi part + an e2m3 pass over the lo part, in one kernel and into the same accumulators
     // (gemm.hip, phase 2).  `rows` are [hi | lo] rows (lo at +K elements, row stride ld): the lo halves are written as e2m3 operand tiles into the a6 workspace
@@ -750,14 +745,13 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, (pqx ? 2 : pf) * Hq, (e->precise || pqx) ? xn + Hq : nullptr));
-            if (G) TRY(adapter_u(e, xn, (pqx ? 2 : pf) * Hq, (e->precise || pqx) ? Hq : 0, T, H, &e->AD[li].ad[0], &e->AD[li].ad[1], &e->AD[li].ad[2], s));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * Hq, e->precise ? xn + Hq : nullptr));
+            if (G) TRY(adapter_u(e, xn, pf * Hq, e->precise ? Hq : 0, T, H, &e->AD[li].ad[0], &e->AD[li].ad[1], &e->AD[li].ad[2], s));
         }
         {
-            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * Hq * e->qkv_n * (pqx ? 2 : pf));
+            SpanGuard g(e, s, TC_GEMM_QKV, 2.0 * tok * Hq * e->qkv_n * pf);
             GemmParams p = q8 ? gp8(x8, H, sx, l.wqkv8, l.sqkv, T, e->qkv_n, H, qkv, e->qkv_n)
-                              : gp2(e, xn, Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise || pqx);
-            if (pq && !pqx) { p.ldc = 2 * (int64_t)e->qkv_n; p.lo_off = e->qkv_n; }      // plain A (K walked once), the f32 accumulator leaves as [hi | lo]
+                              : gp2(e, xn, Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise);
             if (lo6) {                                                                    // hi part in fp16, lo part in e2m3; [hi | lo] outputs as before
                 p = gp(c.compute_dtype, xn, 2 * Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, (int)Hq, qkv, 2 * (int64_t)e->qkv_n); p.lo_off = e->qkv_n;
                 TRY(attach_lo6(p, xn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wqkv_aug6 : l.wqkv6));
@@ -769,10 +763,10 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             SpanGuard g(e, s, TC_ATTN, 0);
             AttnParams a;
             a.dtype = c.compute_dtype;
-            a.qkv = qkv; a.ldq = (int64_t)pfq * e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
+            a.qkv = qkv; a.ldq = (int64_t)pf * e->qkv_n; a.num_heads = c.num_heads; a.num_kv_heads = c.num_kv_heads;
             a.key_visible = b->key_visible; a.seq_start = b->seq_start; a.seq_len = b->seq_len; a.pfx_start = b->pfx_start; a.pfx_len = b->pfx_len;
-            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pfq * Hq; a.scale = 0.08838834764831845f;
-            a.v_lo_off = pfq == 2 ? e->qkv_n : 0; a.out_lo_off = pfq == 2 ? Hq : 0;
+            a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * Hq; a.scale = 0.08838834764831845f;
+            a.v_lo_off = pf == 2 ? e->qkv_n : 0; a.out_lo_off = pf == 2 ? Hq : 0;
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
             if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
@@ -781,17 +775,17 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         if (o8 && !fuse_o) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
         if (prune && li == c.num_layers - 1) {
             // ---- last layer, live rows only: gather (attention output -> the free `act` workspace, residual -> resid_live), then the same four kernels on n_live rows
-            bf16_t* attn_live = act;                                         // [n_live, pfq * Hq] 16-bit (act is not in use until the gate|up GEMM below)
+            bf16_t* attn_live = act;                                         // [n_live, pf * Hq] 16-bit (act is not in use until the gate|up GEMM below)
             float* rl = (float*)e->resid_live.p;
             {
                 SpanGuard g0(e, s, TC_MISC, 0);
-                TRY(launch_gather_rows(attn_live, attn, live_rows, n_live, (int64_t)pfq * Hq * 2, T, 0u, s));
-                if (G) TRY(adapter_u(e, attn_live, (int64_t)pfq * Hq, e->precise ? Hq : 0, n_live, H, &e->AD[li].ad[3], nullptr, nullptr, s));
+                TRY(launch_gather_rows(attn_live, attn, live_rows, n_live, (int64_t)pf * Hq * 2, T, 0u, s));
+                if (G) TRY(adapter_u(e, attn_live, (int64_t)pf * Hq, e->precise ? Hq : 0, n_live, H, &e->AD[li].ad[3], nullptr, nullptr, s));
                 TRY(launch_gather_rows(rl, resid, live_rows, n_live, (int64_t)H * 4, T, 0x7fc00000u, s));      // a row outside the batch: NaN (poisoned score)
             }
             const double tl = (double)n_live;
             { SpanGuard g(e, s, TC_GEMM_O, 2.0 * tl * Hq * H * pf);
-              GemmParams p = gp2(e, attn_live, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0; if (pq) p.lda = 2 * Hq;   // pq: the hi halves of [hi | lo] rows
+              GemmParams p = gp2(e, attn_live, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, rl, H, 0, e->precise); p.ldc = H; p.lo_off = 0;
               if (lo6) { p = gp(c.compute_dtype, attn_live, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, n_live, H, (int)Hq, rl, H);
                          TRY(attach_lo6(p, attn_live, 2 * Hq, n_live, (int)Hq, G ? e->AD[li].wo_aug6 : l.wo6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
@@ -799,24 +793,23 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
               TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
-              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm); if (pm && !pa) { p.lo_off = 0; p.ldc = I; }
-              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu6)); }
+              GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm);
+              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu6)); }
               TRY(launch_gemm(EPI_SWIGLU, p, s)); }
-            { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * (pa ? 2 : 1));
-              GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pa); p.ldc = H; p.lo_off = 0;
-              if (lo6 && pa) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, n_live, H, I, rl, H); TRY(attach_lo6(p, act, 2 * (int64_t)I, n_live, I, l.wd6)); }
+            { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * pfm);
+              GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pm); p.ldc = H; p.lo_off = 0;
+              if (lo6 && pm) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, n_live, H, I, rl, H); TRY(attach_lo6(p, act, 2 * (int64_t)I, n_live, I, l.wd6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             *final_resid = rl; *final_is_live = true;
             break;
         }
-        if (G) { SpanGuard g(e, s, TC_MISC, 0); TRY(adapter_u(e, attn, (int64_t)pfq * Hq, e->precise ? Hq : 0, T, H, &e->AD[li].ad[3], nullptr, nullptr, s)); }
+        if (G) { SpanGuard g(e, s, TC_MISC, 0); TRY(adapter_u(e, attn, (int64_t)pf * Hq, e->precise ? Hq : 0, T, H, &e->AD[li].ad[3], nullptr, nullptr, s)); }
         {
             SpanGuard g(e, s, TC_GEMM_O, 2.0 * tok * Hq * H * pf);
             GemmParams p = o8 ? gp8(a8, H, fuse_o ? nullptr : sa, l.wo8, l.so, T, H, H, resid, H)
                               : gp2(e, attn, Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, T, H, resid, H, 0, e->precise);
             if (fuse_o) { p.a_mx = (const uint8_t*)e->attn_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
-            if (pq) p.lda = 2 * Hq;                                       // the hi halves of the attention output's [hi | lo] rows
             if (lo6) {
                 p = gp(c.compute_dtype, attn, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, T, H, (int)Hq, resid, H);
                 TRY(attach_lo6(p, attn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wo_aug6 : l.wo6));
@@ -832,21 +825,20 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tok * H * I * pfm);
             GemmParams p = g8 ? gp8(x8, H, sx, l.wgu8, l.sgu, T, 2 * I, H, act, I) : gp2(e, xn, H, l.wgu, T, 2 * I, act, I, I, pm);
-            if (pm && !pa) { p.lo_off = 0; p.ldc = I; }                 // A = [hi | lo] (K walked twice), plain 16-bit output
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             if (lo6 && pm) {
-                p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, T, 2 * I, H, act, pa ? 2 * (int64_t)I : I); p.lo_off = pa ? I : 0;
+                p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, T, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I;
                 TRY(attach_lo6(p, xn, 2 * (int64_t)H, T, H, l.wgu6));
             }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
         if (d8 && !fuse) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(act, I, T, I, c.compute_dtype, act8, sact, s)); }
         {
-            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * (pa ? 2 : 1));
-            GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0, pa);
+            SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tok * H * I * pfm);
+            GemmParams p = d8 ? gp8(act8, I, fuse ? nullptr : sact, l.wd8, l.sd, T, H, I, resid, H) : gp2(e, act, I, l.wd, T, H, resid, H, 0, pm);
             if (fuse) { p.a_mx = (const uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             p.ldc = H; p.lo_off = 0;
-            if (lo6 && pa) {
+            if (lo6 && pm) {
                 p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, T, H, I, resid, H);
                 TRY(attach_lo6(p, act, 2 * (int64_t)I, T, I, l.wd6));
             }
@@ -1216,11 +1208,6 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
         e->lo6 = value != 0; return BLIM_OK;
     }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }
-    if (!strcmp(key, "precise_act")) { e->precise_act = value != 0; return BLIM_OK; }
-    if (!strcmp(key, "precise_qk")) {
-        if (value && e->f8) { blim_set_error("option 'precise_qk' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }
-        e->precise_qk = value < 0 ? 0 : value > 2 ? 2 : value; return BLIM_OK;
-    }
     if (!strcmp(key, "precise")) {
         if (value && e->f8) { blim_set_error("option 'precise' needs a 16-bit engine (fp16 or bf16)"); return BLIM_ERR_ARG; }
         e->precise = value != 0;

@@ -78,11 +78,6 @@ struct blim_engine {
     // cheap TVG calls only (their scores are ~10x smaller in magnitude than the VTG ones: DESIGN.md section 4).
     bool precise = false;
     bool precise_mlp = true;       // option "precise_mlp": compensate the MLP branch too (87 % of the flops, ~20 % of the error variance)
-    int precise_qk = 0;           // option "precise_qk" (plain mode only): q / k / v leave the QKV GEMM as hi + lo (a split of its f32 accumulator: no extra flops) and the
-                                   // attention runs on them compensated -- the logits of keys with massive activations stop amplifying the 16-bit rounding of q and k;
-                                   // 2: the QKV GEMM's input (the first norm's output) is hi + lo as well (K walked twice on that GEMM only)
-    bool precise_act = true;       // option "precise_act": in the compensated MLP branch, the SwiGLU output / down-proj input travels as hi + lo too (0: plain 16-bit
-                                   // act, the down GEMM walks K once: 1.71x instead of 2x the flops of a plain layer; ~6 % of the plain mode's error variance comes back)
     bool precise_embeds = false;   // option "precise_embeds": in precise mode the INPUT embeddings (blim_assemble output, blim_decode / blim_score_* input) and
                                    // the projector outputs feeding them are [hi | lo] rows of width 2H too (the fused TVG path; the literal
                                    // forward() keeps the reference's [B, L, H] embeddings)

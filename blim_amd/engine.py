@@ -208,13 +208,13 @@ class Engine:
         _check(self.lib.blim_create(C.byref(cfg), C.byref(h)), "blim_create")
         self.h = h
         self.device = torch.device("cuda", torch.cuda.current_device())
-        # blim_create honours BLIM_PRECISE_MLP / BLIM_PRECISE_ACT (A/B runs): the Python-side cache of those options starts from the same values, so that
-        # set_precise() neither clobbers an override nor believes in a default the engine does not have
-        # mirrors the engine's default of option "precise_lo6" (include/blim.h): the compensated modes' second pass over K in e4m3 on fp16 engines
+        # blim_create honours BLIM_PRECISE_MLP (A/B runs): the Python-side cache of that option starts from the same value, so that set_precise() neither clobbers
+        # an override nor believes in a default the engine does not have
+        # mirrors the engine's default of option "precise_lo6" (include/blim.h): the compensated modes' second pass over K in e2m3 on fp16 engines
         self.lo6 = (dtype == "f16" and dims.hidden_size % 128 == 0 and dims.intermediate_size % 128 == 0 and max(dims.hidden_size, dims.intermediate_size) <= 20480
                     and os.environ.get("BLIM_PRECISE_LO6", "1") != "0")
         self._precise_mlp = os.environ.get("BLIM_PRECISE_MLP", "1") != "0"
-        self._precise_act = os.environ.get("BLIM_PRECISE_ACT", "1") != "0"
+        self.weights_version = 0          # bumped by every weight / adapter change: what a measured numeric mode was measured on (modeling.py: resolve_*)
 
     def close(self):
         if getattr(self, "h", None):
@@ -234,6 +234,7 @@ class Engine:
         assert tuple(arr.shape) == tuple(shape), (name, arr.shape, shape)
         a = np.ascontiguousarray(arr, dtype=np.float32)
         _check(self.lib.blim_load_weight(self.h, name.encode(), a.ctypes.data, DTYPE_F32, 0), f"blim_load_weight({name})")
+        self.weights_version += 1
 
     def load_weights(self, weights: Dict[str, np.ndarray]):
         """weights: canonical name -> float32 numpy array; every tensor of the model must be present."""
@@ -246,6 +247,7 @@ class Engine:
 
     def init_synthetic_weights(self, seed: int):
         _check(self.lib.blim_init_synthetic_weights(self.h, seed), "blim_init_synthetic_weights")
+        self.weights_version += 1
 
     # ---- LoRA adapters kept apart (blim.h: blim_load_adapter; the reference's --resume flow, main.py:96-105, 125-128)
     def load_adapter(self, weight_name: str, A: np.ndarray, B: np.ndarray, lora_r: int, lora_alpha: float):
@@ -254,9 +256,11 @@ class Engine:
         assert tuple(A.shape) == (lora_r, n_in) and tuple(B.shape) == (n_out, lora_r), (weight_name, A.shape, B.shape, (n_out, n_in), lora_r)
         a = np.ascontiguousarray(A, dtype=np.float32); b = np.ascontiguousarray(B, dtype=np.float32)
         _check(self.lib.blim_load_adapter(self.h, weight_name.encode(), a.ctypes.data, b.ctypes.data, int(lora_r), float(lora_alpha)), f"blim_load_adapter({weight_name})")
+        self.weights_version += 1
 
     def clear_adapters(self):
         _check(self.lib.blim_clear_adapters(self.h), "blim_clear_adapters")
+        self.weights_version += 1
 
     def num_adapters(self) -> int:
         return int(self.lib.blim_num_adapters(self.h))
@@ -273,12 +277,13 @@ class Engine:
     def can_precise(self) -> bool:
         return self.dtype in ("f16", "bf16")
 
-    def set_precise(self, on: bool, embeds: bool = False, mlp: bool = True, act: Optional[bool] = None):
-        """Compensated mode for the following calls (fp16 engines; a no-op request on others): every 16-bit activation travels as
-        hi + lo and the GEMMs walk K twice.  The host turns it on for the TVG calls, whose scores are ~10x smaller in magnitude than
-        the VTG ones and need the extra bits to hold 1e-3 at 28 layers; 2x GEMM flops on those calls only.
-        embeds=True: the input embeddings (assemble -> decode / score_*) are [hi | lo] rows of width 2H as well -- the fused path,
-        whose projected video features are produced in this mode; the literal forward() keeps [B, L, H] embeddings."""
+    def set_precise(self, on: bool, embeds: bool = False, mlp: bool = True):
+        """Compensated mode for the following calls (16-bit engines; a no-op request on others): every 16-bit activation travels as hi + lo and the GEMMs take
+        both parts (fp16 engines: the lo part on the e2m3 MFMA, option "precise_lo6").  The host turns it on for the TVG calls, whose scores are ~10x smaller in
+        magnitude than the VTG ones, and for the VTG calls of checkpoints that need it (`--vtg_precise`).
+        embeds=True: the input embeddings (assemble -> decode / score_*) are [hi | lo] rows of width 2H as well -- the fused path, whose projected video features
+        are produced in this mode; the literal forward() keeps [B, L, H] embeddings.  mlp=False: only the attention branch (QKV, attention, o_proj) and the
+        scored rows are compensated -- the TVG calls' "attn" mode."""
         on = bool(on) and self.can_precise
         embeds = bool(embeds) and on
         if on != getattr(self, "_precise", False):
@@ -287,19 +292,10 @@ class Engine:
         if embeds != getattr(self, "_precise_embeds", False):
             self.set_option("precise_embeds", int(embeds))
             self._precise_embeds = embeds
-        mlp = bool(mlp) and os.environ.get("BLIM_PRECISE_MLP", "1") != "0"      # mlp=False: only the attention branch (QKV, attention, o_proj) is compensated
+        mlp = bool(mlp) and os.environ.get("BLIM_PRECISE_MLP", "1") != "0"
         if on and mlp != getattr(self, "_precise_mlp", True):
             self.set_option("precise_mlp", int(mlp))
             self._precise_mlp = mlp
-        # act: the SwiGLU output / down-proj input as hi + lo as well (default on).  Left plain, the down GEMM walks K once and a compensated fp16 layer costs
-        # 1.71x instead of 2x a plain one; on N(0, 0.02^2) weights the TVG scores then stay within 2.5e-4 of the fp32 reference at 28 layers of the 7B
-        # configuration (3.7e-5 with it), which made plain the fp16 default for a while -- but on weights with a trained checkpoint's dynamic ranges
-        # (tests/golden/heavy7b.npz: residual channels at 1e4) the TVG prior moved by 2.5e-3 without it and 9e-5 with it, so the ~10 % on the TVG calls is
-        # paid.  bf16 engines always needed it (8-bit mantissas: 2e-3 without).  DESIGN.md section 4.
-        act = (True if act is None else bool(act)) and os.environ.get("BLIM_PRECISE_ACT", "1") != "0"
-        if on and act != getattr(self, "_precise_act", True):
-            self.set_option("precise_act", int(act))
-            self._precise_act = act
 
     # ---- component ops (torch device tensors in/out)
     def project_video(self, feats, which: int):

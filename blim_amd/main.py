@@ -67,17 +67,17 @@ def get_args_parser():
                    help="fp8 mode: which GEMMs take e4m3 operands (bit 0 qkv, 1 o_proj, 2 gate|up, 3 down, 4 lm_head).  Default 31 (all) on a base checkpoint, "
                         "12 (the MLP only) when --resume names a fine-tuned checkpoint: LoRA adapts q/k/v/o_proj and lm_head, whose merged rank-8 update is below one "
                         "e4m3 step of the base weight -- those GEMMs stay in fp16, the MLP (87 %% of a layer's flops, not adapted) runs in fp8")
-    p.add_argument("--vtg_precise", default="auto", choices=["auto", "none", "qk", "qkx", "attn", "act0", "full"],
+    p.add_argument("--vtg_precise", default="auto", choices=["auto", "none", "full"],
                    help="compensated (hi + lo) activations on the VTG calls.  auto (default): measured on the loaded checkpoint before the first pass -- up to 256 pairs of the "
-                        "evaluation are scored in every mode against the fully compensated one (which sits at 2e-6 .. 1e-5 of the fp32 reference) and the cheapest mode "
-                        "whose largest deviation AND 4.5 x its RMS deviation are inside 1e-3 is kept (PairScorer.calibrate_vtg; the table is printed).  none = plain 16-bit (what auto picks on an fp16 engine unless the checkpoint "
-                        "has massive activations on sink tokens: tests/golden/sink.npz, where plain fp16 -- the reference's own numerics -- is ~3e-3 from the fp32 result); "
-                        "qk = q / k / v and the attention as hi + lo (-2.5 %% speed); qkx = and the QKV GEMM's input (-8.4 %%); attn = the whole attention branch (-16 %%); "
-                        "full = every activation (2x the GEMM flops: the mode in which a bf16 engine holds 1e-3 at 7B depth)")
-    p.add_argument("--tvg_precise", default="auto", choices=["auto", "attn", "act0", "full"],
+                        "evaluation are scored plain and fully compensated (which sits at 2e-6 .. 1e-4 of the fp32 reference) and plain is kept if its largest deviation, 4.5 x its "
+                        "RMS deviation and the largest deviation predicted for the whole evaluation's entries are inside 1e-3 (PairScorer.calibrate_vtg; the table is printed; measured "
+                        "again whenever weights or adapters change).  none = plain 16-bit: the reference's own numerics, and what auto keeps on an fp16 engine unless the "
+                        "checkpoint has massive activations (tests/golden/sink.npz, heavy7b.npz: plain fp16 is 3 - 5e-3 from the fp32 result there).  full = every activation "
+                        "(fp16 engines: second pass on the e2m3 MFMA, 0.67x the plain rate; the mode in which a bf16 engine holds 1e-3 at 7B depth, at 0.5x)")
+    p.add_argument("--tvg_precise", default="auto", choices=["auto", "attn", "full"],
                    help="how much of the TVG calls' MLP branch runs compensated (their embeddings, QKV, attention, o_proj and head always do on a 16-bit engine).  auto (default): "
-                        "measured like --vtg_precise auto, on the TVG likelihood and prior of up to 256 pairs; attn = MLP plain (1.6x faster than full), act0 = MLP input compensated, "
-                        "SwiGLU output plain (1.1x), full = everything (what weights with massive residual channels need: tests/golden/heavy7b.npz)")
+                        "measured like --vtg_precise auto, on the TVG likelihood and prior of up to 256 pairs; attn = MLP plain (1.6x faster than full), "
+                        "full = everything (what weights with massive residual channels need: tests/golden/heavy7b.npz)")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")
     p.add_argument("--no_dedup", action="store_false", dest="dedup", help="score the pairs both directions share twice, as the reference does")

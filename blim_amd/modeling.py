@@ -34,14 +34,67 @@ class BlimModel:
         self.training = False
         self._proj_cache = {}
         self._tvg_rows = False          # set by prepare_inputs_labels_for_multimodal(tvg=...): the next forward() is a TVG forward
-        # Compensated (hi + lo) activations on the VTG calls: None = plain 16-bit (fp16 engines hold 1e-3 at 28 layers of the 7B model without),
-        # "attn" = the attention branch only (QKV, attention, o_proj) + the final norm / lm_head rows, "full" = the MLP branch too.  bf16 engines
-        # (8-bit mantissas: 1.0 - 1.7e-3 on the VTG scores at 7B depth when plain) default to the mode that holds the 1e-3 bar.
+        # Numeric modes.  What the USER asks for:
+        #   vtg_precise: None = plain 16-bit VTG calls (what the reference's autocast computes; holds 1e-3 at 28 layers of the 7B configuration on N(0, 0.02^2) weights),
+        #                "full" = every activation as hi + lo (what weights with a trained checkpoint's massive activations need; bf16 engines' default: 8-bit
+        #                mantissas miss the bar when plain), "auto" = measured on the loaded checkpoint by evaluation() (PairScorer.calibrate_vtg);
+        #   tvg_precise: the TVG calls always carry hi + lo embeddings, QKV, attention, o_proj and head; "attn" leaves their MLP branch plain (1.6x faster),
+        #                "full" (library default) compensates it too, "auto" = measured (PairScorer.calibrate_tvg).
+        # What "auto" RESOLVED to is kept apart (resolve_vtg / resolve_tvg) together with the engine's weights_version it was measured on: new weights or adapters --
+        # another epoch of the training loop's validation, a reload -- make it unresolved again and the next evaluation() measures again.
+        self._vtg_request = None
+        self._tvg_request = "full"
+        self._vtg_resolved = None                                   # (mode, engine.weights_version)
+        self._tvg_resolved = None
         self.vtg_precise = os.environ.get("BLIM_VTG_PRECISE") or ("full" if self.engine.dtype == "bf16" else None)
-        if self.vtg_precise in ("none", "0", ""):
-            self.vtg_precise = None
-        # How much of the TVG calls' MLP branch is compensated: "full" (library default) | "act0" | "attn" | "auto" (measured by evaluation(): PairScorer.calibrate_tvg)
         self.tvg_precise = os.environ.get("BLIM_TVG_PRECISE") or "full"
+        if not self.engine.can_precise:                             # fp8 engines have no compensated modes: nothing to measure, nothing to ask for
+            self._vtg_request, self._tvg_request = None, "full"
+
+    @property
+    def vtg_precise(self):
+        return self._vtg_request
+
+    @vtg_precise.setter
+    def vtg_precise(self, mode):
+        mode = None if mode in (None, "none", "0", "") else mode
+        if mode not in (None, "full", "auto"):
+            raise ValueError(f"vtg_precise = {mode!r}: one of none, full, auto (round 5 removed the intermediate modes qk / qkx / attn / act0)")
+        self._vtg_request, self._vtg_resolved = mode, None
+
+    @property
+    def tvg_precise(self):
+        return self._tvg_request
+
+    @tvg_precise.setter
+    def tvg_precise(self, mode):
+        if mode not in ("attn", "full", "auto"):
+            raise ValueError(f"tvg_precise = {mode!r}: one of attn, full, auto (round 5 removed act0)")
+        self._tvg_request, self._tvg_resolved = mode, None
+
+    def resolve_vtg(self, mode) -> None:
+        """Records what `vtg_precise = "auto"` was measured to need on the weights now loaded (evaluation() -> PairScorer.calibrate_vtg)."""
+        self._vtg_resolved = (None if mode in (None, "none") else mode, self.engine.weights_version)
+
+    def resolve_tvg(self, mode) -> None:
+        self._tvg_resolved = (mode, self.engine.weights_version)
+
+    def vtg_mode(self):
+        """The mode VTG calls run in: the request, or -- for "auto" -- what it resolved to on the CURRENT weights; "auto" itself while unresolved."""
+        if self._vtg_request != "auto":
+            return self._vtg_request
+        r = self._vtg_resolved
+        return r[0] if (r is not None and r[1] == self.engine.weights_version) else "auto"
+
+    def tvg_mode(self):
+        """Likewise for the TVG calls; an unresolved "auto" runs fully compensated."""
+        if self._tvg_request != "auto":
+            return self._tvg_request
+        r = self._tvg_resolved
+        return r[0] if (r is not None and r[1] == self.engine.weights_version) else "full"
+
+    def tvg_resolved(self) -> bool:
+        return self._tvg_request != "auto" or (self._tvg_resolved is not None and self._tvg_resolved[1] == self.engine.weights_version)
 
     # ---- nn.Module-ish surface used by the eval loop
     def eval(self):
@@ -209,9 +262,10 @@ class BlimModel:
         # (treating it as VTG rows would silently round it to fp16 and run it plain: ~1e-3 on the scores)
         kind = getattr(inputs_embeds, "_blim_rows", None)
         tvg_rows = (kind == "tvg") if kind is not None else (self._tvg_rows or (inputs_embeds.dtype == torch.float32 and self.engine.dtype == "f16" and self.engine.can_precise))
-        if self.vtg_precise == "auto" and not tvg_rows:
-            raise RuntimeError("vtg_precise = 'auto' has not been resolved yet: evaluation() measures it on the loaded checkpoint before its first pass "
-                               "(PairScorer.calibrate_vtg); set BlimModel.vtg_precise to none / qk / qkx / attn / act0 / full to call forward() directly")
+        vmode = self.vtg_mode()
+        if vmode == "auto" and not tvg_rows:
+            raise RuntimeError("vtg_precise = 'auto' has not been resolved on the weights now loaded: evaluation() measures it before its first pass "
+                               "(PairScorer.calibrate_vtg); set BlimModel.vtg_precise to none / full to call forward() directly")
         wide = inputs_embeds.dtype == torch.float32 and self.engine.can_precise and (self.engine.dtype == "bf16" or tvg_rows)
         if wide:                                                          # float32 embeddings of prepare_inputs_labels_for_multimodal (bf16 engines; TVG rows on fp16 ones): back to [hi | lo]
             hi = inputs_embeds.to(self.dtype)
@@ -225,22 +279,16 @@ class BlimModel:
         # a forward over rows prepared with tvg=True runs in the compensated mode, like the fused TVG calls (engine.set_precise); VTG rows
         # follow self.vtg_precise
         if tvg_rows:
-            tm = self.tvg_precise if self.tvg_precise in ("attn", "act0") else "full"        # an unresolved "auto" runs fully compensated
-            self.engine.set_precise(True, embeds=wide, mlp=tm != "attn", act=tm == "full")
+            self.engine.set_precise(True, embeds=wide, mlp=self.tvg_mode() != "attn")       # (an unresolved "auto" runs fully compensated)
         else:
-            on = self.vtg_precise in ("attn", "act0", "full")
-            self.engine.set_precise(on, embeds=wide and on, mlp=self.vtg_precise in ("act0", "full"), act=self.vtg_precise == "full")
-            if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none / qk): plain embeddings
+            on = vmode == "full"
+            self.engine.set_precise(on, embeds=wide and on, mlp=True)
+            if wide and not on:                                           # plain bf16 VTG forward asked for (vtg_precise none): plain embeddings
                 emb = inputs_embeds.to(self.dtype).contiguous()
-        qk = (not tvg_rows) and self.vtg_precise in ("qk", "qkx")          # plain activations, q / k / v and the attention as hi + lo (engine option precise_qk)
-        if qk:
-            self.engine.set_option("precise_qk", 2 if self.vtg_precise == "qkx" else 1)
         try:
             logits, hidden = self.engine.forward(emb, m8, want_logits=want_logits, want_hidden=True)
         finally:
             self.engine.set_precise(False)
-            if qk:
-                self.engine.set_option("precise_qk", 0)
         return SimpleNamespace(loss=None, logits=logits, past_key_values=None, hidden_states=hidden, attentions=None)
 
     __call__ = forward

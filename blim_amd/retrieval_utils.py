@@ -190,16 +190,14 @@ def _split_prompt_response(ids: np.ndarray, labels: np.ndarray):
 
 def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_vocab: int = 0, prune: bool = True) -> float:
     """GEMM FLOPs one engine call EXECUTES (the per-token constants applied to the token counts actually launched; attention,
-    < 1 - 3 %, excluded): decoder layers over n_tokens packed tokens + the head over n_rows scored rows.  `mode`: compensation of the call (None /
-    "qk": plain; "qkx": the QKV GEMM walks K twice; "attn": QKV, o_proj and the head; "act0": gate|up as well; "full": every GEMM -- a TVG call of a
-    16-bit engine runs in one of the last three, TVG_MODES).  prune: the last layer's o_proj / MLP run on the scored rows only (engine option prune_last) when they are < 15/16 of the tokens."""
+    < 1 - 3 %, excluded): decoder layers over n_tokens packed tokens + the head over n_rows scored rows.  `mode`: compensation of the call (None: plain;
+    "attn": QKV, o_proj and the head take hi + lo inputs; "full": every GEMM -- a TVG call of a 16-bit engine runs in one of the last two, TVG_MODES; a VTG
+    call plain or "full", VTG_MODES).  prune: the last layer's o_proj / MLP run on the scored rows only (engine option prune_last) when they are < 15/16 of the tokens."""
     H, I = dims.hidden_size, dims.intermediate_size
     q = 2.0 * H * (dims.num_heads + 2 * dims.num_kv_heads) * dims.head_dim
     o, gu, d = 2.0 * H * H, 4.0 * H * I, 2.0 * H * I
-    fq = 2.0 if mode in ("qkx", "attn", "act0", "full") else 1.0
-    fo = 2.0 if mode in ("attn", "act0", "full") else 1.0
-    fg = 2.0 if mode in ("act0", "full") else 1.0           # gate|up walks K twice; "act0": its output stays plain, so the down projection walks K once
-    fd = 2.0 if mode == "full" else 1.0
+    fq = fo = 2.0 if mode in ("attn", "full") else 1.0      # "attn" (TVG calls only): the attention branch and the scored rows compensated, the MLP branch plain
+    fg = fd = 2.0 if mode == "full" else 1.0
     per_tok = fq * q + fo * o + fg * gu + fd * d
     total = dims.num_layers * per_tok * n_tokens
     if prune and n_rows <= n_tokens - n_tokens // 16:
@@ -212,16 +210,16 @@ def executed_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, n_voc
     return total
 
 
-def e4m3_pass_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, prune: bool = True) -> float:
-    """The part of executed_flops() that runs on the e4m3 MFMA when the engine's option "precise_lo6" is on (fp16 engines, default): the second walk over K of the
-    decoder GEMMs and of lm_head in the compensated modes (attn / act0 / full; `qkx`'s doubled QKV GEMM is a plain-mode kernel and stays 16-bit, and the TVG head's
-    three-term products are 16-bit GEMMs of depth 3 K).  A roofline for such a call prices these flops at the fp8 peak and the rest at the 16-bit one."""
-    if mode not in ("attn", "act0", "full"):
+def lo6_pass_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, prune: bool = True) -> float:
+    """The part of executed_flops() that runs on the e2m3 MFMA when the engine's option "precise_lo6" is on (fp16 engines, default): the second walk over K of the
+    decoder GEMMs and of lm_head in the compensated modes (the TVG head's three-term products are 16-bit GEMMs of depth 3 K).  A roofline for such a call prices
+    these flops at the fp6 peak (4x the 16-bit one) and the rest at the 16-bit one."""
+    if mode not in ("attn", "full"):
         return 0.0
     H, I = dims.hidden_size, dims.intermediate_size
     q = 2.0 * H * (dims.num_heads + 2 * dims.num_kv_heads) * dims.head_dim
     o, gu, d = 2.0 * H * H, 4.0 * H * I, 2.0 * H * I
-    g2 = gu if mode in ("act0", "full") else 0.0
+    g2 = gu if mode == "full" else 0.0
     d2 = d if mode == "full" else 0.0
     total = dims.num_layers * (q + o + g2 + d2) * n_tokens
     if prune and n_rows <= n_tokens - n_tokens // 16:
@@ -231,11 +229,12 @@ def e4m3_pass_flops(dims, n_tokens: int, n_rows: int, kind: str, mode=None, prun
     return total
 
 
-TVG_MODES = ("attn", "act0", "full")    # compensation of the TVG calls (always hi + lo embeddings, QKV, attention, o_proj, head), cheapest first: "attn" leaves the MLP branch plain
-                                        # (1.6x faster than full), "act0" compensates the MLP's input but not the SwiGLU output (1.1x), "full" everything
-VTG_MODES = ("none", "qk", "qkx", "attn", "act0", "full")   # compensation of the VTG calls, cheapest first (0 / -2.5 / -8.4 / -16.5 / -41 / -50 % on the headline step); "act0" = everything
-                                                            # but the SwiGLU output / down-projection input (the TVG calls' mode of the same name)
-VTG_SPLIT_MODES = ("attn", "act0", "full")                  # modes whose VTG rows (embeddings, features) travel as [hi | lo]
+TVG_MODES = ("attn", "full")     # compensation of the TVG calls (always hi + lo embeddings, QKV, attention, o_proj, head), cheapest first: "attn" leaves the MLP branch plain
+                                 # (1.6x faster than full), "full" compensates everything
+VTG_MODES = ("none", "full")     # compensation of the VTG calls: plain 16-bit, or every activation as hi + lo (0.67x the plain rate on fp16 engines with the e2m3 second
+                                 # pass).  Round 4 had four modes between the two (qk, qkx, attn, act0: 0.975 ... 0.70x); on the weight sets where plain fails they
+                                 # either failed too or sat at the edge of the bar, and each was a kernel variant, an engine option and a calibration pass: removed.
+VTG_SPLIT_MODES = ("full",)      # modes whose VTG rows (embeddings, features) travel as [hi | lo]
 
 
 def predicted_max_deviation(dev, n_eval: Optional[int]) -> float:
@@ -285,12 +284,13 @@ class PairScorer:
         self.split_tvg = self.precise_tvg and eng_ is not None and bool(getattr(eng_, "can_precise", False))   # TVG rows as [hi | lo]
         # VTG calls: plain 16-bit on fp16 engines; bf16 engines run them compensated too (modeling.py: vtg_precise), feature rows included --
         # with plain bf16 features the projector's 8-bit rounding alone left 1e-3 on the scores at 7B depth
-        self.vtg_mode = getattr(model.module if hasattr(model, "module") else model, "vtg_precise", None) if (eng_ is not None and getattr(eng_, "can_precise", False)) else None
-        if self.vtg_mode == "auto":                                      # resolved by calibrate_vtg (evaluation() does it before the first pass)
-            self.vtg_mode = None
-        tm = getattr(model.module if hasattr(model, "module") else model, "tvg_precise", None)
-        self.tvg_mode = tm if tm in TVG_MODES else "full"                # "auto" / None: full until calibrate_tvg says otherwise
-        self.split_vtg = self.vtg_mode in VTG_SPLIT_MODES               # "qk": plain activations, only q / k / v and the attention run as hi + lo (engine option precise_qk)
+        m_ = model.module if hasattr(model, "module") else model
+        can = eng_ is not None and bool(getattr(eng_, "can_precise", False))
+        vm = (m_.vtg_mode() if hasattr(m_, "vtg_mode") else getattr(m_, "vtg_precise", None)) if can else None
+        self.vtg_mode = None if vm in ("auto", "none") else vm           # an unresolved "auto": plain until calibrate_vtg decides (evaluation() does it before the first pass)
+        tm = m_.tvg_mode() if hasattr(m_, "tvg_mode") else getattr(m_, "tvg_precise", None)
+        self.tvg_mode = tm if tm in TVG_MODES else "full"                # (an unresolved "auto": full until calibrate_tvg says otherwise)
+        self.split_vtg = self.vtg_mode in VTG_SPLIT_MODES
         self.m = model.module if hasattr(model, "module") else model
         self.engine = self.m.engine
         self.device = self.m.device
@@ -316,7 +316,7 @@ class PairScorer:
             else:
                 self.vocab_cm = _clip_major_vocab(video_vocab, self.device, self.m.dtype)
         self.exec_flops = 0.0            # GEMM FLOPs of the engine calls run so far (executed_flops; bench.py's roofline fractions)
-        self.exec_flops_e4m3 = 0.0       # ... of which on the e4m3 MFMA (e4m3_pass_flops: the compensated modes' second pass under the engine's "precise_lo6")
+        self.exec_flops_lo6 = 0.0        # ... of which on the e2m3 MFMA (lo6_pass_flops: the compensated modes' second pass under the engine's "precise_lo6")
         self.exec_tokens = 0
         self._vfeat: Dict[Tuple[int, bool], object] = {}
         self._upcoming: Dict[bool, List[int]] = {}; self._upcoming_pos: Dict[bool, int] = {}
@@ -583,29 +583,25 @@ class PairScorer:
         self.exec_tokens += plan.n_tokens
         f8 = getattr(self.engine, "dtype", "") == "f8"
         if plan.kind == "vtg":
-            mode = self.vtg_mode                                             # None (fp16 engines) | "qk" | "attn" | "full" (bf16 engines: modeling.py)
+            mode = self.vtg_mode                                             # None | "full"
             self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "vtg", mode, prune=not f8)
             if getattr(self.engine, "lo6", False):
-                self.exec_flops_e4m3 += e4m3_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "vtg", mode, prune=not f8)
+                self.exec_flops_lo6 += lo6_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "vtg", mode, prune=not f8)
             comp = mode in VTG_SPLIT_MODES
-            self.engine.set_precise(comp, embeds=comp, mlp=mode in ("act0", "full"), act=mode == "full")
-            if mode in ("qk", "qkx"):
-                self.engine.set_option("precise_qk", 2 if mode == "qkx" else 1)
+            self.engine.set_precise(comp, embeds=comp, mlp=True)
             try:
                 embeds = self.engine.assemble(plan.src_index, plan.feats)
                 return self.engine.score_vtg(plan.batch, embeds, plan.rows, plan.labels, plan.row_start)
             finally:
                 self.engine.set_precise(False)
-                if mode in ("qk", "qkx"):
-                    self.engine.set_option("precise_qk", 0)
         self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode if self.split_tvg else None,
                                           n_vocab=self.n_vocab, prune=not f8)
         if getattr(self.engine, "lo6", False) and self.split_tvg:
-            self.exec_flops_e4m3 += e4m3_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode, prune=not f8)
+            self.exec_flops_lo6 += lo6_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode, prune=not f8)
         if self.vocab_cm is None and getattr(self.engine, "_vocab_key", None) != self._vocab_key:
             self.engine.set_video_vocab(self._vocab_src)                     # another scorer / the literal path registered its own vocabulary since
         # TVG calls: compensated (3-5 new tokens per pair: cheap); how much of the MLP branch is compensated follows tvg_mode (calibrate_tvg)
-        self.engine.set_precise(self.split_tvg, embeds=self.split_tvg, mlp=self.tvg_mode != "attn", act=self.tvg_mode == "full")
+        self.engine.set_precise(self.split_tvg, embeds=self.split_tvg, mlp=self.tvg_mode != "attn")
         try:
             embeds = self.engine.assemble(plan.src_index, plan.feats)
             return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)
@@ -642,8 +638,8 @@ class PairScorer:
 
     # ---- which compensation the VTG calls need (`--vtg_precise auto`) ---------------------------------------------------------------
     def set_vtg_mode(self, mode) -> None:
-        """Compensation of the following VTG calls: None | "qk" | "qkx" | "attn" | "act0" | "full" (BlimModel.vtg_precise, which is updated too).
-        The cached VTG feature rows are dropped when their layout changes ([hi | lo] rows in the attn / full modes)."""
+        """Compensation of this scorer's following VTG calls: None | "full".  The cached VTG feature rows are dropped when their layout changes ([hi | lo] rows in
+        the compensated mode).  (The model's own record of what `auto` resolved to is BlimModel.resolve_vtg: calibrate_vtg and evaluation() write it.)"""
         mode = None if mode in (None, "none") else mode
         if mode not in (None,) + VTG_MODES[1:]:
             raise ValueError(f"vtg mode {mode!r}: one of {VTG_MODES}")
@@ -653,11 +649,6 @@ class PairScorer:
         if split != self.split_vtg:
             self._vfeat = {k: v for k, v in self._vfeat.items() if k[1]}
         self.vtg_mode, self.split_vtg = mode, split
-        self.m.vtg_precise = mode
-
-    # what a cheaper VTG mode's largest deviation is expected to be, relative to the plain mode's, on weights where plain fails (15 mode x weight-set populations,
-    # profiles/r04_vtg_modes_population.md): used ONLY to skip measuring modes that cannot make it -- a mode is never accepted unmeasured
-    _VTG_GAIN = {"qk": 0.85, "qkx": 0.65, "attn": 0.30, "act0": 0.18}
 
     def _gather_dev(self, dev: np.ndarray, share) -> np.ndarray:
         """Multi-rank calibration: every rank scored its own block of the sample; all ranks get all deviations (one all-gather of <= 256 floats)."""
@@ -699,7 +690,10 @@ class PairScorer:
         mode x weight-set populations of 16,000 entries), and the one underestimate that would have let a mode through with an entry at 1.1e-3 read 0.82e-3.
         Returns (mode name, {mode: {max, rms, pred}} for the modes tried)."""
         pairs = np.asarray(pairs, dtype=np.int64)
-        if not bool(getattr(self.engine, "can_precise", False)):              # fp8 engines have no compensated modes
+        resolve = getattr(self.m, "resolve_vtg", lambda mode: None)
+        if not bool(getattr(self.engine, "can_precise", False)):              # fp8 engines have no compensated modes: plain it is (and resolved: ADVICE r4)
+            self.set_vtg_mode(None)
+            resolve("none")
             return "none", {}
         n_all = len(pairs)
         pairs, share = self._my_block(pairs, share)                           # share = (world, rank): each rank scores its block, the deviations are all-gathered
@@ -709,33 +703,33 @@ class PairScorer:
         chosen = "full"
         limit = tail_margin * bar if (n_eval or 0) > n_all else bar
         for mode in VTG_MODES[:-1]:
-            if "none" in table and mode in self._VTG_GAIN and table["none"]["pred"] * self._VTG_GAIN[mode] > 2.0 * limit:
-                continue                                                       # cannot make it (expected at > 2 x the limit): not worth a pass over the sample
             self.set_vtg_mode(mode)
             dev = np.abs(self.vtg(pairs).astype(np.float64) - ref) / np.abs(ref) if len(pairs) else np.zeros(0)
             dev = self._gather_dev(dev, share)
             table[mode] = {"max": float(np.max(dev)), "rms": float(np.sqrt(np.mean(dev * dev))), "pred": predicted_max_deviation(dev, n_eval)}
             if np.all(np.isfinite(dev)) and table[mode]["max"] <= bar and z * table[mode]["rms"] <= bar and table[mode]["pred"] <= limit:
                 chosen = mode
-                break                                                          # the dearer modes are not needed
+                break                                                          # the dearer mode is not needed
         self.set_vtg_mode(chosen)
+        resolve(chosen)
         return chosen, table
 
     def set_tvg_mode(self, mode) -> None:
         if mode not in TVG_MODES:
             raise ValueError(f"tvg mode {mode!r}: one of {TVG_MODES}")
         self.tvg_mode = mode
-        self.m.tvg_precise = mode
 
     def calibrate_tvg(self, pairs, bar: float = 1e-3, z: float = 4.5, n_eval: Optional[int] = None, tail_margin: float = 0.8, share=None):
         """The TVG calls' counterpart of calibrate_vtg (same criterion, same yardstick = the fully compensated mode).  Every TVG call of a 16-bit engine carries its
         embeddings, QKV, attention, o_proj and head as hi + lo; what is decided here is the MLP branch (87 % of the flops): `attn` leaves it plain (1.6x faster than
-        `full`), `act0` compensates its input but not the SwiGLU output (1.1x).  Gaussian-like weights need neither more than `attn` since the TVG head is exact
+        `full`).  Gaussian-like weights need neither more than `attn` since the TVG head is exact
         (round 4); weights with massive residual channels need `full` (tests/golden/heavy7b.npz: the prior moved by 2.5e-3 with a plain SwiGLU output) -- measured per
         checkpoint on the likelihood AND the prior (the prior's queries see one prefix token and their own segment: the most sensitive pass)."""
         pairs = np.asarray(pairs, dtype=np.int64)
+        resolve = getattr(self.m, "resolve_tvg", lambda mode: None)
         self.set_tvg_mode("full")
         if not self.split_tvg:                                             # fp8 / fp32-less engines: nothing to choose
+            resolve("full")
             return "full", {}
         n_all = len(pairs)
         pairs, share = self._my_block(pairs, share)
@@ -755,6 +749,7 @@ class PairScorer:
                 chosen = mode
                 break
         self.set_tvg_mode(chosen)
+        resolve(chosen)
         return chosen, table
 
     def vtg(self, pairs, cpn=False) -> np.ndarray:
@@ -884,6 +879,12 @@ def evaluation(model, data_loader, device, tokenizer, args):
     if scorer is None and not literal:
         scorer = PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
                             tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
+    elif isinstance(scorer, PairScorer):                 # a caller's scorer: follow what the model asks for / has resolved NOW
+        m0 = model.module
+        if hasattr(m0, "vtg_mode") and m0.vtg_mode() != "auto":
+            scorer.set_vtg_mode(m0.vtg_mode())
+        if hasattr(m0, "tvg_mode"):
+            scorer.set_tvg_mode(m0.tvg_mode())
     stats = {"pairs_requested": 0, "pairs_scored": 0}
 
     def agree(chosen, modes, setter):
@@ -897,36 +898,50 @@ def evaluation(model, data_loader, device, tokenizer, args):
                 setter(chosen)
         return chosen
 
-    if getattr(model.module, "vtg_precise", None) == "auto":
-        # `--vtg_precise auto` (the driver's default): measure on this checkpoint which compensation the VTG calls need (PairScorer.calibrate_vtg)
-        cal = scorer if isinstance(scorer, PairScorer) else PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
-                                                                       tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
-        kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
-        n_eval_vtg = num_videos * kt_ * (2 if args.cpn else 1) + num_texts * kv_                 # VTG-type entries of the whole evaluation (every rank's)
-        cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None      # every rank scores its block of the sample; deviations all-gathered
-        chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk, n_queries=32, per_query=8), n_eval=n_eval_vtg, share=cal_share)      # 256 pairs, 32 distinct prefixes
-        chosen = agree(chosen, VTG_MODES, cal.set_vtg_mode)
-        stats["vtg_precise"] = chosen; stats["vtg_precise_table"] = table
-        if rank == 0:
-            print("vtg_precise auto: deviation from the fully compensated mode on the calibration pairs (max / rms): "
-                  + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e} (predicted max {v['pred']:.1e})" for k, v in table.items()) + f" -> {chosen}", file=sys.stderr, flush=True)
-    if getattr(model.module, "tvg_precise", None) == "auto" and finetuned:
+    def new_scorer():
+        return PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab, tvg_video_labels, args.num_clips,
+                          max_tokens=getattr(args, "max_tokens", 24576))
+
+    mod = model.module
+    if getattr(mod, "vtg_precise", None) == "auto":
+        # `--vtg_precise auto` (the driver's default): which compensation the VTG calls need is MEASURED on this checkpoint (PairScorer.calibrate_vtg) -- once per set
+        # of weights: what an earlier evaluation() resolved stands while the engine's weights and adapters are unchanged (BlimModel.vtg_mode) and is measured again
+        # after every change (the training loop's validation loads new adapters every epoch: main.py:166)
+        if hasattr(mod, "vtg_mode") and mod.vtg_mode() != "auto":
+            stats["vtg_precise"] = mod.vtg_mode() or "none"
+            if isinstance(scorer, PairScorer):
+                scorer.set_vtg_mode(mod.vtg_mode())
+        else:
+            cal = scorer if isinstance(scorer, PairScorer) else new_scorer()
+            kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
+            n_eval_vtg = num_videos * kt_ * (2 if args.cpn else 1) + num_texts * kv_                 # VTG-type entries of the whole evaluation (every rank's)
+            cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None      # every rank scores its block of the sample; deviations all-gathered
+            chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk, n_queries=32, per_query=8), n_eval=n_eval_vtg, share=cal_share)      # 256 pairs, 32 distinct prefixes
+            chosen = agree(chosen, VTG_MODES, lambda m_: (cal.set_vtg_mode(m_), getattr(mod, "resolve_vtg", lambda x: None)(m_)))
+            stats["vtg_precise"] = chosen; stats["vtg_precise_table"] = table
+            if rank == 0:
+                print("vtg_precise auto: deviation from the fully compensated mode on the calibration pairs (max / rms): "
+                      + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e} (predicted max {v['pred']:.1e})" for k, v in table.items()) + f" -> {chosen}", file=sys.stderr, flush=True)
+    if getattr(mod, "tvg_precise", None) == "auto" and finetuned:
         # likewise for the TVG calls' MLP branch (PairScorer.calibrate_tvg); zero-shot evaluations run no TVG pass
-        cal = scorer if isinstance(scorer, PairScorer) else PairScorer(model, vtg_ids, vtg_masks, vtg_labels, tvg_ids, tvg_masks, tvg_labels, video, video_vocab,
-                                                                       tvg_video_labels, args.num_clips, max_tokens=getattr(args, "max_tokens", 24576))
-        # a few TEXT queries and their top videos, as the t2v TVG passes score them: the text prefix is shared by a query's 16 videos, so a mode costs ~2k tokens
-        # (16 video queries x 16 texts would be 256 distinct text prefixes: 15k tokens per mode, 0.6 s of a 2.3 s rank share at 8 GPUs -- measured, round 4)
-        # -- but MANY queries with few videos each: a TVG score's deviation depends mostly on its text prefix, so 8 queries x 16 videos were 8 effective samples
-        # (heavy7b weights, N = 1,000: sample rms 2.7e-5 against 5.0e-5 over the whole evaluation, and `attn` was let through with 5 of 48,000 entries above the bar)
-        tp = calibration_pairs(t2v_iv2, args.topk, n_queries=64, per_query=4)      # 256 pairs x (likelihood, prior) = 512 entries, 64 distinct text prefixes
-        kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
-        cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None
-        chosen, table = cal.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1), n_eval=num_videos * kt_ + num_texts * kv_ * (2 if args.cpn else 1), share=cal_share)
-        chosen = agree(chosen, TVG_MODES, cal.set_tvg_mode)
-        stats["tvg_precise"] = chosen; stats["tvg_precise_table"] = table
-        if rank == 0:
-            print("tvg_precise auto: deviation from the fully compensated mode on the calibration pairs, likelihood + prior (max / rms): "
-                  + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e} (predicted max {v['pred']:.1e})" for k, v in table.items()) + f" -> {chosen}", file=sys.stderr, flush=True)
+        if hasattr(mod, "tvg_resolved") and mod.tvg_resolved():
+            stats["tvg_precise"] = mod.tvg_mode()
+            if isinstance(scorer, PairScorer):
+                scorer.set_tvg_mode(mod.tvg_mode())
+        else:
+            cal = scorer if isinstance(scorer, PairScorer) else new_scorer()
+            # a few TEXT queries and their top videos, as the t2v TVG passes score them: the text prefix is shared by a query's videos -- but MANY queries with few
+            # videos each: a TVG score's deviation depends mostly on its text prefix, so 8 queries x 16 videos were 8 effective samples (heavy7b weights, N = 1,000:
+            # sample rms 2.7e-5 against 5.0e-5 over the whole evaluation, and `attn` was let through with 5 of 48,000 entries above the bar)
+            tp = calibration_pairs(t2v_iv2, args.topk, n_queries=64, per_query=4)      # 256 pairs x (likelihood, prior) = 512 entries, 64 distinct text prefixes
+            kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
+            cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None
+            chosen, table = cal.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1), n_eval=num_videos * kt_ + num_texts * kv_ * (2 if args.cpn else 1), share=cal_share)
+            chosen = agree(chosen, TVG_MODES, lambda m_: (cal.set_tvg_mode(m_), getattr(mod, "resolve_tvg", lambda x: None)(m_)))
+            stats["tvg_precise"] = chosen; stats["tvg_precise_table"] = table
+            if rank == 0:
+                print("tvg_precise auto: deviation from the fully compensated mode on the calibration pairs, likelihood + prior (max / rms): "
+                      + ", ".join(f"{k} {v['max']:.1e} / {v['rms']:.1e} (predicted max {v['pred']:.1e})" for k, v in table.items()) + f" -> {chosen}", file=sys.stderr, flush=True)
     mark("setup")
 
     def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):
@@ -1101,7 +1116,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
     mark("done")
     if isinstance(scorer, PairScorer):
         stats["executed_flops"] = scorer.exec_flops; stats["executed_tokens"] = scorer.exec_tokens
-        stats["executed_flops_e4m3"] = getattr(scorer, "exec_flops_e4m3", 0.0)
+        stats["executed_flops_lo6"] = getattr(scorer, "exec_flops_lo6", 0.0)
     args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank, host_marks=marks)
     t2v_dict["internvideo2"] = t2v_iv2.cpu().numpy()
     v2t_dict["internvideo2"] = v2t_iv2.cpu().numpy()

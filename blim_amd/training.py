@@ -251,6 +251,7 @@ class Trainer:
     def merge_into_engine(self) -> None:
         """Engine weights <- W + alpha/r * B A (+ visual_head): what evaluation() then scores (val_one_epoch after every epoch, main.py:166)."""
         _check(self.lib.blim_train_merge(self.h, _stream()), "blim_train_merge")
+        self.engine.weights_version += 1          # (a numeric mode measured on the weights before the merge no longer stands: modeling.py)
 
     def adapters_into_engine(self) -> None:
         """The current adapters + visual_head handed to the scoring engine as SEPARATE matrices (blim_load_adapter): the in-training validation then scores

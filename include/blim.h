@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BLIM_ABI_VERSION 8
+#define BLIM_ABI_VERSION 9
 #define BLIM_ERR_ARG (-1)
 #define BLIM_ERR_HIP (-2)
 #define BLIM_ERR_STATE (-3)
@@ -225,21 +225,15 @@ int blim_debug_gemm_stamps(void* device_buf);
  *   <= 7e-4 from the fp32 reference at 28 layers of the 7B configuration).  The host turns it on for the TVG calls of both dtypes and for the
  *   VTG calls of bf16 engines -- the mode in which BASELINE.json's named dtype holds the 1e-3 bar (blim_amd/modeling.py: vtg_precise);
  * "precise_embeds" (0/1): in precise mode the input embeddings / projector outputs are [hi | lo] rows of width 2 * hidden as well;
- * "precise_mlp" (0/1, default 1): 0 leaves the MLP branch plain in precise mode (TVG calls 1.6x faster; TVG deviation at 7B depth
- *   8e-4 instead of 4e-5: tests/test_gpu_parity.py::test_depth_* with BLIM_PRECISE_MLP=0);
- * "precise_act" (0/1, default 1): 0 leaves the SwiGLU output / down-proj input plain in precise mode (the down GEMM walks K once: a compensated layer costs
- *   1.71x instead of 2x a plain one).  Leave it on: with 0 the TVG scores are 2.5e-4 instead of 3.7e-5 off at 7B depth on Gaussian weights, but 2.5e-3 on weights with a
- *   trained checkpoint's dynamic ranges (tests/golden/heavy7b.npz); bf16 engines lose 2e-3 without it on any weights;
- * "precise_qk" (0/1/2, default 0; plain mode only): q / k / v leave the QKV GEMM as [hi | lo] (a split of its f32 accumulator: no extra GEMM flops) and the attention runs
- *   on them compensated; everything else stays plain 16-bit.  For checkpoints whose attention sees keys with massive activations (sink tokens): the logits there amplify
- *   the 16-bit rounding of q and k (tests/golden/sink.npz: plain fp16 VTG 3.2e-3 off the fp32 reference, 1.2e-3 with this option at -2.5 % speed, 5.3e-4 with
- *   "precise" + "precise_mlp" = 0 at -16.5 %).  2: the QKV GEMM's input (the first norm's output) travels as hi + lo as well -- that GEMM walks K twice, nothing
- *   else changes: 6.6e-4 on the same fixture at -8.4 %, the cheapest setting inside the 1e-3 bar there;
+ * "precise_mlp" (0/1, default 1): 0 leaves the MLP branch plain in precise mode -- the TVG calls' "attn" mode (1.6x faster than fully compensated; TVG deviation at
+ *   7B depth 8e-4 instead of 4e-5 on Gaussian weights, 3e-3 on weights with massive activations: `--tvg_precise auto` measures which one a checkpoint needs);
  * "precise_lo6" (0/1; fp16 engines with hidden / intermediate sizes that are multiples of 128: default 1, env BLIM_PRECISE_LO6=0 turns it off; other engines refuse 1):
- *   in precise mode the decoder GEMMs' second walk over K -- the product of W with the activations' LO parts, 2^-11 of the values -- runs on the e4m3 MFMA at twice
- *   the rate, inside the same kernel and into the same accumulators (e4m3 copies of the decoder weights with power-of-two row scales, +1 byte per weight, built on
- *   the first compensated call; the lo parts quantised per (row, 128 columns)).  A fully compensated call costs 1.6x a plain one instead of 2x (1,677 against 1,336
- *   pairs/s on the headline step) and stays within 4e-5 of the fp32 reference where the fp16 second pass reads 4e-6 (28 layers of the 7B configuration);
+ *   in precise mode the decoder GEMMs' (and lm_head's) second walk over K -- the product of W with the activations' LO parts, 2^-11 of the values -- runs on the
+ *   block-scaled MFMA with e2m3 operands (6 bits, one power-of-two scale per 32 values: four times the 16-bit MFMA rate on gfx950), inside the same kernel and into
+ *   the same accumulators.  Weights: e2m3 tile images built on the first compensated call (+0.78 byte per decoder / head weight: 5.9 GB at 7B; a failed allocation
+ *   is BLIM_ERR_NOMEM with the matrix named); activations: the lo parts a producer wrote are re-written as operand tiles (one HBM-bound pass per GEMM input).  A
+ *   fully compensated call costs 1.49x a plain one instead of 2x and stays within 4e-5 of the fp32 reference where the fp16 second pass reads 4e-6 (28 layers of
+ *   the 7B configuration); on weights with a trained checkpoint's massive activations the two differ by <= 1.6e-4 over 16,000 scores (rms 9e-6);
  * "prune_last" (0/1, default 1): calls that name the rows they read (blim_decode with out_rows, blim_score_*) run the LAST layer's o_proj / norm / MLP
  *   on those rows only (same values bit for bit; the other rows' K / V are still produced); after such a call the "resid" / "attn" / "act" workspaces of
  *   blim_debug_read hold the last layer's state of the live rows only -- bring-up code reads them after calls without out_rows, or sets 0;

@@ -411,22 +411,19 @@ def test_executed_flops_formula_and_calibration_pairs():
     assert RU.executed_flops(d, tok, rows, "vtg", None) == 28 * F * tok + head * rows - (F - qkv) * (tok - rows)
     assert RU.executed_flops(d, tok, tok, "vtg", None) == 28 * F * tok + head * tok                    # nothing to prune when every row is read
     assert RU.executed_flops(d, tok, rows, "vtg", "full", prune=False) == 2 * (28 * F * tok + head * rows)
-    assert RU.executed_flops(d, tok, rows, "vtg", "qkx", prune=False) == 28 * (F + qkv) * tok + head * rows
     assert RU.executed_flops(d, tok, rows, "vtg", "attn", prune=False) == 28 * (F + qkv + 2 * 3584 * 3584) * tok + 2 * head * rows
-    assert RU.executed_flops(d, tok, rows, "vtg", "qk", prune=False) == RU.executed_flops(d, tok, rows, "vtg", None, prune=False)
     tvg_head = (2 * 3584 * 1024 + 2 * 1024 * 1000) * 400                                               # visual head + vocabulary product: three-term when compensated
     assert RU.executed_flops(d, 1000, 400, "tvg", "full", n_vocab=1000, prune=False) == 2 * 28 * F * 1000 + 3 * tvg_head
     mlp_gu, mlp_d = 4 * 3584 * 18944, 2 * 3584 * 18944
-    assert RU.executed_flops(d, 1000, 400, "tvg", "act0", n_vocab=1000, prune=False) == 28 * (2 * F - mlp_d) * 1000 + 3 * tvg_head      # TVG_MODES: the down projection walks K once
-    assert RU.executed_flops(d, 1000, 400, "tvg", "attn", n_vocab=1000, prune=False) == 28 * (2 * F - mlp_d - mlp_gu) * 1000 + 3 * tvg_head
+    assert RU.executed_flops(d, 1000, 400, "tvg", "attn", n_vocab=1000, prune=False) == 28 * (2 * F - mlp_d - mlp_gu) * 1000 + 3 * tvg_head      # TVG "attn": the MLP branch walks K once
     assert RU.executed_flops(d, 1000, 400, "tvg", None, n_vocab=1000, prune=False) == 28 * F * 1000 + tvg_head
-    assert RU.TVG_MODES == ("attn", "act0", "full")
-    # the e4m3 share (engine option "precise_lo6"): the second walk over K of the compensated decoder GEMMs and of lm_head; never in the plain modes, nor qkx's doubled QKV
-    assert RU.e4m3_pass_flops(d, tok, rows, "vtg", None) == 0 and RU.e4m3_pass_flops(d, tok, rows, "vtg", "qkx") == 0
-    assert RU.e4m3_pass_flops(d, tok, rows, "vtg", "full", prune=False) == RU.executed_flops(d, tok, rows, "vtg", "full", prune=False) / 2
-    assert RU.e4m3_pass_flops(d, tok, rows, "vtg", "attn", prune=False) == 28 * (qkv + 2 * 3584 * 3584) * tok + head * rows
-    assert RU.e4m3_pass_flops(d, 1000, 400, "tvg", "act0", prune=False) == 28 * (F - mlp_d) * 1000            # the TVG head's three-term products are 16-bit GEMMs
-    assert RU.e4m3_pass_flops(d, tok, rows, "vtg", "full") == RU.executed_flops(d, tok, rows, "vtg", "full") - RU.executed_flops(d, tok, rows, "vtg", None)
+    assert RU.TVG_MODES == ("attn", "full") and RU.VTG_MODES == ("none", "full")                         # round 5: the intermediate modes (qk, qkx, act0, VTG attn) are gone
+    # the e2m3 share (engine option "precise_lo6"): the second walk over K of the compensated decoder GEMMs and of lm_head; never in the plain mode
+    assert RU.lo6_pass_flops(d, tok, rows, "vtg", None) == 0
+    assert RU.lo6_pass_flops(d, tok, rows, "vtg", "full", prune=False) == RU.executed_flops(d, tok, rows, "vtg", "full", prune=False) / 2
+    assert RU.lo6_pass_flops(d, tok, rows, "vtg", "attn", prune=False) == 28 * (qkv + 2 * 3584 * 3584) * tok + head * rows
+    assert RU.lo6_pass_flops(d, 1000, 400, "tvg", "full", prune=False) == 28 * F * 1000                   # the TVG head's three-term products are 16-bit GEMMs
+    assert RU.lo6_pass_flops(d, tok, rows, "vtg", "full") == RU.executed_flops(d, tok, rows, "vtg", "full") - RU.executed_flops(d, tok, rows, "vtg", None)
     sims = torch.from_numpy(np.random.RandomState(0).randn(40, 50).astype(np.float32))
     p = RU.calibration_pairs(sims, topk=5)
     assert p.shape == (16 * 5, 2) and len(np.unique(p[:, 0])) == 16 and p[:, 0].min() == 0 and p[:, 0].max() == 39
@@ -462,3 +459,31 @@ def test_predicted_max_deviation_extrapolates_the_samples_tail():
     assert RU.predicted_max_deviation(np.array([0.0, np.nan]), N) == 0.0
     assert RU.predicted_max_deviation(x[:10], N) == x[:10].max()                    # too small a sample to fit: its maximum
 
+
+
+def test_auto_numeric_modes_are_requests_and_their_resolution_follows_the_weights():
+    """BlimModel keeps what the user ASKED for (vtg_precise / tvg_precise: none | full | auto, attn | full | auto) apart from what `auto` RESOLVED to, and the resolution
+    stands only while the engine's weights and adapters are the ones it was measured on (the first evaluation() used to overwrite "auto" with its choice, and
+    the training loop's validation scored every later epoch's adapters in the mode measured on the first)."""
+    import types
+    from blim_amd.modeling import BlimModel
+    m = BlimModel.__new__(BlimModel)                                       # no engine needed for this logic: a stand-in with the two attributes it reads
+    m.engine = types.SimpleNamespace(weights_version=0, can_precise=True, dtype="f16")
+    m._vtg_request, m._tvg_request, m._vtg_resolved, m._tvg_resolved = None, "full", None, None
+    assert m.vtg_mode() is None and m.tvg_mode() == "full"
+    m.vtg_precise, m.tvg_precise = "auto", "auto"
+    assert m.vtg_mode() == "auto" and m.tvg_mode() == "full" and not m.tvg_resolved()          # unresolved: VTG says so, TVG runs fully compensated
+    m.resolve_vtg("none"); m.resolve_tvg("attn")
+    assert m.vtg_precise == "auto" and m.tvg_precise == "auto"                                  # the requests are untouched
+    assert m.vtg_mode() is None and m.tvg_mode() == "attn" and m.tvg_resolved()
+    m.engine.weights_version += 1                                                               # a weight or an adapter was (re)loaded
+    assert m.vtg_mode() == "auto" and m.tvg_mode() == "full" and not m.tvg_resolved()
+    m.resolve_vtg("full")
+    assert m.vtg_mode() == "full"
+    m.vtg_precise = "none"
+    assert m.vtg_precise is None and m.vtg_mode() is None
+    for bad in ("qk", "qkx", "attn", "act0"):
+        with pytest.raises(ValueError):
+            m.vtg_precise = bad
+    with pytest.raises(ValueError):
+        m.tvg_precise = "act0"

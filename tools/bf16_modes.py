@@ -10,7 +10,7 @@ case = sys.argv[1] if len(sys.argv) > 1 else "full7b"
 g = np.load(os.path.join(P.GOLD, f"{case}.npz"))
 for dtype in ("bf16", "f16"):
     t = P._build(case, device_synth=True, dtype=dtype)
-    for mode in ((None, "attn", "full") if dtype == "bf16" else (None,)):
+    for mode in ((None, "full") if dtype == "bf16" else (None,)):
         t.model.vtg_precise = mode                  # read by PairScorer at construction (inside _six_passes)
         t0 = time.time()
         w = P._worst_rel(P._six_passes(t, False), g)

@@ -1,4 +1,4 @@
-"""Development aid: the `sink` / `heavy` fixtures' VTG passes on an fp16 engine with vtg_precise = none / attn / full."""
+"""Development aid: the `sink` / `heavy` fixtures' VTG passes on an fp16 engine with vtg_precise = none / full."""
 import os, sys, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,7 +16,7 @@ for case in sys.argv[1:] or ["sink"]:
     prob = synth.make_problem(SPEC["pseed"], SPEC["n"], dims, tok_per_clip=SPEC["tok_per_clip"], text_len=SPEC["text_len"])
     model.set_tvg_prefix_length(prob.tvg_prefix_length)
     t = types.SimpleNamespace(spec=SPEC, dims=dims, model=model, prob=prob, dtype="f16", case=case)
-    for mode in (None, "qk", "qkx", "attn", "full"):
+    for mode in (None, "full"):
         model.vtg_precise = mode
         for lit in (False, True):
             w = P._worst_rel(P._six_passes(t, lit, names=("v2t_vtg", "v2t_vtg_cpn", "t2v_vtg")), g)

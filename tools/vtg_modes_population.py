@@ -54,7 +54,7 @@ ref, t_ref = run("full")                                           # the yardsti
 if lo6_default:
     model.engine.set_option("precise_lo6", 1)
 print(f"[{a.weights}] N = {a.n}: {len(pairs)} v2t VTG pairs, relative deviation from the fully compensated mode with a 16-bit second pass ({t_ref:.1f} s = {len(pairs) / t_ref:.0f} pairs/s)", flush=True)
-print("| mode (e4m3 second pass where compensated: the default) | pairs/s | max | rms | median | 99 % | 99.9 % | entries > 1e-3 | predicted max from the 256-pair sample (n_eval = 48,000) |\n|---|---|---|---|---|---|---|---|---|")
+print("| mode (e2m3 second pass where compensated: the default) | pairs/s | max | rms | median | 99 % | 99.9 % | entries > 1e-3 | predicted max from the 256-pair sample (n_eval = 48,000) |\n|---|---|---|---|---|---|---|---|---|")
 rows = []
 for mode in RU.VTG_MODES:
     got, dt = run(mode)
