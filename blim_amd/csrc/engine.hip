@@ -770,6 +770,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
             if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
+            if (e->masked_query_zero) TRY(launch_zero_rows(attn, (int64_t)pf * Hq, b->key_visible, T, (int)(pf * Hq), s));
         }
         const bool fuse_o = o8 && e->f8_fuse;
         if (o8 && !fuse_o) { SpanGuard g(e, s, TC_QUANT, 0); TRY(launch_quant_rows(attn, H, T, H, c.compute_dtype, a8, sa, s)); }
@@ -1202,6 +1203,10 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
     if (!strcmp(key, "f8_fuse")) { e->f8_fuse = value != 0; return BLIM_OK; }
     if (!strcmp(key, "precise_embeds")) { e->precise_embeds = value != 0; return BLIM_OK; }
     if (!strcmp(key, "prune_last")) { e->prune_last = value != 0; return BLIM_OK; }
+    if (!strcmp(key, "masked_query_zero")) {
+        if (value && e->f8) { blim_set_error("option 'masked_query_zero' needs a 16-bit engine (the fp8 mode's attention output leaves the kernel quantised)"); return BLIM_ERR_ARG; }
+        e->masked_query_zero = value != 0; return BLIM_OK;
+    }
     if (!strcmp(key, "precise_lo6")) {
         if (value && (e->f8 || e->c.compute_dtype != DT_F16)) { blim_set_error("option 'precise_lo6' needs an fp16 engine"); return BLIM_ERR_ARG; }
         if (value && (e->c.hidden_size % 128 || e->c.intermediate_size % 128)) { blim_set_error("option 'precise_lo6': hidden and intermediate sizes must be multiples of 128"); return BLIM_ERR_ARG; }

@@ -78,6 +78,9 @@ struct blim_engine {
     // cheap TVG calls only (their scores are ~10x smaller in magnitude than the VTG ones: DESIGN.md section 4).
     bool precise = false;
     bool precise_mlp = true;       // option "precise_mlp": compensate the MLP branch too (87 % of the flops, ~20 % of the error variance)
+    bool masked_query_zero = false; // option "masked_query_zero" (PARITY-UNPINNED): query positions the key mask hides write a zero attention output -- what the reference's
+                                   // flash-attention-2 class does (modeling_qwen2_flash.py:526-563: dropped before flash_attn_varlen_func, zero-padded back) where its
+                                   // eager / SDPA classes, the pinned semantics, compute such rows like any other
     bool precise_embeds = false;   // option "precise_embeds": in precise mode the INPUT embeddings (blim_assemble output, blim_decode / blim_score_* input) and
                                    // the projector outputs feeding them are [hi | lo] rows of width 2H too (the fused TVG path; the literal
                                    // forward() keeps the reference's [B, L, H] embeddings)

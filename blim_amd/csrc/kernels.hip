@@ -565,6 +565,19 @@ int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const 
     return BLIM_OK;
 }
 
+// rows of a 16-bit matrix whose flag byte is zero are cleared (engine option "masked_query_zero": the attention output of masked query positions)
+__global__ __launch_bounds__(256) void zero_rows_kernel(uint16_t* x, int64_t ld, const uint8_t* keep, int64_t n_rows, int width) {
+    const int64_t r = blockIdx.x;
+    if (keep[r]) return;
+    uint4* row = (uint4*)(x + r * ld);
+    for (int c = threadIdx.x; c < width / 8; c += 256) row[c] = make_uint4(0u, 0u, 0u, 0u);
+}
+int launch_zero_rows(bf16_t* x, int64_t ld, const uint8_t* keep, int64_t n_rows, int width, hipStream_t s) {
+    ARG_CHECK(x && keep && n_rows > 0 && width > 0 && width % 8 == 0 && ld % 8 == 0 && ld >= width);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, s, x, ld, keep, n_rows, width);
+    LAUNCH_CHECK("zero_rows");
+    return BLIM_OK;
+}
 // ---------------------------------------------------------------------------- lo6 quantiser (kernels.hpp; image: gemm.hpp A6 / W6)
 __device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e with 2^e >= x (x > 0, finite)
     int ex; const float m = frexpf(x, &ex);                      // x = m 2^ex, m in [0.5, 1)

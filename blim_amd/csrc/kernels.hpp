@@ -16,6 +16,7 @@ int launch_h16_to_f32(float* out, const bf16_t* in, int64_t n, int dtype, hipStr
 int launch_gather_rows(void* dst, const void* src, const int32_t* rows, int64_t n_rows, int64_t row_bytes, int64_t n_src, uint32_t fill, hipStream_t s);   // dst[r] = src[rows[r]]
 int launch_hilo_to_f32(float* out, const bf16_t* in, int64_t n_rows, int H, int dtype, hipStream_t s);   // [hi | lo] 16-bit rows of width 2H -> f32 [n_rows, H]
 int launch_f32_to_bf16(bf16_t* out, const float* in, int64_t n, hipStream_t s);
+int launch_zero_rows(bf16_t* x, int64_t ld, const uint8_t* keep, int64_t n_rows, int width, hipStream_t s);      // x[r, :width] = 0 where keep[r] == 0
 
 // out[i, :] = bf16( w * x[rows ? rows[i] : i, :] * rsqrt(mean(x^2) + eps) ); optionally also f32 copy.
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,

@@ -52,6 +52,16 @@ def check_config(rep: Report, model_path: str, num_clips: int):
         rep.add(False, "config.json inside the scoring path's splice", str(e))
         return None, cfg
     rep.add(dims.hidden_size // dims.num_heads == 128, "head_dim 128 (the attention / RoPE kernels' size)", str(dims.hidden_size // dims.num_heads))
+    # Which attention class the reference would build from this config (modeling_qwen2_flash.py:736: QWEN2_ATTENTION_CLASSES[config._attn_implementation]; main.py:96
+    # passes no attn_implementation, so transformers takes the config's value, else flash_attention_2 when flash-attn is importable -- setup.sh:7 installs it -- else
+    # sdpa).  Parity is pinned to the eager / SDPA semantics; under flash_attention_2 masked query rows yield a zero attention output, which moves the TVG-CPN prior.
+    impl = cfg.get("_attn_implementation", cfg.get("attn_implementation"))
+    impl_note = (f"config.json names {impl!r}" if impl else "config.json names none: the reference's run took flash_attention_2 if flash-attn was installed (setup.sh:7), sdpa otherwise")
+    if impl == "flash_attention_2" or impl is None:
+        impl_note += ("  WARN: under flash_attention_2 the reference drops masked positions before the attention kernel and pads zeros back (modeling_qwen2_flash.py:526-563); "
+                      "this engine's default computes such rows (eager / SDPA semantics, what its goldens pin).  To compare with numbers from a flash-attn run: --masked_query_zero "
+                      "(parity-unpinned; only the t2v candidate_prior changes)")
+    rep.add(True, "attention implementation the checkpoint's config selects", impl_note)
     rep.add(cfg.get("tokenizer_padding_side", "right") == "right", "tokenizer_padding_side = right (modeling_videochat_flash.py:472-485)", str(cfg.get("tokenizer_padding_side", "right")))
     return dims, cfg
 

@@ -78,6 +78,11 @@ def get_args_parser():
                    help="how much of the TVG calls' MLP branch runs compensated (their embeddings, QKV, attention, o_proj and head always do on a 16-bit engine).  auto (default): "
                         "measured like --vtg_precise auto, on the TVG likelihood and prior of up to 256 pairs; attn = MLP plain (1.6x faster than full), "
                         "full = everything (what weights with massive residual channels need: tests/golden/heavy7b.npz)")
+    p.add_argument("--masked_query_zero", action="store_true",
+                   help="PARITY-UNPINNED: masked query positions write a zero attention output, as the reference's flash-attention-2 class does (modeling_qwen2_flash.py:526-563) "
+                        "where its eager / SDPA classes -- the semantics this engine's parity is pinned to -- compute them like any other row.  Changes the TVG-CPN prior only "
+                        "(its first gathered row is a masked position).  For comparing against numbers produced by a reference run with flash-attn installed; "
+                        "`python -m blim_amd.first_contact` reports which attention class a checkpoint's config selects")
     p.add_argument("--literal", action="store_true", help="run the reference's per-batch control flow instead of the fused PairScorer")
     p.add_argument("--compat_allreduce_offset", action="store_true")
     p.add_argument("--no_dedup", action="store_false", dest="dedup", help="score the pairs both directions share twice, as the reference does")
@@ -181,6 +186,9 @@ def main(args):
         loader = load_data(args, tokenizer=tokenizer, split="test")
         if not args.eval:
             train_loader = load_data(args, tokenizer=tokenizer, split="train")
+    if getattr(args, "masked_query_zero", False):
+        model.masked_query_zero = True
+        print("[note] --masked_query_zero: flash-attention-2 semantics for masked query rows (parity-unpinned; the default, eager / SDPA semantics, is what the goldens pin)")
     if model.engine.can_precise:
         model.tvg_precise = args.tvg_precise
     if args.vtg_precise is not None and model.engine.can_precise:
@@ -214,10 +222,14 @@ def main(args):
         st = getattr(args, "_eval_stats", {})
         dt = time.time() - t1
         free_b, total_b = torch.cuda.mem_get_info()
+        # executed GEMM FLOPs of this process's engine calls (retrieval_utils.executed_flops) against the dense MFMA peaks: the compensated calls' e2m3 second pass at
+        # the fp6 peak, an fp8 engine's calls at the fp8 peak, the rest at the 16-bit one (MI355X_MICROARCH.md: 2.5 / 5 / 10 PFLOP/s)
+        fl, f6 = float(st.get("executed_flops", 0.0)), float(st.get("executed_flops_lo6", 0.0))
+        at_peak = ((fl - f6) / (5.0e15 if model.engine.dtype == "f8" else 2.5e15) + f6 / 1.0e16)
         print(f"evaluation: {st.get('pairs_requested', 0)} (query, candidate) pairs of this rank's row blocks, {st.get('pairs_scored', 0)} scored by the engine "
               f"(the rest shared between directions), in {dt:.2f}s = {st.get('pairs_requested', 0) / dt:.0f} pairs/s per process "
-              f"(world {st.get('world', world)}, host planning and loading included); device memory in use {(total_b - free_b) / 2**30:.1f} GiB, "
-              f"torch peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+              f"(world {st.get('world', world)}, host planning and loading included); executed {fl / 1e12:.1f} TFLOP = {at_peak / dt:.3f} of the MFMA peak; "
+              f"device memory in use {(total_b - free_b) / 2**30:.1f} GiB, torch peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if args.shard is not None:
         model.engine.close()
         return None                                           # one rank's share: the matrices are partial, no recall table

@@ -72,6 +72,17 @@ class BlimModel:
             raise ValueError(f"tvg_precise = {mode!r}: one of attn, full, auto (round 5 removed act0)")
         self._tvg_request, self._tvg_resolved = mode, None
 
+    @property
+    def masked_query_zero(self) -> bool:
+        return bool(getattr(self, "_masked_query_zero", False))
+
+    @masked_query_zero.setter
+    def masked_query_zero(self, on) -> None:
+        """PARITY-UNPINNED switch (engine option of the same name, include/blim.h): masked query positions write a zero attention output, as the reference's
+        flash-attention-2 class does (modeling_qwen2_flash.py:526-563); default off = its eager / SDPA classes, the semantics every golden vector was recorded with."""
+        self.engine.set_option("masked_query_zero", int(bool(on)))
+        self._masked_query_zero = bool(on)
+
     def resolve_vtg(self, mode) -> None:
         """Records what `vtg_precise = "auto"` was measured to need on the weights now loaded (evaluation() -> PairScorer.calibrate_vtg)."""
         self._vtg_resolved = (None if mode in (None, "none") else mode, self.engine.weights_version)

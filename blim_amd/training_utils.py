@@ -61,28 +61,25 @@ def calculate_cpn_score(t2v, v2t, t2v_prior, v2t_prior, t2v_ids, v2t_ids):
 
 
 def combine_and_rank(t2v_dict, v2t_dict, args, n: int) -> Dict[str, Dict[str, float]]:
-    """training_utils.py:145-169 (rank 0 part of val_one_epoch)."""
+    """The rank-0 part of val_one_epoch (training_utils.py:145-169): recall of the first-stage scores and of the two likelihoods, then -- with the candidate prior
+    subtracted at strength alpha (CPN, :153-155) -- of the debiased candidate likelihood, and of the ensemble: c0 / c1 mix query and (debiased) candidate likelihood
+    per direction, c2 / c3 mix that with the first-stage scores (:161-164).  A zero-shot run (--eval without --resume) has no t2v candidate pass and no v2t query
+    pass: the reference substitutes zero matrices, which get_recall's sentinel reports as 0."""
     ids = {i: i for i in range(n)}
     finetuned = (getattr(args, "resume", "") != "") or not getattr(args, "eval", True)
-    results = {}
-    z = lambda: np.zeros((n, n))
-    for name in ["internvideo2", "candidate_likelihood", "query_likelihood", "cpn_candidate_likelihood", "blim"]:
-        if name == "cpn_candidate_likelihood":
-            if args.cpn:
-                cpn_t2v = t2v_dict["candidate_likelihood"] - args.alpha[0] * t2v_dict["candidate_prior"] if finetuned else z()
-                cpn_v2t = v2t_dict["candidate_likelihood"] - args.alpha[1] * v2t_dict["candidate_prior"]
-                results[name] = get_recall(cpn_t2v, cpn_v2t, ids, ids)
-            else:
-                cpn_t2v = t2v_dict["candidate_likelihood"] if finetuned else z()
-                cpn_v2t = v2t_dict["candidate_likelihood"]
-        elif name == "blim":
-            blim_t2v = args.c[0] * t2v_dict["query_likelihood"] + (1 - args.c[0]) * cpn_t2v
-            blim_v2t = args.c[1] * v2t_dict["query_likelihood"] + (1 - args.c[1]) * cpn_v2t if finetuned else cpn_v2t
-            blim_t2v = args.c[2] * blim_t2v + (1 - args.c[2]) * t2v_dict["internvideo2"]
-            blim_v2t = args.c[3] * blim_v2t + (1 - args.c[3]) * v2t_dict["internvideo2"]
-            results[name] = get_recall(blim_t2v, blim_v2t, ids, ids)
-        else:
-            results[name] = get_recall(t2v_dict.get(name, z()), v2t_dict.get(name, z()), ids, ids)
+    zeros = np.zeros((n, n))
+    results = {name: get_recall(t2v_dict.get(name, zeros), v2t_dict.get(name, zeros), ids, ids) for name in ("internvideo2", "candidate_likelihood", "query_likelihood")}
+    t2v_cand = t2v_dict["candidate_likelihood"] if finetuned else zeros
+    v2t_cand = v2t_dict["candidate_likelihood"]
+    if args.cpn:
+        if finetuned:
+            t2v_cand = t2v_cand - args.alpha[0] * t2v_dict["candidate_prior"]
+        v2t_cand = v2t_cand - args.alpha[1] * v2t_dict["candidate_prior"]
+        results["cpn_candidate_likelihood"] = get_recall(t2v_cand, v2t_cand, ids, ids)
+    c0, c1, c2, c3 = args.c
+    t2v_lm = c0 * t2v_dict["query_likelihood"] + (1 - c0) * t2v_cand
+    v2t_lm = c1 * v2t_dict["query_likelihood"] + (1 - c1) * v2t_cand if finetuned else v2t_cand
+    results["blim"] = get_recall(c2 * t2v_lm + (1 - c2) * t2v_dict["internvideo2"], c3 * v2t_lm + (1 - c3) * v2t_dict["internvideo2"], ids, ids)
     return results
 
 

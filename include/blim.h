@@ -234,6 +234,13 @@ int blim_debug_gemm_stamps(void* device_buf);
  *   is BLIM_ERR_NOMEM with the matrix named); activations: the lo parts a producer wrote are re-written as operand tiles (one HBM-bound pass per GEMM input).  A
  *   fully compensated call costs 1.49x a plain one instead of 2x and stays within 4e-5 of the fp32 reference where the fp16 second pass reads 4e-6 (28 layers of
  *   the 7B configuration); on weights with a trained checkpoint's massive activations the two differ by <= 1.6e-4 over 16,000 scores (rms 9e-6);
+ * "masked_query_zero" (0/1, default 0; 16-bit engines; PARITY-UNPINNED): query positions the key mask hides (blim_batch.key_visible == 0) write a ZERO attention output
+ *   instead of attending to their visible keys.  The default is the semantics parity is pinned to -- the reference's eager / SDPA attention classes
+ *   (modeling_qwen2_flash.py:288-310, 701-709), where a masked query row is computed like any other.  Its flash-attention-2 class drops such positions before the
+ *   kernel and pads zeros back (modeling_qwen2_flash.py:526-563); main.py:96 passes no attn_implementation, so which class a real run used depends on the
+ *   checkpoint's config and on whether flash-attn was installed (setup.sh:7).  The only scores that differ are the TVG-CPN prior's (its first gathered row is a
+ *   masked position: modeling_videochat_flash.py:414-417).  flash-attn cannot be imported in the build environment: this option restates those lines, it is not
+ *   checked against a recorded run (tests/test_gpu_parity.py::test_masked_query_zero_option_matches_its_restatement);
  * "prune_last" (0/1, default 1): calls that name the rows they read (blim_decode with out_rows, blim_score_*) run the LAST layer's o_proj / norm / MLP
  *   on those rows only (same values bit for bit; the other rows' K / V are still produced); after such a call the "resid" / "attn" / "act" workspaces of
  *   blim_debug_read hold the last layer's state of the live rows only -- bring-up code reads them after calls without out_rows, or sets 0;

@@ -217,9 +217,14 @@ class OracleModel:
         return mask, cpn, embeds, out_lab
 
     # --- decoder, modeling_qwen2_flash.py:952-1156 + 1392-1478
-    def decoder_layer(self, i: int, x: np.ndarray, add_mask: np.ndarray, cos: np.ndarray, sin: np.ndarray, parts: Optional[dict] = None) -> np.ndarray:
+    def decoder_layer(self, i: int, x: np.ndarray, add_mask: np.ndarray, cos: np.ndarray, sin: np.ndarray, parts: Optional[dict] = None,
+                      zero_rows: Optional[np.ndarray] = None) -> np.ndarray:
         """modeling_qwen2_flash.py:742-800 with eager attention :247-326.  `parts` (optional dict) receives the
-        intermediates q/k/v (after RoPE, [B,L,heads*hd]), attn, act for bring-up comparisons."""
+        intermediates q/k/v (after RoPE, [B,L,heads*hd]), attn, act for bring-up comparisons.
+        zero_rows ([B, L] bool, optional; PARITY-UNPINNED): query positions whose attention output is zero -- what Qwen2FlashAttention2 produces for
+        positions the 2-D attention mask drops (modeling_qwen2_flash.py:526-563: _upad_input removes them before flash_attn_varlen_func, pad_input puts zeros
+        back; the kept tokens keep their positions, RoPE and causal order, so everything else equals the eager result).  flash_attn cannot be imported in the
+        build container: this is a restatement of those lines, not a recorded behaviour."""
         c, w = self.cfg, self.w
         P = f"layers.{i}."
         B, L, H = x.shape
@@ -241,6 +246,8 @@ class OracleModel:
         p = np.exp(s)
         p = p / np.sum(p, axis=-1, keepdims=True, dtype=np.float32)
         a = (p @ v).transpose(0, 2, 1, 3).reshape(B, L, nh * hd)
+        if zero_rows is not None:
+            a = np.where(zero_rows[:, :, None], np.float32(0.0), a)
         x = x + a @ w[P + "o_proj.w"].T
         h = rms_norm(x, w[P + "post_norm"], c.rms_eps)
         g = silu(h @ w[P + "gate_proj.w"].T) * (h @ w[P + "up_proj.w"].T)
@@ -255,8 +262,9 @@ class OracleModel:
         B, L, _ = x.shape
         cos, sin = rope_tables(c.head_dim, c.rope_theta, L)             # positions arange(L), :998-1003
         am = additive_mask(key_mask, L)
+        zr = (np.asarray(key_mask) == 0) if getattr(self, "masked_query_zero", False) else None       # (parity-unpinned flash-attention semantics: decoder_layer)
         for i in range(c.num_layers if n_layers is None else n_layers):
-            x = self.decoder_layer(i, x, am, cos, sin)
+            x = self.decoder_layer(i, x, am, cos, sin, zero_rows=zr)
         return rms_norm(x, self.w["final_norm"], c.rms_eps).astype(np.float32)
 
     def forward(self, embeds: np.ndarray, key_mask: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

@@ -1,0 +1,83 @@
+"""GPU (-m gpu): BASELINE.json's configurations 3 and 4 at their OWN size on the real 7B dimensions, one rank's share of the multi-GPU job on one GPU.
+
+The goldens pin the numerics up to N = 64; the fuzz tests run dense and top-32 evaluations in miniature (N = 48, two layers).  What these two add is the size:
+N = 4,917 videos and texts with top-32 candidates, CPN and the ensemble (config 4: "ActivityNet val ... top-32 re-rank + CPN + InternVideo2 score ensemble, 8 x MI355X"),
+and dense candidates, k = N = 1,000 (config 3: "MSRVTT-1kA full 1000 x 1000 dense P(T|V) + P(V|T) score matrix ... sharded over 8 x MI355X") -- through the driver
+(`python -m blim_amd.main --eval --synthetic N --synthetic_7b --shard W r`: the rank's own row blocks of /root/reference/retrieval_utils.py:213-215, 233-235, no merge),
+seeded synthetic weights and data.  No oracle runs at this size; asserted are the properties the path has at any size (README.md:117-144, training_utils.py:145-169):
+every computed entry finite, log P(text i | video j) the SAME number in v2t.candidate_likelihood[j, i] and t2v.query_likelihood[i, j] wherever both directions
+computed it (likewise the TVG pair), the v2t prior independent of the query video, the recall table's shape.  Prints pairs/s and the executed-FLOP fraction."""
+import os
+import re
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, n, topk, shard, extra=()):
+    dump = str(tmp_path / "scores.npz")
+    cmd = [sys.executable, "-m", "blim_amd.main", "--eval", "--synthetic", str(n), "--synthetic_7b", "--cpn", "--resume", "x", "--topk", str(topk), "--alpha", "0.7", "0.9",
+           "--c", "0.5", "0.5", "0.8", "0.8", "--shard", str(shard[0]), str(shard[1]), "--dump_scores", dump, "--output_dir", str(tmp_path / "out"), *extra]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    m = re.search(r"evaluation: (\d+) \(query, candidate\) pairs.*?, (\d+) scored by the engine.*?in ([0-9.]+)s = (\d+) pairs/s per process.*?executed ([0-9.]+) TFLOP = ([0-9.]+) of the MFMA peak", r.stdout)
+    assert m, r.stdout[-2000:]
+    d = dict(np.load(dump))
+    modes = [l for l in (r.stdout + r.stderr).splitlines() if "_precise auto" in l]
+    return d, dict(pairs=int(m.group(1)), scored=int(m.group(2)), seconds=float(m.group(3)), pairs_per_s=int(m.group(4)), tflop=float(m.group(5)), frac=float(m.group(6))), modes
+
+
+def _properties(d, n, block_v, block_t, dense):
+    names = {"v2t": ("candidate_likelihood", "candidate_prior", "query_likelihood"), "t2v": ("query_likelihood", "candidate_likelihood", "candidate_prior")}
+    for side, ks in names.items():
+        for k in ks:
+            S = d[f"{side}_{k}"]
+            assert S.shape == (n, n) and np.isfinite(S).all(), (side, k)
+            assert (S != -100.0).any(), (side, k)                                                  # (which block is filled follows the pair's owner: a row block of the
+                                                                                                   # (video, text) matrix for VTG pairs, a column block for TVG pairs)
+    # one number per (video, text) pair, whichever direction asked for it
+    for a, b in (("v2t_candidate_likelihood", "t2v_query_likelihood"), ("v2t_query_likelihood", "t2v_candidate_likelihood")):
+        A, B = d[a], d[b].T
+        both = (A != -100.0) & (B != -100.0)
+        assert both.any() and np.array_equal(A[both], B[both]), (a, b)
+    # the v2t prior does not depend on the query video: every computed entry of a text's column is the same number
+    P = d["v2t_candidate_prior"]
+    for i in np.nonzero((P != -100.0).sum(axis=0) > 1)[0][:200]:
+        col = P[:, i][P[:, i] != -100.0]
+        assert np.ptp(col) == 0.0, i
+    # the recall table of training_utils.py:145-169 on these matrices (partial: one rank's blocks -- the shape is what is checked here)
+    from blim_amd import training_utils as TU
+    args = types.SimpleNamespace(cpn=True, alpha=[0.7, 0.9], c=[0.5, 0.5, 0.8, 0.8], resume="x", eval=True)
+    t2v = {k[4:]: v for k, v in d.items() if k.startswith("t2v_")}; v2t = {k[4:]: v for k, v in d.items() if k.startswith("v2t_")}
+    t2v.setdefault("internvideo2", np.ones((n, n), np.float32)); v2t.setdefault("internvideo2", np.ones((n, n), np.float32))
+    table = TU.combine_and_rank(t2v, v2t, args, n)
+    assert list(table) == ["internvideo2", "candidate_likelihood", "query_likelihood", "cpn_candidate_likelihood", "blim"]
+    assert all(len(v) == 9 and all(np.isfinite(x) for x in v.values()) for v in table.values())
+
+
+def test_config4_activitynet_size_top32_cpn_ensemble_rank0_of_8(tmp_path, capsys):
+    n, W = 4917, 8
+    d, st, modes = _run(tmp_path, n, 32, (W, 0))
+    step = n // W + 1
+    _properties(d, n, (0, step), (0, step), dense=False)
+    assert st["pairs"] == 6 * step * 32 and 0.2 < st["frac"] < 0.7, st
+    with capsys.disabled():
+        print(f"\n[config 4: N = {n}, top-32, CPN + ensemble, rank 0 of {W}] {st['pairs']} pairs ({st['scored']} scored) in {st['seconds']} s = {st['pairs_per_s']} pairs/s, "
+              f"executed {st['tflop']} TFLOP = {st['frac']:.3f} of the MFMA peak; " + " | ".join(m.split(": ", 1)[0] + " -> " + m.rsplit("-> ", 1)[-1] for m in modes))
+
+
+def test_config3_msrvtt_dense_1000x1000_rank0_of_32(tmp_path, capsys):
+    n, W = 1000, 32
+    d, st, modes = _run(tmp_path, n, n, (W, 0))
+    step = n // W + 1
+    _properties(d, n, (0, step), (0, step), dense=True)
+    assert st["pairs"] == 6 * step * n and 0.2 < st["frac"] < 0.7, st
+    with capsys.disabled():
+        print(f"\n[config 3: N = {n} dense (k = N), 1 / {W} of the job] {st['pairs']} pairs ({st['scored']} scored) in {st['seconds']} s = {st['pairs_per_s']} pairs/s, "
+              f"executed {st['tflop']} TFLOP = {st['frac']:.3f} of the MFMA peak; " + " | ".join(m.split(": ", 1)[0] + " -> " + m.rsplit("-> ", 1)[-1] for m in modes))

@@ -665,6 +665,46 @@ def test_auto_modes_hold_the_bar_over_a_whole_evaluation(weights, capsys):
         assert d["vtg_chosen"] == "full", d                                        # massive residual channels: plain fp16 leaves 0.5 % of the entries above the bar
 
 
+@pytest.mark.parametrize("literal", [True, False], ids=["literal-api", "fused-pairscorer"])
+def test_masked_query_zero_option_matches_its_restatement(literal):
+    """Engine option "masked_query_zero" (default OFF; PARITY-UNPINNED): masked query positions write a zero attention output -- the reference's flash-attention-2
+    class (modeling_qwen2_flash.py:526-563: such positions are dropped before flash_attn_varlen_func and zero-padded back), which cannot be imported here.  Checked
+    against the oracle's restatement of those lines (OracleModel.masked_query_zero), not against a recorded run: the TVG-CPN prior, whose first gathered row is a
+    masked position (modeling_videochat_flash.py:414-417), changes; passes whose scored rows are never masked do not; with the option off every golden is unchanged
+    (the rest of this file)."""
+    t = _build("tiny", dtype="f16")
+    try:
+        om = O.OracleModel(O.OracleConfig(**t.d), t.w); om.set_tvg_prefix_length(t.prob.tvg_prefix_length)
+        prob, spec = t.prob, t.spec
+        tvg = O.padding_ids([np.asarray(r) for r in prob.tvg_ids], [np.asarray(r) for r in prob.tvg_labels], [np.asarray(r) for r in prob.tvg_masks], synth.PAD_ID)
+        n = spec["n"]
+
+        def oracle_prior(zero):
+            om.masked_query_zero = zero
+            S = np.full((n, n), -100.0, np.float32)
+            return O.compute_t2v_scores_x(S, prob.t2v_sims[:spec.get("queries", n)], 0, tvg[0], tvg[2], tvg[1], [np.asarray(v) for v in prob.video], prob.video_vocab, prob.tvg_video_labels,
+                                          om, spec["topk"], spec["bs"], t.dims.num_clips, "tvg", cpn=True)
+
+        want_off, want_on = oracle_prior(False), oracle_prior(True)
+        m = want_off != -100.0
+        assert float(np.max(np.abs(want_on[m] - want_off[m]) / np.abs(want_off[m]))) > 1e-2            # the two semantics really differ on this pass
+        got_off = _six_passes(t, literal, names=("t2v_tvg_cpn", "t2v_tvg"))
+        t.model.masked_query_zero = True
+        got_on = _six_passes(t, literal, names=("t2v_tvg_cpn", "t2v_tvg"))
+        t.model.masked_query_zero = False
+        rel = lambda a, b: float(np.max(np.abs(a[m].astype(np.float64) - b[m]) / np.abs(b[m])))
+        assert rel(got_off["t2v_tvg_cpn"], want_off) < SCORE_RTOL and rel(got_on["t2v_tvg_cpn"], want_on) < SCORE_RTOL, (rel(got_off["t2v_tvg_cpn"], want_off), rel(got_on["t2v_tvg_cpn"], want_on))
+        assert np.array_equal(got_on["t2v_tvg"], got_off["t2v_tvg"])                                    # no scored row of the likelihood pass is a masked position
+        with pytest.raises(eng.BlimError, match="16-bit engine"):
+            e8 = eng.Engine(synth.ModelDims(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=1, num_heads=2, num_kv_heads=1, mm_hidden_size=64), max_positions=64, dtype="f8")
+            try:
+                e8.set_option("masked_query_zero", 1)
+            finally:
+                e8.close()
+    finally:
+        t.model.engine.close()
+
+
 def test_benched_step_plan_meets_the_reference_golden(capsys):
     """The batch bench.py times, itself: plan 0 of rank 0 (55 video queries x top-16 texts = 880 pairs, 32,560 packed tokens, real 7B
     configuration, weight seed 0) is built by bench.build_step_plans and run once; `full7b_bench.npz` holds what the REFERENCE's own

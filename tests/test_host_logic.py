@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.blim_abi_version() == 8          # v8: blim_load_adapter (LoRA adapters kept apart); v7: blim_batch.own_start (segmented sequences); v6: blim_train_step (one merged pass); v5: blim_train_*; v4: blim_vision_*, option "precise"
+    assert lib.blim_abi_version() == 9          # v9: blim_gemm_f16_lo6 + blim_f6_tiles_bytes, options precise_lo6 / masked_query_zero in, precise_qk / precise_act / precise_lo8 out; v8: blim_load_adapter (LoRA adapters kept apart); v7: blim_batch.own_start (segmented sequences); v6: blim_train_step (one merged pass); v5: blim_train_*; v4: blim_vision_*, option "precise"
     assert lib.blim_timing_num_classes() >= 8
 
 

@@ -171,9 +171,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert ss["emulated_world"] == 8 and len(ss["emulated_rank_seconds"]) == 8 and ss["predicted_seconds"] == max(ss["emulated_rank_seconds"])
     assert abs(ss["predicted_speedup"] - ss["seconds"] / ss["predicted_seconds"]) < 0.02 and ss["pairs_scored_rank0"] <= ss["pairs"]
     # the fixed job has a roofline fraction of its own (executed GEMM FLOPs of all its engine calls / time / peak), and so has every emulated rank
-    # the e4m3 second pass of the compensated (TVG) calls is priced at the fp8 peak, everything else at the 16-bit one
-    at_peak = (ss["executed_tflop_job"] - ss["executed_tflop_job_e4m3_pass"]) / 2500.0 + ss["executed_tflop_job_e4m3_pass"] / 5000.0
-    assert 0 < ss["executed_tflop_job_e4m3_pass"] < 0.2 * ss["executed_tflop_job"]
+    # the e2m3 second pass of the compensated (TVG) calls is priced at the fp6 peak, everything else at the 16-bit one
+    at_peak = (ss["executed_tflop_job"] - ss["executed_tflop_job_e2m3_pass"]) / 2500.0 + ss["executed_tflop_job_e2m3_pass"] / 10000.0
+    assert 0 < ss["executed_tflop_job_e2m3_pass"] < 0.2 * ss["executed_tflop_job"]
     assert 0 < ss["frac_mfma_peak"] < 1 and abs(ss["frac_mfma_peak"] - at_peak / ss["seconds"]) < 3e-3 and len(ss["emulated_rank_frac_mfma_peak"]) == 8
     assert abs(ss["executed_tflop_job"] / ss["seconds"] - ss["executed_tflops_per_gpu"]) < 0.02 * ss["executed_tflops_per_gpu"] + 0.2
     # the headline step's executed FLOPs leave out the last layer's o_proj / MLP on the rows nobody reads (prune_last)
@@ -183,7 +183,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f16"
     assert "workload" in d["config"] and "model" not in d["config"]
     cm = d["compensated_mode"]              # the same step with fully compensated VTG calls, reported beside the headline (never as `value`)
-    assert cm["vtg_compensated"] == "full" and cm["finite"] is True and 0.4 * d["value"] < cm["value"] < 0.9 * d["value"] and cm["second_pass"].startswith("e4m3")
+    assert cm["vtg_compensated"] == "full" and cm["finite"] is True and 0.4 * d["value"] < cm["value"] < 0.9 * d["value"] and cm["second_pass"].startswith("e2m3")
     assert 0 < cm["frac_mfma_peak_whole_step"] < 1
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
