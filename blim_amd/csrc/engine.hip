@@ -1,6 +1,7 @@
 // C-ABI of the scoring engine (include/blim.h): weight store, workspaces and the launch sequence of
 // the decoder / scoring heads.  One engine per process per GPU; all kernels are launched on the
 // caller's stream.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>

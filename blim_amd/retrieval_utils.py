@@ -652,10 +652,12 @@ class PairScorer:
 
     def _gather_dev(self, dev: np.ndarray, share) -> np.ndarray:
         """Multi-rank calibration: every rank scored its own block of the sample; all ranks get all deviations (one all-gather of <= 256 floats)."""
-        if share is None:
-            return dev
         import torch
-        W = int(share[0])
+        W = int(share[0]) if share is not None else 0
+        if share is None or not dist_utils.is_dist_avail_and_initialized() or W != torch.distributed.get_world_size():
+            # one process playing rank r of W (`--shard`, bench.py's emulated ranks and its warm-up, also inside a real job): nobody to gather from -- it decides on its
+            # own block; the COST of a rank's share of the calibration is what such a run stands for
+            return dev
         n = int(share[2])                                                   # the largest block
         buf = torch.full((n,), -1.0, dtype=torch.float64, device=self.device)            # padding: -1 (a deviation is >= 0; a non-finite one travels as +inf and rejects the mode)
         dev = np.where(np.isfinite(dev), dev, np.inf)
@@ -915,7 +917,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
             cal = scorer if isinstance(scorer, PairScorer) else new_scorer()
             kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
             n_eval_vtg = num_videos * kt_ * (2 if args.cpn else 1) + num_texts * kv_                 # VTG-type entries of the whole evaluation (every rank's)
-            cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None      # every rank scores its block of the sample; deviations all-gathered
+            cal_share = (W, rank) if ((collective and dist_utils.is_dist_avail_and_initialized()) or emulate is not None) else None   # every rank scores its block of the sample;
+                                                                                                   # deviations all-gathered (shard emulation: the rank's own block, nobody to gather from)
             chosen, table = cal.calibrate_vtg(calibration_pairs(v2t_iv2, args.topk, n_queries=32, per_query=8), n_eval=n_eval_vtg, share=cal_share)      # 256 pairs, 32 distinct prefixes
             chosen = agree(chosen, VTG_MODES, lambda m_: (cal.set_vtg_mode(m_), getattr(mod, "resolve_vtg", lambda x: None)(m_)))
             stats["vtg_precise"] = chosen; stats["vtg_precise_table"] = table
@@ -935,7 +938,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
             # sample rms 2.7e-5 against 5.0e-5 over the whole evaluation, and `attn` was let through with 5 of 48,000 entries above the bar)
             tp = calibration_pairs(t2v_iv2, args.topk, n_queries=64, per_query=4)      # 256 pairs x (likelihood, prior) = 512 entries, 64 distinct text prefixes
             kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
-            cal_share = (W, rank) if (collective and dist_utils.is_dist_avail_and_initialized()) else None
+            cal_share = (W, rank) if ((collective and dist_utils.is_dist_avail_and_initialized()) or emulate is not None) else None
             chosen, table = cal.calibrate_tvg(np.stack([tp[:, 1], tp[:, 0]], axis=1), n_eval=num_videos * kt_ + num_texts * kv_ * (2 if args.cpn else 1), share=cal_share)
             chosen = agree(chosen, TVG_MODES, lambda m_: (cal.set_tvg_mode(m_), getattr(mod, "resolve_tvg", lambda x: None)(m_)))
             stats["tvg_precise"] = chosen; stats["tvg_precise_table"] = table

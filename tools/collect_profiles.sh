@@ -8,6 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strong --no-compensated $*"
+echo "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strong --no-compensated $*" > $OUT/command.txt      # (tools/parse_profiles.py records it in profiles/CURRENT.json)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_stats.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > /dev/null 2> $OUT/write.err

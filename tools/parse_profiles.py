@@ -41,3 +41,12 @@ if glob.glob(f"{src}/mfma/*/*_counter_collection.csv") and glob.glob(f"{src}/clk
     print("\n".join(lines))
 for k, v in out.items():
     print(k[:50], f"{v['hbm_bytes_per_launch'] / 1e9:.2f} GB/launch", v["avg_ns"])
+# the tag travels with the summary: profiles/CURRENT.json names, per kind of run ("plain_<dtype>" / "full_<dtype>"), the traffic file bench.py's roofline object looks up
+# (usage: parse_profiles.py <tag> [plain|full] [dtype]) -- no more "newest file name wins"
+if len(sys.argv) > 2:
+    kind, dtype = sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "f16")
+    cur_path = "profiles/CURRENT.json"
+    cur = json.load(open(cur_path)) if os.path.exists(cur_path) else {}
+    cur.setdefault("traffic", {})[f"{kind}_{dtype}"] = f"{tag}_traffic.json"
+    cur.setdefault("command", {})[f"{kind}_{dtype}"] = open(f"{src}/command.txt").read().strip() if os.path.exists(f"{src}/command.txt") else None
+    json.dump(cur, open(cur_path, "w"), indent=1)
