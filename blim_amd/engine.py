@@ -141,6 +141,19 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def vocab_key_of(video_vocab):
+    """Identity of a video vocabulary tensor for "is this the one the engine holds?" (literal TVG path): address, shape, torch's in-place version counter AND a content
+    fingerprint -- callers pass temporaries such as `vocab.to(dev)`, and the caching allocator hands the next temporary of the same shape the same address, so
+    (address, shape) alone let another data set's vocabulary score against a stale registered copy.  The fingerprint is two sums over 4,096 strided values
+    (one tiny device -> host copy per call of the literal, non-hot path)."""
+    if not hasattr(video_vocab, "data_ptr"):
+        return (id(video_vocab),)
+    flat = video_vocab.reshape(-1)
+    pick = flat[:: max(1, flat.numel() // 4096)][:4096].double()
+    fp = (float(pick.sum()), float((pick * pick).sum()))
+    return (video_vocab.data_ptr(), tuple(video_vocab.shape), int(getattr(video_vocab, "_version", 0)), fp)
+
+
 class PackedBatch:
     """Device-side description of packed sequences (blim_batch).  Built from host numpy arrays."""
 
@@ -351,7 +364,7 @@ class Engine:
         assert v.shape[0] == self.dims.num_clips and v.shape[2] == self.dims.mm_hidden_size, tuple(v.shape)
         _check(self.lib.blim_set_video_vocab(self.h, _ptr(v), int(v.shape[1]), _stream()), "blim_set_video_vocab")
         self.n_vocab = int(v.shape[1])
-        self._vocab_key = (video_vocab.data_ptr() if hasattr(video_vocab, "data_ptr") else id(video_vocab), tuple(video_vocab.shape))
+        self._vocab_key = vocab_key_of(video_vocab)
 
     def tvg_logits_f32(self, vh_f32, n_pairs: int):
         """vh_f32 [n_pairs * clips, M] float32 -> logits [n_pairs, clips, n_vocab] against the registered vocabulary (three-term compensated product)."""

@@ -81,8 +81,8 @@ def _tvg_logits_literal(model, hidden_states, tvg_labels, video_vocab, num_clips
     if getattr(eng_, "can_precise", False):
         # 16-bit engines: float32 visual-head outputs against the vocabulary registered as hi + lo operands (three-term compensated product: a 16-bit cast of
         # either side alone left 2 - 8e-4 on the bf16 engine's literal TVG scores)
-        key = (video_vocab.data_ptr(), tuple(video_vocab.shape))
-        if getattr(eng_, "_vocab_key", None) != key:
+        from .engine import vocab_key_of
+        if getattr(eng_, "_vocab_key", None) != vocab_key_of(video_vocab):      # (address + shape + version + content fingerprint: a recycled address is not the same vocabulary)
             eng_.set_video_vocab(video_vocab)
         return eng_.tvg_logits_f32(emb.reshape(-1, emb.shape[-1]).float().contiguous(), emb.shape[0])
     vh = emb.to(model.module.dtype).reshape(-1, emb.shape[-1]).contiguous()

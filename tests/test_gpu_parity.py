@@ -1034,6 +1034,38 @@ def test_evaluation_and_val_one_epoch_end_to_end(tiny, literal):
     assert set(t2v0) == {"query_likelihood", "internvideo2"} and set(v2t0) == {"candidate_likelihood", "candidate_prior", "internvideo2"}
 
 
+def test_auto_modes_are_measured_again_when_weights_or_adapters_change():
+    """`--vtg_precise / --tvg_precise auto` is a REQUEST: evaluation() measures it on the weights loaded, a second evaluation() on the same weights reuses the answer (no
+    calibration calls), and any weight / adapter change -- the training loop's per-epoch validation loads new adapters every epoch, main.py:166 -- makes it unresolved so
+    that the next evaluation() measures again.  (the first evaluation used to overwrite "auto" with its choice, and every later epoch's adapters were scored in
+    the mode measured on the first epoch's.)"""
+    t = _build("tiny", dtype="f16")
+    try:
+        tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+        mk = lambda: types.SimpleNamespace(topk=t.spec["topk"], batch_size_eval=t.spec["bs"], num_clips=t.dims.num_clips, cpn=True, resume="ckpt", eval=True, dataset="SYNTH",
+                                           alpha=[0.4, 0.8], c=[0.3, 0.6, 0.9, 0.7], iv2_scores={"v2t": torch.from_numpy(t.prob.v2t_sims), "t2v": torch.from_numpy(t.prob.t2v_sims)})
+        loader, ddp = _SynthLoader(t.prob, bs=4), DDPLike(t.model)
+        t.model.vtg_precise, t.model.tvg_precise = "auto", "auto"
+        a1 = mk(); r1 = RU.evaluation(ddp, loader, t.model.device, tok, a1)
+        assert "vtg_precise_table" in a1._eval_stats and "tvg_precise_table" in a1._eval_stats                       # measured
+        assert t.model.vtg_precise == "auto" and t.model.tvg_precise == "auto" and t.model.vtg_mode() != "auto" and t.model.tvg_resolved()
+        a2 = mk(); r2 = RU.evaluation(ddp, loader, t.model.device, tok, a2)
+        assert "vtg_precise_table" not in a2._eval_stats and "tvg_precise_table" not in a2._eval_stats               # same weights: the answers stand
+        assert a2._eval_stats["vtg_precise"] == a1._eval_stats["vtg_precise"] and a2._eval_stats["tvg_precise"] == a1._eval_stats["tvg_precise"]
+        for d1, d2 in zip(r1, r2):
+            assert all(np.array_equal(d1[k], d2[k]) for k in d1)
+        H, r = t.dims.hidden_size, 8
+        g_ = np.random.RandomState(0)
+        t.model.engine.load_adapter("layers.0.o_proj.w", (g_.randn(r, H) * 0.02).astype(np.float32), (g_.randn(H, r) * 0.02).astype(np.float32), r, 32.0)
+        assert t.model.vtg_mode() == "auto" and not t.model.tvg_resolved()                                          # new adapters: unresolved again
+        a3 = mk(); RU.evaluation(ddp, loader, t.model.device, tok, a3)
+        assert "vtg_precise_table" in a3._eval_stats and "tvg_precise_table" in a3._eval_stats                       # ... and measured again
+        t.model.engine.load_weight("final_norm", np.ones(H, np.float32))
+        assert t.model.vtg_mode() == "auto"
+    finally:
+        t.model.engine.close()
+
+
 # ----------------------------------------------------------------------------- fp8 mode (BASELINE config 5; SURVEY.md 8f-2)
 # Building blocks are checked exactly (the quantiser against torch's own e4m3 cast, the block-scaled MFMA GEMM on integer
 # data); the end-to-end scores are compared with the same fp32 golden vectors and their deviation is REPORTED and bounded
