@@ -180,10 +180,12 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
     nz = lambda a: np.where(a == 0, np.float32(1e-6), a)
     ddp = DDPLike(model)
 
+    peers = {}                                                               # TVG clip features of the W = 1 run: what the all-gather of a real job delivers to each rank
+
     def run(shard):
         args = types.SimpleNamespace(topk=topk, num_clips=dims.num_clips, cpn=True, resume="x", eval=True, dataset="MSRVTT", batch_size_eval=16,
                                      iv2_scores={"v2t": torch.from_numpy(nz(prob.v2t_sims)), "t2v": torch.from_numpy(nz(prob.t2v_sims))},
-                                     max_tokens=32768, dedup=True, shard=shard)
+                                     max_tokens=32768, dedup=True, shard=shard, keep_tvg_feats=shard is None, peer_tvg_feats=peers if shard is not None else None)
         model.clear_cache()
         model.tvg_precise = tvg_precise if model.engine.can_precise else "full"   # "auto" (the driver's default): calibrated by every run, INSIDE its timed region
         if pg:
@@ -194,6 +196,8 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st = args._eval_stats
+        if shard is None:
+            peers.update(getattr(args, "_tvg_feats", {}))
         st["executed_flops_job"] = st.get("executed_flops", 0.0)
         st["executed_flops_lo6_job"] = st.get("executed_flops_lo6", 0.0)
         if pg:
@@ -225,16 +229,24 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
            "tvg_precise": f"{tvg_precise} -> {st['tvg_precise']}" if "tvg_precise" in st else getattr(model, "tvg_precise", "full"),
            "pairs_scored_rank0": st["pairs_scored"], "finite": bool(ok), "host_marks_rank0": st["host_marks"]}
     if world == 1 and emulate > 1:
-        per_rank, per_rank_frac = [], []
+        per_rank, per_rank_frac, n_have, n_same = [], [], 0, 0
         for r in range(emulate):
-            d_r, st_r, _ = run((emulate, r))
+            d_r, st_r, (t2v_r, v2t_r) = run((emulate, r))
             per_rank.append(round(d_r, 3))
+            for whole, part in ((t2v, t2v_r), (v2t, v2t_r)):                     # what the rank scored is what the one-process job scored there (entries it does not own: -100)
+                for k_, m_ in part.items():
+                    if k_ != "internvideo2" and k_ in whole and m_.shape == whole[k_].shape:
+                        have = m_ != -100.0
+                        n_have += int(have.sum()); n_same += int((m_[have] == whole[k_][have]).sum())
             per_rank_frac.append(round(at_peak(st_r.get("executed_flops", 0.0), st_r.get("executed_flops_lo6", 0.0)) / d_r, 4))
             if r == 0:
                 out["emulated_rank0_host_marks"] = st_r["host_marks"]
         out.update({"emulated_world": emulate, "emulated_rank_seconds": per_rank, "predicted_seconds": max(per_rank),
                     "predicted_speedup": round(dt / max(per_rank), 2), "emulated_rank_frac_mfma_peak": per_rank_frac,
-                    "predicted_note": f"slowest of the {emulate} ranks' own shares run one after another on this GPU; merge (one all-gather of < 1 MB) excluded"})
+                    "emulated_entries": n_have, "emulated_entries_bit_equal_to_world_1": n_same,
+                    "predicted_note": f"slowest of the {emulate} ranks' own shares run one after another on this GPU; each projects the TVG clip features of its own video "
+                                      "block and takes the other blocks' from the W = 1 run (PairScorer.adopt_tvg_feats), as a real job's all-gather delivers them; that "
+                                      "all-gather (57 MB) and the merge (one all-gather of < 1 MB) are not on an emulated rank's clock"})
     return out
 
 

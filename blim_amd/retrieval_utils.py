@@ -392,6 +392,23 @@ class PairScorer:
                 self._vfeat[(j, True)] = parts[r][(j - rs) * per:(j - rs + 1) * per]
         return True
 
+    def adopt_tvg_feats(self, world: int, rank: int, peers) -> bool:
+        """Shard emulation's stand-in for share_tvg_feats (one process plays rank `rank` of `world`; there is nobody to gather from): the rank projects the
+        videos of its OWN row block here, as share_tvg_feats would, and takes the other blocks' clip features from `peers` ({video index: [clips, width] device
+        rows}, e.g. an earlier evaluation's, handed in by the caller) -- what the all-gather would have delivered; the all-gather's own time is NOT part of
+        an emulated rank's clock.  Rows of another width (another TVG mode) are not adopted; such videos are projected on demand as before."""
+        N = len(self.video)
+        if world <= 1 or not peers or len({tuple(v.shape) for v in self.video}) != 1:
+            return False
+        s_, e_ = dist_utils.row_block(N, world, rank)
+        self.expect(np.arange(s_, e_), True)
+        mine = [self.video_feat(j, True) for j in range(s_, e_)]
+        width = int(mine[0].shape[1]) if mine else self.m.dims.hidden_size * (2 if self.split_tvg else 1)
+        for j, f in peers.items():
+            if not (s_ <= j < e_) and (int(j), True) not in self._vfeat and int(f.shape[1]) == width and f.dtype == self.m.dtype:
+                self._vfeat[(int(j), True)] = f
+        return True
+
     def _project_chunk(self, j: int, tvg: bool) -> None:
         shape = tuple(self.video[j].shape)
         chunk = [j]
@@ -491,9 +508,24 @@ class PairScorer:
 
     def iter_tvg(self, pairs: np.ndarray, cpn: bool = False):
         """pairs: [P, 2] (video j, text i); score = log P(video j | text i) (mean over clips)."""
-        pairs = np.asarray(pairs, dtype=np.int64)
+        return self.iter_tvg_jobs([(pairs, cpn)])
+
+    def iter_tvg_jobs(self, jobs):
+        """Several TVG passes -- [(pairs, cpn), ...] -- planned into the SAME engine calls: outputs are concatenated in job order.  A plan does not know which pass
+        a sequence belongs to (visibility is per token, a prior's prefix is its own sequence), so a small likelihood pass and its prior fill one call instead of
+        leaving two partly filled ones -- what a rank's share of a sharded evaluation and the calibration sample consist of."""
+        box, base = [_PackState(self, "tvg")], 0
+        for pairs, cpn in jobs:
+            pairs = np.asarray(pairs, dtype=np.int64)
+            yield from self._plan_tvg(pairs, bool(cpn), box, base)
+            base += len(pairs)
+        if box[0].n_pairs:
+            yield box[0].finish()
+
+    def _plan_tvg(self, pairs: np.ndarray, cpn: bool, box, base: int):
+        """Plans one TVG pass into the pack state box[0] (replaced whenever a call is full and yielded); output slot of pair p = base + p."""
         C = self.num_clips
-        st = _PackState(self, "tvg")
+        st = box[0]
         # The continuations of one prefix -- the C - 1 clip tokens of every candidate video of a text (prior: last prompt token + clip tokens) -- are
         # packed into ONE sequence whose segments do not see each other (blim_batch.own_start): the 32-query attention blocks are dense instead of
         # holding 3 - 4 queries each (2,919 -> ~500 blocks per 13,700-token call at the reference's shapes) and the planner adds one sequence per
@@ -516,7 +548,7 @@ class PairScorer:
                 while pos_in < len(lst):
                     room = (self.max_tokens - st.n_tok - (len(ptoks) if p0 is None else 0)) // C
                     if st.n_tok and room < 1:
-                        yield st.finish(); st = _PackState(self, "tvg"); p0 = None
+                        yield st.finish(); st = box[0] = _PackState(self, "tvg"); p0 = None
                         room = (self.max_tokens - len(ptoks)) // C
                     n = max(1, min(len(lst) - pos_in, room, SEG_MAX // C))
                     if p0 is None:                       # the prefix is packed once per engine call; every merged sequence of the group names it
@@ -531,7 +563,7 @@ class PairScorer:
                         own.append(np.full(C, m_ * C, np.int32))
                     s0 = st.add_seq(np.concatenate(toks), np.concatenate(posn), np.concatenate(vis), (p0, len(ptoks)), own_start=np.concatenate(own))
                     for m_, (k, outs) in enumerate(lst[pos_in:pos_in + n]):
-                        st.add_pair(list(range(s0 + m_ * C, s0 + (m_ + 1) * C)), np.array([self.tvg_video_labels[k[3]]], np.int32), np.array(outs))
+                        st.add_pair(list(range(s0 + m_ * C, s0 + (m_ + 1) * C)), np.array([self.tvg_video_labels[k[3]]], np.int32), base + np.array(outs))
                     pos_in += n
         else:
             order = np.lexsort((pairs[:, 0], pairs[:, 1]))
@@ -551,7 +583,7 @@ class PairScorer:
                     per = max(C - 1, 1)
                     room = (self.max_tokens - st.n_tok - (plen if p0 is None else 0)) // per
                     if st.n_tok and room < 1:
-                        yield st.finish(); st = _PackState(self, "tvg"); p0 = None
+                        yield st.finish(); st = box[0] = _PackState(self, "tvg"); p0 = None
                         room = (self.max_tokens - plen) // per
                     n = max(1, min(len(idxs) - pos_in, room, SEG_MAX // per))
                     if p0 is None:                       # the prompt is packed once per engine call; every merged sequence of the text names it
@@ -572,10 +604,8 @@ class PairScorer:
                             rows += list(range(s0 + m_ * (C - 1), s0 + (m_ + 1) * (C - 1)))
                         else:
                             self.video_feat(int(pairs[idx, 0]), True)
-                        st.add_pair(rows, np.array([self.tvg_video_labels[int(pairs[idx, 0])]], np.int32), np.array([idx]))
+                        st.add_pair(rows, np.array([self.tvg_video_labels[int(pairs[idx, 0])]], np.int32), np.array([base + idx]))
                     pos_in += n
-        if st.n_pairs:
-            yield st.finish()
 
     # ---- execution (device) ---------------------------------------------------------------------
     def run(self, plan: Plan):
@@ -735,7 +765,7 @@ class PairScorer:
             return "full", {}
         n_all = len(pairs)
         pairs, share = self._my_block(pairs, share)
-        both = lambda: (np.concatenate([self.tvg(pairs, False), self.tvg(pairs, True)]).astype(np.float64) if len(pairs) else np.zeros(0))
+        both = lambda: (self.score(self.iter_tvg_jobs([(pairs, False), (pairs, True)]), 2 * len(pairs)).astype(np.float64) if len(pairs) else np.zeros(0))   # likelihood and prior in the same engine calls
         ref = both()
         table, chosen = {}, "full"
         for mode in TVG_MODES[:-1]:
@@ -765,6 +795,10 @@ class PairScorer:
 
     def tvg_device(self, pairs, cpn=False):
         return self.score_device(self.iter_tvg(pairs, cpn), len(pairs))
+
+    def tvg_jobs_device(self, jobs):
+        """Several TVG passes through shared engine calls (iter_tvg_jobs); scores concatenated in job order."""
+        return self.score_device(self.iter_tvg_jobs(jobs), sum(len(p) for p, _ in jobs))
 
 
 class _PackState:
@@ -1012,12 +1046,25 @@ def evaluation(model, data_loader, device, tokenizer, args):
         own_v = need.copy(); own_v[:vs] = False; own_v[ve:] = False                            # VTG: rows of my videos
         M_vtg = score_owned("vtg", own_v)
         mark("vtg")
-        M_tvg_T = None
+        M_tvg_T = S_t2v_prior = None
         if finetuned:
             if collective and hasattr(scorer, "share_tvg_feats"):
                 scorer.share_tvg_feats(W, rank)                                                # each rank projects its block of videos; one all-gather of the clip features
+            elif emulate is not None and getattr(args, "peer_tvg_feats", None) and hasattr(scorer, "adopt_tvg_feats"):
+                scorer.adopt_tvg_feats(W, rank, args.peer_tvg_feats)                           # shard emulation: own block projected, the peers' blocks as the all-gather delivers them
             own_t = need.copy(); own_t[:, :ts] = False; own_t[:, te:] = False                  # TVG: columns of my texts
-            M_tvg_T = score_owned("tvg", own_t).T.contiguous()                                # text-major: a row block
+            jj_, ii_ = np.nonzero(own_t)
+            if args.cpn and te > ts and len(jj_) and hasattr(scorer, "tvg_jobs_device"):
+                # the likelihoods of my texts' pairs and the t2v prior of my texts (keyed on (prompt, video)) are planned into the SAME engine calls: a rank's
+                # share of either is a fraction of one call at 8 ranks
+                pl_, pp_ = np.stack([jj_, ii_], axis=1), _topk_pairs(t2v_iv2[ts:te], ts, args.topk, False)
+                sc = scorer.tvg_jobs_device([(pl_, False), (pp_, True)])
+                stats["pairs_scored"] += len(pl_) + len(pp_)
+                M_ = full(Nv, Nt); M_[to_dev(jj_), to_dev(ii_)] = sc[: len(pl_)]
+                M_tvg_T = M_.T.contiguous()
+                S_t2v_prior = full(Nt, Nv); S_t2v_prior[to_dev(pp_[:, 1]), to_dev(pp_[:, 0])] = sc[len(pl_):]
+            else:
+                M_tvg_T = score_owned("tvg", own_t).T.contiguous()                            # text-major: a row block
             mark("tvg")
         prior_t = None
         if args.cpn:
@@ -1036,8 +1083,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
                 prior_t = torch.full((Nt,), -100.0, dtype=torch.float32, device=device)
                 prior_t[ts:te] = mine[: te - ts]
         mark("v2t_prior")
-        S_t2v_prior = None
-        if finetuned and args.cpn:                                                             # t2v TVG prior: keyed on (prompt, video); rows of my texts
+        if finetuned and args.cpn and S_t2v_prior is None:                                     # t2v TVG prior: keyed on (prompt, video); rows of my texts
             S_t2v_prior = full(Nt, Nv)
             if te > ts:
                 pairs = _topk_pairs(t2v_iv2[ts:te], ts, args.topk, False)
@@ -1121,6 +1167,8 @@ def evaluation(model, data_loader, device, tokenizer, args):
         stats["executed_flops"] = scorer.exec_flops; stats["executed_tokens"] = scorer.exec_tokens
         stats["executed_flops_lo6"] = getattr(scorer, "exec_flops_lo6", 0.0)
     args._eval_stats = dict(stats, seconds=time.time() - t_start, world=W, rank=rank, host_marks=marks)
+    if getattr(args, "keep_tvg_feats", False) and isinstance(scorer, PairScorer):                # bench.py: what a later shard emulation adopts as its peers' blocks
+        args._tvg_feats = {j: f for (j, tvg_), f in scorer._vfeat.items() if tvg_}
     t2v_dict["internvideo2"] = t2v_iv2.cpu().numpy()
     v2t_dict["internvideo2"] = v2t_iv2.cpu().numpy()
     if getattr(args, "verbose", False) and rank == 0:

@@ -910,6 +910,13 @@ def test_segmented_tvg_sequences_equal_one_sequence_per_pair():
             # fp16 engines) SwiGLU output travels on -- measured 5e-6; with every activation compensated (option precise_act = 1) <= 2e-6
             print(f"segmented vs alone, cpn={cpn}: max rel {float(np.max(np.abs(full - alone) / np.abs(alone))):.2e}")
             np.testing.assert_allclose(full, alone, rtol=5e-5)
+        # several passes planned into the same engine calls (iter_tvg_jobs: a rank's likelihood pass + its prior, the calibration sample): one call instead of
+        # two, every sequence the same as in its own pass -> the same bits
+        plans = list(sc.iter_tvg_jobs([(pairs, False), (pairs[:20], True)]))
+        assert len(plans) == 1 and plans[0].n_pairs == len(pairs) + 20
+        both = sc.score(iter(plans), len(pairs) + 20)
+        np.testing.assert_array_equal(both[: len(pairs)], sc.tvg(pairs, False))
+        np.testing.assert_array_equal(both[len(pairs):], sc.tvg(pairs[:20], True))
     finally:
         model.engine.close()
 
