@@ -6,6 +6,7 @@
 // 16 lanes of every ds_read_b128 hardware lane group touch 16 different 4-bank groups.  The permutation is applied on the per-lane
 // global SOURCE address (the LDS-DMA destination is lane-linear).
 #include "gemm.hpp"
+#include <type_traits>
 
 #define BM 256
 #define BN 256
@@ -301,88 +302,46 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         typedef int i32x2 __attribute__((ext_vector_type(2)));
         const char* g6A = LO6 ? (const char*)p.A6 + (int64_t)tm * nk6 * F6_TILE_BYTES : nullptr;
         const char* g6W = LO6 ? (const char*)p.W6 + (int64_t)tn * nk6 * F6_TILE_BYTES : nullptr;
-        // one operand tile of K-step k into ring slot `slot` (0-5): this wave's 6 KiB-blocks of e2m3 and its quarter of the scale KiB (7 LDS-DMA per wave)
-        auto stage6 = [&](int slot, int k, bool isW) __attribute__((always_inline)) {
-#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 3   // ablation build: phase 2 stages its first two steps only, then runs on stale tiles
-            if (k >= 2) return;
-#endif
-            const char* g = (isW ? g6W : g6A) + (int64_t)k * F6_TILE_BYTES;
-            char* d = smem + slot * F6_TILE_BYTES;
-            uint32_t l16 = (uint32_t)lane * 16u;                     // (unsigned 32-bit lane offset + scalar base: the saddr + voffset form of the LDS-DMA, as in the 16-bit loop)
-            asm volatile("" : "+v"(l16));
-#pragma unroll
-            for (int i = 0; i < 6; ++i) glds16(g + (wg + 4 * i) * 1024 + l16, d + (wg + 4 * i) * 1024);
-            // (the scale KiB as 16-byte pieces of the first 16 lanes, 256 B per wave: with the 4-byte form of the LDS-DMA the compiler's wait-count pass put an
-            // s_waitcnt vmcnt(0) in front of the NEXT step's fragment reads -- it tracks that form as an LDS store any LDS read may alias -- and every K-step
-            // waited for the tiles just requested: 1.2 us per step whatever the layout)
-            if (lane < 16) glds16(g + 24576 + wg * 256 + l16, d + 24576 + wg * 256);
-        };
         uint2 sc6a = make_uint2(0, 0);                                // this lane's eight A-side scale bytes of the step (one per 16-row fragment)
         uint32_t sc6w = 0;                                            // ... and its four W-side ones
-        // a step's 26 fragment / scale reads with the 7 LDS-DMA of one operand tile (K-step kd into ring slot `dslot`; on = false: none) between them, one after
-        // every fourth read: the wave's LDS-DMA issue (~70 cycles each: the CU's 64 B / clk path into LDS is shared by the four staging waves) overlaps the
-        // LDS's answers to its reads.  (Requested in a block -- before the reads, after them, or in front of the computing group's MFMAs -- the seven cost the
-        // interval ~500 cycles on top: tools/gemm_waits_lo6.py.)
-        // piece q (0-6) of this wave's share of one operand tile (K-step kd into ring slot `dslot`): six KiB-blocks of e2m3 and a quarter of the scale KiB
+        // piece q (0-6) of this wave's share of one operand tile (K-step kd into ring slot `dslot`): six KiB-blocks of e2m3 and a quarter of the scale KiB.
+        // Issued as an asm statement, not through the builtin: while an LDS-DMA the compiler KNOWS about is in flight, its wait-count pass treats it as a pending
+        // access to both memories and answers every LDS-read dependency with s_waitcnt lgkmcnt(0) -- all of a wave's refills awaited in front of every MFMA that
+        // needed one of them.  (So the pass does not count these either: phase 2's vmcnt waits are asm statements too.)
+        const uint32_t lds0 = (uint32_t)(__UINTPTR_TYPE__)(lptr_t)smem;
         auto dma6 = [&](int q, int dslot, int kd, bool isW, bool on) __attribute__((always_inline)) {
-#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 3
-            on = false;
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 3   // ablation build: only the tiles requested in front of the pass (K-steps 0 - 2) are staged, then it runs on stale tiles
+            on = on && kd < 3;
 #endif
-            __builtin_amdgcn_sched_barrier(0);
             if (on) {
                 const char* g = (isW ? g6W : g6A) + (int64_t)kd * F6_TILE_BYTES;
-                char* d = smem + dslot * F6_TILE_BYTES;
+                const uint32_t d = lds0 + dslot * F6_TILE_BYTES;
                 uint32_t o16 = (uint32_t)lane * 16u;
                 asm volatile("" : "+v"(o16));
-                if (q < 6) glds16(g + (wg + 4 * q) * 1024 + o16, d + (wg + 4 * q) * 1024);
-                else if (lane < 16) glds16(g + 24576 + wg * 256 + o16, d + 24576 + wg * 256);
+                if (q < 6) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d + (wg + 4 * q) * 1024), "v"(o16), "s"(g + (wg + 4 * q) * 1024) : "m0");
+                else if (lane < 16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d + 24576 + wg * 256), "v"(o16), "s"(g + 24576 + wg * 256) : "m0");
             }
-            __builtin_amdgcn_sched_barrier(0);
         };
-        constexpr int DMA_IN_READS = 4;                               // pieces 0-3 between the fragment reads, 4-6 between the MFMAs: both intervals of a step the same length
-        auto load_frags6 = [&](int slotA, int slotB, int dslot, int kd, bool isW, bool on) __attribute__((always_inline)) {
-            const char* ta = smem + slotA * F6_TILE_BYTES;
-            const char* tb = smem + slotB * F6_TILE_BYTES;
-            int l16 = lane * 16;
-            asm volatile("" : "+v"(l16));
-            auto dma = [&](int q) __attribute__((always_inline)) { if (q < DMA_IN_READS) dma6(q, dslot, kd, isW, on); };
-            auto rd = [&](const char* blk) __attribute__((always_inline)) {
-                const i32x4 l = *(const i32x4*)(blk + l16);
-                const i32x2 h = *(const i32x2*)(blk + 1024 + (l16 >> 1));
-                return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], 0, 0};
-            };
-            // (scales read through ext-vector types like the fragments: behind loads typed uint32_t / uint2 the compiler's wait-count pass put an s_waitcnt vmcnt(0) --
-            // every outstanding LDS-DMA -- in front of each step's fragment reads)
-            typedef int i32x1 __attribute__((ext_vector_type(1)));
-            const i32x1 sw_ = *(const i32x1*)(tb + 24576 + wn * 256 + (l16 >> 2));             // ((wn * 4 + g) * 16 + r) * 4 = wn * 256 + lane * 4
-            const i32x2 sa_ = *(const i32x2*)(ta + 24576 + wm * 512 + (l16 >> 1));             // ((wm * 4 + g) * 16 + r) * 8 = wm * 512 + lane * 8
-            sc6w = (uint32_t)sw_[0]; sc6a = make_uint2((uint32_t)sa_[0], (uint32_t)sa_[1]);
-            dma(0);
-            fb8[0] = rd(tb + (4 * wn + 0) * 1536); fb8[1] = rd(tb + (4 * wn + 1) * 1536); fb8[2] = rd(tb + (4 * wn + 2) * 1536);
-            dma(1);
-            fb8[3] = rd(tb + (4 * wn + 3) * 1536); fa8[0] = rd(ta + (8 * wm + 0) * 1536); fa8[1] = rd(ta + (8 * wm + 1) * 1536);
-            dma(2);
-            fa8[2] = rd(ta + (8 * wm + 2) * 1536); fa8[3] = rd(ta + (8 * wm + 3) * 1536); fa8[4] = rd(ta + (8 * wm + 4) * 1536);
-            dma(3);
-            fa8[5] = rd(ta + (8 * wm + 5) * 1536); fa8[6] = rd(ta + (8 * wm + 6) * 1536); fa8[7] = rd(ta + (8 * wm + 7) * 1536);
+        // one whole operand tile of K-step k into ring slot `slot` (0-5) by the four waves of ONE group: 7 pieces per wave
+        auto stage6 = [&](int slot, int k, bool isW) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) dma6(q, slot, k, isW, true);
         };
-        auto compute6 = [&](int dslot, int kd, bool isW, bool on) __attribute__((always_inline)) {
-#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 1   // ablation build (make ablate_p2; timing only, wrong results): no MFMAs in phase 2
-            return;
-#endif
-            __builtin_amdgcn_s_setprio(1);
-#define L6_MMA(MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[NI], fa8[MI], acc[MI][NI], 2, 2, NI, (int)sc6w, (MI & 3), (int)((MI) < 4 ? sc6a.x : sc6a.y));   // cbsz = blgp = 2: e2m3
-#define L6_ROW(MI) L6_MMA(MI, 0) L6_MMA(MI, 1) L6_MMA(MI, 2) L6_MMA(MI, 3)
-            L6_ROW(0) L6_ROW(1)
-            dma6(4, dslot, kd, isW, on);
-            L6_ROW(2) L6_ROW(3)
-            dma6(5, dslot, kd, isW, on);
-            L6_ROW(4) L6_ROW(5)
-            dma6(6, dslot, kd, isW, on);
-            L6_ROW(6) L6_ROW(7)
-#undef L6_ROW
-#undef L6_MMA
-            __builtin_amdgcn_s_setprio(0);
+        // one 16-row fragment: ds_read_b128 + ds_read_b64 (qa = tile + lane * 16, qb = tile + 1024 + lane * 8, formed once per step; off = 1536 x fragment index)
+        auto rd6 = [&](const char* qa, const char* qb, int off) __attribute__((always_inline)) {
+            const i32x4 l = *(const i32x4*)(qa + off);
+            const i32x2 h = *(const i32x2*)(qb + off);
+            return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], 0, 0};
+        };
+        // (scales read through ext-vector types like the fragments: behind loads typed uint32_t / uint2 the compiler's wait-count pass put an s_waitcnt vmcnt(0) --
+        // every outstanding LDS-DMA -- in front of each step's fragment reads)
+        typedef int i32x1 __attribute__((ext_vector_type(1)));
+        auto rd6_sw = [&](const char* tb) __attribute__((always_inline)) {
+            return (uint32_t)(*(const i32x1*)(tb + 24576 + wn * 256 + lane * 4))[0];           // ((wn * 4 + g) * 16 + r) * 4 = wn * 256 + lane * 4
+        };
+        auto rd6_sa = [&](const char* ta) __attribute__((always_inline)) {
+            const i32x2 v = *(const i32x2*)(ta + 24576 + wm * 512 + lane * 8);                 // ((wm * 4 + g) * 16 + r) * 8 = wm * 512 + lane * 8
+            return make_uint2((uint32_t)v[0], (uint32_t)v[1]);
         };
         int sa = 0;
         mx_request(0);
@@ -421,14 +380,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_T(2);
                 PHASE_BARRIER();
                 WP_T(3);
+                if constexpr (LO6) { if (kt + 1 == nk) break; }         // (the last interval of the two-pass kernels: below)
                 if (kt + 1 < nk) frags_and_dma(adv(sa, 2), adv(sa, 3), sa, kt + 2, kt + 2 < nk);   // fragments of kt+1, W(kt+2)
-                else if constexpr (LO6) {
-                    // last 16-bit step: this group has nothing left to read while the A group computes from registers, and no wave reads LDS any more -- the
-                    // second pass's first two K-steps (both operands) are requested HERE, under the A group's last 64 MFMAs
-                    stage6(0, 0, false); stage6(1, 0, true);
-                    if (nk6 > 1) { stage6(2, 1, false); stage6(3, 1, true); }
-                    if (nk6 > 2) stage6(4, 2, false);
-                }
 #ifdef GEMM_WAIT_PROF
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -438,38 +391,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_ACC();
                 sa = adv(sa, 2);
             }
-            }
+            // last 16-bit interval: this group has nothing left to read while the A group computes from registers, and no wave reads LDS any more
             if constexpr (LO6) {
-                // phase 2, W group.  Ring slot of A(k): 2 (k % 3), of W(k): 2 (k % 3) + 1.  Requested so far (by this group, above): both operands of steps 0 and 1.
-                if (nk6 > 2) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");          // my shares of A(0) W(0) landed
-                else if (nk6 > 1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the second pass's first three K-steps (both operands) are requested HERE, under the A group's last 64 MFMAs.  In front of them an
+                // s_waitcnt vmcnt(0) INSTRUCTION the compiler's wait-count pass models (free: the asm form has just waited): it counts the 16-bit loop's LDS-DMA
+                // (builtins) as pending for ever behind asm waits, and a pending LDS-DMA makes it answer every LDS-read dependency with lgkmcnt(0) (phase 2, below)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                stage6(0, 0, false); stage6(1, 0, true);
+                if (nk6 > 1) { stage6(2, 1, false); stage6(3, 1, true); }
+                if (nk6 > 2) { stage6(4, 2, false); stage6(5, 2, true); }
                 PHASE_BARRIER();
-                int s3 = 0;                                              // k % 3
-#ifdef GEMM_WAIT_PROF   // (instrumented build: the sums below are phase 2's alone -- reads | barrier | dma + mfma | vmcnt | barrier)
-                for (int q_ = 0; q_ < 5; ++q_) wp_acc[q_] = 0;
-#endif
-                for (int k = 0; k < nk6; ++k) {
-                    const int s3n = s3 == 0 ? 2 : s3 - 1;                // (k + 2) % 3 = (k - 1) % 3: the slot pair step k-1 left (both groups have read it)
-                    WP_T(0);
-                    load_frags6(2 * s3, 2 * s3 + 1, 2 * s3n + 1, k + 2, true, k + 2 < nk6);     // ... and W(k+2) into the slot W(k-1) left
-#ifdef GEMM_WAIT_PROF
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                    WP_T(1);
-                    PHASE_BARRIER();                                     // end of interval 2k
-                    WP_T(2);
-                    compute6(2 * s3n + 1, k + 2, true, k + 2 < nk6);
-                    WP_T(3);
-                    if (k + 2 < nk6) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");    // my share of W(k+1) (and, k = 0, of A(1), A(2)) landed
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    WP_T(4);
-                    PHASE_BARRIER();                                     // end of interval 2k + 1
-                    WP_T(5);
-                    WP_ACC();
-                    s3 = s3 == 2 ? 0 : s3 + 1;
-                }
-                PHASE_BARRIER();                                         // end of interval 2 nk6 (the A group's last compute)
+            }
             }
         } else {
             stage8(0, 0);                                            // A0
@@ -503,35 +435,133 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_ACC();
                 sa = adv(sa, 2);
             }
-            if constexpr (LO6) {
-                PHASE_BARRIER();                                         // (the W group has waited for A(0) W(0))
-                PHASE_BARRIER();                                         // end of interval 0 (the W group's first fragment reads)
-                int s3 = 0;
-#ifdef GEMM_WAIT_PROF
-                for (int q_ = 0; q_ < 5; ++q_) wp_acc[q_] = 0;
-#endif
-                for (int k = 0; k < nk6; ++k) {                          // phase 2, A group (half a step behind the W group: above)
-                    const int s3n = s3 == 0 ? 2 : s3 - 1;
-                    WP_T(0);
-                    load_frags6(2 * s3, 2 * s3 + 1, 2 * s3n, k + 2, false, k >= 1 && k + 2 < nk6);  // ... and A(k+2) into the slot A(k-1) left (A(0..2): requested and awaited by the W group)
-                    // A(k+1) is read by the W group in the NEXT interval: my share of it has to be there before this interval's barrier
-                    if (k >= 1 && k + 2 < nk6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (only the four pieces of A(k+2) just requested may be outstanding)
-                    else if (k >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef GEMM_WAIT_PROF
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                    WP_T(1);
-                    PHASE_BARRIER();                                     // end of interval 2k + 1
-                    WP_T(2);
-                    compute6(2 * s3n, k + 2, false, k >= 1 && k + 2 < nk6);
-                    WP_T(3);
-                    WP_T(4);
-                    PHASE_BARRIER();                                     // end of interval 2k + 2
-                    WP_T(5);
-                    WP_ACC();
-                    s3 = s3 == 2 ? 0 : s3 + 1;
-                }
+            if constexpr (LO6) __builtin_amdgcn_s_waitcnt(0x0F70);   // (modelled, free: as in the W group above)
+        }
+        if constexpr (LO6) {
+            // ---- phase 2, all eight waves alike.  Every fragment register is refilled IN PLACE between its last MFMA and its next one, and the 32 MFMAs of a step
+            // are walked in four quadrants (4 A fragments x 2 W fragments) whose order alternates from step to step, so that the refills spread over the whole step
+            // and each has at least eight MFMAs (128 cycles) to arrive:
+            //   step (CA, CB):  QA rows 0-3 x cols CA   | reads fw[CB] fw[CB+1] fa[4] fa[5] of the step's own tile
+            //                   QB rows 0-3 x cols CB   | reads fa[6] fa[7]                 (the last reads of this tile)
+            //                   -- barrier: every wave has left this tile; the next tile has landed everywhere
+            //                   QC rows 4-7 x cols CB   | reads fa[0] fa[1] of the NEXT tile
+            //                   QD rows 4-7 x cols CA   | reads fa[2] fa[3], the scales, fw[CB] fw[CB+1] of the next tile      -> next step: (CB, CA)
+            // LDS reads and LDS-DMA requests issue in the shadow of the wave's own MFMAs and the SIMD's other wave fills the matrix pipe whenever this one waits.
+            // (All of a step's refills behind its last column and its LDS-DMA behind the first -- 18 reads in one burst of all eight waves, seven requests in
+            // another -- took the same 1.1 us per step as the two-group ping-pong before it: tools/gemm_waits_lo6.py.)
+            // Ring: A(k) in slot 2 (k % 3), W(k) in 2 (k % 3) + 1.  Between the barriers of steps k and k+1 the waves request tile k+3 into the slots tile k left
+            // (W group: W tiles, A group: A tiles; 7 LDS-DMA per wave).  Tiles 0 - 2 were requested by the W group under the last 16-bit MFMAs.
+            // NO inline asm from here to the end of the pass: behind an asm statement with a memory clobber (the 16-bit loops' s_waitcnt and barrier forms) the
+            // compiler's wait-count pass answered every LDS dependency with s_waitcnt lgkmcnt(0) -- each refill's latency exposed in front of the next MFMA that
+            // needed ANY fragment.  The waits below are s_waitcnt INSTRUCTIONS the pass models (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 |
+            // vmcnt[5:4] << 14), the compiler-level ordering of LDS reads against the barrier is a wavefront-scope fence (no instruction).
+#define P2_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")")   /* (no memory clobber: see above) */
+#define P2_BARRIER()                                                                 \
+            __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): own LDS reads complete */ \
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                       \
+            __builtin_amdgcn_s_barrier();                                                \
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+            if (grp == 0) {
+                if (nk6 > 2) P2_VMCNT(28);                               // my shares of A(0) W(0) landed
+                else if (nk6 > 1) P2_VMCNT(14);
+                else P2_VMCNT(0);
             }
+            P2_BARRIER();
+            const int qoa = 8 * wm * 1536 + lane * 16, qoa8 = 8 * wm * 1536 + 1024 + lane * 8;       // this lane's byte offsets inside an A / a W tile image
+            const int qob = F6_TILE_BYTES + 4 * wn * 1536 + lane * 16, qob8 = F6_TILE_BYTES + 4 * wn * 1536 + 1024 + lane * 8;
+            sc6w = rd6_sw(smem + F6_TILE_BYTES); sc6a = rd6_sa(smem);
+            fb8[0] = rd6(smem + qob, smem + qob8, 0); fb8[1] = rd6(smem + qob, smem + qob8, 1536);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa8[i] = rd6(smem + qoa, smem + qoa8, i * 1536);
+            int s3 = 0;                                                  // k % 3
+#ifdef GEMM_WAIT_PROF   // (instrumented build: the sums below are phase 2's alone -- QA + QB | vmcnt | barrier | QC | QD)
+            for (int q_ = 0; q_ < 5; ++q_) wp_acc[q_] = 0;
+#endif
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 1   // ablation builds (make ablate_p2; timing only, wrong results): 1 = no MFMAs in phase 2, 2 = no fragment refills, 3 = no LDS-DMA
+#define L6_MMA(MI, NI)
+#else
+#define L6_MMA(MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb8[NI], fa8[MI], acc[MI][NI], 2, 2, NI, (int)sc6w, (MI & 3), (int)((MI) < 4 ? sc6a.x : sc6a.y));   // cbsz = blgp = 2: e2m3
+#endif
+#define L6_SB() __builtin_amdgcn_sched_barrier(0)
+            auto step6 = [&](int k, auto ca_, auto cb_) __attribute__((always_inline)) {
+                constexpr int CA = decltype(ca_)::value, CB = decltype(cb_)::value;
+                const int s3n = s3 == 2 ? 0 : s3 + 1, s3p = s3 == 0 ? 2 : s3 - 1;      // slots of tile k+1 / of tiles k-1 and k+2
+                const char* t0 = smem + (2 * s3) * F6_TILE_BYTES;                        // this step's tile (A image; the W image follows it)
+                const char* t1 = smem + (2 * s3n) * F6_TILE_BYTES;                       // the next step's
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 2
+                const bool rl = false, own = false;
+#else
+                const bool rl = k + 1 < nk6, own = true;                 // there is a next step: refill from its tile
+#endif
+                const bool on2 = k >= 1 && k + 2 < nk6;                  // pieces 4-6 of tile k+2 (0-3: requested in the previous step) into the slots of tile k-1
+                const bool on3 = k + 3 < nk6;                            // pieces 0-3 of tile k+3 into the slots of tile k, behind the barrier
+                const int d2 = 2 * s3p + (grp == 0 ? 1 : 0), d3 = 2 * s3 + (grp == 0 ? 1 : 0);
+                const bool isW = grp == 0;
+                uint2 sc6a_n = sc6a; uint32_t sc6w_n = sc6w;
+                WP_T(0);
+                __builtin_amdgcn_s_setprio(1);
+                // QA
+                L6_MMA(0, CA) L6_SB(); if (own) fb8[CB] = rd6(t0 + qob, t0 + qob8, CB * 1536); L6_SB();
+                L6_MMA(1, CA) L6_SB(); dma6(4, d2, k + 2, isW, on2); L6_SB();
+                L6_MMA(2, CA) L6_SB(); if (own) fb8[CB + 1] = rd6(t0 + qob, t0 + qob8, (CB + 1) * 1536); L6_SB();
+                L6_MMA(3, CA) L6_SB();
+                L6_MMA(0, CA + 1) L6_SB(); if (own) fa8[4] = rd6(t0 + qoa, t0 + qoa8, 4 * 1536); L6_SB();
+                L6_MMA(1, CA + 1) L6_SB(); dma6(5, d2, k + 2, isW, on2); L6_SB();
+                L6_MMA(2, CA + 1) L6_SB(); if (own) fa8[5] = rd6(t0 + qoa, t0 + qoa8, 5 * 1536); L6_SB();
+                L6_MMA(3, CA + 1) L6_SB();
+                // QB
+                L6_MMA(0, CB) L6_SB(); if (own) fa8[6] = rd6(t0 + qoa, t0 + qoa8, 6 * 1536); L6_SB();
+                L6_MMA(1, CB) L6_SB(); if (own) fa8[7] = rd6(t0 + qoa, t0 + qoa8, 7 * 1536); L6_SB();
+                L6_MMA(2, CB) L6_SB(); dma6(6, d2, k + 2, isW, on2); L6_SB();
+                L6_MMA(3, CB)
+                L6_MMA(0, CB + 1) L6_MMA(1, CB + 1) L6_MMA(2, CB + 1) L6_MMA(3, CB + 1)
+                L6_SB();
+                WP_T(1);
+                // every read of tile k has been requested (and is awaited in front of the barrier).  Tile k+1: my pieces of it were requested two barriers ago --
+                // only the seven of tile k+2 may stay in flight (k = 0: the W group's fourteen of A(2) W(2))
+                if (k == 0) { if (nk6 > 2) P2_VMCNT(14); else P2_VMCNT(0); }
+                else if (k + 2 < nk6) P2_VMCNT(7);
+                else P2_VMCNT(0);
+                WP_T(2);
+                P2_BARRIER();
+                WP_T(3);
+                // QC
+                L6_MMA(4, CB) L6_SB(); if (rl) fa8[0] = rd6(t1 + qoa, t1 + qoa8, 0); L6_SB();
+                L6_MMA(5, CB) L6_SB(); dma6(0, d3, k + 3, isW, on3); L6_SB();
+                L6_MMA(6, CB) L6_SB(); if (rl) fa8[1] = rd6(t1 + qoa, t1 + qoa8, 1536); L6_SB();
+                L6_MMA(7, CB) L6_SB(); dma6(1, d3, k + 3, isW, on3); L6_SB();
+                L6_MMA(4, CB + 1) L6_SB(); if (rl) { sc6w_n = rd6_sw(t1 + F6_TILE_BYTES); sc6a_n = rd6_sa(t1); } L6_SB();
+                L6_MMA(5, CB + 1) L6_MMA(6, CB + 1) L6_MMA(7, CB + 1)
+                L6_SB();
+                WP_T(4);
+                // QD (fw[CB], fw[CB + 1] are free: their refills for the next step go first)
+                if (rl) fb8[CB] = rd6(t1 + qob, t1 + qob8, CB * 1536);
+                L6_SB();
+                L6_MMA(4, CA) L6_SB(); if (rl) fb8[CB + 1] = rd6(t1 + qob, t1 + qob8, (CB + 1) * 1536); L6_SB();
+                L6_MMA(5, CA) L6_SB(); dma6(2, d3, k + 3, isW, on3); L6_SB();
+                L6_MMA(6, CA) L6_SB(); if (rl) fa8[2] = rd6(t1 + qoa, t1 + qoa8, 2 * 1536); L6_SB();
+                L6_MMA(7, CA) L6_SB(); dma6(3, d3, k + 3, isW, on3); L6_SB();
+                L6_MMA(4, CA + 1) L6_SB(); if (rl) fa8[3] = rd6(t1 + qoa, t1 + qoa8, 3 * 1536); L6_SB();
+                L6_MMA(5, CA + 1) L6_MMA(6, CA + 1) L6_MMA(7, CA + 1)
+                L6_SB();
+                __builtin_amdgcn_s_setprio(0);
+                sc6a = sc6a_n; sc6w = sc6w_n;
+                WP_T(5);
+                WP_ACC();
+                s3 = s3n;
+            };
+            {
+                int k = 0;
+                for (; k + 1 < nk6; k += 2) {
+                    step6(k, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                    step6(k + 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+                }
+                if (k < nk6) step6(k, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            }
+#undef L6_SB
+#undef P2_BARRIER
+#undef P2_VMCNT
+#undef L6_MMA
         }
 #undef PHASE_BARRIER
 #ifdef GEMM_WAIT_PROF

@@ -116,9 +116,9 @@ def test_no_spills_in_the_16_bit_kernels(src, pattern, gemm_kernels, tmp_path):
         seen += 1
         if src == "gemm.hip" and re.search(r"gemm_kernelILi\dELi1ELb[01]ELb1E", name):
             # the two-phase "lo6" kernels (fp16 pass + e2m3 pass over the lo part in one accumulator set, gemm.hip phase 2).  Round 4's e4m3 form spilled 14 - 17 VGPRs around
-            # the hand-over between its two loops; round 5's rows continue into the second pass's operands and nothing is handed over: <= 3 spilled VGPRs, all of them
+            # the hand-over between its two loops; round 5's second pass refills its fragment registers in place and nothing is handed over: <= 6 spilled VGPRs, all of them
             # kernel-invariant values stored once per kernel and reloaded in the tile prologue / epilogue -- and NO basic block of a K loop touches scratch
-            assert meta["vgpr_spills"] <= 4, (name, meta)
+            assert meta["vgpr_spills"] <= 6, (name, meta)
             body = ks[name][0]
             # basic blocks and their successors
             heads = [0] + [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
@@ -142,9 +142,10 @@ def test_no_spills_in_the_16_bit_kernels(src, pattern, gemm_kernels, tmp_path):
                 if fall and b + 1 < len(heads):
                     succ[b].add(b + 1)
             n_mfma = {b: sum("v_mfma" in l for l in body[h:(heads[b + 1] if b + 1 < len(heads) else len(body))]) for b, h in enumerate(heads)}
+            n_scale = {b: sum("v_mfma_scale" in l for l in body[h:(heads[b + 1] if b + 1 < len(heads) else len(body))]) for b, h in enumerate(heads)}
             has_scratch = {b: any("scratch_" in l for l in body[h:(heads[b + 1] if b + 1 < len(heads) else len(body))]) for b, h in enumerate(heads)}
             loops = set()
-            for b0 in [b for b, n in n_mfma.items() if n >= 8]:           # (the second pass's 32 MFMAs sit in four blocks of eight: an LDS-DMA piece, under a branch, between them)
+            for b0 in [b for b, n in n_mfma.items() if n >= 8 or n_scale[b] >= 1]:   # (the second pass's MFMAs sit in many small blocks: an LDS-DMA piece, under a branch, between them)
                 # shortest cycle through b0 (its K loop; the persistent tile loop's cycle is far longer): BFS with predecessors
                 prev, frontier = {}, [b0]
                 found = None
@@ -167,11 +168,12 @@ def test_no_spills_in_the_16_bit_kernels(src, pattern, gemm_kernels, tmp_path):
                 while u != b0:
                     cyc.append(u)
                     u = prev[u]
-                if len(cyc) > 24:                                                # only the tile loop goes through this block: a peeled K-step, executed once per tile
+                if len(cyc) > 100 or not all("Depth=2" in " ".join(body[heads[b]:heads[b] + 3]) for b in cyc):   # only the (depth-1) tile loop goes through this block: a peeled K-step, executed once per tile
                     continue
                 loops.add(frozenset(cyc))
                 assert not any(has_scratch[b] for b in cyc), (name, "scratch traffic inside a K loop", [body[heads[b]] for b in cyc if b])
-            assert len(loops) >= 4, (name, len(loops))                          # two wave groups x two phases
+            assert len(loops) >= 3, (name, len(loops))                          # the 16-bit loops of the two wave groups + the second pass's common loop
+            assert any(any(n_scale[b] for b in cyc) for cyc in loops), (name, "no K loop of block-scaled MFMAs found")
             continue
         assert meta["vgpr_spills"] == 0 and meta["scratch"] == 0, (name, meta)
     assert seen >= 4
