@@ -291,14 +291,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         // and e2m3 with one E8M0 scale per 32 values delivers what round 4's e4m3 did (profiles/r05_lo_format_emulation.txt: 16,000-entry populations on the
         // trained-like weight sets).  With the MFMAs at a quarter of the 16-bit time the pass is bound by what it moves, so it moves as little as the format allows:
         // the operands come as ready-made LDS images of dense tiles (gemm.hpp: 25 KiB per 256 rows x 128 values instead of the 32 KiB of a byte per value), staged by
-        // lane-linear LDS-DMA copies into a ring of SIX slots (three per operand: every tile is requested two K-steps before its first read), read as one
-        // ds_read_b128 + one ds_read_b64 per fragment plus one scale read per operand and step.
-        // Schedule: a ping-pong of two ROTATED loops (a group reads and consumes a step's fragments inside one iteration: fragments carried over a back edge cost
-        // this kernel its registers), the A group half a step behind the W group:
-        //   interval 2k:     W group reads the fragments of step k, stages W(k+2)  | A group computes step k-1
-        //   interval 2k + 1: W group computes step k                             | A group reads the fragments of step k, stages A(k+2)
-        // (As one lock-step loop -- both groups reading, then both computing -- a step of the padded 32-KiB form took 1.5 us: 0.6 us of fragment reads with the
-        // matrix pipe idle, then 0.7 us of MFMAs with the LDS idle; make ablate_p2.)
+        // lane-linear LDS-DMA copies into a ring of SIX slots (three per operand: every tile is requested two barriers before its first read), read as one
+        // ds_read_b128 + one ds_read_b64 per fragment plus one scale read per operand and step.  The schedule is behind the 16-bit loops ("phase 2, all eight waves
+        // alike"); the forms it replaced -- both wave groups reading, then both computing (1.5 us per step); a half-step-shifted ping-pong of the two groups (1.1 us) --
+        // and what bounds it are in profiles/r05_p2_schedule_study.md.
         typedef int i32x2 __attribute__((ext_vector_type(2)));
         const char* g6A = LO6 ? (const char*)p.A6 + (int64_t)tm * nk6 * F6_TILE_BYTES : nullptr;
         const char* g6W = LO6 ? (const char*)p.W6 + (int64_t)tn * nk6 * F6_TILE_BYTES : nullptr;

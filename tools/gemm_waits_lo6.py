@@ -1,7 +1,8 @@
 """Where a wave's time goes inside one K-step of the compensated GEMM's SECOND pass (gemm.hip phase 2; instrumented + ablation libraries: `make -C blim_amd/csrc ablate_p2`).
 
-Every wave, per step: [column 0: 8 MFMAs] [vmcnt: my LDS-DMA pieces of the next tile] [barrier] [columns 1 - 2: 16 MFMAs, 3 fragment refills, 7 LDS-DMA] [column 3: 8 MFMAs,
-9 fragment refills + scales].  Numbers are s_memtime ticks (10 ns) summed over the pass's K loop of each tile, averaged over tiles; one line per ablation build:
+Every wave, per step: [quadrants A + B: 16 MFMAs, 6 refills from the step's own tile, 3 LDS-DMA] [vmcnt: my LDS-DMA pieces of the next tile] [barrier] [quadrant C: 8 MFMAs,
+2 refills + scales from the next tile, 2 LDS-DMA] [quadrant D: 8 MFMAs, 4 refills, 2 LDS-DMA].  Numbers are shader-clock cycles (s_memtime) summed over the pass's K loop of each tile,
+averaged over tiles; one line per ablation build:
 0 = as shipped, 1 = no MFMAs, 2 = no fragment refills, 3 = no LDS-DMA after the first tiles (1 - 3: timing only, wrong results).
 
     python tools/gemm_waits_lo6.py            # all four builds, each in its own process
@@ -9,7 +10,7 @@ Every wave, per step: [column 0: 8 MFMAs] [vmcnt: my LDS-DMA pieces of the next 
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-names = ("col0", "vmcnt", "barrier", "cols1-2", "col3")
+names = ("qa+qb", "vmcnt", "barrier", "qc", "qd")
 LABEL = {0: "as shipped", 1: "no MFMAs", 2: "no fragment refills", 3: "no LDS-DMA"}
 
 
@@ -34,7 +35,7 @@ def one(v):
         for g in range(2):
             tot = wt[:, g].sum(axis=1).mean()
             parts = wt[:, g].mean(axis=0)
-            line += f"\n   waves {4 * g}-{4 * g + 3}: {tot / (K // 128) * 10:.0f} ns per e2m3 K-step | " + "  ".join(f"{n} {v_ / (K // 128) * 10:.0f}" for n, v_ in zip(names, parts))
+            line += f"\n   waves {4 * g}-{4 * g + 3}: {tot / (K // 128):.0f} cycles per e2m3 K-step | " + "  ".join(f"{n} {v_ / (K // 128):.0f}" for n, v_ in zip(names, parts))
         print(line, flush=True)
         del a, w
 
