@@ -443,7 +443,21 @@ class PairScorer:
     def iter_vtg(self, pairs: np.ndarray, cpn: bool = False):
         """pairs: [P, 2] (video j, text i).  cpn=True: video keys masked -> the score depends on the text only.
         Yields one Plan per engine call, so that packing call k+1 (host) overlaps call k (device)."""
-        pairs = np.asarray(pairs, dtype=np.int64)
+        return self.iter_vtg_jobs([(pairs, cpn)])
+
+    def iter_vtg_jobs(self, jobs):
+        """Several VTG passes -- [(pairs, cpn), ...] -- planned into the SAME engine calls (outputs concatenated in job order): a plan does not know which pass a
+        sequence belongs to (a prior's prompt is its own sequence with the video's positions left out), so a rank's text-block prior rides in the last, partly
+        filled call of its likelihood pass instead of being a latency-bound call of its own (iter_tvg_jobs: the TVG counterpart)."""
+        items, base = [], 0
+        for pairs, cpn in jobs:
+            pairs = np.asarray(pairs, dtype=np.int64)
+            items += self._vtg_items(pairs, bool(cpn), base)
+            base += len(pairs)
+        yield from self._pack_vtg(items)
+
+    def _vtg_items(self, pairs: np.ndarray, cpn: bool, base: int):
+        """Groups of one VTG pass: (video j or None for a prior, its token count, texts, output slots per text), output slot of pair p = base + p."""
         if cpn:
             texts, inv = np.unique(pairs[:, 1], return_inverse=True)
             # the prior masks the video keys but keeps their positions: every video must contribute the same number of tokens,
@@ -456,20 +470,22 @@ class PairScorer:
             for ti, i in enumerate(texts):
                 pre, post, _ = self.vtg_split[int(i)]
                 groups.setdefault((pre.tobytes(), post.tobytes()), []).append(ti)
-            items = [(None, nv, [int(texts[t]) for t in g], [np.nonzero(inv == t)[0] for t in g]) for g in groups.values()]
-        else:
-            order = np.lexsort((pairs[:, 1], pairs[:, 0]))
-            self.expect(pairs[order, 0], False)
-            items = []
-            j_prev, cur = None, None
-            for idx in order:
-                j, i = int(pairs[idx, 0]), int(pairs[idx, 1])
-                pre, post, _ = self.vtg_split[i]
-                key = (j, pre.tobytes(), post.tobytes())
-                if key != j_prev:
-                    cur = (j, None, [], [])
-                    items.append(cur); j_prev = key
-                cur[2].append(i); cur[3].append(np.array([idx]))
+            return [(None, nv, [int(texts[t]) for t in g], [base + np.nonzero(inv == t)[0] for t in g]) for g in groups.values()]
+        order = np.lexsort((pairs[:, 1], pairs[:, 0]))
+        self.expect(pairs[order, 0], False)
+        items = []
+        j_prev, cur = None, None
+        for idx in order:
+            j, i = int(pairs[idx, 0]), int(pairs[idx, 1])
+            pre, post, _ = self.vtg_split[i]
+            key = (j, pre.tobytes(), post.tobytes())
+            if key != j_prev:
+                cur = (j, None, [], [])
+                items.append(cur); j_prev = key
+            cur[2].append(i); cur[3].append(np.array([base + idx]))
+        return items
+
+    def _pack_vtg(self, items):
         # pack groups into super-batches
         st = _PackState(self, "vtg")
         for (j, nv, texts_g, outs_g) in items:
@@ -793,6 +809,10 @@ class PairScorer:
     def vtg_device(self, pairs, cpn=False):
         return self.score_device(self.iter_vtg(pairs, cpn), len(pairs))
 
+    def vtg_jobs_device(self, jobs):
+        """Several VTG passes through shared engine calls (iter_vtg_jobs); scores concatenated in job order."""
+        return self.score_device(self.iter_vtg_jobs(jobs), sum(len(p) for p, _ in jobs))
+
     def tvg_device(self, pairs, cpn=False):
         return self.score_device(self.iter_tvg(pairs, cpn), len(pairs))
 
@@ -1044,7 +1064,18 @@ def evaluation(model, data_loader, device, tokenizer, args):
             return M
 
         own_v = need.copy(); own_v[:vs] = False; own_v[ve:] = False                            # VTG: rows of my videos
-        M_vtg = score_owned("vtg", own_v)
+        prior_mine = None
+        jv_, iv_ = np.nonzero(own_v)
+        if args.cpn and te > ts and len(jv_) and hasattr(scorer, "vtg_jobs_device"):
+            # ... and the v2t prior of my block of texts (below) in the SAME engine calls: at 8 ranks it is one small, latency-bound call of its own otherwise
+            pl_ = np.stack([jv_, iv_], axis=1)
+            tp_ = np.stack([np.zeros(te - ts, dtype=np.int64), np.arange(ts, te, dtype=np.int64)], axis=1)
+            sc = scorer.vtg_jobs_device([(pl_, False), (tp_, True)])
+            stats["pairs_scored"] += len(pl_) + (te - ts)
+            M_vtg = full(Nv, Nt); M_vtg[to_dev(jv_), to_dev(iv_)] = sc[: len(pl_)]
+            prior_mine = sc[len(pl_):]
+        else:
+            M_vtg = score_owned("vtg", own_v)
         mark("vtg")
         M_tvg_T = S_t2v_prior = None
         if finetuned:
@@ -1070,7 +1101,9 @@ def evaluation(model, data_loader, device, tokenizer, args):
         if args.cpn:
             # the v2t prior log P(text | masked video) does not depend on the query video: every rank scores its block of TEXTS once
             mine = torch.full((Nt // W + 1,), -100.0, dtype=torch.float32, device=device)
-            if te > ts:
+            if prior_mine is not None:
+                mine[: te - ts] = prior_mine
+            elif te > ts:
                 tp = np.stack([np.zeros(te - ts, dtype=np.int64), np.arange(ts, te, dtype=np.int64)], axis=1)
                 mine[: te - ts] = scorer.vtg_device(tp, True) if hasattr(scorer, "vtg_device") else \
                     torch.from_numpy(np.asarray(scorer.vtg(tp, True), dtype=np.float32)).to(device)

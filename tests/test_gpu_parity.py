@@ -917,6 +917,14 @@ def test_segmented_tvg_sequences_equal_one_sequence_per_pair():
         both = sc.score(iter(plans), len(pairs) + 20)
         np.testing.assert_array_equal(both[: len(pairs)], sc.tvg(pairs, False))
         np.testing.assert_array_equal(both[len(pairs):], sc.tvg(pairs[:20], True))
+        # ... and the VTG counterpart (a rank's likelihood pass + the prior of its block of texts)
+        vp = np.array([[j, 3] for j in range(5)] + [[j, 5] for j in range(3)] + [[7, 9]])
+        tp = np.array([[0, 3], [0, 5], [0, 7], [0, 9]])
+        plans = list(sc.iter_vtg_jobs([(vp, False), (tp, True)]))
+        assert len(plans) == 1
+        both = sc.score(iter(plans), len(vp) + len(tp))
+        np.testing.assert_array_equal(both[: len(vp)], sc.vtg(vp, False))
+        np.testing.assert_array_equal(both[len(vp):], sc.vtg(tp, True))
     finally:
         model.engine.close()
 
