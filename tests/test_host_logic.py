@@ -217,6 +217,30 @@ def test_tvg_plan_packs_the_candidates_of_a_text_into_segmented_sequences():
     assert plain.batch.own_start is None
 
 
+def test_several_passes_planned_into_the_same_engine_calls():
+    """iter_vtg_jobs / iter_tvg_jobs: a likelihood pass and a prior in ONE plan -- the same sequences as the two separate plans, back to back (token counts, positions,
+    key visibility add up; output slots of the second job follow the first's); a job list that does not fit one call splits and still covers every slot once."""
+    sc, prob = _scorer()
+    for kind, first, second in (("vtg", np.array([[0, 0], [0, 1], [3, 1], [2, 4]]), np.array([[0, 0], [0, 1], [0, 4]])),
+                                ("tvg", np.array([[0, 2], [1, 2], [5, 2], [4, 3]]), np.array([[0, 2], [1, 2], [0, 3]]))):
+        plan_of = sc.plan_vtg if kind == "vtg" else sc.plan_tvg
+        jobs_of = sc.iter_vtg_jobs if kind == "vtg" else sc.iter_tvg_jobs
+        (a,), (b,) = plan_of(first, False), plan_of(second, True)
+        (m,) = list(jobs_of([(first, False), (second, True)]))
+        assert m.n_tokens == a.n_tokens + b.n_tokens and m.n_rows == a.n_rows + b.n_rows and m.n_pairs == a.n_pairs + b.n_pairs
+        assert np.array_equal(m.batch.positions.numpy(), np.concatenate([a.batch.positions.numpy(), b.batch.positions.numpy()]))
+        assert np.array_equal(m.batch.seq_len.numpy(), np.concatenate([a.batch.seq_len.numpy(), b.batch.seq_len.numpy()]))
+        assert np.array_equal(m.batch.pfx_start.numpy()[: a.batch.n_seqs], a.batch.pfx_start.numpy())
+        assert np.array_equal(m.batch.pfx_start.numpy()[a.batch.n_seqs:], b.batch.pfx_start.numpy() + np.where(b.batch.pfx_len.numpy() > 0, a.n_tokens, 0))
+        slots = sorted(int(x) for o in m.out_index for x in o)
+        assert slots == list(range(len(first) + len(second)))
+        assert sorted(int(x) for o in m.out_index[a.n_pairs:] for x in o) == list(range(len(first), len(first) + len(second)))
+    sc.max_tokens = 120
+    pairs = np.array([[j, i] for j in range(6) for i in range(6)])
+    plans = list(sc.iter_tvg_jobs([(pairs, False), (pairs, True)]))
+    assert len(plans) > 1 and sorted(int(x) for p in plans for o in p.out_index for x in o) == list(range(72))
+
+
 def test_plans_split_at_the_token_budget():
     sc, prob = _scorer()
     sc.max_tokens = 150
