@@ -1159,7 +1159,7 @@ def _e2m3_tiles_decode(tiles, n_rows, K, w_side):
     return codes[:n_rows], e8[:n_rows]
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (700, 512, 3584), (512, 256, 18944)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (256, 512, 256), (300, 520, 384), (520, 300, 512), (256, 256, 640), (4096, 4608, 256), (700, 512, 3584), (512, 256, 18944)])   # 1 - 5 K-steps of the second pass (its loop is unrolled by two around a three-slot ring), more tiles than CUs, the decoder's depths
 def test_lo6_gemm_quantiser_and_kernel_vs_numpy(M, N, K):
     """blim_gemm_f16_lo6 = the engine's compensated GEMM: C = hi . W^T on the fp16 MFMA + e2m3(lo) . e2m3(W)^T on the block-scaled MFMA, one kernel, one set of
     accumulators.  (a) the quantiser writes exactly the operand tiles numpy's statement of the rule gives (codes, scale bytes, lane order, zero padding rows), for
