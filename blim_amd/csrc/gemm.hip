@@ -300,22 +300,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
         const char* g6W = LO6 ? (const char*)p.W6 + (int64_t)tn * nk6 * F6_TILE_BYTES : nullptr;
         uint2 sc6a = make_uint2(0, 0);                                // this lane's eight A-side scale bytes of the step (one per 16-row fragment)
         uint32_t sc6w = 0;                                            // ... and its four W-side ones
-        // piece q (0-6) of this wave's share of one operand tile (K-step kd into ring slot `dslot`): six KiB-blocks of e2m3 and a quarter of the scale KiB.
-        // Issued as an asm statement, not through the builtin: while an LDS-DMA the compiler KNOWS about is in flight, its wait-count pass treats it as a pending
-        // access to both memories and answers every LDS-read dependency with s_waitcnt lgkmcnt(0) -- all of a wave's refills awaited in front of every MFMA that
-        // needed one of them.  (So the pass does not count these either: phase 2's vmcnt waits are asm statements too.)
-        const uint32_t lds0 = (uint32_t)(__UINTPTR_TYPE__)(lptr_t)smem;
+        // piece q (0-6) of this wave's share of one operand tile (K-step kd into ring slot `dslot`): six KiB-blocks of e2m3 and a quarter of the scale KiB
+        // (the scale KiB as 16-byte pieces of the first 16 lanes, 256 B per wave: the 4-byte form of the LDS-DMA is tracked by the compiler's wait-count pass as an
+        // LDS store any LDS read may alias, and it put an s_waitcnt vmcnt(0) in front of the next step's fragment reads)
         auto dma6 = [&](int q, int dslot, int kd, bool isW, bool on) __attribute__((always_inline)) {
 #if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 3   // ablation build: only the tiles requested in front of the pass (K-steps 0 - 2) are staged, then it runs on stale tiles
             on = on && kd < 3;
 #endif
             if (on) {
                 const char* g = (isW ? g6W : g6A) + (int64_t)kd * F6_TILE_BYTES;
-                const uint32_t d = lds0 + dslot * F6_TILE_BYTES;
-                uint32_t o16 = (uint32_t)lane * 16u;
+                char* d = smem + dslot * F6_TILE_BYTES;
+                uint32_t o16 = (uint32_t)lane * 16u;                 // (unsigned 32-bit lane offset + scalar base: the saddr + voffset form of the LDS-DMA, as in the 16-bit loop)
                 asm volatile("" : "+v"(o16));
-                if (q < 6) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d + (wg + 4 * q) * 1024), "v"(o16), "s"(g + (wg + 4 * q) * 1024) : "m0");
-                else if (lane < 16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d + 24576 + wg * 256), "v"(o16), "s"(g + 24576 + wg * 256) : "m0");
+                if (q < 6) glds16(g + (wg + 4 * q) * 1024 + o16, d + (wg + 4 * q) * 1024);
+                else if (lane < 16) glds16(g + 24576 + wg * 256 + o16, d + 24576 + wg * 256);
             }
         };
         // one whole operand tile of K-step k into ring slot `slot` (0-5) by the four waves of ONE group: 7 pieces per wave
@@ -389,10 +387,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }
             // last 16-bit interval: this group has nothing left to read while the A group computes from registers, and no wave reads LDS any more
             if constexpr (LO6) {
-                // the second pass's first three K-steps (both operands) are requested HERE, under the A group's last 64 MFMAs.  In front of them an
-                // s_waitcnt vmcnt(0) INSTRUCTION the compiler's wait-count pass models (free: the asm form has just waited): it counts the 16-bit loop's LDS-DMA
-                // (builtins) as pending for ever behind asm waits, and a pending LDS-DMA makes it answer every LDS-read dependency with lgkmcnt(0) (phase 2, below)
-                __builtin_amdgcn_s_waitcnt(0x0F70);
+                // the second pass's first three K-steps (both operands) are requested HERE, under the A group's last 64 MFMAs
                 stage6(0, 0, false); stage6(1, 0, true);
                 if (nk6 > 1) { stage6(2, 1, false); stage6(3, 1, true); }
                 if (nk6 > 2) { stage6(4, 2, false); stage6(5, 2, true); }
@@ -431,7 +426,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_ACC();
                 sa = adv(sa, 2);
             }
-            if constexpr (LO6) __builtin_amdgcn_s_waitcnt(0x0F70);   // (modelled, free: as in the W group above)
         }
         if constexpr (LO6) {
             // ---- phase 2, all eight waves alike.  Every fragment register is refilled IN PLACE between its last MFMA and its next one, and the 32 MFMAs of a step
@@ -447,16 +441,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             // another -- took the same 1.1 us per step as the two-group ping-pong before it: tools/gemm_waits_lo6.py.)
             // Ring: A(k) in slot 2 (k % 3), W(k) in 2 (k % 3) + 1.  Between the barriers of steps k and k+1 the waves request tile k+3 into the slots tile k left
             // (W group: W tiles, A group: A tiles; 7 LDS-DMA per wave).  Tiles 0 - 2 were requested by the W group under the last 16-bit MFMAs.
-            // NO inline asm from here to the end of the pass: behind an asm statement with a memory clobber (the 16-bit loops' s_waitcnt and barrier forms) the
-            // compiler's wait-count pass answered every LDS dependency with s_waitcnt lgkmcnt(0) -- each refill's latency exposed in front of the next MFMA that
-            // needed ANY fragment.  The waits below are s_waitcnt INSTRUCTIONS the pass models (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 |
-            // vmcnt[5:4] << 14), the compiler-level ordering of LDS reads against the barrier is a wavefront-scope fence (no instruction).
-#define P2_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")")   /* (no memory clobber: see above) */
-#define P2_BARRIER()                                                                 \
-            __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): own LDS reads complete */ \
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                       \
-            __builtin_amdgcn_s_barrier();                                                \
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+            // (The compiler's wait-count pass answers every LDS-read dependency of this loop with s_waitcnt lgkmcnt(0): it counts the LDS-DMA builtins as accesses to
+            // both memories and, behind asm waits, as pending for ever.  With the pass's LDS-DMA and vmcnt waits as asm statements and one modelled vmcnt(0) between
+            // the passes it emits counted lgkmcnt(N) waits -- measured +0.7 %, and gone again once every asm request saved and restored M0, which the compiler
+            // reserves for itself: profiles/r05_p2_schedule_study.md.  Kept: the builtins.)
+#define P2_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define P2_BARRIER() PHASE_BARRIER()
             if (grp == 0) {
                 if (nk6 > 2) P2_VMCNT(28);                               // my shares of A(0) W(0) landed
                 else if (nk6 > 1) P2_VMCNT(14);
