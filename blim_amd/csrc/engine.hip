@@ -137,6 +137,7 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     // fp16 engines: the compensated modes' second pass over K runs in e2m3 (gemm.hip, phase 2) unless BLIM_PRECISE_LO6=0 / option "precise_lo6" = 0
     e->lo6 = !e->f8 && cfg->compute_dtype == DT_F16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 && cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480;
     if (getenv("BLIM_PRECISE_LO6") && atoi(getenv("BLIM_PRECISE_LO6")) == 0) e->lo6 = false;
+    if (getenv("BLIM_LO6_FUSED_TILES") && atoi(getenv("BLIM_LO6_FUSED_TILES")) == 0) e->lo6_fuse = false;
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -183,7 +184,7 @@ extern "C" void blim_destroy(blim_engine* e) {
     for (void* p : e->ad_owned) hipFree(p);
     if (e->lm6) hipFree(e->lm6);
     DevBuf* bufs[] = {&e->visual_head3, &e->hs3, &e->vocab3, &e->vocab1, &e->vh3, &e->feats_aug, &e->hid_aug, &e->resid_live, &e->resid, &e->xn, &e->qkv, &e->attn, &e->act, &e->hsel, &e->lse_part, &e->lab_logit, &e->logprob, &e->stage,
-                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale, &e->a6, &e->h6};
+                      &e->proj_tmp, &e->vh, &e->tvg_logits, &e->dense_idx, &e->rope_rows, &e->act_mx, &e->attn_mx, &e->x8, &e->a8, &e->act8, &e->hsel8, &e->rscale, &e->a6, &e->a6b, &e->h6};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& s : e->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     delete e;
@@ -736,6 +737,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     // adapters apart the adapted projections use the augmented weights' images.
     const bool lo6 = e->lo6 && e->precise;
     if (lo6) TRY(ensure(e->a6, f6_tiles_bytes(T, (int)std::max<int64_t>(I, Hq))));
+    const bool fuse6 = lo6 && pm && e->lo6_fuse && (2 * I) % 256 == 0;         // the gate | up epilogue writes the down GEMM's A6 tiles (gemm.hpp: out6) into a second buffer
+    if (fuse6) TRY(ensure(e->a6b, f6_tiles_bytes(T, (int)I)));
     auto attach_lo6 = [&](GemmParams& p, const bf16_t* rows, int64_t ld, int64_t n, int K, const uint8_t* w6) -> int {
         { SpanGuard gq(e, s, TC_QUANT, 0); TRY(launch_f6_tiles(rows + K, ld, n, K, c.compute_dtype, false, (uint8_t*)e->a6.p, s)); }
         p.A6 = (const uint8_t*)e->a6.p; p.W6 = w6; p.K6 = K;
@@ -796,11 +799,11 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
               GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm);
-              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu6)); }
+              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu6)); if (fuse6) p.out6 = (uint8_t*)e->a6b.p; }
               TRY(launch_gemm(EPI_SWIGLU, p, s)); }
             { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * pfm);
               GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pm); p.ldc = H; p.lo_off = 0;
-              if (lo6 && pm) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, n_live, H, I, rl, H); TRY(attach_lo6(p, act, 2 * (int64_t)I, n_live, I, l.wd6)); }
+              if (lo6 && pm) { p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, n_live, H, I, rl, H); if (fuse6) { p.A6 = (const uint8_t*)e->a6b.p; p.W6 = l.wd6; p.K6 = (int)I; } else TRY(attach_lo6(p, act, 2 * (int64_t)I, n_live, I, l.wd6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             *final_resid = rl; *final_is_live = true;
             break;
@@ -831,6 +834,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (lo6 && pm) {
                 p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, T, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I;
                 TRY(attach_lo6(p, xn, 2 * (int64_t)H, T, H, l.wgu6));
+                if (fuse6) p.out6 = (uint8_t*)e->a6b.p;
             }
             TRY(launch_gemm(EPI_SWIGLU, p, s));
         }
@@ -842,7 +846,8 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             p.ldc = H; p.lo_off = 0;
             if (lo6 && pm) {
                 p = gp(c.compute_dtype, act, 2 * (int64_t)I, l.wd, T, H, I, resid, H);
-                TRY(attach_lo6(p, act, 2 * (int64_t)I, T, I, l.wd6));
+                if (fuse6) { p.A6 = (const uint8_t*)e->a6b.p; p.W6 = l.wd6; p.K6 = (int)I; }
+                else TRY(attach_lo6(p, act, 2 * (int64_t)I, T, I, l.wd6));
             }
             TRY(launch_gemm(EPI_RESID, p, s));
         }

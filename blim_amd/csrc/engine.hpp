@@ -96,12 +96,12 @@ struct blim_engine {
     // option "precise_lo6" (fp16 engines): in the compensated modes the second walk over K -- the product with the activations' LO parts -- runs on the block-scaled
     // MFMA with e2m3 operands at four times the 16-bit rate (gemm.hip, phase 2), against e2m3 tile images of the decoder weights and the head, built lazily
     // (finalize_lo6: + 0.78 byte per decoder / head weight, 5.9 GB at 7B)
-    bool lo6 = false, lo6_ready = false;
+    bool lo6 = false, lo6_ready = false, lo6_fuse = true;         // lo6_fuse: the SwiGLU epilogue writes the down GEMM's e2m3 input tiles itself (env BLIM_LO6_FUSED_TILES=0: a pass over its lo rows does)
     uint8_t* lm6 = nullptr;                                      // lm_head (or its augmented copy) as e2m3 tiles; K = lm6_k
     int lm6_k = 0;
     const void* lm6_src = nullptr;                               // the matrix lm6 was derived from
     std::set<const void*> c6_dirty;                              // base matrices (re)placed since their e2m3 image was built
-    DevBuf a6, h6;                                               // e2m3 tile images of the current GEMM input's lo part / of the scored rows' lo parts
+    DevBuf a6, a6b, h6;                                               // e2m3 tile images of the current GEMM input's lo part / of the scored rows' lo parts
     std::set<std::string> merged_pending;                        // after blim_train_merge: the adapted weights that still hold W + s B A (lora_merged stays set until all are re-placed)
     bool lora_merged = false;                                    // blim_train_merge wrote W + (alpha / r) B A into the base weights: adapters apart on top would apply the update twice
     std::vector<void*> aug_owned;                                // the augmented copies + A16 tables (freed on rebuild)

@@ -6,6 +6,7 @@
 // 16 lanes of every ds_read_b128 hardware lane group touch 16 different 4-bank groups.  The permutation is applied on the per-lane
 // global SOURCE address (the LDS-DMA destination is lane-linear).
 #include "gemm.hpp"
+#include "kernels.hpp"
 #include <type_traits>
 
 #define BM 256
@@ -858,6 +859,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             }   // staging by the waves of this pass
             __syncthreads();
             stamp(4);
+            bool lo_as_tiles = false;
+            if constexpr (EPI == EPI_SWIGLU && SPLIT && LO6) {
+                if (p.out6 != nullptr) {
+                    // the lo half of this pass's 128 staged rows as e2m3 operand tiles of the consuming GEMM (gemm.hpp: out6): thread = (row r of a 16-row fragment
+                    // group, one of its four 32-value blocks); a wave's stores cover one group's KiB + half KiB of the image
+                    lo_as_tiles = true;
+                    const int r = tid_e & 15, g = (tid_e >> 4) & 3, fl = tid_e >> 6;            // fl: 4 (staged wm) + mi
+                    const int ls = 64 * (fl >> 2) + 16 * (fl & 3) + r;                          // staged row
+                    const int rl = 128 * (fl >> 2) + 64 * hp + 16 * (fl & 3) + r;               // tile row
+                    F6Block q;
+                    if (row0 + rl < p.M) {
+                        float f[32];
+                        const char* src = smem + LO_OFF + ls * RS + g * 64;
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const uint4 v = *(const uint4*)(src + 16 * c4);
+                            const uint16_t* e16 = (const uint16_t*)&v;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) f[8 * c4 + j] = from16<ODT>(e16[j]);
+                        }
+                        q = e2m3_block(f);
+                    } else { q.d[0] = q.d[1] = q.d[2] = q.d[3] = q.d[4] = q.d[5] = 0u; q.e8 = 0u; }
+                    uint8_t* t = p.out6 + ((int64_t)tm * ntn + tn) * F6_TILE_BYTES;
+                    const int fb = rl >> 4;
+                    *(uint4*)(t + fb * 1536 + g * 256 + r * 16) = make_uint4(q.d[0], q.d[1], q.d[2], q.d[3]);
+                    *(uint2*)(t + fb * 1536 + 1024 + g * 128 + r * 8) = make_uint2(q.d[4], q.d[5]);
+                    t[24576 + ((rl >> 7) * 4 + g) * 128 + (rl & 15) * 8 + ((rl >> 4) & 7)] = (uint8_t)q.e8;
+                }
+            }
             constexpr int LPR = NC * 2 / 16;                      // lanes (16 B each) per output row
             const int n_out = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
             const int oc0 = (EPI == EPI_SWIGLU) ? col0 / 2 : col0;
@@ -908,7 +938,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 for (int i = 0; i < NV; ++i) v[i] = *(const uint4*)(lsrc + i * RPP * RS);
 #pragma unroll
                 for (int i = 0; i < NV; ++i) *(uint4*)(out + (int64_t)tile_row(i * RPP) * p.ldc) = v[i];
-                if constexpr (SPLIT) {                            // ... and the lo tile of the same rows
+                if (SPLIT && !lo_as_tiles) {                      // ... and the lo tile of the same rows
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < NV; ++i) v[i] = *(const uint4*)(lsrc + LO_OFF + i * RPP * RS);
@@ -949,7 +979,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                     }
                 };
                 store8(out, v);
-                if constexpr (SPLIT) store8(out + p.lo_off, *(const uint4*)(smem + LO_OFF + rl * RS + seg * 16));
+                if (SPLIT && !lo_as_tiles) store8(out + p.lo_off, *(const uint4*)(smem + LO_OFF + rl * RS + seg * 16));
                 if constexpr (EPI == EPI_BF16 && !SPLIT) {
                     if (p.swiglu_act != nullptr && (seg & 3) < 2) {      // edge tiles: same rule as above (N = 2 I is a multiple of 32)
                         constexpr int ODT = out16<DT>::value;
@@ -1129,6 +1159,7 @@ int launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
         if (p.a_mx) q.a_mx = p.a_mx + r0;                         // r0 is a whole number of 256-row tiles: the table is tile-major inside a K-step
         if (p.out_mx) q.out_mx = p.out_mx + r0;
         if (p.A6) q.A6 = p.A6 + (r0 / BM) * (int64_t)(p.K6 / 128) * F6_TILE_BYTES;     // tile-major: a chunk is a whole number of 256-row tiles
+        if (p.out6) q.out6 = p.out6 + (r0 / BM) * (int64_t)(p.N / BN) * F6_TILE_BYTES;
         if (p.labels) q.labels = p.labels + r0;
         if (p.lse_part) q.lse_part = p.lse_part + r0 * ntn;
         if (p.label_logit) q.label_logit = p.label_logit + r0;
@@ -1167,6 +1198,7 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     // lo6: the A operand's lo part and W as e2m3 tile images (gemm.hpp)
     ARG_CHECK(!p.A6 || (p.dtype == DT_F16 && p.W6 && p.w_wrap_k == 0 && p.K6 > 0 && p.K6 % 128 == 0 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE)));
     ARG_CHECK(!p.out_mx || (epi == EPI_SWIGLU && p.N % 256 == 0 && p.ldc % 16 == 0));
+    ARG_CHECK(!p.out6 || (epi == EPI_SWIGLU && p.A6 && p.lo_off > 0 && p.N % 256 == 0));
     ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice
     ARG_CHECK(p.lo_off == 0 || epi == EPI_BF16 || epi == EPI_QKV || epi == EPI_SWIGLU);
     ARG_CHECK((int64_t)p.M * p.lda * es < (1ll << 32) && (int64_t)p.N * (p.w_wrap_k > 0 ? p.w_wrap_k : p.K) * es < (1ll << 32));  // 32-bit operand offsets

@@ -69,6 +69,10 @@ struct GemmParams {
     const uint8_t* A6;
     const uint8_t* W6;
     int K6;
+    // EPI_SWIGLU with split (hi | lo) outputs: out6 != nullptr -> the epilogue ALSO writes the lo part of its output as e2m3 operand tiles -- the A6 operand of the
+    // GEMM that consumes it (the tile's 128 output columns are one K-step of that GEMM, so workgroup (tm, tn) writes tile [tm][tn] whole: bit-identical to
+    // launch_f6_tiles on the lo rows) -- and does NOT store the lo half at C + lo_off: the rows' lo parts are neither written nor re-read.  N % 256 == 0.
+    uint8_t* out6;
     int f16_saturate;        // fp16 outputs: saturate to +-65504 instead of +-inf (common.hpp: f16_saturate_on).  engine.hip's gp() sets it; the one
                              // 16-bit GRADIENT store of the trainer clears it (the loss scaler must see an overflow as inf)
     int group_m;             // M-tiles per band of the tile order (8; BLIM_GEMM_GROUP_M)

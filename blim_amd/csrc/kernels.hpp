@@ -51,3 +51,42 @@ int launch_rmsnorm_f8(const float* x, int64_t ldx, int64_t n_rows, int H, const 
 // w_side: the scale table of a W operand (4 fragments per lane) instead of an A operand's (8).
 int launch_f6_tiles(const bf16_t* in, int64_t ld, int64_t n_rows, int K, int dtype, bool w_side, uint8_t* out, hipStream_t s);
 static inline size_t f6_tiles_bytes(int64_t n_rows, int K) { return (size_t)((n_rows + 255) / 256) * (K / 128) * 25600; }
+
+// ---- the e2m3 block quantiser of the "lo6" operand tiles (device code: kernels.hip's tile writer and the SwiGLU epilogue of gemm.hip, which writes the tiles of its
+// own output's lo part)
+__device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e with 2^e >= x (x > 0, finite)
+    int ex; const float m = frexpf(x, &ex);                      // x = m 2^ex, m in [0.5, 1)
+    return m == 0.5f ? ex - 1 : ex;
+}
+// 32 values -> their e2m3 block: six dwords of packed 6-bit codes (value j at bits [6 j, 6 j + 6): sign | 2-bit exponent | 3-bit mantissa, OCP MX: magnitudes
+// m / 8 (exponent 0) and (1 + m / 8) 2^(e - 1), largest 7.5; round to nearest even on that grid) and the E8M0 byte of the block's power-of-two scale -- the smallest
+// 2^s with max|x| 2^-s <= 7.5.  A block that is all zero, or holds an inf / NaN, is stored as zeros (the hi part carries non-finite values through the first pass).
+struct F6Block { uint32_t d[6]; uint32_t e8; };
+__device__ __forceinline__ F6Block e2m3_block(const float (&f)[32]) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(f[j]));
+    F6Block b;
+    const bool live = m > 0.f && m < 3.0e38f;
+    int ex = live ? pow2_exp_ge(m * (1.0f / 7.5f)) : -127;
+    ex = max(-127, min(127, ex));
+    const float inv = live ? ldexpf(1.0f, -ex) : 0.f;
+    b.e8 = (uint32_t)(ex + 127);
+    uint32_t c[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float a = fminf(fabsf(f[j]) * inv, 7.5f);
+        const int bin = a < 2.f ? 0 : a < 4.f ? 1 : 2;                   // step 1/8 below 2 (subnormals and the first binade share it), 1/4 below 4, 1/2 above
+        const int q = (int)rintf(a * (bin == 0 ? 8.f : bin == 1 ? 4.f : 2.f));
+        const int code = min(q + 8 * bin, 31);                             // [0, 16] | 8 + [8, 16] | 16 + [8, 15]: continuous across the binades
+        c[j] = (uint32_t)code | (f[j] < 0.f ? 32u : 0u);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                          // 16 codes = 96 bits = three dwords
+        const uint32_t* k = c + 16 * h;
+        b.d[3 * h + 0] = k[0] | k[1] << 6 | k[2] << 12 | k[3] << 18 | k[4] << 24 | k[5] << 30;
+        b.d[3 * h + 1] = k[5] >> 2 | k[6] << 4 | k[7] << 10 | k[8] << 16 | k[9] << 22 | k[10] << 28;
+        b.d[3 * h + 2] = k[10] >> 4 | k[11] << 2 | k[12] << 8 | k[13] << 14 | k[14] << 20 | k[15] << 26;
+    }
+    return b;
+}

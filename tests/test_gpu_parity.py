@@ -812,6 +812,25 @@ def test_e2m3_second_pass_of_the_compensated_gemms(case, capsys):
     assert 0.0 < max(between.values()) < 1e-4, between
 
 
+def test_swiglu_epilogue_writes_the_same_e2m3_tiles_as_the_pass_over_its_rows(monkeypatch):
+    """Fully compensated fp16 calls: the gate | up GEMM's SwiGLU epilogue writes the lo part of its output straight as the down GEMM's e2m3 operand tiles
+    (GemmParams.out6; the lo half of the rows is neither stored nor re-read).  Same bits as the separate pass over the stored lo rows (BLIM_LO6_FUSED_TILES=0):
+    every score of the six passes, 7B width (I = 18,944: 148 tile columns), ragged last row tile, fused and literal."""
+    got = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("BLIM_LO6_FUSED_TILES", fused)
+        t = _build("wide", layers=2, device_synth=True, dtype="f16")
+        try:
+            t.model.vtg_precise = "full"; t.model.tvg_precise = "full"
+            got[fused] = [_six_passes(t, lit) for lit in (False, True)]
+        finally:
+            t.model.engine.close()
+    for a, b in zip(got["1"], got["0"]):
+        for name in a:
+            assert np.isfinite(a[name][a[name] != -100]).all()
+            np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+
+
 def test_e2m3_weight_images_follow_the_weights():
     """The e2m3 images the compensated modes' second pass reads (option "precise_lo6") are derived state, rebuilt PER MATRIX when its source is replaced in a live engine.
     A stale image would be a SILENT error of ~2^-11 of the weight change -- so: an engine that has already run compensated calls gets another weight set loaded over the first
