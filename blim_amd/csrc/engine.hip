@@ -739,6 +739,12 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     if (lo6) TRY(ensure(e->a6, f6_tiles_bytes(T, (int)std::max<int64_t>(I, Hq))));
     const bool fuse6 = lo6 && pm && e->lo6_fuse && (2 * I) % 256 == 0;         // the gate | up epilogue writes the down GEMM's A6 tiles (gemm.hpp: out6) into a second buffer
     if (fuse6) TRY(ensure(e->a6b, f6_tiles_bytes(T, (int)I)));
+    // ... and the RMSNorm kernels write the tiles of their own output's lo part (kernels.hpp: launch_rmsnorm out6) -- the rows' lo halves are then stored only for
+    // the adapters' rank-r inputs: norm1 -> QKV input when no adapter is apart (with adapters the GEMM input carries their u columns, written after the norm);
+    // norm2 -> gate | up input (no adapters on the MLP)
+    const bool n1_tiles = lo6 && e->lo6_fuse && !G && rmsnorm_can_write_tiles((int)H, H, pf * Hq);
+    const bool n2_tiles = lo6 && pm && e->lo6_fuse && rmsnorm_can_write_tiles((int)H, H, pfm * H);
+    auto attach_lo6_ready = [&](GemmParams& p, int K, const uint8_t* w6) { p.A6 = (const uint8_t*)e->a6.p; p.W6 = w6; p.K6 = K; };
     auto attach_lo6 = [&](GemmParams& p, const bf16_t* rows, int64_t ld, int64_t n, int K, const uint8_t* w6) -> int {
         { SpanGuard gq(e, s, TC_QUANT, 0); TRY(launch_f6_tiles(rows + K, ld, n, K, c.compute_dtype, false, (uint8_t*)e->a6.p, s)); }
         p.A6 = (const uint8_t*)e->a6.p; p.W6 = w6; p.K6 = K;
@@ -749,7 +755,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * Hq, e->precise ? xn + Hq : nullptr));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * Hq, (e->precise && !n1_tiles) ? xn + Hq : nullptr, true, n1_tiles ? (uint8_t*)e->a6.p : nullptr));
             if (G) TRY(adapter_u(e, xn, pf * Hq, e->precise ? Hq : 0, T, H, &e->AD[li].ad[0], &e->AD[li].ad[1], &e->AD[li].ad[2], s));
         }
         {
@@ -758,7 +764,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
                               : gp2(e, xn, Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, qkv, e->qkv_n, e->qkv_n, e->precise);
             if (lo6) {                                                                    // hi part in fp16, lo part in e2m3; [hi | lo] outputs as before
                 p = gp(c.compute_dtype, xn, 2 * Hq, G ? (const void*)e->AD[li].wqkv_aug : (const void*)l.wqkv, T, e->qkv_n, (int)Hq, qkv, 2 * (int64_t)e->qkv_n); p.lo_off = e->qkv_n;
-                TRY(attach_lo6(p, xn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wqkv_aug6 : l.wqkv6));
+                if (n1_tiles) attach_lo6_ready(p, (int)Hq, l.wqkv6); else TRY(attach_lo6(p, xn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wqkv_aug6 : l.wqkv6));
             }
             p.bias = l.bqkv; p.rope_cols = (c.num_heads + c.num_kv_heads) * 128; p.rope_rows = rope_rows; p.rope_stride = round_up(T, 256);
             TRY(launch_gemm(EPI_QKV, p, s));
@@ -795,11 +801,11 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
                          TRY(attach_lo6(p, attn_live, 2 * Hq, n_live, (int)Hq, G ? e->AD[li].wo_aug6 : l.wo6)); }
               TRY(launch_gemm(EPI_RESID, p, s)); }
             { SpanGuard g(e, s, TC_NORM, 0);
-              TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr)); }
+              TRY(launch_rmsnorm(rl, H, nullptr, n_live, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, (pm && !n2_tiles) ? xn + H : nullptr, true, n2_tiles ? (uint8_t*)e->a6.p : nullptr)); }
             // SwiGLU output [n_live, pfm * I]: `act` holds attn_live only until o_proj above has run (stream order), so it is free again here
             { SpanGuard g(e, s, TC_GEMM_GATEUP, 4.0 * tl * H * I * pfm);
               GemmParams p = gp2(e, xn, H, l.wgu, n_live, 2 * I, act, I, I, pm);
-              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I; TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu6)); if (fuse6) p.out6 = (uint8_t*)e->a6b.p; }
+              if (lo6 && pm) { p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, n_live, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I; if (n2_tiles) attach_lo6_ready(p, (int)H, l.wgu6); else TRY(attach_lo6(p, xn, 2 * (int64_t)H, n_live, H, l.wgu6)); if (fuse6) p.out6 = (uint8_t*)e->a6b.p; }
               TRY(launch_gemm(EPI_SWIGLU, p, s)); }
             { SpanGuard g(e, s, TC_GEMM_DOWN, 2.0 * tl * H * I * pfm);
               GemmParams p = gp2(e, act, I, l.wd, n_live, H, rl, H, 0, pm); p.ldc = H; p.lo_off = 0;
@@ -824,7 +830,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (g8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
-            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, pm ? xn + H : nullptr));
+            else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, (pm && !n2_tiles) ? xn + H : nullptr, true, n2_tiles ? (uint8_t*)e->a6.p : nullptr));
         }
         const bool fuse = g8 && d8 && e->f8_fuse;      // fp8: the gate|up epilogue emits e4m3 + one E8M0 scale per (token, 128 outputs) itself
         {
@@ -833,7 +839,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             if (fuse) { p.C = act8; p.ldc = I; p.out_mx = (uint8_t*)e->act_mx.p; p.mx_stride = Tp; }
             if (lo6 && pm) {
                 p = gp(c.compute_dtype, xn, 2 * (int64_t)H, l.wgu, T, 2 * I, H, act, 2 * (int64_t)I); p.lo_off = I;
-                TRY(attach_lo6(p, xn, 2 * (int64_t)H, T, H, l.wgu6));
+                if (n2_tiles) attach_lo6_ready(p, (int)H, l.wgu6); else TRY(attach_lo6(p, xn, 2 * (int64_t)H, T, H, l.wgu6));
                 if (fuse6) p.out6 = (uint8_t*)e->a6b.p;
             }
             TRY(launch_gemm(EPI_SWIGLU, p, s));

@@ -233,13 +233,44 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
 // lanes' partial sums of squares are formed differs.
 template <int DT>
 __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
-                                                           bf16_t* out_bf16, float* out_f32, int64_t n_src, int64_t ldo, bf16_t* out_lo, int saturate) {
+                                                           bf16_t* out_bf16, float* out_f32, int64_t n_src, int64_t ldo, bf16_t* out_lo, int saturate, uint8_t* out6) {
+    // out6: the four rows' lo parts are staged in LDS as 16-bit values and leave as e2m3 operand tiles (below); the grid then covers the rows up to the next
+    // multiple of 256 (zero rows of the last tile)
+    extern __shared__ __attribute__((aligned(16))) char lo_s[];          // [4][H + 8] 16-bit values when out6
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rows) return;
+    const int nc = H / 8;
+    const int64_t lrs = (int64_t)(H + 8) * 2;                            // staged row stride (bytes)
+    char* lrow = lo_s + (threadIdx.x >> 6) * lrs;
+    auto tiles = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        const int nblk = H / 32, nk6 = H / 128;
+        for (int item = threadIdx.x; item < 4 * nblk; item += 256) {
+            const int rw = item & 3, blk = item >> 2;
+            const int64_t row = (int64_t)blockIdx.x * 4 + rw;
+            float f[32];
+            const char* src = lo_s + rw * lrs + blk * 64;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const uint4 v = *(const uint4*)(src + 16 * c4);
+                const uint16_t* e16 = (const uint16_t*)&v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[8 * c4 + j] = from16<DT>(e16[j]);
+            }
+            const F6Block q = e2m3_block(f);
+            const int rl = (int)(row & 255), fb = rl >> 4, rr = rl & 15, g = blk & 3;
+            uint8_t* t = out6 + ((row >> 8) * nk6 + (blk >> 2)) * F6_TILE_BYTES;
+            *(uint4*)(t + fb * 1536 + g * 256 + rr * 16) = make_uint4(q.d[0], q.d[1], q.d[2], q.d[3]);
+            *(uint2*)(t + fb * 1536 + 1024 + g * 128 + rr * 8) = make_uint2(q.d[4], q.d[5]);
+            t[24576 + ((rl >> 7) * 4 + g) * 128 + (rl & 15) * 8 + ((rl >> 4) & 7)] = (uint8_t)q.e8;
+        }
+    };
+    if (r >= n_rows) {
+        if (out6) { for (int c = lane; c < nc; c += 64) *(uint4*)(lrow + 16 * c) = make_uint4(0u, 0u, 0u, 0u); tiles(); }
+        return;
+    }
     if constexpr (DT == DT_F16) { if (saturate) f16_saturate_on(); }
     const int64_t src = rows ? rows[r] : r;
-    const int nc = H / 8;
     if (src < 0 || src >= n_src) {
         const float qnan = __builtin_nanf("");
         const uint32_t q2 = pack2<DT>(qnan, qnan);
@@ -247,7 +278,9 @@ __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(const float* x, int64
             if (out_bf16) *(uint4*)(out_bf16 + r * ldo + 8 * c) = make_uint4(q2, q2, q2, q2);
             if (out_lo) *(uint4*)(out_lo + r * ldo + 8 * c) = make_uint4(0u, 0u, 0u, 0u);
             if (out_f32) { *(float4*)(out_f32 + r * H + 8 * c) = make_float4(qnan, qnan, qnan, qnan); *(float4*)(out_f32 + r * H + 8 * c + 4) = make_float4(qnan, qnan, qnan, qnan); }
+            if (out6) *(uint4*)(lrow + 16 * c) = make_uint4(0u, 0u, 0u, 0u);
         }
+        if (out6) tiles();
         return;
     }
     const float* xr = x + src * ldx;
@@ -272,29 +305,39 @@ __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(const float* x, int64
             const float o[8] = {g0.x * (v[i][0].x * inv), g0.y * (v[i][0].y * inv), g0.z * (v[i][0].z * inv), g0.w * (v[i][0].w * inv),
                                 g1.x * (v[i][1].x * inv), g1.y * (v[i][1].y * inv), g1.z * (v[i][1].z * inv), g1.w * (v[i][1].w * inv)};
             if (out_bf16) *(uint4*)(out_bf16 + r * ldo + 8 * c) = make_uint4(pack2<DT>(o[0], o[1]), pack2<DT>(o[2], o[3]), pack2<DT>(o[4], o[5]), pack2<DT>(o[6], o[7]));
-            if (out_lo) {
+            if (out_lo || out6) {
                 float d[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d[j] = o[j] - from16<DT>(to16<DT>(o[j]));
-                *(uint4*)(out_lo + r * ldo + 8 * c) = make_uint4(pack2<DT>(d[0], d[1]), pack2<DT>(d[2], d[3]), pack2<DT>(d[4], d[5]), pack2<DT>(d[6], d[7]));
+                const uint4 dv = make_uint4(pack2<DT>(d[0], d[1]), pack2<DT>(d[2], d[3]), pack2<DT>(d[4], d[5]), pack2<DT>(d[6], d[7]));
+                if (out_lo) *(uint4*)(out_lo + r * ldo + 8 * c) = dv;
+                if (out6) *(uint4*)(lrow + 16 * c) = dv;
             }
             if (out_f32) { *(float4*)(out_f32 + r * H + 8 * c) = make_float4(o[0], o[1], o[2], o[3]); *(float4*)(out_f32 + r * H + 8 * c + 4) = make_float4(o[4], o[5], o[6], o[7]); }
         }
     }
+    if (out6) tiles();
 }
 static int g_rmsnorm_wide = getenv("BLIM_RMSNORM_WIDE") ? atoi(getenv("BLIM_RMSNORM_WIDE")) : 1;
+bool rmsnorm_can_write_tiles(int H, int64_t ldx, int64_t ldo) {
+    if (ldo == 0) ldo = H;
+    return g_rmsnorm_wide && H % 128 == 0 && H <= 4096 && H > 256 && ldo % 8 == 0 && ldx % 4 == 0;
+}
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
-                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src, int64_t ldo, bf16_t* out_lo, bool saturate) {
+                   bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src, int64_t ldo, bf16_t* out_lo, bool saturate, uint8_t* out6) {
     const int sat = saturate ? 1 : 0;
     if (!rows) n_src = n_rows;
     if (ldo == 0) ldo = H;
     ARG_CHECK(ldo % 4 == 0 && (!out_lo || out_h16));
     ARG_CHECK(x && w && n_rows > 0 && H % 4 == 0 && ldx % 4 == 0 && (out_h16 || out_f32));
+    ARG_CHECK(!out6 || (out_h16 && rmsnorm_can_write_tiles(H, ldx, ldo)));
     const int nv = H / 4;
     const dim3 grid((unsigned)((n_rows + 3) / 4));
     if (g_rmsnorm_wide && H % 8 == 0 && H <= 4096 && H > 256 && ldo % 8 == 0 && ldx % 4 == 0) {
-        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_F16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat);
-        else hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_BF16>), grid, dim3(256), 0, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat);
+        const dim3 grid_w(out6 ? (unsigned)(((n_rows + 255) / 256) * 64) : grid.x);
+        const size_t lds = out6 ? (size_t)4 * (H + 8) * 2 : 0;
+        if (dtype == DT_F16) hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_F16>), grid_w, dim3(256), lds, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat, out6);
+        else hipLaunchKernelGGL((rmsnorm_wide_kernel<DT_BF16>), grid_w, dim3(256), lds, s, x, ldx, rows, n_rows, H, w, eps, out_h16, out_f32, n_src, ldo, out_lo, sat, out6);
         LAUNCH_CHECK("rmsnorm");
         return BLIM_OK;
     }

@@ -22,7 +22,10 @@ int launch_zero_rows(bf16_t* x, int64_t ld, const uint8_t* keep, int64_t n_rows,
 int launch_rmsnorm(const float* x, int64_t ldx, const int32_t* rows, int64_t n_rows, int H, const float* w, float eps,
                    bf16_t* out_h16, int dtype, float* out_f32, hipStream_t s, int64_t n_src = 0,    // n_src: valid source rows when `rows` gathers
                    int64_t ldo = 0, bf16_t* out_lo = nullptr,    // ldo: row stride of out_h16 / out_lo (0 = H); out_lo: compensated mode, lo = 16-bit(x - f32(hi))
-                   bool saturate = true);                        // fp16 stores saturate at +-65504 (scoring path); false: overflow to inf (the trainer: its loss scaler must see it)
+                   bool saturate = true,                         // fp16 stores saturate at +-65504 (scoring path); false: overflow to inf (the trainer: its loss scaler must see it)
+                   uint8_t* out6 = nullptr);                     // the lo parts ALSO (or, with out_lo == nullptr, ONLY) as the e2m3 operand tiles of the consuming GEMM (gemm.hpp: A6; bit-identical
+                                                                 // to launch_f6_tiles on the lo rows, rows up to the next multiple of 256 zero-filled); needs rmsnorm_can_write_tiles(...)
+bool rmsnorm_can_write_tiles(int H, int64_t ldx, int64_t ldo);   // (the wide kernel's shapes: H % 128 == 0, 256 < H <= 4096)
 
 // mean over groups of `group` consecutive rows: out[i,:] = mean_j in[i*group + j, :]   (16-bit in/out, f32 accumulate)
 int launch_group_mean(bf16_t* out, const bf16_t* in, int64_t n_out, int group, int H, int dtype, hipStream_t s, bool split = false);
