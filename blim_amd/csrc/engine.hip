@@ -138,6 +138,7 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     e->lo6 = !e->f8 && cfg->compute_dtype == DT_F16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 && cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480;
     if (getenv("BLIM_PRECISE_LO6") && atoi(getenv("BLIM_PRECISE_LO6")) == 0) e->lo6 = false;
     if (getenv("BLIM_LO6_FUSED_TILES") && atoi(getenv("BLIM_LO6_FUSED_TILES")) == 0) e->lo6_fuse = false;
+    if (getenv("BLIM_LO6_FUSED_MASK")) e->lo6_fuse_mask = atoi(getenv("BLIM_LO6_FUSED_MASK"));
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
     e->qkv_n = (cfg->num_heads + 2 * cfg->num_kv_heads) * 128;
     e->L.resize(cfg->num_layers);
@@ -737,13 +738,13 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     // adapters apart the adapted projections use the augmented weights' images.
     const bool lo6 = e->lo6 && e->precise;
     if (lo6) TRY(ensure(e->a6, f6_tiles_bytes(T, (int)std::max<int64_t>(I, Hq))));
-    const bool fuse6 = lo6 && pm && e->lo6_fuse && (2 * I) % 256 == 0;         // the gate | up epilogue writes the down GEMM's A6 tiles (gemm.hpp: out6) into a second buffer
+    const bool fuse6 = lo6 && pm && e->lo6_fuse && (e->lo6_fuse_mask & 1) && (2 * I) % 256 == 0;         // the gate | up epilogue writes the down GEMM's A6 tiles (gemm.hpp: out6) into a second buffer
     if (fuse6) TRY(ensure(e->a6b, f6_tiles_bytes(T, (int)I)));
     // ... and the RMSNorm kernels write the tiles of their own output's lo part (kernels.hpp: launch_rmsnorm out6) -- the rows' lo halves are then stored only for
     // the adapters' rank-r inputs: norm1 -> QKV input when no adapter is apart (with adapters the GEMM input carries their u columns, written after the norm);
     // norm2 -> gate | up input (no adapters on the MLP)
-    const bool n1_tiles = lo6 && e->lo6_fuse && !G && rmsnorm_can_write_tiles((int)H, H, pf * Hq);
-    const bool n2_tiles = lo6 && pm && e->lo6_fuse && rmsnorm_can_write_tiles((int)H, H, pfm * H);
+    const bool n1_tiles = lo6 && e->lo6_fuse && (e->lo6_fuse_mask & 2) && !G && rmsnorm_can_write_tiles((int)H, H, pf * Hq);
+    const bool n2_tiles = lo6 && pm && e->lo6_fuse && (e->lo6_fuse_mask & 2) && rmsnorm_can_write_tiles((int)H, H, pfm * H);
     auto attach_lo6_ready = [&](GemmParams& p, int K, const uint8_t* w6) { p.A6 = (const uint8_t*)e->a6.p; p.W6 = w6; p.K6 = K; };
     auto attach_lo6 = [&](GemmParams& p, const bf16_t* rows, int64_t ld, int64_t n, int K, const uint8_t* w6) -> int {
         { SpanGuard gq(e, s, TC_QUANT, 0); TRY(launch_f6_tiles(rows + K, ld, n, K, c.compute_dtype, false, (uint8_t*)e->a6.p, s)); }
@@ -778,7 +779,6 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * Hq; a.scale = 0.08838834764831845f;
             a.v_lo_off = pf == 2 ? e->qkv_n : 0; a.out_lo_off = pf == 2 ? Hq : 0;
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
-            if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
             if (e->masked_query_zero) TRY(launch_zero_rows(attn, (int64_t)pf * Hq, b->key_visible, T, (int)(pf * Hq), s));
         }

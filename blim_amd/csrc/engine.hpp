@@ -96,7 +96,7 @@ struct blim_engine {
     // option "precise_lo6" (fp16 engines): in the compensated modes the second walk over K -- the product with the activations' LO parts -- runs on the block-scaled
     // MFMA with e2m3 operands at four times the 16-bit rate (gemm.hip, phase 2), against e2m3 tile images of the decoder weights and the head, built lazily
     // (finalize_lo6: + 0.78 byte per decoder / head weight, 5.9 GB at 7B)
-    bool lo6 = false, lo6_ready = false, lo6_fuse = true;         // lo6_fuse: the SwiGLU epilogue writes the down GEMM's e2m3 input tiles itself (env BLIM_LO6_FUSED_TILES=0: a pass over its lo rows does)
+    bool lo6 = false, lo6_ready = false, lo6_fuse = true; int lo6_fuse_mask = 3;   // mask (debug, env BLIM_LO6_FUSED_MASK): 1 SwiGLU epilogue, 2 RMSNorm         // lo6_fuse: the SwiGLU epilogue writes the down GEMM's e2m3 input tiles itself (env BLIM_LO6_FUSED_TILES=0: a pass over its lo rows does)
     uint8_t* lm6 = nullptr;                                      // lm_head (or its augmented copy) as e2m3 tiles; K = lm6_k
     int lm6_k = 0;
     const void* lm6_src = nullptr;                               // the matrix lm6 was derived from

@@ -65,25 +65,32 @@ __device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e w
 // m / 8 (exponent 0) and (1 + m / 8) 2^(e - 1), largest 7.5; round to nearest even on that grid) and the E8M0 byte of the block's power-of-two scale -- the smallest
 // 2^s with max|x| 2^-s <= 7.5.  A block that is all zero, or holds an inf / NaN, is stored as zeros (the hi part carries non-finite values through the first pass).
 struct F6Block { uint32_t d[6]; uint32_t e8; };
+// the block's scale from its largest magnitude: E8M0 byte (return value) and 2^-s (inv; 0 for an all-zero or non-finite block)
+__device__ __forceinline__ uint32_t e2m3_scale(float m, float& inv) {
+    const bool live = m > 0.f && m < 3.0e38f;
+    int ex = live ? pow2_exp_ge(m * (1.0f / 7.5f)) : -127;
+    ex = max(-127, min(127, ex));
+    inv = live ? ldexpf(1.0f, -ex) : 0.f;
+    return (uint32_t)(ex + 127);
+}
+// one value's 6-bit code under that scale
+__device__ __forceinline__ uint32_t e2m3_code(float f, float inv) {
+    const float a = fminf(fabsf(f) * inv, 7.5f);
+    const int bin = a < 2.f ? 0 : a < 4.f ? 1 : 2;                       // step 1/8 below 2 (subnormals and the first binade share it), 1/4 below 4, 1/2 above
+    const int q = (int)rintf(a * (bin == 0 ? 8.f : bin == 1 ? 4.f : 2.f));
+    const int code = min(q + 8 * bin, 31);                                 // [0, 16] | 8 + [8, 16] | 16 + [8, 15]: continuous across the binades
+    return (uint32_t)code | (f < 0.f ? 32u : 0u);
+}
 __device__ __forceinline__ F6Block e2m3_block(const float (&f)[32]) {
     float m = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(f[j]));
     F6Block b;
-    const bool live = m > 0.f && m < 3.0e38f;
-    int ex = live ? pow2_exp_ge(m * (1.0f / 7.5f)) : -127;
-    ex = max(-127, min(127, ex));
-    const float inv = live ? ldexpf(1.0f, -ex) : 0.f;
-    b.e8 = (uint32_t)(ex + 127);
+    float inv;
+    b.e8 = e2m3_scale(m, inv);
     uint32_t c[32];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const float a = fminf(fabsf(f[j]) * inv, 7.5f);
-        const int bin = a < 2.f ? 0 : a < 4.f ? 1 : 2;                   // step 1/8 below 2 (subnormals and the first binade share it), 1/4 below 4, 1/2 above
-        const int q = (int)rintf(a * (bin == 0 ? 8.f : bin == 1 ? 4.f : 2.f));
-        const int code = min(q + 8 * bin, 31);                             // [0, 16] | 8 + [8, 16] | 16 + [8, 15]: continuous across the binades
-        c[j] = (uint32_t)code | (f[j] < 0.f ? 32u : 0u);
-    }
+    for (int j = 0; j < 32; ++j) c[j] = e2m3_code(f[j], inv);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                                          // 16 codes = 96 bits = three dwords
         const uint32_t* k = c + 16 * h;

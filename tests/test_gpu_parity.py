@@ -812,10 +812,11 @@ def test_e2m3_second_pass_of_the_compensated_gemms(case, capsys):
     assert 0.0 < max(between.values()) < 1e-4, between
 
 
-def test_swiglu_epilogue_writes_the_same_e2m3_tiles_as_the_pass_over_its_rows(monkeypatch):
-    """Fully compensated fp16 calls: the gate | up GEMM's SwiGLU epilogue writes the lo part of its output straight as the down GEMM's e2m3 operand tiles
-    (GemmParams.out6; the lo half of the rows is neither stored nor re-read).  Same bits as the separate pass over the stored lo rows (BLIM_LO6_FUSED_TILES=0):
-    every score of the six passes, 7B width (I = 18,944: 148 tile columns), ragged last row tile, fused and literal."""
+def test_producers_write_the_same_e2m3_tiles_as_the_pass_over_their_rows(monkeypatch):
+    """Fully compensated fp16 calls: the kernels that PRODUCE a compensated GEMM's input write the lo part of their output straight as that GEMM's e2m3 operand
+    tiles -- RMSNorm (QKV and gate | up inputs), the gate | up GEMM's SwiGLU epilogue (down input) -- and the lo halves of
+    those rows are neither stored nor re-read.  Same bits as the separate pass over stored lo rows (BLIM_LO6_FUSED_TILES=0): every score of the six passes, 7B
+    width (I = 18,944: 148 tile columns), ragged last row tiles, fused and literal."""
     got = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("BLIM_LO6_FUSED_TILES", fused)
