@@ -779,6 +779,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
             a.blk_seq = b->blk_seq; a.blk_q0 = b->blk_q0; a.own_start = b->own_start; a.n_blocks = b->n_blocks; a.out = attn; a.ldo = (int64_t)pf * Hq; a.scale = 0.08838834764831845f;
             a.v_lo_off = pf == 2 ? e->qkv_n : 0; a.out_lo_off = pf == 2 ? Hq : 0;
             a.out8 = nullptr; a.ldo8 = 0; a.out_mx = nullptr; a.mx_stride = 0; a.lse_out = nullptr;
+            if (o8 && e->f8_fuse) { a.out8 = a8; a.ldo8 = H; a.out_mx = (uint8_t*)e->attn_mx.p; a.mx_stride = Tp; }   // fp8: e4m3 + E8M0 per (token, head)
             TRY(launch_attention(a, e->attn_tr, s));
             if (e->masked_query_zero) TRY(launch_zero_rows(attn, (int64_t)pf * Hq, b->key_visible, T, (int)(pf * Hq), s));
         }
