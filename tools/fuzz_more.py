@@ -10,6 +10,8 @@ from blim_amd.modeling import BlimModel, DDPLike
 from oracle import blim_oracle as O
 
 D = dict(vocab_size=151700, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, mm_hidden_size=64)
+if os.environ.get("BLIM_FUZZ_DIMS") == "h512":      # wide enough for the RMSNorm kernel that writes e2m3 tiles (H > 256), 2 I a multiple of 256 (SwiGLU-written tiles), 9 and 4 second-pass K-steps
+    D = dict(vocab_size=151700, hidden_size=512, intermediate_size=1152, num_layers=2, num_heads=4, num_kv_heads=2, mm_hidden_size=64)
 PASSES = [("v2t", "vtg", False), ("v2t", "vtg", True), ("v2t", "tvg", False), ("t2v", "vtg", False), ("t2v", "tvg", False), ("t2v", "tvg", True)]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
