@@ -609,6 +609,16 @@ extern "C" int blim_reserve(blim_engine* e, int64_t max_tokens, int64_t max_rows
     ARG_CHECK(e && max_tokens >= 0 && max_rows >= 0);
     if (max_tokens) TRY(reserve_tokens(e, max_tokens));
     if (max_rows) TRY(reserve_rows(e, max_rows));
+    // compensated calls of a "precise_lo6" engine need the weights' e2m3 images (+0.78 B per decoder / head weight) and two tile workspaces: with the weights in place
+    // and the compensated mode on they are built HERE -- a shortage of device memory is this call's BLIM_ERR_NOMEM (the matrix named), not a scoring call's
+    if (e->lo6 && e->precise && blim_weights_ready(e) == BLIM_OK) {
+        TRY(finalize_lo6(e));
+        if (max_tokens) {
+            const int64_t Hq = e->c.hidden_size + e->aug;
+            TRY(ensure(e->a6, f6_tiles_bytes(max_tokens, (int)std::max<int64_t>(e->c.intermediate_size, Hq))));
+            if (e->lo6_fuse) TRY(ensure(e->a6b, f6_tiles_bytes(max_tokens, e->c.intermediate_size)));
+        }
+    }
     return BLIM_OK;
 }
 
