@@ -308,6 +308,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 #if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 3   // ablation build: only the tiles requested in front of the pass (K-steps 0 - 2) are staged, then it runs on stale tiles
             on = on && kd < 3;
 #endif
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 >= 4   // ablation builds (round 6, profiles/r06_lo4_bound.md): the bytes of an e2m1 image instead of an e2m3 one (17 of 25 KiB: pieces 4, 5 not
+            on = on && !((q == 4 || q == 5) && (isW || GEMM_ABLATE_P2 == 5));   // requested, fragments read as ONE ds_read_b128) -- 4 = the W operand, 5 = both.  Timing only, wrong results
+#endif
             if (on) {
                 const char* g = (isW ? g6W : g6A) + (int64_t)kd * F6_TILE_BYTES;
                 char* d = smem + dslot * F6_TILE_BYTES;
@@ -328,6 +331,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             const i32x2 h = *(const i32x2*)(qb + off);
             return (i32x8){l[0], l[1], l[2], l[3], h[0], h[1], 0, 0};
         };
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 >= 4
+        auto rd6_4 = [&](const char* qa, const char* qb, int off) __attribute__((always_inline)) {
+            const i32x4 l = *(const i32x4*)(qa + off);
+            return (i32x8){l[0], l[1], l[2], l[3], l[0], l[1], 0, 0};
+        };
+#define RD6W rd6_4
+#if GEMM_ABLATE_P2 == 5
+#define RD6A rd6_4
+#else
+#define RD6A rd6
+#endif
+#else
+#define RD6W rd6
+#define RD6A rd6
+#endif
         // (scales read through ext-vector types like the fragments: behind loads typed uint32_t / uint2 the compiler's wait-count pass put an s_waitcnt vmcnt(0) --
         // every outstanding LDS-DMA -- in front of each step's fragment reads)
         typedef int i32x1 __attribute__((ext_vector_type(1)));
@@ -457,9 +475,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             const int qoa = 8 * wm * 1536 + lane * 16, qoa8 = 8 * wm * 1536 + 1024 + lane * 8;       // this lane's byte offsets inside an A / a W tile image
             const int qob = F6_TILE_BYTES + 4 * wn * 1536 + lane * 16, qob8 = F6_TILE_BYTES + 4 * wn * 1536 + 1024 + lane * 8;
             sc6w = rd6_sw(smem + F6_TILE_BYTES); sc6a = rd6_sa(smem);
-            fb8[0] = rd6(smem + qob, smem + qob8, 0); fb8[1] = rd6(smem + qob, smem + qob8, 1536);
+            fb8[0] = RD6W(smem + qob, smem + qob8, 0); fb8[1] = RD6W(smem + qob, smem + qob8, 1536);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa8[i] = rd6(smem + qoa, smem + qoa8, i * 1536);
+            for (int i = 0; i < 4; ++i) fa8[i] = RD6A(smem + qoa, smem + qoa8, i * 1536);
             int s3 = 0;                                                  // k % 3
 #ifdef GEMM_WAIT_PROF   // (instrumented build: the sums below are phase 2's alone -- QA + QB | vmcnt | barrier | QC | QD)
             for (int q_ = 0; q_ < 5; ++q_) wp_acc[q_] = 0;
@@ -488,17 +506,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_T(0);
                 __builtin_amdgcn_s_setprio(1);
                 // QA
-                L6_MMA(0, CA) L6_SB(); if (own) fb8[CB] = rd6(t0 + qob, t0 + qob8, CB * 1536); L6_SB();
+                L6_MMA(0, CA) L6_SB(); if (own) fb8[CB] = RD6W(t0 + qob, t0 + qob8, CB * 1536); L6_SB();
                 L6_MMA(1, CA) L6_SB(); dma6(4, d2, k + 2, isW, on2); L6_SB();
-                L6_MMA(2, CA) L6_SB(); if (own) fb8[CB + 1] = rd6(t0 + qob, t0 + qob8, (CB + 1) * 1536); L6_SB();
+                L6_MMA(2, CA) L6_SB(); if (own) fb8[CB + 1] = RD6W(t0 + qob, t0 + qob8, (CB + 1) * 1536); L6_SB();
                 L6_MMA(3, CA) L6_SB();
-                L6_MMA(0, CA + 1) L6_SB(); if (own) fa8[4] = rd6(t0 + qoa, t0 + qoa8, 4 * 1536); L6_SB();
+                L6_MMA(0, CA + 1) L6_SB(); if (own) fa8[4] = RD6A(t0 + qoa, t0 + qoa8, 4 * 1536); L6_SB();
                 L6_MMA(1, CA + 1) L6_SB(); dma6(5, d2, k + 2, isW, on2); L6_SB();
-                L6_MMA(2, CA + 1) L6_SB(); if (own) fa8[5] = rd6(t0 + qoa, t0 + qoa8, 5 * 1536); L6_SB();
+                L6_MMA(2, CA + 1) L6_SB(); if (own) fa8[5] = RD6A(t0 + qoa, t0 + qoa8, 5 * 1536); L6_SB();
                 L6_MMA(3, CA + 1) L6_SB();
                 // QB
-                L6_MMA(0, CB) L6_SB(); if (own) fa8[6] = rd6(t0 + qoa, t0 + qoa8, 6 * 1536); L6_SB();
-                L6_MMA(1, CB) L6_SB(); if (own) fa8[7] = rd6(t0 + qoa, t0 + qoa8, 7 * 1536); L6_SB();
+                L6_MMA(0, CB) L6_SB(); if (own) fa8[6] = RD6A(t0 + qoa, t0 + qoa8, 6 * 1536); L6_SB();
+                L6_MMA(1, CB) L6_SB(); if (own) fa8[7] = RD6A(t0 + qoa, t0 + qoa8, 7 * 1536); L6_SB();
                 L6_MMA(2, CB) L6_SB(); dma6(6, d2, k + 2, isW, on2); L6_SB();
                 L6_MMA(3, CB)
                 L6_MMA(0, CB + 1) L6_MMA(1, CB + 1) L6_MMA(2, CB + 1) L6_MMA(3, CB + 1)
@@ -513,22 +531,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 P2_BARRIER();
                 WP_T(3);
                 // QC
-                L6_MMA(4, CB) L6_SB(); if (rl) fa8[0] = rd6(t1 + qoa, t1 + qoa8, 0); L6_SB();
+                L6_MMA(4, CB) L6_SB(); if (rl) fa8[0] = RD6A(t1 + qoa, t1 + qoa8, 0); L6_SB();
                 L6_MMA(5, CB) L6_SB(); dma6(0, d3, k + 3, isW, on3); L6_SB();
-                L6_MMA(6, CB) L6_SB(); if (rl) fa8[1] = rd6(t1 + qoa, t1 + qoa8, 1536); L6_SB();
+                L6_MMA(6, CB) L6_SB(); if (rl) fa8[1] = RD6A(t1 + qoa, t1 + qoa8, 1536); L6_SB();
                 L6_MMA(7, CB) L6_SB(); dma6(1, d3, k + 3, isW, on3); L6_SB();
                 L6_MMA(4, CB + 1) L6_SB(); if (rl) { sc6w_n = rd6_sw(t1 + F6_TILE_BYTES); sc6a_n = rd6_sa(t1); } L6_SB();
                 L6_MMA(5, CB + 1) L6_MMA(6, CB + 1) L6_MMA(7, CB + 1)
                 L6_SB();
                 WP_T(4);
                 // QD (fw[CB], fw[CB + 1] are free: their refills for the next step go first)
-                if (rl) fb8[CB] = rd6(t1 + qob, t1 + qob8, CB * 1536);
+                if (rl) fb8[CB] = RD6W(t1 + qob, t1 + qob8, CB * 1536);
                 L6_SB();
-                L6_MMA(4, CA) L6_SB(); if (rl) fb8[CB + 1] = rd6(t1 + qob, t1 + qob8, (CB + 1) * 1536); L6_SB();
+                L6_MMA(4, CA) L6_SB(); if (rl) fb8[CB + 1] = RD6W(t1 + qob, t1 + qob8, (CB + 1) * 1536); L6_SB();
                 L6_MMA(5, CA) L6_SB(); dma6(2, d3, k + 3, isW, on3); L6_SB();
-                L6_MMA(6, CA) L6_SB(); if (rl) fa8[2] = rd6(t1 + qoa, t1 + qoa8, 2 * 1536); L6_SB();
+                L6_MMA(6, CA) L6_SB(); if (rl) fa8[2] = RD6A(t1 + qoa, t1 + qoa8, 2 * 1536); L6_SB();
                 L6_MMA(7, CA) L6_SB(); dma6(3, d3, k + 3, isW, on3); L6_SB();
-                L6_MMA(4, CA + 1) L6_SB(); if (rl) fa8[3] = rd6(t1 + qoa, t1 + qoa8, 3 * 1536); L6_SB();
+                L6_MMA(4, CA + 1) L6_SB(); if (rl) fa8[3] = RD6A(t1 + qoa, t1 + qoa8, 3 * 1536); L6_SB();
                 L6_MMA(5, CA + 1) L6_MMA(6, CA + 1) L6_MMA(7, CA + 1)
                 L6_SB();
                 __builtin_amdgcn_s_setprio(0);
@@ -546,6 +564,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 if (k < nk6) step6(k, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
             }
 #undef L6_SB
+#undef RD6W
+#undef RD6A
 #undef P2_BARRIER
 #undef P2_VMCNT
 #undef L6_MMA

@@ -3,7 +3,8 @@
 Every wave, per step: [quadrants A + B: 16 MFMAs, 6 refills from the step's own tile, 3 LDS-DMA] [vmcnt: my LDS-DMA pieces of the next tile] [barrier] [quadrant C: 8 MFMAs,
 2 refills + scales from the next tile, 2 LDS-DMA] [quadrant D: 8 MFMAs, 4 refills, 2 LDS-DMA].  Numbers are shader-clock cycles (s_memtime) summed over the pass's K loop of each tile,
 averaged over tiles; one line per ablation build:
-0 = as shipped, 1 = no MFMAs, 2 = no fragment refills, 3 = no LDS-DMA after the first tiles (1 - 3: timing only, wrong results).
+0 = as shipped, 1 = no MFMAs, 2 = no fragment refills, 3 = no LDS-DMA after the first tiles, 4 / 5 = the W operand / both operands moved and read with the byte count of an
+e2m1 (fp4) image (round 6: an upper bound on what a mixed-format pass could gain) (1 - 5: timing only, wrong results).
 
     python tools/gemm_waits_lo6.py            # all four builds, each in its own process
 """
@@ -11,7 +12,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 names = ("qa+qb", "vmcnt", "barrier", "qc", "qd")
-LABEL = {0: "as shipped", 1: "no MFMAs", 2: "no fragment refills", 3: "no LDS-DMA"}
+LABEL = {0: "as shipped", 1: "no MFMAs", 2: "no fragment refills", 3: "no LDS-DMA", 4: "W operand with an e2m1 image's bytes (17 of 25 KiB)", 5: "both operands with e2m1 bytes"}
 
 
 def one(v):
@@ -44,6 +45,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         one(int(sys.argv[1]))
     else:
-        for v in (0, 1, 2, 3):
+        for v in (0, 1, 2, 3, 4, 5):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], capture_output=True, text=True)
             print(r.stdout if r.returncode == 0 else f"[{v}] failed: {r.stderr[-800:]}", flush=True)
