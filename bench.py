@@ -181,11 +181,13 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
     ddp = DDPLike(model)
 
     peers = {}                                                               # TVG clip features of the W = 1 run: what the all-gather of a real job delivers to each rank
+    agreed = {}                                                              # ... and the numeric modes the W = 1 run's calibration chose: what a real job's ranks agree on
 
     def run(shard):
         args = types.SimpleNamespace(topk=topk, num_clips=dims.num_clips, cpn=True, resume="x", eval=True, dataset="MSRVTT", batch_size_eval=16,
                                      iv2_scores={"v2t": torch.from_numpy(nz(prob.v2t_sims)), "t2v": torch.from_numpy(nz(prob.t2v_sims))},
-                                     max_tokens=32768, dedup=True, shard=shard, keep_tvg_feats=shard is None, peer_tvg_feats=peers if shard is not None else None)
+                                     max_tokens=32768, dedup=True, shard=shard, keep_tvg_feats=shard is None, peer_tvg_feats=peers if shard is not None else None,
+                                     agreed_modes=agreed if (shard is not None and agreed) else None)
         model.clear_cache()
         model.tvg_precise = tvg_precise if model.engine.can_precise else "full"   # "auto" (the driver's default): calibrated by every run, INSIDE its timed region
         if pg:
@@ -198,6 +200,9 @@ def strong_scaling(model, world, rank, dev, n=1000, topk=16, emulate=8, pg=False
         st = args._eval_stats
         if shard is None:
             peers.update(getattr(args, "_tvg_feats", {}))
+            for kind in ("vtg", "tvg"):          # (mode, did the decision need the confirmation sample): an emulated rank measures its block of the same stages and adopts the mode
+                if f"{kind}_precise_table" in st:
+                    agreed[kind] = (st[f"{kind}_precise"], any("confirm" in v for v in st[f"{kind}_precise_table"].values()))
         st["executed_flops_job"] = st.get("executed_flops", 0.0)
         st["executed_flops_lo6_job"] = st.get("executed_flops_lo6", 0.0)
         if pg:
@@ -404,6 +409,7 @@ def main():
         try:
             model.vtg_precise = "full"
             (sc_c, pl_c, _, _), = build_step_plans(model, rank, 1, Q, K)
+            model.engine.reserve(pl_c.n_tokens, pl_c.n_rows, compensated=True)   # the weights' e2m3 images and the tile workspaces: a memory shortage is reported here
             sc_c.run(pl_c)                                        # warm-up: feature rows in the [hi | lo] layout, the e2m3 weight images
             torch.cuda.synchronize(); tc = time.perf_counter()
             for _ in range(3):

@@ -390,7 +390,9 @@ static int finalize_lo6(blim_engine* e) {
         return launch_f6_tiles(w, K, n, K, dt, true, *img, 0);
     };
     for (auto& l : e->L) {
-        TRY(base(&l.wqkv6, l.wqkv, e->qkv_n, H, "q/k/v_proj")); TRY(base(&l.wo6, l.wo, H, H, "o_proj"));
+        // adapters apart: QKV and o_proj read the augmented matrices' images only -- the base images are not built (0.6 GB at 7B and two quantisation passes per layer saved);
+        // their matrices stay in c6_dirty (below), so the images are built once the adapters are cleared
+        if (!e->aug) { TRY(base(&l.wqkv6, l.wqkv, e->qkv_n, H, "q/k/v_proj")); TRY(base(&l.wo6, l.wo, H, H, "o_proj")); }
         TRY(base(&l.wgu6, l.wgu, 2 * (int64_t)I, H, "gate/up_proj")); TRY(base(&l.wd6, l.wd, H, I, "down_proj"));
     }
     if (e->aug) {                         // adapters apart: the adapted projections' augmented weights [W | B_hi | B_lo | 0] (K = H + aug, a multiple of 128)
@@ -419,7 +421,11 @@ static int finalize_lo6(blim_engine* e) {
         e->lm6_src = (const void*)src;
     }
     HIP_TRY(hipDeviceSynchronize());
-    e->c6_dirty.clear();
+    if (e->aug) {                         // (skipped above: still to be derived when the adapters go)
+        std::set<const void*> keep;
+        for (auto& l : e->L) { if (!l.wqkv6 || e->c6_dirty.count((const void*)l.wqkv)) keep.insert((const void*)l.wqkv); if (!l.wo6 || e->c6_dirty.count((const void*)l.wo)) keep.insert((const void*)l.wo); }
+        e->c6_dirty.swap(keep);
+    } else e->c6_dirty.clear();
     e->lo6_ready = true;
     return BLIM_OK;
 }
@@ -711,7 +717,7 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
     TRY(build_aug(e));
     TRY(reserve_tokens(e, T));
     TRY(finalize_f8(e));
-    TRY(finalize_lo6(e));
+    if (e->precise) TRY(finalize_lo6(e));      // (plain calls never read the e2m3 images: a plain-only run -- zero-shot, --vtg_precise none -- neither builds nor allocates them)
     float* resid = (float*)e->resid.p;
     const bool prune = e->prune_last && live_rows && n_live > 0 && n_live <= T - T / 16 && !e->f8;
     if (prune) TRY(ensure(e->resid_live, (size_t)round_up(n_live, 256) * H * 4));
@@ -766,6 +772,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (q8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm1, c.rms_eps, x8, sx, s));
+#ifdef ENGINE_ABLATE_NORMFOLD   // timing-only build (make ablate_normfold; profiles/r06_normfold_bound.md): plain calls skip every RMSNorm pass a residual epilogue could have produced
+            else if (!e->precise && !G && li > 0 && e->lse_part.p) { }
+#endif
             else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm1, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pf * Hq, (e->precise && !n1_tiles) ? xn + Hq : nullptr, true, n1_tiles ? (uint8_t*)e->a6.p : nullptr));
             if (G) TRY(adapter_u(e, xn, pf * Hq, e->precise ? Hq : 0, T, H, &e->AD[li].ad[0], &e->AD[li].ad[1], &e->AD[li].ad[2], s));
         }
@@ -836,11 +845,17 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
                 p = gp(c.compute_dtype, attn, 2 * Hq, G ? (const void*)e->AD[li].wo_aug : (const void*)l.wo, T, H, (int)Hq, resid, H);
                 TRY(attach_lo6(p, attn, 2 * Hq, T, (int)Hq, G ? e->AD[li].wo_aug6 : l.wo6));
             }
+#ifdef ENGINE_ABLATE_NORMFOLD
+            if (!e->precise && !G && !o8 && e->lse_part.p) { p.swiglu_act = (uint16_t*)xn; p.swiglu_act_ld = H; p.col_scale = l.norm2; p.lse_part = (float2*)e->lse_part.p; }
+#endif
             TRY(launch_gemm(EPI_RESID, p, s));
         }
         {
             SpanGuard g(e, s, TC_NORM, 0);
             if (g8) TRY(launch_rmsnorm_f8(resid, H, T, H, l.norm2, c.rms_eps, x8, sx, s));
+#ifdef ENGINE_ABLATE_NORMFOLD
+            else if (!e->precise && !G && e->lse_part.p) { }
+#endif
             else TRY(launch_rmsnorm(resid, H, nullptr, T, H, l.norm2, c.rms_eps, xn, c.compute_dtype, nullptr, s, 0, pfm * H, (pm && !n2_tiles) ? xn + H : nullptr, true, n2_tiles ? (uint8_t*)e->a6.p : nullptr));
         }
         const bool fuse = g8 && d8 && e->f8_fuse;      // fp8: the gate|up epilogue emits e4m3 + one E8M0 scale per (token, 128 outputs) itself
@@ -866,6 +881,9 @@ static int run_layers(blim_engine* e, const blim_batch* b, const void* embeds, h
                 if (fuse6) { p.A6 = (const uint8_t*)e->a6b.p; p.W6 = l.wd6; p.K6 = (int)I; }
                 else TRY(attach_lo6(p, act, 2 * (int64_t)I, T, I, l.wd6));
             }
+#ifdef ENGINE_ABLATE_NORMFOLD
+            if (!e->precise && !G && !d8 && e->lse_part.p && li + 1 < c.num_layers) { p.swiglu_act = (uint16_t*)xn; p.swiglu_act_ld = H; p.col_scale = e->L[li + 1].norm1; p.lse_part = (float2*)e->lse_part.p; }
+#endif
             TRY(launch_gemm(EPI_RESID, p, s));
         }
     }

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
             // the passes it emits counted lgkmcnt(N) waits -- measured +0.7 %, and gone again once every asm request saved and restored M0, which the compiler
             // reserves for itself: profiles/r05_p2_schedule_study.md.  Kept: the builtins.)
 #define P2_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define P2_BARRIER() PHASE_BARRIER()
+#define P2_BARRIER() PHASE_BARRIER()      // = s_waitcnt lgkmcnt(0) + s_barrier: a wave's LDS reads of the tile it leaves have RETURNED before any wave may overwrite its slots
             if (grp == 0) {
                 if (nk6 > 2) P2_VMCNT(28);                               // my shares of A(0) W(0) landed
                 else if (nk6 > 1) P2_VMCNT(14);
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 L6_MMA(0, CB + 1) L6_MMA(1, CB + 1) L6_MMA(2, CB + 1) L6_MMA(3, CB + 1)
                 L6_SB();
                 WP_T(1);
-                // every read of tile k has been requested (and is awaited in front of the barrier).  Tile k+1: my pieces of it were requested two barriers ago --
+                // every read of tile k has been requested (and is awaited in front of the barrier: P2_BARRIER's own lgkmcnt(0)).  Tile k+1: my pieces of it were requested two barriers ago --
                 // only the seven of tile k+2 may stay in flight (k = 0: the W group's fourteen of A(2) W(2))
                 if (k == 0) { if (nk6 > 2) P2_VMCNT(14); else P2_VMCNT(0); }
                 else if (k + 2 < nk6) P2_VMCNT(7);
@@ -1047,6 +1047,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                             const int row = row0 + 128 * h + rl;
                             const float4 v = *(const float4*)(smem + rl * RS + lane * 16);
                             if (row < p.M) *(float4*)((float*)p.C + (int64_t)row * p.ldc + col) = make_float4(o[i].x + (v.x + rb.x), o[i].y + (v.y + rb.y), o[i].z + (v.z + rb.z), o[i].w + (v.w + rb.w));
+#ifdef GEMM_ABLATE_NORMFOLD   // timing-only build (round 6, profiles/r06_normfold_bound.md; results are wrong by construction): what folding the FOLLOWING RMSNorm into this epilogue
+                              // would add to it -- the 16-bit copy of the new residual row times the norm's weight (the next GEMM's A operand) and the row's sum of squares per
+                              // column tile -- with the row scaled by its tile-local rms so that the values downstream keep the magnitudes of normalised activations
+                            if (p.swiglu_act != nullptr && row < p.M) {
+                                const float4 nv = make_float4(o[i].x + (v.x + rb.x), o[i].y + (v.y + rb.y), o[i].z + (v.z + rb.z), o[i].w + (v.w + rb.w));
+                                float ss = nv.x * nv.x + nv.y * nv.y + nv.z * nv.z + nv.w * nv.w;
+#pragma unroll
+                                for (int m_ = 1; m_ < 64; m_ <<= 1) ss += __shfl_xor(ss, m_);
+                                const float r = rsqrtf(ss * (1.0f / 256.0f) + 1e-6f);
+                                const float4 wv = *(const float4*)(p.col_scale + col);
+                                const uint16_t h0 = to16<ODT>(nv.x * wv.x * r), h1 = to16<ODT>(nv.y * wv.y * r), h2 = to16<ODT>(nv.z * wv.z * r), h3 = to16<ODT>(nv.w * wv.w * r);
+                                *(uint2*)(p.swiglu_act + (int64_t)row * p.swiglu_act_ld + col) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+                                if (lane == 0) ((float*)p.lse_part)[(int64_t)row * ntn + tn] = ss;
+                            }
+#endif
                         }
                     } else {
 #pragma unroll 1

@@ -63,7 +63,8 @@ __device__ __forceinline__ int pow2_exp_ge(float x) {            // smallest e w
 }
 // 32 values -> their e2m3 block: six dwords of packed 6-bit codes (value j at bits [6 j, 6 j + 6): sign | 2-bit exponent | 3-bit mantissa, OCP MX: magnitudes
 // m / 8 (exponent 0) and (1 + m / 8) 2^(e - 1), largest 7.5; round to nearest even on that grid) and the E8M0 byte of the block's power-of-two scale -- the smallest
-// 2^s with max|x| 2^-s <= 7.5.  A block that is all zero, or holds an inf / NaN, is stored as zeros (the hi part carries non-finite values through the first pass).
+// 2^s with max|x| 2^-s <= 7.5.  A block that is all zero or holds an inf is stored as zeros (codes 0, scale byte 0), and so is every NaN element (the hi part carries
+// non-finite values through the first pass).
 struct F6Block { uint32_t d[6]; uint32_t e8; };
 // the block's scale from its largest magnitude: E8M0 byte (return value) and 2^-s (inv; 0 for an all-zero or non-finite block)
 __device__ __forceinline__ uint32_t e2m3_scale(float m, float& inv) {
@@ -73,8 +74,9 @@ __device__ __forceinline__ uint32_t e2m3_scale(float m, float& inv) {
     inv = live ? ldexpf(1.0f, -ex) : 0.f;
     return (uint32_t)(ex + 127);
 }
-// one value's 6-bit code under that scale
+// one value's 6-bit code under that scale (0 in a block stored as zeros: inv == 0; a NaN beside live values -- the block maximum's fmaxf skips it -- is stored as 0 as well)
 __device__ __forceinline__ uint32_t e2m3_code(float f, float inv) {
+    if (!(f == f) || inv == 0.f) return 0u;
     const float a = fminf(fabsf(f) * inv, 7.5f);
     const int bin = a < 2.f ? 0 : a < 4.f ? 1 : 2;                       // step 1/8 below 2 (subnormals and the first binade share it), 1/4 below 4, 1/2 above
     const int q = (int)rintf(a * (bin == 0 ? 8.f : bin == 1 ? 4.f : 2.f));

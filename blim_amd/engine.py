@@ -278,8 +278,18 @@ class Engine:
     def num_adapters(self) -> int:
         return int(self.lib.blim_num_adapters(self.h))
 
-    def reserve(self, max_tokens: int, max_rows: int):
-        _check(self.lib.blim_reserve(self.h, max_tokens, max_rows), "blim_reserve")
+    def reserve(self, max_tokens: int, max_rows: int, compensated: bool = False):
+        """Pre-size the workspaces.  compensated=True (16-bit engines): size them for compensated calls ([hi | lo] rows) and, on a "precise_lo6" engine, build the weights'
+        e2m3 images and tile workspaces NOW -- a shortage of device memory is this call's error, not a scoring call's (blim.h: blim_reserve looks at the engine's
+        compensated state, which the scoring paths only switch on around each call)."""
+        if compensated and self.can_precise:
+            self.set_precise(True, embeds=True, mlp=True)
+            try:
+                _check(self.lib.blim_reserve(self.h, max_tokens, max_rows), "blim_reserve")
+            finally:
+                self.set_precise(False)
+        else:
+            _check(self.lib.blim_reserve(self.h, max_tokens, max_rows), "blim_reserve")
 
     def set_option(self, key: str, value: int):
         _check(self.lib.blim_set_option(self.h, key.encode(), value), "blim_set_option")

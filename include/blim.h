@@ -119,9 +119,10 @@ int blim_clear_adapters(blim_engine* e);
 /* Number of adapters currently loaded (negative on a NULL engine). */
 int blim_num_adapters(blim_engine* e);
 
-/* Pre-size workspaces (optional; they grow on demand, which synchronises the device).  On an engine in the compensated mode with option "precise_lo6" (and its
- * weights in place) this call also builds the weights' e2m3 images and the tile workspaces: running out of device memory is reported here (BLIM_ERR_NOMEM, the
- * matrix named) instead of inside the first compensated scoring call. */
+/* Pre-size workspaces (optional; they grow on demand, which synchronises the device).  On an engine in the compensated mode (option "precise" = 1 at the time of the
+ * call: blim_amd/engine.py's reserve(compensated=True) brackets the call with it) with option "precise_lo6" and its weights in place, this call also builds the
+ * weights' e2m3 images and the tile workspaces: running out of device memory is reported here (BLIM_ERR_NOMEM, the matrix named) instead of inside the first
+ * compensated scoring call.  Plain calls never build or read the images. */
 int blim_reserve(blim_engine* e, int64_t max_tokens, int64_t max_rows);
 
 /* ---- K1: projector.  feats bf16 [n_rows, mm_hidden] -> out bf16 [n_rows, hidden]; which = 0 `mlp`, 1 `tvg_mlp`.

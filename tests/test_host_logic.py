@@ -485,6 +485,67 @@ def test_predicted_max_deviation_extrapolates_the_samples_tail():
 
 
 
+class _FakeCalScorer:
+    """Stand-in for PairScorer under calibration.CalibrationMixin: vtg() returns a per-pair "true" score, perturbed in the plain mode by a seeded per-pair deviation."""
+
+    def __init__(self, dev_of_pair):
+        from blim_amd.calibration import CalibrationMixin
+        self.__class__ = type("Fake", (_FakeCalScorer, CalibrationMixin), {})
+        self.dev_of_pair, self.mode, self.engine, self.m = dev_of_pair, None, types.SimpleNamespace(can_precise=True), types.SimpleNamespace()
+        self.calls = []
+
+    def set_vtg_mode(self, mode):
+        self.mode = None if mode in (None, "none") else mode
+
+    def vtg(self, pairs, cpn=False):
+        self.calls.append((self.mode, len(pairs)))
+        base = -1.0 - 0.001 * (pairs[:, 0] % 7)
+        return (base if self.mode == "full" else base * (1.0 + self.dev_of_pair(pairs))).astype(np.float64)
+
+
+def test_auto_confirmation_sample_before_an_extrapolated_reject():
+    """calibration.CalibrationMixin._decide (round 6).  A 256-pair sample whose own statistics are inside the bar but whose log-normal tail fit,
+    read off at the 472,000 entries of an ActivityNet-sized evaluation, is not: Gaussian-like deviations (rms 7e-5: the largest of 472,000 is ~ 3.5e-4) used to be sent
+    to the compensated mode by the 2.2 x overshoot of that fit.  Now a confirmation sample (2,048 pairs) is measured first and the tail read from its top eighth:
+    Gaussian-like deviations are ACCEPTED, a genuinely heavy tail (log-normal, sigma 0.9, median 1e-4: the heavy7b law, largest of 48,000 = 3.9e-3) stays REJECTED, a
+    sample that is outside the bar by itself is rejected without the second stage, and an emulated rank (`adopt`) measures the job's stages but takes the job's decision."""
+    from blim_amd import retrieval_utils as RU
+    rng = np.random.RandomState(5)
+    sims = rng.randn(600, 600).astype(np.float32)
+    first = RU.calibration_pairs(sims, 16, n_queries=32, per_query=8)
+    confirm = RU.calibration_pairs(sims, 16, n_queries=256, per_query=8)
+    assert len(first) == 256 and len(confirm) == 2048
+    table_of = lambda law: {(int(a), int(b)): v for (a, b), v in zip(confirm, law(len(confirm)))} | {(int(a), int(b)): v for (a, b), v in zip(first, law(len(first)))}
+    mk = lambda tab: _FakeCalScorer(lambda pairs: np.array([tab[(int(a), int(b))] for a, b in pairs]))
+    # (1) Gaussian-like, rms 7e-5
+    gauss = table_of(lambda n: np.abs(rng.randn(n)) * 7e-5)
+    sc = mk(gauss)
+    chosen, table = sc.calibrate_vtg(first, n_eval=472000, confirm_pairs=confirm)
+    e = table["none"]
+    assert e["max"] < 1e-3 and 4.5 * e["rms"] < 1e-3 and e["pred"] > 8e-4, e                      # stage 1 alone would have rejected (the false reject)
+    assert "confirm" in e and e["confirm"]["n"] >= 2048 and e["confirm"]["pred"] < 8e-4 and e["confirm"]["accepted"], e
+    assert chosen == "none" and sc.mode is None
+    assert sum(n for m, n in sc.calls if m == "full") == e["confirm"]["n"]                        # every measured pair scored once per mode
+    # without a confirmation sample: the old behaviour
+    assert mk(gauss).calibrate_vtg(first, n_eval=472000)[0] == "full"
+    # the same sample at MSRVTT size (48,000 entries) is accepted by stage 1 alone
+    sc = mk(gauss); chosen, table = sc.calibrate_vtg(first, n_eval=48000, confirm_pairs=confirm)
+    assert chosen == "none" and "confirm" not in table["none"]
+    # (2) heavy tail: rejected, with or without the second stage
+    heavy = table_of(lambda n: 1e-4 * np.exp(0.9 * rng.randn(n)))
+    sc = mk(heavy); chosen, table = sc.calibrate_vtg(first, n_eval=48000, confirm_pairs=confirm)
+    assert chosen == "full" and sc.mode == "full", table
+    # (3) a sample outside the bar by itself: no second stage
+    bad = table_of(lambda n: np.abs(rng.randn(n)) * 6e-4)
+    sc = mk(bad); chosen, table = sc.calibrate_vtg(first, n_eval=472000, confirm_pairs=confirm)
+    assert chosen == "full" and "confirm" not in table["none"] and sum(n for m, n in sc.calls if m == "full") == 256
+    # (4) an emulated rank 3 of 8: its block of both stages, the job's decision
+    sc = mk(gauss); chosen, table = sc.calibrate_vtg(first, n_eval=472000, confirm_pairs=confirm, share=(8, 3), adopt=("none", True))
+    assert chosen == "none" and table["none"]["adopted"] == "none" and sum(n for m, n in sc.calls if m == "full") == 256 // 8 + (len(confirm) - len({tuple(p) for p in first} & {tuple(p) for p in confirm})) // 8
+    sc = mk(gauss); chosen, table = sc.calibrate_vtg(first, n_eval=472000, confirm_pairs=confirm, share=(8, 3), adopt=("full", False))
+    assert chosen == "full" and sum(n for m, n in sc.calls if m == "full") == 32
+
+
 def test_auto_numeric_modes_are_requests_and_their_resolution_follows_the_weights():
     """BlimModel keeps what the user ASKED for (vtg_precise / tvg_precise: none | full | auto, attn | full | auto) apart from what `auto` RESOLVED to, and the resolution
     stands only while the engine's weights and adapters are the ones it was measured on (the first evaluation() used to overwrite "auto" with its choice, and

@@ -93,6 +93,67 @@ def test_two_ranks_give_the_single_process_recall_table(tmp_path):
         assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k], b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
 
 
+def _same_npz(a, b, rtol=0.0):
+    assert set(a.files) == set(b.files) and len(a.files) == 8
+    for k in a.files:
+        if rtol:
+            assert np.allclose(a[k], b[k], rtol=rtol, atol=0.0) and np.array_equal(a[k] == -100.0, b[k] == -100.0), k
+            continue
+        assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k], b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
+
+
+@pytest.mark.parametrize("n, extra", [(19, []), (19, ["--no_dedup"]), (5, [])], ids=["N19-short-and-empty-blocks", "N19-six-passes", "N5-fewer-rows-than-ranks"])
+def test_eight_ranks_through_the_real_engine_give_the_single_process_matrices(tmp_path, n, extra):
+    """The 8-rank job the driver's scaling run starts, with the REAL engine in every rank: eight processes on cuda:0 (gloo in place of RCCL so that they can share the
+    device), `--cpn`, both settings of pair ownership.  N = 19 at W = 8 is the reference's `step = N // W + 1 = 3` (retrieval_utils.py:213-215): six blocks of three
+    rows, one of ONE row and an EMPTY one; N = 5: three ranks own nothing at all.  Calibration (`--vtg_precise / --tvg_precise auto`) is sharded over the eight ranks and
+    gathered, the TVG clip features are projected per block and all-gathered, the prior is text-sharded, all matrices merge in one all-gather -- and the recall table
+    and every score matrix must equal the one-process run bit for bit (/root/reference/retrieval_utils.py:213-215, 233-235, 252-262).  `--no_dedup` keeps the reference's
+    six row-sharded passes: there a v2t TVG pair shares its merged sequence (PairScorer._plan_tvg: the candidates of one text, segments of ONE sequence) with whichever
+    other candidates of that text fall into the RANK's row block, so its attention sums associate differently from the one-process run's: equal to 2e-6 relative (observed:
+    8 ulp on one entry), same computed / not-computed pattern, same recall table."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--eval", "--synthetic", str(n), "--cpn", "--resume", "x", "--alpha", "0.4", "0.8", "--c", "0.3", "0.6", "0.9", "0.7", "--topk", "4"] + extra
+    env = dict(os.environ, PYTHONPATH=root)
+    r1 = subprocess.run([sys.executable, "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w1"), "--dump_scores", str(tmp_path / "w1.npz")], cwd=root, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    env8 = dict(env, BLIM_DIST_BACKEND="gloo", BLIM_FORCE_DEVICE="0", OMP_NUM_THREADS="1")
+    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                         "--master-port", str({(19, 0): 29571, (19, 1): 29573, (5, 0): 29575}[(n, len(extra))]), "-m", "blim_amd.main"] + common + ["--output_dir", str(tmp_path / "w8"), "--dump_scores", str(tmp_path / "w8.npz")],
+                        cwd=root, env=env8, capture_output=True, text=True, timeout=900)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    assert "world size 8" in r8.stdout
+    t1, t8 = open(tmp_path / "w1" / "log.txt").read(), open(tmp_path / "w8" / "log.txt").read()
+    assert "blim" in t1 and t1 == t8
+    _same_npz(np.load(tmp_path / "w1.npz"), np.load(tmp_path / "w8.npz"), rtol=2e-6 if extra else 0.0)
+
+
+def test_bench_gpus_8_on_one_gpu_keeps_the_json_contract(tmp_path):
+    """`python bench.py --gpus 8` as the driver's scaling run invokes it -- the parent starts torch.distributed.run with eight ranks -- here with all eight on cuda:0
+    over gloo (the 7B replica is 15 GB: eight fit one MI355X): one JSON line from rank 0, `n_gpus: 8`, whole-job pairs/s = 8 ranks' pairs / the slowest rank's time,
+    weak scaling, the strong-scaling leg's fixed job run by all eight ranks with its collectives."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, BLIM_DIST_BACKEND="gloo", BLIM_FORCE_DEVICE="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--queries", "8", "--strong-n", "96"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
+    assert abs(d["value"] - 8 * d["config"]["pairs_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]        # whole-job aggregate over the 8 ranks
+    assert "cpu_baseline" not in d and "roofline" in d and d["roofline"]["frac"] > 0
+    ss = d["strong_scaling"]
+    assert ss["world"] == 8 and ss["finite"] is True and ss["pairs"] == 6 * 96 * 16 and "emulated_world" not in ss
+
+
 def _rccl_env(root, port):
     """One rank, world size 1, backend nccl (= RCCL) on cuda:0, every collective branch forced (blim_amd/distributed.py:force_collective)."""
     env = dict(os.environ, PYTHONPATH=root, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
