@@ -316,6 +316,8 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed-size N = 1000 evaluation (strong-scaling leg)")
     ap.add_argument("--strong-only", action="store_true", help="only the strong-scaling leg (development aid; prints that object alone)")
     ap.add_argument("--strong-n", type=int, default=1000)
+    ap.add_argument("--leg-timeout", type=int, default=420, help="seconds after which the legs behind the timed steps (strong scaling, compensated mode, CPU baseline) are given up: "
+                                                                 "rank 0 prints the headline line with the timeout recorded in it (0 = no watchdog)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -391,6 +393,87 @@ def main():
     rep = model.engine.timing_report()
     model.engine.timing_enable(False)
 
+    vtg_headline = model.vtg_precise                            # (the compensated leg below switches the model's mode for its own timing)
+
+    def emit(ss, comp, cpu=True):
+        """Rank 0's ONE JSON line (everything in it but `strong_scaling`, `compensated_mode` and `cpu_baseline` was measured above)."""
+        if rank == 0:
+            total_pairs = n_pairs * a.steps * world
+            value = total_pairs / dt
+            # executed GEMM FLOPs of one step (attention excluded, < 1 %): the per-token constants on the packed tokens, the compensated modes' doubled GEMMs,
+            # MINUS the last layer's o_proj / MLP on the rows nobody reads (engine option prune_last: 4,400 of the 32,560 tokens of a step are video-prefix rows)
+            exec_flops_step = RU.executed_flops(dims, n_tok, n_rows, "vtg", vtg_headline, prune=model.engine.dtype != "f8")
+            assert vtg_headline is not None or model.engine.dtype == "f8" or \
+                abs(exec_flops_step - (LAYERS * FLOP_TOKEN_LAYER * n_tok + FLOP_HEAD_ROW * n_rows - (FLOP_TOKEN_LAYER - 2 * H * (H + 2 * 512)) * (n_tok - n_rows))) < 1e6
+            dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
+            d = rep[dom]
+            ach = d["flops"] / d["calls"] / (d["ms"] / d["calls"] * 1e-3) / 1e12
+            peak = PEAK_FP8_TFLOPS if model.engine.dtype == "f8" else PEAK_BF16_TFLOPS
+            # compensated mode on an fp16 engine (option "precise_lo6", default): the second walk over K runs on the e2m3 MFMA -- those flops are priced at the fp6
+            # peak, the rest at the 16-bit one: peak_mixed = flops / (flops16 / P16 + flops6 / P6).  Plain mode (the headline): share 0, nothing changes.
+            lo6 = bool(getattr(model.engine, "lo6", False))
+            lo6_step = RU.lo6_pass_flops(dims, n_tok, n_rows, "vtg", vtg_headline, prune=True) if lo6 else 0.0
+            mixed = lambda total, f6: total / ((total - f6) / PEAK_BF16_TFLOPS + f6 / PEAK_FP6_TFLOPS) if total > 0 else PEAK_BF16_TFLOPS
+            peak_step = mixed(exec_flops_step, lo6_step) if model.engine.dtype != "f8" else peak
+            dom_lo6 = 0.5 if (lo6_step > 0 and rep[dom]["flops"] > 0 and dom != "attention") else 0.0       # fully compensated: half of every GEMM's flops are its second pass
+            if model.engine.dtype != "f8":
+                peak = mixed(1.0, dom_lo6)
+            tr = measured_traffic(dom, model.engine.dtype, compensated=vtg_headline == "full")
+            es = 1 if model.engine.dtype == "f8" else 2
+            alg_bytes = {"gemm_gateup_swiglu": n_tok * H * es + 2 * I * H * es + n_tok * I * 2, "gemm_down_resid": n_tok * I * es + H * I * es + 2 * n_tok * H * 4,
+                         "gemm_qkv_rope": n_tok * H * es + 4608 * H * es + n_tok * 4608 * 2, "gemm_o_resid": n_tok * H * es + H * H * es + 2 * n_tok * H * 4,
+                         "lm_head_lse": n_rows * H * es + V * H * es}.get(dom)
+            out = {
+                "metric": "candidate-pairs/sec (7B, 96+32 tok)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": model.engine.dtype, "data": "synthetic",
+                "config": {"workload": "SYN v2t-VTG re-rank: Qwen2-7B dims (28 layers), seeded synthetic weights, 96 video + 32 text tokens per pair, "
+                                       f"top-{K} text candidates per video query, {Q} queries ({n_pairs} pairs, {n_tok} packed tokens, {n_rows} label rows) per step per GPU",
+                           "prefix_reuse": True, "vtg_compensated": vtg_headline or "none", "pairs_per_step_per_gpu": n_pairs, "tokens_per_step_per_gpu": n_tok,
+                           "parallelism": f"query rows sharded over {world} GPU(s); RCCL all-gather of score rows at the end"},
+                "algorithmic_gflop_per_pair": round(f_pair(128, 32) / 1e9, 1),
+                "executed_gflop_per_pair": round(exec_flops_step / n_pairs / 1e9, 1),
+                "executed_tflops_per_gpu": round(exec_flops_step * a.steps / dt / 1e12, 1),
+                "executed_gflop_per_pair_e2m3": round(lo6_step / n_pairs / 1e9, 1),
+                "frac_mfma_peak_whole_step": round(exec_flops_step * a.steps / dt / 1e12 / peak_step, 4),
+                "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                             "peak_note": None if dom_lo6 == 0.0 else "half of this kernel's flops are the e2m3 second pass of the compensated mode: peak = 2 / (1 / 2500 + 1 / 10000)",
+                             "frac": round(ach / peak, 4), "traffic": tr[0] if tr else None,
+                             "traffic_source": (f"{tr[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 x FETCH_SIZE + WRITE_SIZE, "
+                                                "fabric side of L2, Infinity-Cache hits included); looked up, not re-measured in this run") if tr else None,
+                             "algorithmic_bytes_per_launch": alg_bytes,
+                             "traffic_over_algorithmic": round(tr[0] / alg_bytes, 2) if (tr and alg_bytes) else None,
+                             "avg_launch_ms": round(d["ms"] / d["calls"], 4), "flop_per_launch": d["flops"] / d["calls"]},
+                "kernel_classes_ms": {k: round(v["ms"], 3) for k, v in rep.items() if v["calls"]},
+            }
+            if comp is not None:
+                out["compensated_mode"] = comp
+            if ss is not None:
+                out["strong_scaling"] = ss
+            if cpu and world == 1 and not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+            print(json.dumps(out), flush=True)
+
+    # ---- watchdog: the legs below run AFTER the headline was measured, and the strong-scaling leg is the only part of this file whose collectives have never met more than
+    # one GPU (no multi-GPU box was available to the builder).  Should it hang, every rank leaves after --leg-timeout seconds and rank 0 still prints the headline line
+    # (with the timeout recorded inside it) instead of the launcher's time limit ending the run with nothing.
+    import threading
+    done = threading.Event()
+
+    def on_timeout():
+        if done.is_set():
+            return
+        msg = f"watchdog: the legs after the timed steps did not finish within {a.leg_timeout} s on rank {rank}"
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+        if rank == 0:
+            emit({"error": msg}, None, cpu=False)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0 if rank == 0 else 5)
+    dog = threading.Timer(float(a.leg_timeout), on_timeout)
+    dog.daemon = True
+    if a.leg_timeout > 0:
+        dog.start()
+
     # ---- strong-scaling leg (all ranks): one fixed-size N = 1000 evaluation, after and outside the timed steps above
     ss, ss_failed = None, False
     if not a.no_strong:
@@ -428,62 +511,8 @@ def main():
         finally:
             model.vtg_precise = None
 
-    if rank == 0:
-        total_pairs = n_pairs * a.steps * world
-        value = total_pairs / dt
-        # executed GEMM FLOPs of one step (attention excluded, < 1 %): the per-token constants on the packed tokens, the compensated modes' doubled GEMMs,
-        # MINUS the last layer's o_proj / MLP on the rows nobody reads (engine option prune_last: 4,400 of the 32,560 tokens of a step are video-prefix rows)
-        exec_flops_step = RU.executed_flops(dims, n_tok, n_rows, "vtg", model.vtg_precise, prune=model.engine.dtype != "f8")
-        assert model.vtg_precise is not None or model.engine.dtype == "f8" or \
-            abs(exec_flops_step - (LAYERS * FLOP_TOKEN_LAYER * n_tok + FLOP_HEAD_ROW * n_rows - (FLOP_TOKEN_LAYER - 2 * H * (H + 2 * 512)) * (n_tok - n_rows))) < 1e6
-        dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
-        d = rep[dom]
-        ach = d["flops"] / d["calls"] / (d["ms"] / d["calls"] * 1e-3) / 1e12
-        peak = PEAK_FP8_TFLOPS if model.engine.dtype == "f8" else PEAK_BF16_TFLOPS
-        # compensated mode on an fp16 engine (option "precise_lo6", default): the second walk over K runs on the e2m3 MFMA -- those flops are priced at the fp6
-        # peak, the rest at the 16-bit one: peak_mixed = flops / (flops16 / P16 + flops6 / P6).  Plain mode (the headline): share 0, nothing changes.
-        lo6 = bool(getattr(model.engine, "lo6", False))
-        lo6_step = RU.lo6_pass_flops(dims, n_tok, n_rows, "vtg", model.vtg_precise, prune=True) if lo6 else 0.0
-        mixed = lambda total, f6: total / ((total - f6) / PEAK_BF16_TFLOPS + f6 / PEAK_FP6_TFLOPS) if total > 0 else PEAK_BF16_TFLOPS
-        peak_step = mixed(exec_flops_step, lo6_step) if model.engine.dtype != "f8" else peak
-        dom_lo6 = 0.5 if (lo6_step > 0 and rep[dom]["flops"] > 0 and dom != "attention") else 0.0       # fully compensated: half of every GEMM's flops are its second pass
-        if model.engine.dtype != "f8":
-            peak = mixed(1.0, dom_lo6)
-        tr = measured_traffic(dom, model.engine.dtype, compensated=model.vtg_precise == "full")
-        es = 1 if model.engine.dtype == "f8" else 2
-        alg_bytes = {"gemm_gateup_swiglu": n_tok * H * es + 2 * I * H * es + n_tok * I * 2, "gemm_down_resid": n_tok * I * es + H * I * es + 2 * n_tok * H * 4,
-                     "gemm_qkv_rope": n_tok * H * es + 4608 * H * es + n_tok * 4608 * 2, "gemm_o_resid": n_tok * H * es + H * H * es + 2 * n_tok * H * 4,
-                     "lm_head_lse": n_rows * H * es + V * H * es}.get(dom)
-        out = {
-            "metric": "candidate-pairs/sec (7B, 96+32 tok)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": model.engine.dtype, "data": "synthetic",
-            "config": {"workload": "SYN v2t-VTG re-rank: Qwen2-7B dims (28 layers), seeded synthetic weights, 96 video + 32 text tokens per pair, "
-                                   f"top-{K} text candidates per video query, {Q} queries ({n_pairs} pairs, {n_tok} packed tokens, {n_rows} label rows) per step per GPU",
-                       "prefix_reuse": True, "vtg_compensated": model.vtg_precise or "none", "pairs_per_step_per_gpu": n_pairs, "tokens_per_step_per_gpu": n_tok,
-                       "parallelism": f"query rows sharded over {world} GPU(s); RCCL all-gather of score rows at the end"},
-            "algorithmic_gflop_per_pair": round(f_pair(128, 32) / 1e9, 1),
-            "executed_gflop_per_pair": round(exec_flops_step / n_pairs / 1e9, 1),
-            "executed_tflops_per_gpu": round(exec_flops_step * a.steps / dt / 1e12, 1),
-            "executed_gflop_per_pair_e2m3": round(lo6_step / n_pairs / 1e9, 1),
-            "frac_mfma_peak_whole_step": round(exec_flops_step * a.steps / dt / 1e12 / peak_step, 4),
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "peak_note": None if dom_lo6 == 0.0 else "half of this kernel's flops are the e2m3 second pass of the compensated mode: peak = 2 / (1 / 2500 + 1 / 10000)",
-                         "frac": round(ach / peak, 4), "traffic": tr[0] if tr else None,
-                         "traffic_source": (f"{tr[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 x FETCH_SIZE + WRITE_SIZE, "
-                                            "fabric side of L2, Infinity-Cache hits included); looked up, not re-measured in this run") if tr else None,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "traffic_over_algorithmic": round(tr[0] / alg_bytes, 2) if (tr and alg_bytes) else None,
-                         "avg_launch_ms": round(d["ms"] / d["calls"], 4), "flop_per_launch": d["flops"] / d["calls"]},
-            "kernel_classes_ms": {k: round(v["ms"], 3) for k, v in rep.items() if v["calls"]},
-        }
-        if comp is not None:
-            out["compensated_mode"] = comp
-        if ss is not None:
-            out["strong_scaling"] = ss
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+    done.set(); dog.cancel()
+    emit(ss, comp)
     if ss_failed and pg:
         # a rank that failed inside the leg may have left the others inside one of its collectives: no barrier here (it could never complete).  The failed rank
         # exits non-zero without tearing the group down, so the launcher ends the job instead of hanging; rank 0's line above (if it is the one that failed) says why

@@ -230,6 +230,11 @@ def main(args):
               f"(the rest shared between directions), in {dt:.2f}s = {st.get('pairs_requested', 0) / dt:.0f} pairs/s per process "
               f"(world {st.get('world', world)}, host planning and loading included); executed {fl / 1e12:.1f} TFLOP = {at_peak / dt:.3f} of the MFMA peak; "
               f"device memory in use {(total_b - free_b) / 2**30:.1f} GiB, torch peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+        if st.get("calibration_whole_sample"):
+            # `--shard W r` on its own: nobody to gather the calibration sample from, so this process measured all of it (the decision is the job's); a real rank scores 1 / W
+            cal, Wj = float(st.get("calibration_seconds", 0.0)), int(st.get("world", 1))
+            print(f"calibration: {cal:.2f}s for the job's whole sample (this process has no peers); at a rank's 1/{Wj} share of it the evaluation above takes "
+                  f"{dt - cal * (1.0 - 1.0 / Wj):.2f}s = {st.get('pairs_requested', 0) / (dt - cal * (1.0 - 1.0 / Wj)):.0f} pairs/s per process")
     if args.shard is not None:
         model.engine.close()
         return None                                           # one rank's share: the matrices are partial, no recall table

@@ -259,6 +259,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
                          for k, v in table.items())
 
     mod = model.module
+    t_cal = time.time()
     if getattr(mod, "vtg_precise", None) == "auto":
         # `--vtg_precise auto` (the driver's default): which compensation the VTG calls need is MEASURED on this checkpoint (PairScorer.calibrate_vtg) -- once per set
         # of weights: what an earlier evaluation() resolved stands while the engine's weights and adapters are unchanged (BlimModel.vtg_mode) and is measured again
@@ -303,6 +304,11 @@ def evaluation(model, data_loader, device, tokenizer, args):
             if rank == 0:
                 print("tvg_precise auto: deviation from the fully compensated mode on the calibration pairs, likelihood + prior (max / rms): "
                       + fmt_table(table) + f" -> {chosen}", file=sys.stderr, flush=True)
+    if "vtg_precise_table" in stats or "tvg_precise_table" in stats:
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        stats["calibration_seconds"] = round(time.time() - t_cal, 4)
+        # an emulated rank with no decision handed in measured the job's WHOLE sample (share_of): W times a real rank's share of this time
+        stats["calibration_whole_sample"] = bool(emulate is not None and getattr(args, "agreed_modes", None) is None and W > 1)
     mark("setup")
 
     def run_pass(S, sims_rows, start, query_is_video, ftype, cpn):

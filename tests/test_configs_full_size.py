@@ -8,7 +8,8 @@ seeded synthetic weights and data.  No oracle runs at this size; asserted are th
 every computed entry finite, log P(text i | video j) the SAME number in v2t.candidate_likelihood[j, i] and t2v.query_likelihood[i, j] wherever both directions
 computed it (likewise the TVG pair), the v2t prior independent of the query video, the recall table's shape -- and, since round 6, the numeric modes
 `auto` resolves to on these Gaussian weights (plain VTG calls, `attn` TVG calls: profiles/r06_calibrator_false_rejects.md) and a FLOOR on the pairs/s of each configuration
-(0.85 x the rate measured in round 6 on the slowest box seen; the pool's boxes differ by +-4 %): a 2x throughput regression, or a calibrator that sends these weights to the
+(0.85 x the rate measured in round 6; the pool's boxes differ by +-4 %; the rate is the one with the calibration at a rank's 1 / W share -- a `--shard` process has no
+peers and measures the job's whole calibration sample, main.py prints both figures): a 2x throughput regression, or a calibrator that sends these weights to the
 compensated mode again, turns the suite red.  Prints pairs/s and the executed-FLOP fraction."""
 import os
 import re
@@ -21,7 +22,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 # pairs/s floors = 0.85 x the rates of profiles/r06_gputest_parity_lines.txt (config 4 with plain VTG calls; round 5 ran it compensated at 3,574); see the module docstring
-FLOOR_CONFIG4 = 3038
+FLOOR_CONFIG4 = 3770
 FLOOR_CONFIG3 = 11950
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -34,10 +35,12 @@ def _run(tmp_path, n, topk, shard, extra=()):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     m = re.search(r"evaluation: (\d+) \(query, candidate\) pairs.*?, (\d+) scored by the engine.*?in ([0-9.]+)s = (\d+) pairs/s per process.*?executed ([0-9.]+) TFLOP = ([0-9.]+) of the MFMA peak", r.stdout)
     assert m, r.stdout[-2000:]
+    adj = re.search(r"at a rank's 1/\d+ share of it the evaluation above takes ([0-9.]+)s = (\d+) pairs/s per process", r.stdout)
     d = dict(np.load(dump))
     modes = [l for l in (r.stdout + r.stderr).splitlines() if "_precise auto" in l]
     assert len(modes) == 2, modes                                                                     # both calibrations ran (and printed their tables)
-    return d, dict(pairs=int(m.group(1)), scored=int(m.group(2)), seconds=float(m.group(3)), pairs_per_s=int(m.group(4)), tflop=float(m.group(5)), frac=float(m.group(6))), modes
+    return d, dict(pairs=int(m.group(1)), scored=int(m.group(2)), seconds=float(m.group(3)), pairs_per_s=int(m.group(4)), tflop=float(m.group(5)), frac=float(m.group(6)),
+                   rank_share_pairs_per_s=int(adj.group(2)) if adj else int(m.group(4))), modes
 
 
 def _properties(d, n, block_v, block_t, dense):
@@ -76,9 +79,10 @@ def test_config4_activitynet_size_top32_cpn_ensemble_rank0_of_8(tmp_path, capsys
     assert st["pairs"] == 6 * step * 32 and 0.2 < st["frac"] < 0.7, st
     resolved = {m.split("_precise auto")[0].split()[-1]: m.rsplit("-> ", 1)[-1].strip() for m in modes}
     assert resolved == {"vtg": "none", "tvg": "attn"}, modes                    # Gaussian weights: plain holds over the whole evaluation (0 of 40,000 entries over 1e-3, max 3.4e-4)
-    assert st["pairs_per_s"] >= FLOOR_CONFIG4, (st, FLOOR_CONFIG4)
+    assert st["rank_share_pairs_per_s"] >= FLOOR_CONFIG4, (st, FLOOR_CONFIG4)
     with capsys.disabled():
-        print(f"\n[config 4: N = {n}, top-32, CPN + ensemble, rank 0 of {W}] {st['pairs']} pairs ({st['scored']} scored) in {st['seconds']} s = {st['pairs_per_s']} pairs/s, "
+        print(f"\n[config 4: N = {n}, top-32, CPN + ensemble, rank 0 of {W}] {st['pairs']} pairs ({st['scored']} scored) in {st['seconds']} s = {st['pairs_per_s']} pairs/s "
+              f"({st['rank_share_pairs_per_s']} with the calibration at a rank's share: this process measured the job's whole sample), "
               f"executed {st['tflop']} TFLOP = {st['frac']:.3f} of the MFMA peak; " + " | ".join(m.split(": ", 1)[0] + " -> " + m.rsplit("-> ", 1)[-1] for m in modes))
 
 
@@ -90,7 +94,8 @@ def test_config3_msrvtt_dense_1000x1000_rank0_of_32(tmp_path, capsys):
     assert st["pairs"] == 6 * step * n and 0.2 < st["frac"] < 0.7, st
     resolved = {m.split("_precise auto")[0].split()[-1]: m.rsplit("-> ", 1)[-1].strip() for m in modes}
     assert resolved == {"vtg": "none", "tvg": "attn"}, modes
-    assert st["pairs_per_s"] >= FLOOR_CONFIG3, (st, FLOOR_CONFIG3)
+    assert st["rank_share_pairs_per_s"] >= FLOOR_CONFIG3, (st, FLOOR_CONFIG3)
     with capsys.disabled():
-        print(f"\n[config 3: N = {n} dense (k = N), 1 / {W} of the job] {st['pairs']} pairs ({st['scored']} scored) in {st['seconds']} s = {st['pairs_per_s']} pairs/s, "
+        print(f"\n[config 3: N = {n} dense (k = N), 1 / {W} of the job] {st['pairs']} pairs ({st['scored']} scored) in {st['seconds']} s = {st['pairs_per_s']} pairs/s "
+              f"({st['rank_share_pairs_per_s']} with the calibration at a rank's share: this process measured the job's whole sample), "
               f"executed {st['tflop']} TFLOP = {st['frac']:.3f} of the MFMA peak; " + " | ".join(m.split(": ", 1)[0] + " -> " + m.rsplit("-> ", 1)[-1] for m in modes))
