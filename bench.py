@@ -311,6 +311,8 @@ def main():
     ap.add_argument("--tvg-precise", default="auto", choices=["auto", "attn", "full"],
                     help="strong-scaling leg only (the headline step is a VTG pass): how much of the TVG calls' MLP branch runs compensated; auto = measured on the "
                          "job's own pairs inside the timed region, as main.py's default does (blim_amd/retrieval_utils.py: PairScorer.calibrate_tvg)")
+    ap.add_argument("--second-pass", default=None, choices=["e2m3", "16bit"], help="second walk over K of the compensated calls (default: e2m3 on fp16 engines, 16bit on bf16 engines; "
+                                                                                   "bf16 + e2m3 is the fast form of the bf16 engine's compensated mode)")
     ap.add_argument("--no-compensated", action="store_true", help="skip the extra timing of the same step with fully compensated VTG calls (reported as `compensated_mode`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed-size N = 1000 evaluation (strong-scaling leg)")
@@ -347,6 +349,8 @@ def main():
     model = BlimModel(dims, max_positions=1024, dtype=a.dtype)
     model.engine.init_synthetic_weights(0)                       # torch seed 0 of BASELINE.md -> engine seed 0
     model.vtg_precise = None if (a.vtg_precise == "none" or a.dtype == "f8") else a.vtg_precise
+    if a.second_pass and model.engine.can_precise:
+        model.second_pass = a.second_pass
     if a.strong_only:
         ss = strong_scaling(model, world, rank, dev, n=a.strong_n, topk=a.topk, pg=pg, tvg_precise=a.tvg_precise)
         if rank == 0:

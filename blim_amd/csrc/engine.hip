@@ -134,9 +134,12 @@ extern "C" int blim_create(const blim_config* cfg, blim_engine** out) {
     if (cfg->compute_dtype == BLIM_COMPUTE_F8) { e->f8 = true; e->c.compute_dtype = BLIM_COMPUTE_F16; }
     if (getenv("BLIM_F8_FUSE")) e->f8_fuse = atoi(getenv("BLIM_F8_FUSE"));
     if (getenv("BLIM_PRECISE_MLP")) e->precise_mlp = atoi(getenv("BLIM_PRECISE_MLP")) != 0;
-    // fp16 engines: the compensated modes' second pass over K runs in e2m3 (gemm.hip, phase 2) unless BLIM_PRECISE_LO6=0 / option "precise_lo6" = 0
+    // fp16 engines: the compensated modes' second pass over K runs in e2m3 (gemm.hip, phase 2) unless BLIM_PRECISE_LO6=0 / option "precise_lo6" = 0.  bf16 engines keep the
+    // 16-bit second pass by default (their parity mode: 1 - 3e-6 at 7B depth) and take the e2m3 pass with option "precise_lo6" = 1 / BLIM_PRECISE_LO6=1 (round 6)
     e->lo6 = !e->f8 && cfg->compute_dtype == DT_F16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 && cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480;
     if (getenv("BLIM_PRECISE_LO6") && atoi(getenv("BLIM_PRECISE_LO6")) == 0) e->lo6 = false;
+    if (getenv("BLIM_PRECISE_LO6") && atoi(getenv("BLIM_PRECISE_LO6")) == 1 && !e->f8 && cfg->compute_dtype == DT_BF16 && cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 &&
+        cfg->hidden_size <= 20480 && cfg->intermediate_size <= 20480) e->lo6 = true;
     if (getenv("BLIM_LO6_FUSED_TILES") && atoi(getenv("BLIM_LO6_FUSED_TILES")) == 0) e->lo6_fuse = false;
     if (getenv("BLIM_LO6_FUSED_MASK")) e->lo6_fuse_mask = atoi(getenv("BLIM_LO6_FUSED_MASK"));
     const int H = cfg->hidden_size, I = cfg->intermediate_size, V = cfg->vocab_size, M = cfg->mm_hidden_size;
@@ -516,7 +519,7 @@ extern "C" int blim_load_adapter(blim_engine* e, const char* weight_name, const 
     e->lora_r = lora_r; e->lora_scale = scale;
     // three adapters (q, k, v) x r columns x (B_hi, B_lo) need 6 r columns: 64 suffice up to r = 10.  fp16 engines take 128 whenever the e4m3 second pass of the
     // compensated modes is possible (option "precise_lo6": its K-steps are 128 deep, so the augmented K must stay a multiple of 128)
-    const bool lo6_capable = !e->f8 && e->c.compute_dtype == DT_F16 && e->c.hidden_size % 128 == 0 && e->c.intermediate_size % 128 == 0;
+    const bool lo6_capable = !e->f8 && e->c.hidden_size % 128 == 0 && e->c.intermediate_size % 128 == 0;      // (16-bit engines: fp16 by default, bf16 by option)
     e->aug = (6 * lora_r <= 64 && !lo6_capable) ? 64 : 128;
     e->aug_ready = false;
     return BLIM_OK;
@@ -1249,8 +1252,10 @@ extern "C" int blim_set_option(blim_engine* e, const char* key, int32_t value) {
         e->masked_query_zero = value != 0; return BLIM_OK;
     }
     if (!strcmp(key, "precise_lo6")) {
-        if (value && (e->f8 || e->c.compute_dtype != DT_F16)) { blim_set_error("option 'precise_lo6' needs an fp16 engine"); return BLIM_ERR_ARG; }
-        if (value && (e->c.hidden_size % 128 || e->c.intermediate_size % 128)) { blim_set_error("option 'precise_lo6': hidden and intermediate sizes must be multiples of 128"); return BLIM_ERR_ARG; }
+        if (value && e->f8) { blim_set_error("option 'precise_lo6' needs a 16-bit engine (fp16: the default; bf16: opt-in)"); return BLIM_ERR_ARG; }
+        if (value && (e->c.hidden_size % 128 || e->c.intermediate_size % 128 || e->c.hidden_size > 20480 || e->c.intermediate_size > 20480)) {
+            blim_set_error("option 'precise_lo6': hidden and intermediate sizes must be multiples of 128, at most 20480"); return BLIM_ERR_ARG; }
+        if (value && e->aug && e->aug % 128) { blim_set_error("option 'precise_lo6': adapters were loaded with a %d-column K extension; set the option before loading adapters", e->aug); return BLIM_ERR_STATE; }
         e->lo6 = value != 0; return BLIM_OK;
     }
     if (!strcmp(key, "precise_mlp")) { e->precise_mlp = value != 0; return BLIM_OK; }

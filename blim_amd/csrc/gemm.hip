@@ -50,6 +50,11 @@ template <int EPI, int DT, bool SPLIT = false, bool MXA = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[5 * TILE_BYTES];  // 160 KiB ring / 136 KiB (two stages, or the staged C tile)
 
+    // Compiler trap (round 6): the two-pass kernels live at the 256-register limit, and the bf16 instantiations -- the SAME source but for the MFMA opcode and without the
+    // fp16 kernels' two s_setreg (MODE.FP16_OVFL) per tile -- came out with 450 - 630 spilled VGPRs inside the K loops and three quarters of the 16-bit MFMAs writing their
+    // accumulators to other registers than they read.  The s_setreg instructions bound the register allocator's regions; with the same (for bf16: value-preserving, the bit is 0
+    // and stays 0) instructions at the same two places the bf16 kernels allocate like the fp16 ones: 0 - 4 spills (tests/test_isa_guards.py).
+    constexpr bool LO6_BF16_FENCE = MXA && DT == DT_BF16;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     }
     stamp_vb = pid;
     stamp(0);
-    if constexpr (out16<DT>::value == DT_F16) { if (p.f16_saturate) f16_saturate_off(); }     // the MFMAs must see NaN / inf operands as such (common.hpp)
+    if constexpr (out16<DT>::value == DT_F16 || (LO6_BF16_FENCE)) { if (p.f16_saturate) f16_saturate_off(); }     // the MFMAs must see NaN / inf operands as such (common.hpp)
     const int width = p.group_m * ntn;
     const int first_m = (pid / width) * p.group_m;
     const int gsz = min(ntm - first_m, p.group_m);
@@ -582,6 +587,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     int tid_e = tid;                        // the epilogue's copy of the thread index, formed per tile: its derived indices (row / segment / scale slots) are kernel
     asm volatile("" : "+v"(tid_e));         // invariants that LICM hoists out of the persistent loop and, in the fp8 kernels, spills across the K loop
     if constexpr (out16<DT>::value == DT_F16) { if (p.f16_saturate) f16_saturate_on(); }      // fp16 stores of this tile saturate instead of overflowing to inf
+    else if constexpr (LO6_BF16_FENCE) { if (p.f16_saturate) f16_saturate_off(); }
     if (p.debug_skip_epilogue) {   // timing aid (tools/gemm_k_sweep.py): keep the accumulators live, store nothing
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1130,11 +1136,15 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     const int persistent = g_gemm_persistent ? n_cu : ntm * ntn;
     const dim3 grid(ntm * ntn < persistent ? ntm * ntn : persistent);
     if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU || EPI == EPI_RESID || EPI == EPI_LSE) {
-        if (p.A6) {            // fp16 main pass + e2m3 pass over the A operand's lo part (phase 2 of the kernel)
-            if constexpr (EPI == EPI_RESID || EPI == EPI_LSE) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
-            else if (p.lo_off != 0) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, true, true>), grid, dim3(NTHREADS), 0, stream, p);
-            else if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<EPI, DT_F16, false, true>), grid, dim3(NTHREADS), 0, stream, p);
+        if (p.A6) {            // 16-bit main pass + e2m3 pass over the A operand's lo part (phase 2 of the kernel).  fp16 engines: the default second pass; bf16 engines
+                               // (round 6): option "precise_lo6" = 1, the fast form of their compensated mode (the lo part is 2^-9 of the value there: DESIGN.md section 4)
+#define LO6_LAUNCH(DTX)                                                                                                                                  \
+            if constexpr (EPI == EPI_RESID || EPI == EPI_LSE) hipLaunchKernelGGL((gemm_kernel<EPI, DTX, false, true>), grid, dim3(NTHREADS), 0, stream, p);   \
+            else if (p.lo_off != 0) hipLaunchKernelGGL((gemm_kernel<EPI, DTX, true, true>), grid, dim3(NTHREADS), 0, stream, p);                            \
+            else if constexpr (EPI == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<EPI, DTX, false, true>), grid, dim3(NTHREADS), 0, stream, p);              \
             else { blim_set_error("lo6 QKV GEMM: hi | lo outputs only"); return BLIM_ERR_ARG; }
+            if (p.dtype == DT_F16) { LO6_LAUNCH(DT_F16) } else { LO6_LAUNCH(DT_BF16) }
+#undef LO6_LAUNCH
             hipError_t e4 = hipGetLastError();
             if (e4 != hipSuccess) { blim_set_error("gemm launch failed: %s", hipGetErrorString(e4)); return BLIM_ERR_HIP; }
             return BLIM_OK;
@@ -1231,7 +1241,7 @@ static int launch_one(GemmEpi epi, const GemmParams& p_in, hipStream_t stream) {
     ARG_CHECK((!p.a_mx && !p.out_mx) || (p.dtype == DT_F8 && p.mx_stride >= (int64_t)((p.M + BM - 1) / BM) * 256));
     ARG_CHECK(!p.a_mx || epi == EPI_RESID);                      // MX-scaled A operand: instantiated for the down projection (fp8)
     // lo6: the A operand's lo part and W as e2m3 tile images (gemm.hpp)
-    ARG_CHECK(!p.A6 || (p.dtype == DT_F16 && p.W6 && p.w_wrap_k == 0 && p.K6 > 0 && p.K6 % 128 == 0 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE)));
+    ARG_CHECK(!p.A6 || ((p.dtype == DT_F16 || p.dtype == DT_BF16) && p.W6 && p.w_wrap_k == 0 && p.K6 > 0 && p.K6 % 128 == 0 && (epi == EPI_RESID || epi == EPI_QKV || epi == EPI_SWIGLU || epi == EPI_LSE)));
     ARG_CHECK(!p.out_mx || (epi == EPI_SWIGLU && p.N % 256 == 0 && p.ldc % 16 == 0));
     ARG_CHECK(!p.out6 || (epi == EPI_SWIGLU && p.A6 && p.lo_off > 0 && p.N % 256 == 0));
     ARG_CHECK(p.w_wrap_k == 0 || (p.K == 2 * p.w_wrap_k && (int64_t)p.w_wrap_k * es % 128 == 0));   // A = [hi | lo]: W is walked twice

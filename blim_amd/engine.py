@@ -224,8 +224,9 @@ class Engine:
         # blim_create honours BLIM_PRECISE_MLP (A/B runs): the Python-side cache of that option starts from the same value, so that set_precise() neither clobbers
         # an override nor believes in a default the engine does not have
         # mirrors the engine's default of option "precise_lo6" (include/blim.h): the compensated modes' second pass over K in e2m3 on fp16 engines
-        self.lo6 = (dtype == "f16" and dims.hidden_size % 128 == 0 and dims.intermediate_size % 128 == 0 and max(dims.hidden_size, dims.intermediate_size) <= 20480
-                    and os.environ.get("BLIM_PRECISE_LO6", "1") != "0")
+        # (bf16 engines: off by default -- their parity mode runs the second pass in bf16 -- on with set_option("precise_lo6", 1) / BLIM_PRECISE_LO6=1: round 6)
+        lo6_ok = dims.hidden_size % 128 == 0 and dims.intermediate_size % 128 == 0 and max(dims.hidden_size, dims.intermediate_size) <= 20480
+        self.lo6 = lo6_ok and ((dtype == "f16" and os.environ.get("BLIM_PRECISE_LO6", "1") != "0") or (dtype == "bf16" and os.environ.get("BLIM_PRECISE_LO6", "0") == "1"))
         self._precise_mlp = os.environ.get("BLIM_PRECISE_MLP", "1") != "0"
         self.weights_version = 0          # bumped by every weight / adapter change: what a measured numeric mode was measured on (modeling.py: resolve_*)
 

@@ -78,6 +78,10 @@ def get_args_parser():
                    help="how much of the TVG calls' MLP branch runs compensated (their embeddings, QKV, attention, o_proj and head always do on a 16-bit engine).  auto (default): "
                         "measured like --vtg_precise auto, on the TVG likelihood and prior of up to 256 pairs; attn = MLP plain (1.6x faster than full), "
                         "full = everything (what weights with massive residual channels need: tests/golden/heavy7b.npz)")
+    p.add_argument("--second_pass", default=None, choices=["e2m3", "16bit"],
+                   help="what the compensated calls' second walk over K runs in.  e2m3: the block-scaled MFMA on 6-bit operand tiles (fp16 engines: the default; bf16 engines: "
+                        "opt-in, 0.69x the plain rate with about one fp16 rounding's accuracy).  16bit: a second walk in the engine's own format (bf16 engines: the default and the "
+                        "parity mode, 0.5x the plain rate at 1 - 3e-6)")
     p.add_argument("--masked_query_zero", action="store_true",
                    help="PARITY-UNPINNED: masked query positions write a zero attention output, as the reference's flash-attention-2 class does (modeling_qwen2_flash.py:526-563) "
                         "where its eager / SDPA classes -- the semantics this engine's parity is pinned to -- compute them like any other row.  Changes the TVG-CPN prior only "
@@ -189,6 +193,8 @@ def main(args):
     if getattr(args, "masked_query_zero", False):
         model.masked_query_zero = True
         print("[note] --masked_query_zero: flash-attention-2 semantics for masked query rows (parity-unpinned; the default, eager / SDPA semantics, is what the goldens pin)")
+    if getattr(args, "second_pass", None) and model.engine.can_precise:
+        model.second_pass = args.second_pass
     if model.engine.can_precise:
         model.tvg_precise = args.tvg_precise
     if args.vtg_precise is not None and model.engine.can_precise:

@@ -73,6 +73,22 @@ class BlimModel:
         self._tvg_request, self._tvg_resolved = mode, None
 
     @property
+    def second_pass(self) -> str:
+        """What the compensated calls' second walk over K (the activations' lo parts) runs in: "e2m3" (the block-scaled MFMA, gemm.hip phase 2: the default of fp16
+        engines; an opt-in on bf16 engines since round 6: 0.69x the plain rate, about one fp16 rounding's accuracy) or "16bit" (a second walk in the engine's own
+        format: the default and the parity mode of bf16 engines, 0.5x)."""
+        return "e2m3" if bool(getattr(self.engine, "lo6", False)) else "16bit"
+
+    @second_pass.setter
+    def second_pass(self, mode) -> None:
+        if mode not in ("e2m3", "16bit"):
+            raise ValueError(f"second_pass = {mode!r}: one of e2m3, 16bit")
+        if not self.engine.can_precise:
+            raise ValueError("second_pass: fp8 engines have no compensated modes")
+        self.engine.set_option("precise_lo6", 1 if mode == "e2m3" else 0)
+        self._vtg_resolved = self._tvg_resolved = None              # a measured `auto` was measured with the other second pass
+
+    @property
     def masked_query_zero(self) -> bool:
         return bool(getattr(self, "_masked_query_zero", False))
 
