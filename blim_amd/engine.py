@@ -295,21 +295,27 @@ class Engine:
     def set_option(self, key: str, value: int):
         _check(self.lib.blim_set_option(self.h, key.encode(), value), "blim_set_option")
         if key == "precise_lo6":
-            self.lo6 = bool(value)
+            self.lo6 = self._lo6_live = bool(value)
 
     @property
     def can_precise(self) -> bool:
         return self.dtype in ("f16", "bf16")
 
-    def set_precise(self, on: bool, embeds: bool = False, mlp: bool = True):
+    def set_precise(self, on: bool, embeds: bool = False, mlp: bool = True, tvg: bool = False):
         """Compensated mode for the following calls (16-bit engines; a no-op request on others): every 16-bit activation travels as hi + lo and the GEMMs take
         both parts (fp16 engines: the lo part on the e2m3 MFMA, option "precise_lo6").  The host turns it on for the TVG calls, whose scores are ~10x smaller in
         magnitude than the VTG ones, and for the VTG calls of checkpoints that need it (`--vtg_precise`).
         embeds=True: the input embeddings (assemble -> decode / score_*) are [hi | lo] rows of width 2H as well -- the fused path, whose projected video features
         are produced in this mode; the literal forward() keeps [B, L, H] embeddings.  mlp=False: only the attention branch (QKV, attention, o_proj) and the
-        scored rows are compensated -- the TVG calls' "attn" mode."""
+        scored rows are compensated -- the TVG calls' "attn" mode.  tvg=True: the call is a TVG call -- on a bf16 engine that was asked for the e2m3 second pass
+        (`second_pass = "e2m3"`, round 6) it still takes the bf16 second pass: TVG scores are ~10x smaller in magnitude, read 1.7 - 2.6e-4 with the e2m3 pass against
+        1 - 2.4e-5 with the bf16 one at 7B depth, and cost a few percent of an evaluation either way."""
         on = bool(on) and self.can_precise
         embeds = bool(embeds) and on
+        want6 = bool(self.lo6) and not (bool(tvg) and on and self.dtype == "bf16")
+        if want6 != getattr(self, "_lo6_live", bool(self.lo6)):
+            _check(self.lib.blim_set_option(self.h, b"precise_lo6", int(want6)), "blim_set_option")
+            self._lo6_live = want6
         if on != getattr(self, "_precise", False):
             self.set_option("precise", int(on))
             self._precise = on

@@ -226,7 +226,7 @@ def main(args):
     torch.cuda.synchronize()
     if rank == 0:
         st = getattr(args, "_eval_stats", {})
-        dt = time.time() - t1
+        dt = time.time() - t1 - float(getattr(args, "_dump_seconds", 0.0))       # (--dump_scores compresses 8 N x N matrices to disk: not part of an evaluation)
         free_b, total_b = torch.cuda.mem_get_info()
         # executed GEMM FLOPs of this process's engine calls (retrieval_utils.executed_flops) against the dense MFMA peaks: the compensated calls' e2m3 second pass at
         # the fp6 peak, an fp8 engine's calls at the fp8 peak, the rest at the 16-bit one (MI355X_MICROARCH.md: 2.5 / 5 / 10 PFLOP/s)
@@ -236,6 +236,9 @@ def main(args):
               f"(the rest shared between directions), in {dt:.2f}s = {st.get('pairs_requested', 0) / dt:.0f} pairs/s per process "
               f"(world {st.get('world', world)}, host planning and loading included); executed {fl / 1e12:.1f} TFLOP = {at_peak / dt:.3f} of the MFMA peak; "
               f"device memory in use {(total_b - free_b) / 2**30:.1f} GiB, torch peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+        if st.get("host_marks"):
+            print("host marks (stage, seconds since the evaluation began; device work is asynchronous, so a stage's time is its planning + launching): "
+                  + ", ".join(f"{k} {v:.2f}" for k, v in st["host_marks"]))
         if st.get("calibration_whole_sample"):
             # `--shard W r` on its own: nobody to gather the calibration sample from, so this process measured all of it (the decision is the job's); a real rank scores 1 / W
             cal, Wj = float(st.get("calibration_seconds", 0.0)), int(st.get("world", 1))

@@ -306,7 +306,7 @@ class BlimModel:
         # a forward over rows prepared with tvg=True runs in the compensated mode, like the fused TVG calls (engine.set_precise); VTG rows
         # follow self.vtg_precise
         if tvg_rows:
-            self.engine.set_precise(True, embeds=wide, mlp=self.tvg_mode() != "attn")       # (an unresolved "auto" runs fully compensated)
+            self.engine.set_precise(True, embeds=wide, mlp=self.tvg_mode() != "attn", tvg=True)       # (an unresolved "auto" runs fully compensated)
         else:
             on = vmode == "full"
             self.engine.set_precise(on, embeds=wide and on, mlp=True)

@@ -458,12 +458,12 @@ class PairScorer(CalibrationMixin):
                 self.engine.set_precise(False)
         self.exec_flops += executed_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode if self.split_tvg else None,
                                           n_vocab=self.n_vocab, prune=not f8)
-        if getattr(self.engine, "lo6", False) and self.split_tvg:
+        if getattr(self.engine, "lo6", False) and self.split_tvg and getattr(self.engine, "dtype", "") != "bf16":      # (bf16 engines: TVG calls keep the bf16 second pass, Engine.set_precise)
             self.exec_flops_lo6 += lo6_pass_flops(self.m.dims, plan.n_tokens, plan.n_rows, "tvg", self.tvg_mode, prune=not f8)
         if self.vocab_cm is None and getattr(self.engine, "_vocab_key", None) != self._vocab_key:
             self.engine.set_video_vocab(self._vocab_src)                     # another scorer / the literal path registered its own vocabulary since
         # TVG calls: compensated (3-5 new tokens per pair: cheap); how much of the MLP branch is compensated follows tvg_mode (calibrate_tvg)
-        self.engine.set_precise(self.split_tvg, embeds=self.split_tvg, mlp=self.tvg_mode != "attn")
+        self.engine.set_precise(self.split_tvg, embeds=self.split_tvg, mlp=self.tvg_mode != "attn", tvg=True)
         try:
             embeds = self.engine.assemble(plan.src_index, plan.feats)
             return self.engine.score_tvg(plan.batch, embeds, plan.rows, self.vocab_cm, plan.labels)

@@ -88,7 +88,10 @@ def val_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler, tok
     t2v_dict, v2t_dict = evaluation(model, data_loader, device, tokenizer, args)
     dump = getattr(args, "dump_scores", None)
     if dump and dist_utils.is_main_process():                          # engine-side option: the score matrices themselves (mode comparisons)
+        import time
+        t0 = time.time()
         np.savez_compressed(dump, **{f"t2v_{k}": v for k, v in t2v_dict.items()}, **{f"v2t_{k}": v for k, v in v2t_dict.items()})
+        args._dump_seconds = time.time() - t0                          # (a debugging aid's file I/O: main.py keeps it out of the evaluation time it reports)
     if dist_utils.is_main_process():
         return combine_and_rank(t2v_dict, v2t_dict, args, len(data_loader.dataset))
     return None

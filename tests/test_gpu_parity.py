@@ -779,7 +779,7 @@ def test_compensated_fp16_mode_cuts_the_hidden_state_error(capsys):
             e.close()
 
 
-BF16_LO6_BOUND = 1e-3       # (first measurement pending; tightened to the measured figures below)
+BF16_LO6_BOUND = 1.5e-4     # measured (profiles/r06b_gputest_parity_lines.txt): VTG passes 3.1 - 6.8e-5 at 7B depth; the TVG passes of a bf16 engine keep the bf16 second pass (<= 2.4e-5)
 
 
 @pytest.mark.parametrize("case", ["deep", "full7b"])

@@ -114,7 +114,7 @@ def test_no_spills_in_the_16_bit_kernels(src, pattern, gemm_kernels, tmp_path):
         if not re.search(pattern, name) or not meta:
             continue
         seen += 1
-        if src == "gemm.hip" and re.search(r"gemm_kernelILi\dELi1ELb[01]ELb1E", name):
+        if src == "gemm.hip" and re.search(r"gemm_kernelILi\dELi[01]ELb[01]ELb1E", name):           # fp16 (1) and, since round 6, bf16 (0: `--second_pass e2m3`)
             # the two-phase "lo6" kernels (fp16 pass + e2m3 pass over the lo part in one accumulator set, gemm.hip phase 2).  Round 4's e4m3 form spilled 14 - 17 VGPRs around
             # the hand-over between its two loops; round 5's second pass refills its fragment registers in place and nothing is handed over: <= 6 spilled VGPRs, all of them
             # kernel-invariant values stored once per kernel and reloaded in the tile prologue / epilogue -- and NO basic block of a K loop touches scratch
