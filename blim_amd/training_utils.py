@@ -92,6 +92,8 @@ def val_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler, tok
         t0 = time.time()
         np.savez_compressed(dump, **{f"t2v_{k}": v for k, v in t2v_dict.items()}, **{f"v2t_{k}": v for k, v in v2t_dict.items()})
         args._dump_seconds = time.time() - t0                          # (a debugging aid's file I/O: main.py keeps it out of the evaluation time it reports)
+    if getattr(args, "shard", None) is not None:                       # one rank's share played by a single process: the matrices are partial, there is no table to rank
+        return None
     if dist_utils.is_main_process():
         return combine_and_rank(t2v_dict, v2t_dict, args, len(data_loader.dataset))
     return None
