@@ -140,7 +140,9 @@ int main() {
         }
         EXPECT(blim_set_option(e, "no_such_option", 1) == BLIM_ERR_ARG && blim_set_option(e, nullptr, 1) == BLIM_ERR_ARG);
         if (dtype == BLIM_COMPUTE_F8) EXPECT(blim_set_option(e, "precise", 1) != 0 && blim_set_option(e, "precise_lo6", 1) != 0);
-        if (dtype == BLIM_COMPUTE_BF16) EXPECT(blim_set_option(e, "precise_lo6", 1) == BLIM_ERR_ARG);
+        const bool lo6_dims = c.hidden_size % 128 == 0 && c.intermediate_size % 128 == 0;
+        // bf16 engines take the e2m3 second pass as an opt-in since round 6 (same size rule as fp16 engines); left off again for the calls below
+        if (dtype == BLIM_COMPUTE_BF16) { EXPECT(blim_set_option(e, "precise_lo6", 1) == (lo6_dims ? 0 : BLIM_ERR_ARG)); EXPECT(blim_set_option(e, "precise_lo6", 0) == 0); }
         EXPECT(blim_set_option(e, "prune_last", 1) == 0 && blim_set_option(e, "f8_fuse", 1) == 0 && blim_set_option(e, "f8_mask", 31) == 0);
         // ---- workspaces: growth in steps, then the calls in every numeric mode
         for (int64_t t : {64, 300, 5000, 200}) EXPECT(blim_reserve(e, t, t / 2 + 1) == 0);
@@ -152,8 +154,9 @@ int main() {
             for (int mlp = 0; mlp <= precise; ++mlp) {
                 EXPECT(blim_set_option(e, "precise_mlp", mlp) == 0);
                 if (precise) EXPECT(blim_set_option(e, "precise_embeds", mlp) == 0);
-                for (int lo6 = 0; lo6 <= ((precise && dtype == BLIM_COMPUTE_F16) ? 1 : 0); ++lo6) {
-                    if (dtype == BLIM_COMPUTE_F16) EXPECT(blim_set_option(e, "precise_lo6", lo6) == 0);
+                const bool lo6_engine = dtype == BLIM_COMPUTE_F16 || (dtype == BLIM_COMPUTE_BF16 && lo6_dims);
+                for (int lo6 = 0; lo6 <= ((precise && lo6_engine) ? 1 : 0); ++lo6) {
+                    if (lo6_engine) EXPECT(blim_set_option(e, "precise_lo6", lo6) == 0);
                     score_calls(e, c, 3, 40, false);
                     score_calls(e, c, 2, 70, true);
                 }
