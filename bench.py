@@ -472,7 +472,7 @@ def main():
         if rank == 0:
             emit({"error": msg}, None, cpu=False)
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0 if rank == 0 else 5)
+        os._exit(0)          # (every rank: a non-zero exit of any rank makes the launcher tear the job down, possibly before rank 0 has flushed its line)
     dog = threading.Timer(float(a.leg_timeout), on_timeout)
     dog.daemon = True
     if a.leg_timeout > 0:

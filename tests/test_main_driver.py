@@ -212,6 +212,23 @@ def test_rccl_runs_the_bench_collectives_at_world_size_one(tmp_path, capsys):
     assert "RCCL" in d["config"]["parallelism"]
 
 
+def test_bench_watchdog_keeps_the_headline_line_when_a_later_leg_does_not_finish(tmp_path):
+    """bench.py --leg-timeout: the legs behind the timed steps (the strong-scaling leg's collectives have never met more than one GPU) must not be able to cost the headline.
+    With a 1-second limit the watchdog fires inside the strong-scaling leg: still exactly one JSON line, the measured headline in it, the timeout recorded where the leg's
+    object would be, exit code 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "8", "--strong-n", "1000", "--leg-timeout", "1"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["steps"] == 2 and d["roofline"]["frac"] > 0 and "watchdog" in d["strong_scaling"]["error"] and "cpu_baseline" not in d
+    assert "watchdog" in r.stderr
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     """bench.py's output contract: exactly one JSON line on stdout with the driver's keys, the roofline and (at N = 1) the CPU
     baseline objects.  Small workload (8 queries) so that the test takes seconds; the numbers themselves are not checked."""
