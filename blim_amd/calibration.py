@@ -208,3 +208,33 @@ class CalibrationMixin:
         self.set_tvg_mode(chosen)
         resolve(chosen)
         return chosen, {"attn": entry}
+
+    def calibrate_second_pass(self, pairs, bar: float = 1e-3, z: float = 4.5, n_eval: Optional[int] = None, tail_margin: float = 0.8, share=None, confirm_pairs=None, adopt=None):
+        """bf16 engines, `--second_pass auto` (round 6): may the VTG calls' second walk over K run on the e2m3 MFMA (0.705x the plain fp16 rate) instead of in bf16 (0.50x)?
+        Same criterion and stages as calibrate_vtg; the yardstick is the fully compensated mode with the bf16 second pass (1 - 3e-6 from the fp32 reference at 7B depth), the
+        cheap mode the same calls with engine option "precise_lo6" = 1 (3 - 7e-5 on N(0, 0.02^2) weights; on weights with massive activations it inherits about one fp16
+        rounding's noise and is rejected like plain fp16 is there).  The TVG calls of a bf16 engine keep the bf16 pass either way (Engine.set_precise).
+        Returns ("e2m3" | "16bit", table)."""
+        pairs = np.asarray(pairs, dtype=np.int64)
+        resolve = getattr(self.m, "resolve_second_pass", lambda mode: None)
+        if getattr(self.engine, "dtype", "") != "bf16":
+            return ("e2m3" if bool(getattr(self.engine, "lo6", False)) else "16bit"), {}
+        self.set_vtg_mode("full")
+
+        def measure(block, sh):
+            if not len(block):
+                return [self._gather_dev(np.zeros(0), sh)]
+            self.engine.set_option("precise_lo6", 0)
+            ref = self.vtg(block).astype(np.float64)
+            self.engine.set_option("precise_lo6", 1)
+            dev = np.abs(self.vtg(block).astype(np.float64) - ref) / np.abs(ref)
+            return [self._gather_dev(dev, sh)]
+
+        try:
+            chosen, entry = self._decide(measure, pairs, confirm_pairs, share, n_eval, bar, z, tail_margin, "e2m3", "16bit", adopt=adopt)
+        finally:
+            self.engine.set_option("precise_lo6", 0)
+        resolve(chosen)
+        if not hasattr(self.m, "resolve_second_pass"):
+            self.engine.set_option("precise_lo6", 1 if chosen == "e2m3" else 0)
+        return chosen, {"e2m3": entry}

@@ -78,10 +78,11 @@ def get_args_parser():
                    help="how much of the TVG calls' MLP branch runs compensated (their embeddings, QKV, attention, o_proj and head always do on a 16-bit engine).  auto (default): "
                         "measured like --vtg_precise auto, on the TVG likelihood and prior of up to 256 pairs; attn = MLP plain (1.6x faster than full), "
                         "full = everything (what weights with massive residual channels need: tests/golden/heavy7b.npz)")
-    p.add_argument("--second_pass", default=None, choices=["e2m3", "16bit"],
+    p.add_argument("--second_pass", default=None, choices=["e2m3", "16bit", "auto"],
                    help="what the compensated calls' second walk over K runs in.  e2m3: the block-scaled MFMA on 6-bit operand tiles (fp16 engines: the default; bf16 engines: "
                         "opt-in, 0.69x the plain rate with about one fp16 rounding's accuracy).  16bit: a second walk in the engine's own format (bf16 engines: the default and the "
-                        "parity mode, 0.5x the plain rate at 1 - 3e-6)")
+                        "parity mode, 0.5x the plain rate at 1 - 3e-6).  auto (bf16 engines): measured on the loaded checkpoint like --vtg_precise auto -- the e2m3 form is kept "
+                        "when its scores stay inside the bar of the 16-bit form's on the evaluation's own calibration pairs")
     p.add_argument("--masked_query_zero", action="store_true",
                    help="PARITY-UNPINNED: masked query positions write a zero attention output, as the reference's flash-attention-2 class does (modeling_qwen2_flash.py:526-563) "
                         "where its eager / SDPA classes -- the semantics this engine's parity is pinned to -- compute them like any other row.  Changes the TVG-CPN prior only "

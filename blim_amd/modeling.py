@@ -74,19 +74,35 @@ class BlimModel:
 
     @property
     def second_pass(self) -> str:
-        """What the compensated calls' second walk over K (the activations' lo parts) runs in: "e2m3" (the block-scaled MFMA, gemm.hip phase 2: the default of fp16
-        engines; an opt-in on bf16 engines since round 6: 0.69x the plain rate, about one fp16 rounding's accuracy) or "16bit" (a second walk in the engine's own
-        format: the default and the parity mode of bf16 engines, 0.5x)."""
-        return "e2m3" if bool(getattr(self.engine, "lo6", False)) else "16bit"
+        """What the compensated calls' second walk over K (the activations' lo parts) runs in -- the REQUEST: "e2m3" (the block-scaled MFMA, gemm.hip phase 2: the default
+        of fp16 engines; an opt-in on bf16 engines since round 6: 0.69x the plain rate, about one fp16 rounding's accuracy), "16bit" (a second walk in the engine's own
+        format: the default and the parity mode of bf16 engines, 0.5x) or "auto" (bf16 engines: measured on the loaded checkpoint by evaluation(), like vtg_precise "auto":
+        the e2m3 form is kept when its scores stay inside the bar of the 16-bit form's; PairScorer.calibrate_second_pass)."""
+        return getattr(self, "_second_request", None) or ("e2m3" if bool(getattr(self.engine, "lo6", False)) else "16bit")
 
     @second_pass.setter
     def second_pass(self, mode) -> None:
-        if mode not in ("e2m3", "16bit"):
-            raise ValueError(f"second_pass = {mode!r}: one of e2m3, 16bit")
+        if mode not in ("e2m3", "16bit", "auto"):
+            raise ValueError(f"second_pass = {mode!r}: one of e2m3, 16bit, auto")
         if not self.engine.can_precise:
             raise ValueError("second_pass: fp8 engines have no compensated modes")
-        self.engine.set_option("precise_lo6", 1 if mode == "e2m3" else 0)
+        if mode == "auto" and self.engine.dtype != "bf16":
+            mode = "e2m3"                                           # fp16 engines: nothing to measure -- the e2m3 pass is their compensated mode (<= 4e-5 from fp32 on every fixture)
+        self._second_request, self._second_resolved = mode, None
+        if mode != "auto":
+            self.engine.set_option("precise_lo6", 1 if mode == "e2m3" else 0)
+        else:
+            self.engine.set_option("precise_lo6", 0)                # unresolved: the parity form
         self._vtg_resolved = self._tvg_resolved = None              # a measured `auto` was measured with the other second pass
+
+    def resolve_second_pass(self, mode) -> None:
+        """Records what second_pass = "auto" was measured to allow on the weights now loaded, and switches the engine to it."""
+        self._second_resolved = (mode, self.engine.weights_version)
+        self.engine.set_option("precise_lo6", 1 if mode == "e2m3" else 0)
+
+    def second_pass_resolved(self) -> bool:
+        r = getattr(self, "_second_resolved", None)
+        return getattr(self, "_second_request", None) != "auto" or (r is not None and r[1] == self.engine.weights_version)
 
     @property
     def masked_query_zero(self) -> bool:

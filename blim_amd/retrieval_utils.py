@@ -282,6 +282,20 @@ def evaluation(model, data_loader, device, tokenizer, args):
             if rank == 0:
                 print("vtg_precise auto: deviation from the fully compensated mode on the calibration pairs (max / rms): "
                       + fmt_table(table) + f" -> {chosen}", file=sys.stderr, flush=True)
+    if getattr(mod, "second_pass", None) == "auto" and isinstance(scorer, PairScorer) and (mod.vtg_mode() if hasattr(mod, "vtg_mode") else None) == "full":
+        # `--second_pass auto` (bf16 engines, round 6): with the VTG calls compensated, may their second walk over K run on the e2m3 MFMA?  Measured like the modes above
+        if mod.second_pass_resolved():
+            stats["second_pass"] = "e2m3" if bool(getattr(mod.engine, "lo6", False)) else "16bit"
+        else:
+            cal = scorer if isinstance(scorer, PairScorer) else new_scorer()
+            kt_, kv_ = min(args.topk, num_texts), min(args.topk, num_videos)
+            chosen, table = cal.calibrate_second_pass(calibration_pairs(v2t_iv2, args.topk, n_queries=32, per_query=8),
+                                                      n_eval=num_videos * kt_ * (2 if args.cpn else 1) + num_texts * kv_, share=share_of("second"),
+                                                      confirm_pairs=calibration_pairs(v2t_iv2, args.topk, n_queries=256, per_query=8), adopt=adopt_of("second"))
+            chosen = agree(chosen, ("e2m3", "16bit"), lambda m_: mod.resolve_second_pass(m_))
+            stats["second_pass"] = chosen; stats["second_pass_table"] = table
+            if rank == 0:
+                print("second_pass auto: deviation of the e2m3 second pass from the bf16 one on the calibration pairs (max / rms): " + fmt_table(table) + f" -> {chosen}", file=sys.stderr, flush=True)
     if getattr(mod, "tvg_precise", None) == "auto" and finetuned:
         # likewise for the TVG calls' MLP branch (PairScorer.calibrate_tvg); zero-shot evaluations run no TVG pass
         if hasattr(mod, "tvg_resolved") and mod.tvg_resolved():
@@ -304,7 +318,7 @@ def evaluation(model, data_loader, device, tokenizer, args):
             if rank == 0:
                 print("tvg_precise auto: deviation from the fully compensated mode on the calibration pairs, likelihood + prior (max / rms): "
                       + fmt_table(table) + f" -> {chosen}", file=sys.stderr, flush=True)
-    if "vtg_precise_table" in stats or "tvg_precise_table" in stats:
+    if "vtg_precise_table" in stats or "tvg_precise_table" in stats or "second_pass_table" in stats:
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         stats["calibration_seconds"] = round(time.time() - t_cal, 4)
         # an emulated rank with no decision handed in measured the job's WHOLE sample (share_of): W times a real rank's share of this time

@@ -230,7 +230,10 @@ int blim_debug_gemm_stamps(void* device_buf);
  * "precise_embeds" (0/1): in precise mode the input embeddings / projector outputs are [hi | lo] rows of width 2 * hidden as well;
  * "precise_mlp" (0/1, default 1): 0 leaves the MLP branch plain in precise mode -- the TVG calls' "attn" mode (1.6x faster than fully compensated; TVG deviation at
  *   7B depth 8e-4 instead of 4e-5 on Gaussian weights, 3e-3 on weights with massive activations: `--tvg_precise auto` measures which one a checkpoint needs);
- * "precise_lo6" (0/1; fp16 engines with hidden / intermediate sizes that are multiples of 128: default 1, env BLIM_PRECISE_LO6=0 turns it off; other engines refuse 1):
+ * "precise_lo6" (0/1; 16-bit engines with hidden / intermediate sizes that are multiples of 128.  fp16 engines: default 1, env BLIM_PRECISE_LO6=0 turns it off.  bf16 engines
+ *   (round 6): default 0 -- their parity mode walks K a second time in bf16, 1 - 3e-6 at 7B depth -- and 1 is an opt-in (env BLIM_PRECISE_LO6=1, `--second_pass e2m3 | auto`):
+ *   a bf16 value's lo part is 2^-9 of it, hi + e2m3(lo) carry about what one fp16 rounding keeps: VTG scores 3 - 7e-5 from the fp32 reference at 7B depth on N(0, 0.02^2)
+ *   weights at 1.41x the rate of the bf16 second pass.  Set it before loading adapters (their K extension is 128 columns when the option may be used).  fp8 engines refuse 1):
  *   in precise mode the decoder GEMMs' (and lm_head's) second walk over K -- the product of W with the activations' LO parts, 2^-11 of the values -- runs on the
  *   block-scaled MFMA with e2m3 operands (6 bits, one power-of-two scale per 32 values: four times the 16-bit MFMA rate on gfx950), inside the same kernel and into
  *   the same accumulators.  Weights: e2m3 tile images built on the first compensated call (+0.78 byte per decoder / head weight: 5.9 GB at 7B; a failed allocation

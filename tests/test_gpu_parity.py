@@ -1113,6 +1113,46 @@ def test_auto_modes_are_measured_again_when_weights_or_adapters_change():
         t.model.engine.close()
 
 
+def test_second_pass_auto_on_a_bf16_engine_is_measured_and_follows_the_weights(capsys):
+    """`--second_pass auto` (bf16 engines, round 6): evaluation() measures whether the VTG calls' second walk over K may run on the e2m3 MFMA (the calibration pairs scored with the
+    bf16 second pass and with the e2m3 one), switches the engine accordingly, reuses the answer while the weights stand and measures again after a change; either way every matrix
+    stays within the bar of the run with the bf16 second pass."""
+    t = _build("tiny", dtype="bf16")
+    try:
+        tok = types.SimpleNamespace(pad_token_id=synth.PAD_ID)
+        mk = lambda: types.SimpleNamespace(topk=t.spec["topk"], batch_size_eval=t.spec["bs"], num_clips=t.dims.num_clips, cpn=True, resume="ckpt", eval=True, dataset="SYNTH",
+                                           alpha=[0.4, 0.8], c=[0.3, 0.6, 0.9, 0.7], iv2_scores={"v2t": torch.from_numpy(t.prob.v2t_sims), "t2v": torch.from_numpy(t.prob.t2v_sims)})
+        loader, ddp = _SynthLoader(t.prob, bs=4), DDPLike(t.model)
+        assert t.model.vtg_precise == "full" and t.model.second_pass == "16bit" and not t.model.engine.lo6            # a bf16 engine's defaults: the parity form
+        a0 = mk(); r0 = RU.evaluation(ddp, loader, t.model.device, tok, a0)
+        assert "second_pass" not in a0._eval_stats
+        t.model.second_pass = "auto"
+        assert not t.model.second_pass_resolved() and not t.model.engine.lo6
+        a1 = mk(); r1 = RU.evaluation(ddp, loader, t.model.device, tok, a1)
+        st = a1._eval_stats
+        assert st["second_pass"] in ("e2m3", "16bit") and "e2m3" in st["second_pass_table"] and t.model.second_pass_resolved()
+        assert t.model.engine.lo6 == (st["second_pass"] == "e2m3") and t.model.second_pass == "auto"
+        worst = 0.0
+        for d0, d1 in zip(r0, r1):
+            for k in d0:
+                m = d0[k] != -100.0
+                if k != "internvideo2" and m.any():
+                    worst = max(worst, float(np.max(np.abs(d1[k][m] - d0[k][m]) / np.abs(d0[k][m]))))
+        with capsys.disabled():
+            e = st["second_pass_table"]["e2m3"]
+            print(f"\n[tiny bf16] second_pass auto: e2m3 vs bf16 second pass on the calibration pairs max {e['max']:.1e} rms {e['rms']:.1e} -> {st['second_pass']}; "
+                  f"whole evaluation vs the bf16 second pass: worst {worst:.1e}")
+        assert worst < 1e-3
+        a2 = mk(); RU.evaluation(ddp, loader, t.model.device, tok, a2)
+        assert "second_pass_table" not in a2._eval_stats and a2._eval_stats["second_pass"] == st["second_pass"]        # same weights: the answer stands
+        t.model.engine.load_weight("final_norm", np.ones(t.dims.hidden_size, np.float32))
+        assert not t.model.second_pass_resolved()
+        a3 = mk(); RU.evaluation(ddp, loader, t.model.device, tok, a3)
+        assert "second_pass_table" in a3._eval_stats                                                                   # ... and measured again
+    finally:
+        t.model.engine.close()
+
+
 # ----------------------------------------------------------------------------- fp8 mode (BASELINE config 5; SURVEY.md 8f-2)
 # Building blocks are checked exactly (the quantiser against torch's own e4m3 cast, the block-scaled MFMA GEMM on integer
 # data); the end-to-end scores are compared with the same fp32 golden vectors and their deviation is REPORTED and bounded

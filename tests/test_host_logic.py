@@ -485,6 +485,32 @@ def test_predicted_max_deviation_extrapolates_the_samples_tail():
 
 
 
+def test_second_pass_request_and_resolution():
+    """BlimModel.second_pass (round 6): "e2m3" | "16bit" switch the engine option at once; "auto" is a request on bf16 engines (the parity form runs until evaluation()
+    has measured, and again after any weight change) and simply means e2m3 on fp16 engines."""
+    from blim_amd.modeling import BlimModel
+    opts = []
+    mk = lambda dtype, lo6: types.SimpleNamespace(weights_version=0, can_precise=True, dtype=dtype, lo6=lo6,
+                                                    set_option=lambda k, v: (opts.append((k, v)), setattr(m.engine, "lo6", bool(v)) if k == "precise_lo6" else None))
+    m = BlimModel.__new__(BlimModel)
+    m.engine = mk("bf16", False)
+    m._vtg_request, m._tvg_request, m._vtg_resolved, m._tvg_resolved = "full", "full", None, None
+    assert m.second_pass == "16bit" and m.second_pass_resolved()
+    m.second_pass = "e2m3"
+    assert opts[-1] == ("precise_lo6", 1) and m.second_pass == "e2m3"
+    m.second_pass = "auto"
+    assert opts[-1] == ("precise_lo6", 0) and m.second_pass == "auto" and not m.second_pass_resolved()
+    m.resolve_second_pass("e2m3")
+    assert opts[-1] == ("precise_lo6", 1) and m.second_pass == "auto" and m.second_pass_resolved()
+    m.engine.weights_version += 1
+    assert not m.second_pass_resolved()
+    m.engine = mk("f16", True)
+    m.second_pass = "auto"
+    assert m.second_pass == "e2m3" and m.second_pass_resolved()
+    with pytest.raises(ValueError):
+        m.second_pass = "fp4"
+
+
 class _FakeCalScorer:
     """Stand-in for PairScorer under calibration.CalibrationMixin: vtg() returns a per-pair "true" score, perturbed in the plain mode by a seeded per-pair deviation."""
 
