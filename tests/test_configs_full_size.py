@@ -22,15 +22,16 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 # pairs/s floors = 0.85 x the rates measured in round 6 (config 4: 5,738 - 5,903 pairs/s with plain VTG calls -- round 5 ran it compensated at 3,574, and both rounds' printed
-# figures up to r06a still counted the 6 s --dump_scores spends compressing the matrices; config 3: 14,086); see the module docstring
-FLOOR_CONFIG4 = 4800
-FLOOR_CONFIG3 = 11950
+# figures up to r06a still counted the 6 s --dump_scores spends compressing the matrices and the recall table of the partial matrices: 6,403 - 6,602 without; config 3:
+# 14,856); see the module docstring
+FLOOR_CONFIG4 = 5400
+FLOOR_CONFIG3 = 12600
 FLOOR_CONFIG2 = 5000          # one GPU, N = 1,000 top-16, all six passes: 96,000 pairs in ~ 16 s (bench.py's strong-scaling leg: 15.9 s)
 FLOOR_CONFIG5 = 4000          # fp8, rank 0 of 8 of the same job (provisional; set from the first measurement)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, n, topk, shard, extra=()):
+def _run(tmp_path, n, topk, shard, extra=(), n_mode_lines=2):
     dump = str(tmp_path / "scores.npz")
     cmd = [sys.executable, "-m", "blim_amd.main", "--eval", "--synthetic", str(n), "--synthetic_7b", "--cpn", "--resume", "x", "--topk", str(topk), "--alpha", "0.7", "0.9",
            "--c", "0.5", "0.5", "0.8", "0.8", *(["--shard", str(shard[0]), str(shard[1])] if shard else []), "--dump_scores", dump, "--output_dir", str(tmp_path / "out"), *extra]
@@ -41,7 +42,7 @@ def _run(tmp_path, n, topk, shard, extra=()):
     adj = re.search(r"at a rank's 1/\d+ share of it the evaluation above takes ([0-9.]+)s = (\d+) pairs/s per process", r.stdout)
     d = dict(np.load(dump))
     modes = [l for l in (r.stdout + r.stderr).splitlines() if "_precise auto" in l]
-    assert len(modes) == 2, modes                                                                     # both calibrations ran (and printed their tables)
+    assert len(modes) == n_mode_lines, modes                                                          # both calibrations ran and printed their tables (fp8 engines: nothing to calibrate)
     return d, dict(pairs=int(m.group(1)), scored=int(m.group(2)), seconds=float(m.group(3)), pairs_per_s=int(m.group(4)), tflop=float(m.group(5)), frac=float(m.group(6)),
                    rank_share_pairs_per_s=int(adj.group(2)) if adj else int(m.group(4))), modes
 
@@ -126,7 +127,7 @@ def test_config5_lsmdc_size_fp8_top16_rank0_of_8(tmp_path, capsys):
     """BASELINE config 5: "LSMDC, fp8 weights on CDNA4 fp8 MFMA, top-16 re-rank, 8 x MI355X" -- rank 0's share of an N = 1,000 evaluation on an fp8 engine (a REPORTED,
     non-parity mode: DESIGN.md section 4): the size properties and a pairs/s floor; the deltas against fp16 are tests/test_gpu_parity.py::test_fp8_mode_*'s."""
     n, W = 1000, 8
-    d, st, modes = _run(tmp_path, n, 16, (W, 0), extra=("--dtype", "f8"))
+    d, st, modes = _run(tmp_path, n, 16, (W, 0), extra=("--dtype", "f8"), n_mode_lines=0)
     step = n // W + 1
     _properties(d, n, (0, step), (0, step), dense=False)
     assert st["pairs"] == 6 * step * 16 and 0.1 < st["frac"] < 0.7, st
