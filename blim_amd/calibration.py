@@ -71,8 +71,9 @@ class CalibrationMixin:
         import torch
         W = int(share[0]) if share is not None else 0
         if share is None or not dist_utils.is_dist_avail_and_initialized() or W != torch.distributed.get_world_size():
-            # one process playing rank r of W (`--shard`, bench.py's emulated ranks and its warm-up, also inside a real job): nobody to gather from -- it decides on its
-            # own block; the COST of a rank's share of the calibration is what such a run stands for
+            # one process playing rank r of W (bench.py's emulated ranks and its warm-up, also inside a real job): nobody to gather from -- it measures its own block,
+            # the COST a rank's share of the calibration stands for, and takes the job's decision (`adopt`); evaluation() hands a share to such a process only together
+            # with that decision (retrieval_utils.share_of)
             return dev
         n = int(share[2])                                                   # the largest block
         buf = torch.full((n,), -1.0, dtype=torch.float64, device=self.device)            # padding: -1 (a deviation is >= 0; a non-finite one travels as +inf and rejects the mode)
