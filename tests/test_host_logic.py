@@ -485,6 +485,38 @@ def test_predicted_max_deviation_extrapolates_the_samples_tail():
 
 
 
+def test_calibrate_second_pass_decides_between_the_two_second_passes_of_a_bf16_engine():
+    """calibration.CalibrationMixin.calibrate_second_pass with a stand-in scorer: the e2m3 form is measured against the bf16 one through the same stages as the VTG modes
+    (accepted when quiet, rejected when its deviations are outside the bar), the engine is left in the chosen form, and other engines have nothing to measure."""
+    from blim_amd import retrieval_utils as RU
+    from blim_amd.calibration import CalibrationMixin
+
+    class S(CalibrationMixin):
+        def __init__(self, dtype, scale):
+            self.opts, self.scale, self.resolved = [], scale, []
+            self.engine = types.SimpleNamespace(dtype=dtype, lo6=False, can_precise=True, set_option=lambda k, v: (self.opts.append((k, v)), setattr(self.engine, "lo6", bool(v))))
+            self.m = types.SimpleNamespace(resolve_second_pass=lambda mode: (self.resolved.append(mode), self.engine.set_option("precise_lo6", int(mode == "e2m3"))))
+
+        def set_vtg_mode(self, mode):
+            self.mode = mode
+
+        def vtg(self, pairs, cpn=False):
+            base = -2.0 - 0.01 * (pairs[:, 1] % 5)
+            noise = np.random.RandomState(7).randn(100000)[(pairs[:, 0] * 131 + pairs[:, 1]) % 100000]
+            return base * (1.0 + (self.scale * noise if self.engine.lo6 else 0.0))
+
+    sims = np.random.RandomState(1).randn(300, 300).astype(np.float32)
+    first, confirm = RU.calibration_pairs(sims, 16, n_queries=32, per_query=8), RU.calibration_pairs(sims, 16, n_queries=256, per_query=8)
+    quiet = S("bf16", 2e-5)
+    chosen, table = quiet.calibrate_second_pass(first, n_eval=48000, confirm_pairs=confirm)
+    assert chosen == "e2m3" and quiet.resolved == ["e2m3"] and quiet.engine.lo6 and quiet.mode == "full" and table["e2m3"]["max"] < 1e-4
+    loud = S("bf16", 6e-4)
+    chosen, table = loud.calibrate_second_pass(first, n_eval=48000, confirm_pairs=confirm)
+    assert chosen == "16bit" and not loud.engine.lo6 and table["e2m3"]["max"] > 1e-3
+    f16 = S("f16", 1.0); f16.engine.lo6 = True
+    assert f16.calibrate_second_pass(first, n_eval=48000) == ("e2m3", {}) and f16.opts == []
+
+
 def test_second_pass_request_and_resolution():
     """BlimModel.second_pass (round 6): "e2m3" | "16bit" switch the engine option at once; "auto" is a request on bf16 engines (the parity form runs until evaluation()
     has measured, and again after any weight change) and simply means e2m3 on fp16 engines."""
