@@ -529,9 +529,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 WP_T(1);
                 // every read of tile k has been requested (and is awaited in front of the barrier: P2_BARRIER's own lgkmcnt(0)).  Tile k+1: my pieces of it were requested two barriers ago --
                 // only the seven of tile k+2 may stay in flight (k = 0: the W group's fourteen of A(2) W(2))
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 6   // ablation build (round 6: is the pass bound by LDS-DMA LATENCY?): the waits let one more tile stay in flight -- tile k+1 is read without
+                                                     // having been awaited (timing only, wrong results).  If the step got much shorter, a deeper ring would be the lever
+                if (k == 0) { if (nk6 > 2) P2_VMCNT(21); else P2_VMCNT(0); }
+                else if (k + 2 < nk6) P2_VMCNT(14);
+                else P2_VMCNT(0);
+#else
                 if (k == 0) { if (nk6 > 2) P2_VMCNT(14); else P2_VMCNT(0); }
                 else if (k + 2 < nk6) P2_VMCNT(7);
                 else P2_VMCNT(0);
+#endif
                 WP_T(2);
                 P2_BARRIER();
                 WP_T(3);

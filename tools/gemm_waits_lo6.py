@@ -12,7 +12,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 names = ("qa+qb", "vmcnt", "barrier", "qc", "qd")
-LABEL = {0: "as shipped", 1: "no MFMAs", 2: "no fragment refills", 3: "no LDS-DMA", 4: "W operand with an e2m1 image's bytes (17 of 25 KiB)", 5: "both operands with e2m1 bytes"}
+LABEL = {0: "as shipped", 1: "no MFMAs", 2: "no fragment refills", 3: "no LDS-DMA", 4: "W operand with an e2m1 image's bytes (17 of 25 KiB)", 5: "both operands with e2m1 bytes", 6: "vmcnt waits one tile looser (is it LDS-DMA latency?)"}
 
 
 def one(v):
@@ -45,6 +45,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         one(int(sys.argv[1]))
     else:
-        for v in (0, 1, 2, 3, 4, 5):
+        for v in [int(x) for x in os.environ.get("P2_VARIANTS", "0,1,2,3,4,5,6").split(",")]:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], capture_output=True, text=True)
             print(r.stdout if r.returncode == 0 else f"[{v}] failed: {r.stderr[-800:]}", flush=True)
