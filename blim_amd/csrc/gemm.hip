@@ -540,7 +540,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
                 else P2_VMCNT(0);
 #endif
                 WP_T(2);
+#if defined(GEMM_ABLATE_P2) && GEMM_ABLATE_P2 == 7   // ablation build (round 6: is it the per-step rendezvous of the eight waves?): a barrier every OTHER step only (timing only, wrong results)
+                if (k & 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } else { P2_BARRIER(); }
+#else
                 P2_BARRIER();
+#endif
                 WP_T(3);
                 // QC
                 L6_MMA(4, CB) L6_SB(); if (rl) fa8[0] = RD6A(t1 + qoa, t1 + qoa8, 0); L6_SB();

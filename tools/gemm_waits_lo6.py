@@ -12,7 +12,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 names = ("qa+qb", "vmcnt", "barrier", "qc", "qd")
-LABEL = {0: "as shipped", 1: "no MFMAs", 2: "no fragment refills", 3: "no LDS-DMA", 4: "W operand with an e2m1 image's bytes (17 of 25 KiB)", 5: "both operands with e2m1 bytes", 6: "vmcnt waits one tile looser (is it LDS-DMA latency?)"}
+LABEL = {0: "as shipped", 1: "no MFMAs", 2: "no fragment refills", 3: "no LDS-DMA", 4: "W operand with an e2m1 image's bytes (17 of 25 KiB)", 5: "both operands with e2m1 bytes", 6: "vmcnt waits one tile looser (is it LDS-DMA latency?)", 7: "a barrier every other step only (is it the rendezvous?)"}
 
 
 def one(v):
